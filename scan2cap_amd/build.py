@@ -1,0 +1,51 @@
+"""Builds libs2c_hip.so (the gfx950 kernels behind include/s2c_ops.h) with hipcc.
+
+The library is pure HIP + a C ABI -- no torch headers -- so it cross-compiles in
+seconds on a machine without a GPU and travels in-tree to the GPU box.
+"""
+import glob
+import os
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_DIR = os.path.join(_HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libs2c_hip.so")
+
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17",
+    # canonical arithmetic: IEEE binary32, source order, no FMA contraction
+    "-ffp-contract=off",
+    "-shared", "-fPIC", "-Wno-comment",
+]
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def _stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(
+        os.path.join(_HERE, "..", "include", "*.h"))
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile every .hip source into lib/libs2c_hip.so.  Returns the path."""
+    if not force and not _stale():
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "hipcc")
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH] + sources()
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,147 @@
+"""Drop-in replacement of the reference's pybind module `pointnet2._ext`
+(lib/pointnet2/_ext_src/src/bindings.cpp:6-19): the same nine functions, same
+argument order, same tensor layouts and dtypes, same error class (the
+reference's AT_ASSERT checks surface as RuntimeError, include/utils.h:5-25).
+
+Outputs are fresh tensors on the inputs' device; inputs are borrowed.  All work
+is enqueued on the current HIP stream, nothing synchronises.  CPU tensors are
+rejected exactly like the reference ("CPU not supported",
+ball_query.cpp:27-29) -- there is no fallback.
+"""
+import torch
+
+from .. import _C
+
+
+def _check(cond, msg):
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def _chk_f(x, name):
+    _check(x.is_contiguous(), "%s must be a contiguous tensor" % name)
+    _check(x.dtype == torch.float32, "%s must be a float tensor" % name)
+    _check(x.is_cuda, "CPU not supported")
+
+
+def _chk_i(x, name):
+    _check(x.is_contiguous(), "%s must be a contiguous tensor" % name)
+    _check(x.dtype == torch.int32, "%s must be an int tensor" % name)
+    _check(x.is_cuda, "%s must be a CUDA tensor" % name)
+
+
+def _run(name, ref, *args):
+    with torch.cuda.device(ref.device):
+        _C.call(name, *args, _C.stream_ptr())
+
+
+def gather_points(points, idx):
+    """sampling.cpp:15-38.  (B,C,N) f32, (B,m) i32 -> (B,C,m)"""
+    _chk_f(points, "points")
+    _chk_i(idx, "idx")
+    b, c, n = points.shape
+    m = idx.shape[1]
+    out = torch.empty((b, c, m), dtype=torch.float32, device=points.device)
+    _run("s2c_gather_points", points, b, c, n, m, points.data_ptr(),
+         idx.data_ptr(), out.data_ptr())
+    return out
+
+
+def gather_points_grad(grad_out, idx, n):
+    """sampling.cpp:40-65.  (B,C,m), (B,m), n -> (B,C,n)"""
+    _chk_f(grad_out, "grad_out")
+    _chk_i(idx, "idx")
+    b, c, m = grad_out.shape
+    out = torch.empty((b, c, n), dtype=torch.float32, device=grad_out.device)
+    _run("s2c_gather_points_grad", grad_out, b, c, int(n), m,
+         grad_out.data_ptr(), idx.data_ptr(), out.data_ptr())
+    return out
+
+
+def furthest_point_sampling(points, nsamples):
+    """sampling.cpp:66-87.  (B,N,3) f32 -> (B,nsamples) i32"""
+    _chk_f(points, "points")
+    b, n, _ = points.shape
+    out = torch.empty((b, nsamples), dtype=torch.int32, device=points.device)
+    temp = None
+    if n > _C.load().s2c_fps_resident_limit():
+        temp = torch.empty((b, n), dtype=torch.float32, device=points.device)
+    _run("s2c_furthest_point_sampling", points, b, n, int(nsamples),
+         points.data_ptr(), temp.data_ptr() if temp is not None else None,
+         out.data_ptr())
+    return out
+
+
+def three_nn(unknowns, knows):
+    """interpolate.cpp:14-40.  (B,n,3), (B,m,3) -> [dist2 (B,n,3) f32, idx (B,n,3) i32]"""
+    _chk_f(unknowns, "unknowns")
+    _chk_f(knows, "knows")
+    b, n, _ = unknowns.shape
+    m = knows.shape[1]
+    dist2 = torch.empty((b, n, 3), dtype=torch.float32, device=unknowns.device)
+    idx = torch.empty((b, n, 3), dtype=torch.int32, device=unknowns.device)
+    _run("s2c_three_nn", unknowns, b, n, m, unknowns.data_ptr(),
+         knows.data_ptr(), dist2.data_ptr(), idx.data_ptr())
+    return [dist2, idx]
+
+
+def three_interpolate(points, idx, weight):
+    """interpolate.cpp:42-70.  (B,C,m), (B,n,3) i32, (B,n,3) f32 -> (B,C,n)"""
+    _chk_f(points, "points")
+    _chk_i(idx, "idx")
+    _chk_f(weight, "weight")
+    b, c, m = points.shape
+    n = idx.shape[1]
+    out = torch.empty((b, c, n), dtype=torch.float32, device=points.device)
+    _run("s2c_three_interpolate", points, b, c, m, n, points.data_ptr(),
+         idx.data_ptr(), weight.data_ptr(), out.data_ptr())
+    return out
+
+
+def three_interpolate_grad(grad_out, idx, weight, m):
+    """interpolate.cpp:71-99.  (B,C,n), (B,n,3), (B,n,3), m -> (B,C,m)"""
+    _chk_f(grad_out, "grad_out")
+    _chk_i(idx, "idx")
+    _chk_f(weight, "weight")
+    b, c, n = grad_out.shape
+    out = torch.empty((b, c, m), dtype=torch.float32, device=grad_out.device)
+    _run("s2c_three_interpolate_grad", grad_out, b, c, n, int(m),
+         grad_out.data_ptr(), idx.data_ptr(), weight.data_ptr(),
+         out.data_ptr())
+    return out
+
+
+def ball_query(new_xyz, xyz, radius, nsample):
+    """ball_query.cpp:8-32.  NOTE the C++ argument order (new_xyz, xyz, radius,
+    nsample) differs from the Python wrapper's (pointnet2_utils.py:262,282)."""
+    _chk_f(new_xyz, "new_xyz")
+    _chk_f(xyz, "xyz")
+    b, m, _ = new_xyz.shape
+    n = xyz.shape[1]
+    idx = torch.empty((b, m, nsample), dtype=torch.int32, device=new_xyz.device)
+    _run("s2c_ball_query", new_xyz, b, n, m, float(radius), int(nsample),
+         new_xyz.data_ptr(), xyz.data_ptr(), idx.data_ptr())
+    return idx
+
+
+def group_points(points, idx):
+    """group_points.cpp:12-36.  (B,C,N), (B,m,ns) i32 -> (B,C,m,ns)"""
+    _chk_f(points, "points")
+    _chk_i(idx, "idx")
+    b, c, n = points.shape
+    _, m, ns = idx.shape
+    out = torch.empty((b, c, m, ns), dtype=torch.float32, device=points.device)
+    _run("s2c_group_points", points, b, c, n, m, ns, points.data_ptr(),
+         idx.data_ptr(), out.data_ptr())
+    return out
+
+
+def group_points_grad(grad_out, idx, n):
+    """group_points.cpp:38-62.  (B,C,m,ns), (B,m,ns), n -> (B,C,n)"""
+    _chk_f(grad_out, "grad_out")
+    _chk_i(idx, "idx")
+    b, c, m, ns = grad_out.shape
+    out = torch.empty((b, c, n), dtype=torch.float32, device=grad_out.device)
+    _run("s2c_group_points_grad", grad_out, b, c, int(n), m, ns,
+         grad_out.data_ptr(), idx.data_ptr(), out.data_ptr())
+    return out

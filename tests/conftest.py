@@ -1,0 +1,30 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU parity oracle (oracle/s2c_oracle.c via ctypes) -- checker only."""
+    from oracle import oracle as orc
+    orc.build()
+    return orc
+
+
+@pytest.fixture(scope="session")
+def ext():
+    """The product op layer (HIP, through the C ABI)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from scan2cap_amd.pointnet2 import _ext
+    return _ext

@@ -1,0 +1,175 @@
+"""Parity of the nine HIP operators (through the C ABI) against the CPU oracle.
+
+Indices must be bit-exact; float gathers are exact copies; float sums within
+1e-4 (north_star tolerance) -- atomics make the grad sums order-dependent.
+"""
+import numpy as np
+import pytest
+import torch
+
+from scan2cap_amd.synthetic import scene_xyz
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+FPS_CASES = [
+    # (B, N, m, mode)
+    (3, 40, 10, "volume"),        # bs=32, T=64
+    (2, 300, 64, "volume"),       # bs=256
+    (2, 1000, 100, "surface"),    # bs=512, T=512, 2 pts/thread
+    (2, 1024, 256, "volume"),     # T=1024 PPT=1
+    (2, 2048, 1024, "volume"),    # SA2 shape
+    (4, 4096, 512, "surface"),    # cfg1-like
+    (1, 20000, 256, "volume"),    # streaming path, PPT=24
+    (2, 40000, 2048, "volume"),   # SA1 shape (cfg2/cfg3)
+]
+
+
+@pytest.mark.parametrize("B,N,m,mode", FPS_CASES)
+def test_fps_bit_exact(ext, oracle, B, N, m, mode):
+    xyz = scene_xyz(B, N, seed=7 + N, mode=mode)
+    want = oracle.furthest_point_sampling(xyz, m)
+    got = ext.furthest_point_sampling(dev(xyz), m).cpu().numpy()
+    assert got.dtype == np.int32
+    np.testing.assert_array_equal(got, want)
+
+
+def test_fps_degenerate(ext, oracle):
+    # every point skipped (|p|^2 <= 1e-3) -> all picks are 0 (sampling_gpu.cu:90)
+    xyz = np.zeros((2, 128, 3), np.float32)
+    got = ext.furthest_point_sampling(dev(xyz), 16).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.furthest_point_sampling(xyz, 16))
+    assert (got == 0).all()
+    # all points identical and far from the origin: ties everywhere
+    xyz = np.ones((1, 700, 3), np.float32)
+    got = ext.furthest_point_sampling(dev(xyz), 32).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.furthest_point_sampling(xyz, 32))
+    # lattice: masses of exactly equal distances exercise the bit-reversal rule
+    g = np.stack(np.meshgrid(np.arange(16), np.arange(16), np.arange(8),
+                             indexing="ij"), -1).reshape(1, -1, 3)
+    xyz = (g.astype(np.float32) * 0.25 + 1.0)
+    got = ext.furthest_point_sampling(dev(xyz), 200).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.furthest_point_sampling(xyz, 200))
+
+
+BQ_CASES = [
+    # (B, N, m, radius, nsample, mode)
+    (2, 4096, 512, 0.2, 64, "volume"),
+    (2, 4096, 513, 0.4, 32, "surface"),   # m not a multiple of 8 -> ragged block
+    (1, 5000, 100, 0.8, 16, "surface"),   # many hits: early exit
+    (2, 1000, 77, 0.05, 8, "volume"),     # few / no extra hits: padding rule
+    (2, 40000, 2048, 0.2, 64, "volume"),  # SA1 shape
+    (1, 2048, 1024, 0.4, 100, "volume"),  # nsample > 64
+]
+
+
+@pytest.mark.parametrize("B,N,m,radius,ns,mode", BQ_CASES)
+def test_ball_query_bit_exact(ext, oracle, B, N, m, radius, ns, mode):
+    xyz = scene_xyz(B, N, seed=11 + N + m, mode=mode)
+    rng = np.random.default_rng(m)
+    sel = np.stack([rng.choice(N, m, replace=False) for _ in range(B)])
+    new_xyz = np.take_along_axis(xyz, sel[..., None], 1)
+    want = oracle.ball_query(new_xyz, xyz, radius, ns)
+    got = ext.ball_query(dev(new_xyz), dev(xyz), radius, ns).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+
+
+def test_ball_query_no_hit_rows_are_zero(ext, oracle):
+    xyz = scene_xyz(1, 512, seed=3)
+    new_xyz = np.full((1, 9, 3), 50.0, np.float32)  # far away: no hit
+    got = ext.ball_query(dev(new_xyz), dev(xyz), 0.2, 16).cpu().numpy()
+    assert (got == 0).all()
+    np.testing.assert_array_equal(got, oracle.ball_query(new_xyz, xyz, 0.2, 16))
+
+
+def test_gather_group_exact(ext, oracle):
+    rng = np.random.default_rng(0)
+    B, C, N, m, ns = 2, 7, 1000, 130, 12
+    pts = rng.standard_normal((B, C, N)).astype(np.float32)
+    idx1 = rng.integers(0, N, (B, m)).astype(np.int32)
+    idx2 = rng.integers(0, N, (B, m, ns)).astype(np.int32)
+    np.testing.assert_array_equal(
+        ext.gather_points(dev(pts), dev(idx1)).cpu().numpy(),
+        oracle.gather_points(pts, idx1))
+    np.testing.assert_array_equal(
+        ext.group_points(dev(pts), dev(idx2)).cpu().numpy(),
+        oracle.group_points(pts, idx2))
+    # scalar path: npoints*nsample not a multiple of 4
+    idx3 = rng.integers(0, N, (B, 11, 3)).astype(np.int32)
+    np.testing.assert_array_equal(
+        ext.group_points(dev(pts), dev(idx3)).cpu().numpy(),
+        oracle.group_points(pts, idx3))
+
+
+def test_gather_group_grads(ext, oracle):
+    rng = np.random.default_rng(1)
+    B, C, N, m, ns = 2, 5, 600, 96, 16
+    idx1 = rng.integers(0, N, (B, m)).astype(np.int32)
+    idx2 = rng.integers(0, 40, (B, m, ns)).astype(np.int32)  # heavy collisions
+    g1 = rng.standard_normal((B, C, m)).astype(np.float32)
+    g2 = rng.standard_normal((B, C, m, ns)).astype(np.float32)
+    np.testing.assert_allclose(
+        ext.gather_points_grad(dev(g1), dev(idx1), N).cpu().numpy(),
+        oracle.gather_points_grad(g1, idx1, N), rtol=0, atol=TOL)
+    got = ext.group_points_grad(dev(g2), dev(idx2), N).cpu().numpy()
+    want = oracle.group_points_grad(g2, idx2, N)
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=TOL)
+    assert (got[:, :, 40:] == 0).all()
+
+
+@pytest.mark.parametrize("B,n,m", [(2, 512, 256), (2, 1024, 512), (1, 70, 5),
+                                   (1, 33, 2), (2, 300, 1500)])
+def test_three_nn_bit_exact(ext, oracle, B, n, m):
+    xyz = scene_xyz(B, max(n, m) + 256, seed=5 + n)
+    unknown, known = xyz[:, :n].copy(), xyz[:, 100:100 + m].copy()
+    d_want, i_want = oracle.three_nn(unknown, known)
+    d_got, i_got = ext.three_nn(dev(unknown), dev(known))
+    np.testing.assert_array_equal(i_got.cpu().numpy(), i_want)
+    np.testing.assert_array_equal(d_got.cpu().numpy(), d_want)
+
+
+def test_three_interpolate_and_grad(ext, oracle):
+    rng = np.random.default_rng(2)
+    B, C, m, n = 2, 9, 64, 200
+    pts = rng.standard_normal((B, C, m)).astype(np.float32)
+    idx = rng.integers(0, m, (B, n, 3)).astype(np.int32)
+    w = rng.random((B, n, 3)).astype(np.float32)
+    w /= w.sum(-1, keepdims=True)
+    np.testing.assert_array_equal(
+        ext.three_interpolate(dev(pts), dev(idx), dev(w)).cpu().numpy(),
+        oracle.three_interpolate(pts, idx, w))
+    g = rng.standard_normal((B, C, n)).astype(np.float32)
+    np.testing.assert_allclose(
+        ext.three_interpolate_grad(dev(g), dev(idx), dev(w), m).cpu().numpy(),
+        oracle.three_interpolate_grad(g, idx, w, m), rtol=1e-5, atol=TOL)
+
+
+def test_reference_kat_three_interpolate(ext):
+    """lib/pointnet2/pointnet2_test.py:18-30 -- the one test the reference holds."""
+    feats = torch.arange(8, dtype=torch.float32).view(1, 2, 4).cuda()
+    idx = torch.tensor([[[0, 1, 2], [1, 2, 3]]], dtype=torch.int32).cuda()
+    w = torch.tensor([[[1, 1, 1], [2, 2, 2]]], dtype=torch.float32).cuda()
+    out = ext.three_interpolate(feats, idx, w).cpu()
+    f = feats.cpu()
+    want = torch.stack([f[:, :, 0] + f[:, :, 1] + f[:, :, 2],
+                        2 * (f[:, :, 1] + f[:, :, 2] + f[:, :, 3])], -1)
+    assert torch.equal(out, want)
+    g = ext.three_interpolate_grad(torch.ones(1, 2, 2).cuda(), idx, w, 4).cpu()
+    assert torch.equal(g, torch.tensor([[[1., 3., 3., 2.]] * 2]))
+
+
+def test_errors_raise(ext):
+    x = torch.zeros(1, 8, 3)
+    with pytest.raises(RuntimeError):
+        ext.furthest_point_sampling(x, 2)                      # CPU tensor
+    xc = torch.zeros(1, 8, 6).cuda()[:, :, :3]
+    with pytest.raises(RuntimeError):
+        ext.furthest_point_sampling(xc, 2)                     # non-contiguous
+    with pytest.raises(RuntimeError):
+        ext.gather_points(torch.zeros(1, 3, 8).cuda(),
+                          torch.zeros(1, 2, dtype=torch.int64).cuda())  # wrong dtype
