@@ -1,0 +1,53 @@
+"""PointNet++ backbone (4 SA + 2 FP), drop-in for models/backbone_module.py:11-127.
+Same constructor, same `data_dict` keys, same state_dict names (sa1..sa4, fp1, fp2).
+"""
+import torch.nn as nn
+
+from ..pointnet2.pointnet2_modules import PointnetFPModule, PointnetSAModuleVotes
+
+# (npoint, radius, nsample, mlp tail)  -- backbone_module.py:28-62
+_SA_SPECS = (
+    (2048, 0.2, 64, (64, 64, 128)),
+    (1024, 0.4, 32, (128, 128, 256)),
+    (512, 0.8, 16, (128, 128, 256)),
+    (256, 1.2, 16, (128, 128, 256)),
+)
+
+
+class Pointnet2Backbone(nn.Module):
+    def __init__(self, input_feature_dim=0):
+        super().__init__()
+        self.input_feature_dim = input_feature_dim
+        cin = input_feature_dim
+        for i, (npoint, radius, nsample, tail) in enumerate(_SA_SPECS, 1):
+            setattr(self, "sa%d" % i, PointnetSAModuleVotes(
+                npoint=npoint, radius=radius, nsample=nsample,
+                mlp=[cin] + list(tail), use_xyz=True, normalize_xyz=True))
+            cin = tail[-1]
+        self.fp1 = PointnetFPModule(mlp=[256 + 256, 256, 256])
+        self.fp2 = PointnetFPModule(mlp=[256 + 256, 256, 256])
+
+    def _break_up_pc(self, pc):
+        xyz = pc[..., :3].contiguous()
+        features = (pc[..., 3:].transpose(1, 2).contiguous()
+                    if pc.size(-1) > 3 else None)
+        return xyz, features
+
+    def forward(self, data_dict):
+        xyz, features = self._break_up_pc(data_dict["point_clouds"])
+        for i in (1, 2, 3, 4):
+            xyz, features, inds = getattr(self, "sa%d" % i)(xyz, features)
+            if i <= 2:
+                data_dict["sa%d_inds" % i] = inds
+            data_dict["sa%d_xyz" % i] = xyz
+            data_dict["sa%d_features" % i] = features
+        features = self.fp1(data_dict["sa3_xyz"], data_dict["sa4_xyz"],
+                            data_dict["sa3_features"], data_dict["sa4_features"])
+        features = self.fp2(data_dict["sa2_xyz"], data_dict["sa3_xyz"],
+                            data_dict["sa2_features"], features)
+        data_dict["fp2_features"] = features
+        data_dict["fp2_xyz"] = data_dict["sa2_xyz"]
+        num_seed = data_dict["fp2_xyz"].shape[1]
+        # seeds are the first num_seed FPS picks of SA1 (backbone_module.py:125)
+        data_dict["fp2_inds"] = data_dict["sa1_inds"][:, 0:num_seed]
+        return data_dict

@@ -1,0 +1,303 @@
+"""Caption decoders, drop-in for models/caption_module.py: `select_target`
+(:16-38), `SceneCaptionModule` (:40-200) and `TopDownSceneCaptionModule`
+(:202-592).  Same constructors, parameter names and data_dict outputs.
+
+MI355X-first re-design of the control flow (values are unchanged):
+  * `select_target` is one batched IoU + argmax (the reference loops over the
+    batch with `.item()`, :26-33);
+  * the step-invariant `map_feat(obj_feats)` (33.5 of the 33.9 MFLOP of a step,
+    :275) is computed once per sequence instead of once per step;
+  * evaluation decodes ALL K proposals of all scenes as B*K rows in lock-step
+    (the reference runs K x 29 sequential Python iterations with B `.item()`
+    syncs, a dict lookup and an H2D copy each, :529-576); greedy feedback reads a
+    device-resident embedding table built once from the `embeddings` dict;
+  * no host synchronisation inside the step loop.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..box_util import box3d_iou_batch_tensor
+from ..config import CONF
+from .graph_module import query_locals
+
+
+def select_target(data_dict):
+    """Best-IoU proposal for each sample's ground-truth box (caption_module.py:16-38).
+    Returns target_ids (B) int64, target_ious (B) float32."""
+    pred_bbox = data_dict["bbox_corner"]                    # (B,K,8,3)
+    gt_bbox = data_dict["ref_box_corner_label"]             # (B,8,3)
+    ious = box3d_iou_batch_tensor(pred_bbox, gt_bbox.unsqueeze(1).to(pred_bbox.dtype))
+    target_ids = ious.argmax(dim=1)
+    target_ious = torch.gather(ious, 1, target_ids.view(-1, 1)).squeeze(1).float()
+    return target_ids, target_ious
+
+
+def _num_words(data_dict):
+    """max(lang_len) as a Python int.  CapNet.forward resolves it before any
+    kernel is enqueued (one early host read instead of a mid-pipeline sync);
+    standalone callers fall back to reading the tensor here."""
+    n = data_dict.get("_num_words")
+    if n is None:
+        n = int(data_dict["lang_len"].max())
+    return n
+
+
+def _embedding_table(vocabulary, embeddings, emb_size):
+    """(V, emb) float32 table in vocabulary-index order, the device-side
+    equivalent of `embeddings[idx2word[str(idx)]]` (caption_module.py:561-562)."""
+    V = len(vocabulary["word2idx"])
+    table = np.zeros((V, emb_size), np.float32)
+    idx2word = vocabulary["idx2word"]
+    for i in range(V):
+        w = idx2word.get(str(i))
+        if w is not None and w in embeddings:
+            table[i] = np.asarray(embeddings[w], np.float32)
+    return torch.from_numpy(table)
+
+
+def _good_bbox_stats(target_ious, min_iou):
+    good = target_ious > min_iou
+    n = good.sum()
+    mean = (target_ious * good).sum() / n.clamp(min=1)
+    return good, torch.where(n > 0, mean, torch.zeros_like(mean))
+
+
+class SceneCaptionModule(nn.Module):
+    """Plain GRU captioner (no attention), caption_module.py:40-200."""
+
+    def __init__(self, vocabulary, embeddings, emb_size=300, feat_size=128,
+                 hidden_size=512, num_proposals=256):
+        super().__init__()
+        self.vocabulary = vocabulary
+        self.embeddings = embeddings
+        self.num_vocabs = len(vocabulary["word2idx"])
+        self.emb_size, self.feat_size = emb_size, feat_size
+        self.hidden_size, self.num_proposals = hidden_size, num_proposals
+        self.map_feat = nn.Sequential(nn.Linear(feat_size, emb_size), nn.ReLU())
+        self.recurrent_cell = nn.GRUCell(input_size=emb_size, hidden_size=emb_size)
+        self.classifier = nn.Linear(emb_size, self.num_vocabs)
+        self.register_buffer("_emb_table",
+                             _embedding_table(vocabulary, embeddings, emb_size),
+                             persistent=False)
+
+    def step(self, step_input, hidden):
+        hidden = self.recurrent_cell(step_input, hidden)
+        return hidden, hidden
+
+    def forward(self, data_dict, use_tf=True, is_eval=False,
+                max_len=CONF.TRAIN.MAX_DES_LEN):
+        if not is_eval:
+            return self.forward_sample_batch(data_dict, max_len)
+        return self.forward_scene_batch(data_dict, use_tf, max_len)
+
+    def forward_sample_batch(self, data_dict, max_len=CONF.TRAIN.MAX_DES_LEN,
+                             min_iou=CONF.TRAIN.MIN_IOU_THRESHOLD):
+        word_embs = data_dict["lang_feat"]
+        B = word_embs.shape[0]
+        steps = _num_words(data_dict) - 1
+        obj_feats = self.map_feat(data_dict["bbox_feature"])
+        target_ids, target_ious = select_target(data_dict)
+        hidden = torch.gather(
+            obj_feats, 1, target_ids.view(B, 1, 1).expand(B, 1, self.emb_size)).squeeze(1)
+        outputs = []
+        for t in range(max(steps, 1)):
+            out, hidden = self.step(word_embs[:, t], hidden)
+            outputs.append(self.classifier(out).unsqueeze(1))
+        good, mean_iou = _good_bbox_stats(target_ious, min_iou)
+        data_dict["lang_cap"] = torch.cat(outputs, dim=1)
+        data_dict["pred_ious"] = mean_iou
+        data_dict["good_bbox_masks"] = good
+        return data_dict
+
+    def forward_scene_batch(self, data_dict, use_tf=False,
+                            max_len=CONF.TRAIN.MAX_DES_LEN):
+        word_embs = data_dict["lang_feat"]
+        B = word_embs.shape[0]
+        K = self.num_proposals
+        steps = (_num_words(data_dict) - 1) if use_tf else (max_len - 1)
+        obj_feats = self.map_feat(data_dict["bbox_feature"])      # (B,K,emb)
+        hidden = obj_feats.reshape(B * K, self.emb_size)
+        step_input = word_embs[:, 0].repeat_interleave(K, dim=0)
+        outputs = []
+        for t in range(max(steps, 1)):
+            out, hidden = self.step(step_input, hidden)
+            logits = self.classifier(out)                          # (B*K,V)
+            outputs.append(logits.view(B, K, 1, -1))
+            if use_tf:
+                if t + 1 < word_embs.shape[1]:
+                    step_input = word_embs[:, t + 1].repeat_interleave(K, dim=0)
+            else:
+                step_input = self._emb_table[logits.argmax(dim=-1)]
+        data_dict["lang_cap"] = torch.cat(outputs, dim=2)
+        return data_dict
+
+
+class TopDownSceneCaptionModule(nn.Module):
+    def __init__(self, vocabulary, embeddings, emb_size=300, feat_size=128,
+                 hidden_size=512, num_proposals=256, num_locals=-1,
+                 query_mode="corner", use_relation=False, use_oracle=False):
+        super().__init__()
+        self.vocabulary = vocabulary
+        self.embeddings = embeddings
+        self.num_vocabs = len(vocabulary["word2idx"])
+        self.emb_size, self.feat_size = emb_size, feat_size
+        self.hidden_size, self.num_proposals = hidden_size, num_proposals
+        self.num_locals = num_locals
+        self.query_mode = query_mode
+        self.use_relation = use_relation
+        self.use_oracle = use_oracle
+        # top-down recurrent module
+        self.map_topdown = nn.Sequential(
+            nn.Linear(hidden_size + feat_size + emb_size, emb_size), nn.ReLU())
+        self.recurrent_cell_1 = nn.GRUCell(input_size=emb_size, hidden_size=hidden_size)
+        # top-down attention module
+        self.map_feat = nn.Linear(feat_size, hidden_size, bias=False)
+        self.map_hidd = nn.Linear(hidden_size, hidden_size, bias=False)
+        self.attend = nn.Linear(hidden_size, 1, bias=False)
+        # language recurrent module
+        self.map_lang = nn.Sequential(
+            nn.Linear(feat_size + hidden_size, emb_size), nn.ReLU())
+        self.recurrent_cell_2 = nn.GRUCell(input_size=emb_size, hidden_size=hidden_size)
+        self.classifier = nn.Linear(hidden_size, self.num_vocabs)
+        self.register_buffer("_emb_table",
+                             _embedding_table(vocabulary, embeddings, emb_size),
+                             persistent=False)
+
+    # ---- one recurrent step ------------------------------------------------
+    def _step(self, step_input, target_feat, obj_feats, hidden_1, hidden_2,
+              object_masks, mapped_feats=None):
+        """caption_module.py:250-292.  `mapped_feats` = map_feat(obj_feats), which
+        does not depend on the step; callers that loop pass it in."""
+        step_input = self.map_topdown(
+            torch.cat([step_input, hidden_2, target_feat], dim=-1))
+        hidden_1 = self.recurrent_cell_1(step_input, hidden_1)
+        if mapped_feats is None:
+            mapped_feats = self.map_feat(obj_feats)
+        combined = torch.tanh(mapped_feats + self.map_hidd(hidden_1).unsqueeze(1))
+        scores = self.attend(combined)                      # (R,K,1)
+        scores = scores.masked_fill(object_masks == 0, float("-1e30"))
+        masks = F.softmax(scores, dim=1)
+        attended = (obj_feats * masks).sum(1)
+        lang_input = self.map_lang(torch.cat([attended, hidden_1], dim=-1))
+        hidden_2 = self.recurrent_cell_2(lang_input, hidden_2)
+        return hidden_1, hidden_2, masks
+
+    # ---- local context / relations ------------------------------------------
+    def _query_locals(self, data_dict, target_ids, object_masks, include_self=True,
+                      overlay_threshold=CONF.TRAIN.OVERLAID_THRESHOLD):
+        """target_ids (B,) or (B,T) -> local masks (B,K) or (B,T,K)."""
+        single = target_ids.dim() == 1
+        t = target_ids.view(target_ids.shape[0], -1)
+        masks, _ = query_locals(data_dict["bbox_corner"], object_masks, t,
+                                self.num_locals, self.query_mode, include_self,
+                                overlay_threshold)
+        return masks.squeeze(1) if single else masks
+
+    def _add_relation_feat(self, data_dict, obj_feats, target_ids):
+        """caption_module.py:394-414.  The `masked_scatter` there drops relation
+        row t of the target onto the t-th (ascending id) neighbour of the target's
+        adjacency row; rows are gathered by RAW proposal id from a tensor stored in
+        compacted index space -- reproduced as is.
+        obj_feats (B,K,F) target_ids (B,T) -> (B,T,K,F)."""
+        B, T = target_ids.shape
+        K, F_, L = self.num_proposals, self.feat_size, self.num_locals
+        rel = data_dict["edge_feature"]                                  # (B,K,L,F)
+        rel = torch.gather(rel, 1, target_ids.view(B, T, 1, 1).expand(B, T, L, F_))
+        nbr = data_dict.get("_adjacent_ids")
+        if nbr is None:  # adjacency produced elsewhere: recover sorted ids
+            adj = data_dict["adjacent_mat"]
+            nbr = torch.sort(torch.topk(adj, L, dim=-1)[1], dim=-1)[0]
+        nbr = torch.gather(nbr, 1, target_ids.view(B, T, 1).expand(B, T, L))  # (B,T,L)
+        out = obj_feats.unsqueeze(1).expand(B, T, K, F_).clone()
+        out.scatter_add_(2, nbr.unsqueeze(-1).expand(B, T, L, F_), rel)
+        return out
+
+    def forward(self, data_dict, use_tf=True, is_eval=False,
+                max_len=CONF.TRAIN.MAX_DES_LEN):
+        if not is_eval:
+            return self._forward_sample_batch(data_dict, max_len)
+        return self._forward_scene_batch(data_dict, use_tf, max_len)
+
+    # ---- training: teacher-forced decode of the target object --------------
+    def _forward_sample_batch(self, data_dict, max_len=CONF.TRAIN.MAX_DES_LEN,
+                              min_iou=CONF.TRAIN.MIN_IOU_THRESHOLD):
+        word_embs = data_dict["lang_feat"]          # (B,T,emb)
+        obj_feats = data_dict["bbox_feature"]       # (B,K,F)
+        object_masks = data_dict["bbox_mask"]       # (B,K)
+        B = word_embs.shape[0]
+        steps = max(_num_words(data_dict) - 1, 1)
+
+        if self.use_oracle:
+            target_ids = data_dict["bbox_idx"]
+            target_ious = torch.ones(B, device=obj_feats.device)
+        else:
+            target_ids, target_ious = select_target(data_dict)
+        target_feats = torch.gather(
+            obj_feats, 1, target_ids.view(B, 1, 1).expand(B, 1, self.feat_size)).squeeze(1)
+        valid_masks = object_masks if self.num_locals == -1 else \
+            self._query_locals(data_dict, target_ids, object_masks)
+        if self.use_relation:
+            obj_feats = self._add_relation_feat(
+                data_dict, obj_feats, target_ids.view(B, 1)).squeeze(1)
+
+        mapped = self.map_feat(obj_feats)           # hoisted out of the loop
+        step_masks = valid_masks.unsqueeze(-1)
+        hidden_1 = torch.zeros(B, self.hidden_size, device=obj_feats.device)
+        hidden_2 = torch.zeros(B, self.hidden_size, device=obj_feats.device)
+        outputs, masks = [], []
+        for t in range(steps):
+            hidden_1, hidden_2, m = self._step(
+                word_embs[:, t], target_feats, obj_feats, hidden_1, hidden_2,
+                step_masks, mapped)
+            outputs.append(self.classifier(hidden_2).unsqueeze(1))
+            masks.append(m)
+        good, mean_iou = _good_bbox_stats(target_ious, min_iou)
+        data_dict["lang_cap"] = torch.cat(outputs, dim=1)       # (B,T-1,V)
+        data_dict["pred_ious"] = mean_iou
+        data_dict["topdown_attn"] = torch.cat(masks, dim=-1)    # (B,K,T-1)
+        data_dict["valid_masks"] = valid_masks
+        data_dict["good_bbox_masks"] = good
+        return data_dict
+
+    # ---- evaluation: greedy decode of every proposal ------------------------
+    def _forward_scene_batch(self, data_dict, use_tf=False,
+                             max_len=CONF.TRAIN.MAX_DES_LEN):
+        word_embs = data_dict["lang_feat"]
+        obj_feats = data_dict["bbox_feature"]       # (B,K,F)
+        object_masks = data_dict["bbox_mask"]
+        B, K, F_ = obj_feats.shape
+        R = B * K
+        dev = obj_feats.device
+        all_ids = torch.arange(K, device=dev).view(1, K).expand(B, K)
+
+        if self.num_locals == -1:
+            valid = object_masks.unsqueeze(1).expand(B, K, K)
+        else:
+            valid = self._query_locals(data_dict, all_ids, object_masks)   # (B,K,K)
+        if self.use_relation:
+            row_feats = self._add_relation_feat(data_dict, obj_feats, all_ids)
+        else:
+            row_feats = obj_feats.unsqueeze(1).expand(B, K, K, F_)
+        row_feats = row_feats.reshape(R, K, F_)
+        mapped = self.map_feat(row_feats)                                # (R,K,H)
+        step_masks = valid.reshape(R, K, 1)
+        target_feats = obj_feats.reshape(R, F_)
+
+        hidden_1 = torch.zeros(R, self.hidden_size, device=dev)
+        hidden_2 = torch.zeros(R, self.hidden_size, device=dev)
+        step_input = word_embs[:, 0].repeat_interleave(K, dim=0)         # sos
+        outputs, masks = [], []
+        for t in range(max_len - 1):
+            hidden_1, hidden_2, m = self._step(
+                step_input, target_feats, row_feats, hidden_1, hidden_2,
+                step_masks, mapped)
+            logits = self.classifier(hidden_2)                           # (R,V)
+            outputs.append(logits.view(B, K, 1, -1))
+            masks.append(m.view(B, K, K, 1))
+            step_input = self._emb_table[logits.argmax(dim=-1)]          # greedy
+        data_dict["lang_cap"] = torch.cat(outputs, dim=2)       # (B,K,T,V)
+        data_dict["topdown_attn"] = torch.cat(masks, dim=-1)    # (B,K,K,T)
+        data_dict["valid_masks"] = valid                         # (B,K,K)
+        return data_dict

@@ -1,0 +1,95 @@
+"""Set-abstraction and feature-propagation layers used by CapNet -- drop-in for
+lib/pointnet2/pointnet2_modules.py: PointnetSAModuleVotes (:164-272) and
+PointnetFPModule (:356-416).  (The MSG / LFP variants at :26-163, :274-496 are
+not instantiated on the CapNet path.)
+"""
+from typing import List
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import pointnet2_utils
+from . import pytorch_utils as pt_utils
+
+
+class PointnetSAModuleVotes(nn.Module):
+    """FPS -> gather centres -> ball query + group -> SharedMLP -> pool."""
+
+    def __init__(self, *, mlp: List[int], npoint: int = None,
+                 radius: float = None, nsample: int = None, bn: bool = True,
+                 use_xyz: bool = True, pooling: str = "max", sigma: float = None,
+                 normalize_xyz: bool = False, sample_uniformly: bool = False,
+                 ret_unique_cnt: bool = False):
+        super().__init__()
+        self.npoint, self.radius, self.nsample = npoint, radius, nsample
+        self.pooling = pooling
+        self.use_xyz = use_xyz
+        self.sigma = sigma if sigma is not None else (
+            radius / 2 if radius is not None else None)
+        self.normalize_xyz = normalize_xyz
+        self.ret_unique_cnt = ret_unique_cnt
+        if npoint is not None:
+            self.grouper = pointnet2_utils.QueryAndGroup(
+                radius, nsample, use_xyz=use_xyz, ret_grouped_xyz=True,
+                normalize_xyz=normalize_xyz, sample_uniformly=sample_uniformly,
+                ret_unique_cnt=ret_unique_cnt)
+        else:
+            self.grouper = pointnet2_utils.GroupAll(use_xyz, ret_grouped_xyz=True)
+        mlp_spec = mlp
+        if use_xyz and len(mlp_spec) > 0:
+            mlp_spec[0] += 3  # in place, like the reference (:206-207)
+        self.mlp_module = pt_utils.SharedMLP(mlp_spec, bn=bn)
+
+    def forward(self, xyz, features=None, inds=None):
+        """xyz (B,N,3), features (B,C,N) -> new_xyz (B,npoint,3),
+        new_features (B,mlp[-1],npoint), inds (B,npoint) int32."""
+        xyz_flipped = xyz.transpose(1, 2).contiguous()
+        if inds is None:
+            inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
+        else:
+            assert inds.shape[1] == self.npoint
+        new_xyz = pointnet2_utils.gather_operation(
+            xyz_flipped, inds).transpose(1, 2).contiguous() \
+            if self.npoint is not None else None
+
+        grouped_features, grouped_xyz = self.grouper(xyz, new_xyz, features)
+        new_features = self.mlp_module(grouped_features)  # (B,C',npoint,nsample)
+        if self.pooling == "max":
+            new_features = F.max_pool2d(
+                new_features, kernel_size=[1, new_features.size(3)])
+        elif self.pooling == "avg":
+            new_features = F.avg_pool2d(
+                new_features, kernel_size=[1, new_features.size(3)])
+        elif self.pooling == "rbf":
+            rbf = torch.exp(-1 * grouped_xyz.pow(2).sum(1, keepdim=False)
+                            / (self.sigma ** 2) / 2)
+            new_features = torch.sum(new_features * rbf.unsqueeze(1), -1,
+                                     keepdim=True) / float(self.nsample)
+        new_features = new_features.squeeze(-1)
+        return new_xyz, new_features, inds
+
+
+class PointnetFPModule(nn.Module):
+    """three_nn -> inverse-distance weights -> three_interpolate -> concat skip
+    -> SharedMLP (pointnet2_modules.py:371-416)."""
+
+    def __init__(self, *, mlp: List[int], bn: bool = True):
+        super().__init__()
+        self.mlp = pt_utils.SharedMLP(mlp, bn=bn)
+
+    def forward(self, unknown, known, unknow_feats, known_feats):
+        if known is not None:
+            dist, idx = pointnet2_utils.three_nn(unknown, known)
+            dist_recip = 1.0 / (dist + 1e-8)
+            norm = torch.sum(dist_recip, dim=2, keepdim=True)
+            weight = dist_recip / norm
+            interpolated = pointnet2_utils.three_interpolate(
+                known_feats, idx, weight)
+        else:
+            interpolated = known_feats.expand(
+                *known_feats.size()[0:2], unknown.size(1))
+        new_features = (torch.cat([interpolated, unknow_feats], dim=1)
+                        if unknow_feats is not None else interpolated)
+        new_features = self.mlp(new_features.unsqueeze(-1))
+        return new_features.squeeze(-1)

@@ -1,0 +1,168 @@
+"""Autograd wrappers and groupers over the HIP operator layer -- the drop-in for
+lib/pointnet2/pointnet2_utils.py (FurthestPointSampling :51-80, GatherOperation
+:83-117, ThreeNN :120-149, ThreeInterpolate :152-206, GroupingOperation
+:209-257, BallQuery :260-291, QueryAndGroup :294-376, GroupAll :379-425).
+Same call signatures (note ball_query(radius, nsample, xyz, new_xyz)), same
+differentiability: FPS / ball_query / three_nn outputs carry no gradient.
+"""
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from . import _ext
+
+
+class FurthestPointSampling(Function):
+    @staticmethod
+    def forward(ctx, xyz, npoint):
+        inds = _ext.furthest_point_sampling(xyz, npoint)
+        ctx.mark_non_differentiable(inds)
+        return inds
+
+    @staticmethod
+    def backward(ctx, grad=None):
+        return None, None
+
+
+furthest_point_sample = FurthestPointSampling.apply
+
+
+class GatherOperation(Function):
+    @staticmethod
+    def forward(ctx, features, idx):
+        ctx.n = features.size(2)
+        ctx.save_for_backward(idx)
+        return _ext.gather_points(features, idx)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        return _ext.gather_points_grad(grad_out.contiguous(), idx, ctx.n), None
+
+
+gather_operation = GatherOperation.apply
+
+
+class ThreeNN(Function):
+    @staticmethod
+    def forward(ctx, unknown, known):
+        dist2, idx = _ext.three_nn(unknown, known)
+        ctx.mark_non_differentiable(idx)
+        return torch.sqrt(dist2), idx  # pointnet2_utils.py:142
+
+    @staticmethod
+    def backward(ctx, a=None, b=None):
+        return None, None
+
+
+three_nn = ThreeNN.apply
+
+
+class ThreeInterpolate(Function):
+    @staticmethod
+    def forward(ctx, features, idx, weight):
+        ctx.m = features.size(2)
+        ctx.save_for_backward(idx, weight)
+        return _ext.three_interpolate(features, idx, weight)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, weight = ctx.saved_tensors
+        g = _ext.three_interpolate_grad(grad_out.contiguous(), idx, weight, ctx.m)
+        return g, None, None
+
+
+three_interpolate = ThreeInterpolate.apply
+
+
+class GroupingOperation(Function):
+    @staticmethod
+    def forward(ctx, features, idx):
+        ctx.n = features.size(2)
+        ctx.save_for_backward(idx)
+        return _ext.group_points(features, idx)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        return _ext.group_points_grad(grad_out.contiguous(), idx, ctx.n), None
+
+
+grouping_operation = GroupingOperation.apply
+
+
+class BallQuery(Function):
+    @staticmethod
+    def forward(ctx, radius, nsample, xyz, new_xyz):
+        inds = _ext.ball_query(new_xyz, xyz, radius, nsample)
+        ctx.mark_non_differentiable(inds)
+        return inds
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None, None, None
+
+
+ball_query = BallQuery.apply
+
+
+class QueryAndGroup(nn.Module):
+    """Ball query + grouping (pointnet2_utils.py:294-376).
+
+    Returns (B, 3+C, npoint, nsample) [, grouped_xyz (B,3,npoint,nsample)].
+    The centring / radius normalisation are two separate ops exactly as the
+    reference (:350, :352): (p - c) / r is not bit-equal to (p - c) * (1/r).
+    `sample_uniformly` (:336-345, a CPU loop never enabled by CapNet) is not
+    provided.
+    """
+
+    def __init__(self, radius, nsample, use_xyz=True, ret_grouped_xyz=False,
+                 normalize_xyz=False, sample_uniformly=False,
+                 ret_unique_cnt=False):
+        super().__init__()
+        if sample_uniformly or ret_unique_cnt:
+            raise NotImplementedError(
+                "sample_uniformly is outside the CapNet hot path")
+        self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
+        self.ret_grouped_xyz = ret_grouped_xyz
+        self.normalize_xyz = normalize_xyz
+
+    def forward(self, xyz, new_xyz, features=None):
+        idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
+        xyz_trans = xyz.transpose(1, 2).contiguous()
+        grouped_xyz = grouping_operation(xyz_trans, idx)  # (B,3,npoint,nsample)
+        grouped_xyz = grouped_xyz - new_xyz.transpose(1, 2).unsqueeze(-1)
+        if self.normalize_xyz:
+            grouped_xyz = grouped_xyz / self.radius
+        if features is not None:
+            grouped_features = grouping_operation(features, idx)
+            new_features = (torch.cat([grouped_xyz, grouped_features], dim=1)
+                            if self.use_xyz else grouped_features)
+        else:
+            assert self.use_xyz, \
+                "Cannot have not features and not use xyz as a feature!"
+            new_features = grouped_xyz
+        if self.ret_grouped_xyz:
+            return new_features, grouped_xyz
+        return new_features
+
+
+class GroupAll(nn.Module):
+    """pointnet2_utils.py:379-425."""
+
+    def __init__(self, use_xyz=True, ret_grouped_xyz=False):
+        super().__init__()
+        self.use_xyz = use_xyz
+        self.ret_grouped_xyz = ret_grouped_xyz
+
+    def forward(self, xyz, new_xyz, features=None):
+        grouped_xyz = xyz.transpose(1, 2).unsqueeze(2)
+        if features is not None:
+            grouped_features = features.unsqueeze(2)
+            new_features = (torch.cat([grouped_xyz, grouped_features], dim=1)
+                            if self.use_xyz else grouped_features)
+        else:
+            new_features = grouped_xyz
+        if self.ret_grouped_xyz:
+            return new_features, grouped_xyz
+        return new_features

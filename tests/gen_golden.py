@@ -1,0 +1,71 @@
+"""Generates tests/golden/capnet_cfg1.npz by running the REFERENCE's CapNet
+(imported from /root/reference through oracle/ref_harness.py) on seeded
+synthetic inputs with deterministic weights.  Runs only where the reference
+tree exists; the committed .npz holds inputs + expected outputs only.
+
+    python tests/gen_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from oracle import ref_harness  # noqa: E402
+from tests import golden_common as gc  # noqa: E402
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    ref = ref_harness.reference_modules()
+    cfg = gc.GOLDEN_CFG
+    vocabulary, embeddings = gc.vocab_and_embeddings(cfg["V"])
+    msa = gc.mean_size_arr()
+    # the reference's box decode uses the module-level DC (proposal_module.py:17);
+    # give it the same mean sizes the ctor receives
+    ref.DC.mean_size_arr = msa
+    model = ref.capnet.CapNet(vocabulary=vocabulary, embeddings=embeddings,
+                              mean_size_arr=msa, **gc.CAPNET_KW)
+    sd = model.state_dict()
+    with torch.no_grad():
+        gc.det_fill_(sd)
+    model.load_state_dict(sd)
+    inputs = gc.make_inputs(cfg)
+
+    out = {}
+    model.train()
+    with torch.no_grad():
+        dd = model(gc.to_torch(inputs), use_tf=True, is_eval=False)
+    for k, v in gc.extract(dd, gc.TRAIN_KEYS).items():
+        out["train/" + k] = v
+    # sanity: the local top-k never had to pick among 1e30 ties
+    nvalid = dd["bbox_mask"].sum(1)
+    print("valid boxes per scene:", nvalid.tolist(),
+          "edges src/tar:", dd["num_edge_source"].tolist(), dd["num_edge_target"].tolist())
+
+    adj = dd["adjacent_mat"]
+    bad = (adj * (dd["bbox_mask"] == 0).unsqueeze(1).float()).sum().item()
+    diag = torch.diagonal(adj, dim1=1, dim2=2).sum().item()
+    print("adjacency picks that hit invalid objects: %d, self picks: %d "
+          "(both must be 0: no 1e30 tie-breaks)" % (bad, diag))
+    assert bad == 0 and diag == 0
+    model.load_state_dict(sd)  # reset BN running stats touched by the train pass
+    model.eval()
+    with torch.no_grad():
+        dd = model(gc.to_torch(inputs), use_tf=False, is_eval=True)
+    for k, v in gc.extract(dd, gc.EVAL_KEYS).items():
+        out["eval/" + k] = v
+    for k, v in inputs.items():
+        out["in/" + k] = v
+    path = os.path.join(HERE, "golden", "capnet_cfg1.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,137 @@
+"""Deterministic inputs / weights shared by the golden generator
+(tests/gen_golden.py, runs the REFERENCE here) and the parity tests (run the
+build's CapNet, on the GPU or -- with the oracle injected as `_ext` -- on CPU).
+"""
+import zlib
+
+import numpy as np
+import torch
+
+from scan2cap_amd.synthetic import scene_xyz
+
+GOLDEN_CFG = dict(B=2, N=4096, K=32, V=40, num_locals=10, graph_steps=2,
+                  max_words=9, input_feature_dim=1, seed=1234)
+
+CAPNET_KW = dict(num_class=18, num_heading_bin=1, num_size_cluster=18,
+                 input_feature_dim=1, num_proposal=32, num_locals=10,
+                 use_topdown=True, query_mode="corner", graph_mode="edge_conv",
+                 num_graph_steps=2, use_relation=True, use_orientation=True,
+                 num_bins=6)
+
+
+def vocab_and_embeddings(V, seed=0):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    special = ["pad_", "unk", "sos", "eos"]
+    words = special + ["w%d" % i for i in range(V - len(special))]
+    vocabulary = {"word2idx": {w: i for i, w in enumerate(words)},
+                  "idx2word": {str(i): w for i, w in enumerate(words)}}
+    embeddings = {w: (rng.standard_normal(300) * 0.3).astype(np.float32)
+                  for w in words}
+    return vocabulary, embeddings
+
+
+def mean_size_arr(seed=5):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return rng.uniform(0.3, 1.5, size=(18, 3))  # float64, like the npz
+
+
+def det_fill_(state_dict):
+    """In-place deterministic values for every tensor of a state_dict, keyed by
+    name (so the reference module and the build's module get identical weights
+    without sharing any RNG state)."""
+    for key in sorted(state_dict.keys()):
+        t = state_dict[key]
+        if key.startswith("_") or "._" in key:
+            continue
+        rng = np.random.Generator(np.random.PCG64(zlib.crc32(key.encode())))
+        if key.endswith("num_batches_tracked"):
+            t.zero_()
+            continue
+        shape = tuple(t.shape)
+        x = rng.standard_normal(shape)
+        if key.endswith("running_var"):
+            x = 1.0 + 0.1 * np.abs(x)
+        elif key.endswith("running_mean"):
+            x = 0.1 * x
+        elif ".bn" in key and key.endswith("weight") and t.dim() == 1:
+            x = 1.0 + 0.1 * x
+        elif t.dim() == 1:
+            x = 0.1 * x
+        else:
+            fan_in = int(np.prod(shape[1:]))
+            x = x * np.sqrt(2.0 / max(fan_in, 1))
+        t.copy_(torch.from_numpy(x.astype(np.float32)).view(shape))
+    # bias the objectness logit so most proposals are valid objects: the local
+    # top-k then never has to choose among 1e30-tied entries
+    k = "proposal.proposal.6.bias"
+    if k in state_dict:
+        state_dict[k][0] -= 0.02
+        state_dict[k][1] += 0.02
+    return state_dict
+
+
+def make_inputs(cfg=GOLDEN_CFG):
+    B, N, V = cfg["B"], cfg["N"], cfg["V"]
+    rng = np.random.Generator(np.random.PCG64(cfg["seed"]))
+    xyz = scene_xyz(B, N, seed=cfg["seed"], mode="surface", adversarial=True)
+    height = xyz[..., 2:3] - np.percentile(xyz[..., 2], 0.99)
+    pc = np.concatenate([xyz, height.astype(np.float32)], -1).astype(np.float32)
+    vocabulary, embeddings = vocab_and_embeddings(V)
+    words = list(vocabulary["word2idx"].keys())
+    T = 32
+    lang_len = np.array([cfg["max_words"], cfg["max_words"] - 2][:B], np.int64)
+    lang_ids = np.zeros((B, T), np.int64)
+    lang_feat = np.zeros((B, T, 300), np.float32)
+    for b in range(B):
+        toks = [2] + list(rng.integers(4, V, lang_len[b] - 2)) + [3]
+        for t, tok in enumerate(toks):
+            lang_ids[b, t] = tok
+            lang_feat[b, t] = embeddings[words[tok]]
+    centers = rng.uniform([-2, -2, 0.3], [2, 2, 1.0], size=(B, 3))
+    sizes = rng.uniform(0.6, 1.6, size=(B, 3))
+    sx = np.array([1, 1, -1, -1, 1, 1, -1, -1])
+    sy = np.array([1, -1, -1, 1, 1, -1, -1, 1])
+    sz = np.array([1, 1, 1, 1, -1, -1, -1, -1])
+    corners = centers[:, None, :] + 0.5 * sizes[:, None, :] * np.stack([sx, sy, sz], -1)[None]
+    return dict(point_clouds=pc, lang_feat=lang_feat, lang_len=lang_len,
+                lang_ids=lang_ids, ref_box_corner_label=corners.astype(np.float64))
+
+
+def to_torch(inputs, device="cpu"):
+    return {k: torch.from_numpy(v).to(device) for k, v in inputs.items()}
+
+
+# which outputs are stored, and with which sub-sampling (slices per dim)
+TRAIN_KEYS = {
+    "sa1_inds": None, "sa2_inds": None, "sa1_xyz": None, "sa4_xyz": None,
+    "sa1_features": (slice(None), slice(None, None, 8), slice(None, None, 16)),
+    "sa4_features": (slice(None), slice(None, None, 4), slice(None, None, 4)),
+    "fp2_features": (slice(None), slice(None, None, 8), slice(None, None, 8)),
+    "fp2_inds": None, "vote_xyz": None,
+    "vote_features": (slice(None), slice(None, None, 8), slice(None, None, 8)),
+    "aggregated_vote_xyz": None, "aggregated_vote_inds": None,
+    "aggregated_vote_features": None,
+    "objectness_scores": None, "center": None, "heading_scores": None,
+    "heading_residuals": None, "size_scores": None, "size_residuals": None,
+    "sem_cls_scores": None, "bbox_corner": None, "bbox_feature": None,
+    "bbox_mask": None, "adjacent_mat": None, "edge_index": None,
+    "edge_feature": None, "num_edge_source": None, "num_edge_target": None,
+    "edge_orientations": None, "edge_distances": None, "lang_cap": None,
+    "pred_ious": None, "topdown_attn": None, "valid_masks": None,
+    "good_bbox_masks": None,
+}
+EVAL_KEYS = {
+    "bbox_corner": None, "bbox_mask": None, "bbox_feature": None,
+    "adjacent_mat": None, "valid_masks": None,
+    "lang_cap": None, "topdown_attn": None,
+}
+
+
+def extract(data_dict, keys):
+    out = {}
+    for k, sl in keys.items():
+        v = data_dict[k].detach().cpu()
+        if sl is not None:
+            v = v[sl]
+        out[k] = v.numpy()
+    return out

@@ -1,0 +1,80 @@
+"""CapNet forward against golden vectors produced by the REFERENCE's own
+Python modules (tests/gen_golden.py; reference imported in the build container,
+native ops supplied by the oracle).
+
+* CPU flavour (not gpu): the build's host logic -- module tree, device-side box
+  decode, batched graph / caption re-designs -- with the oracle injected as the
+  op layer (a test double; the product never does this).
+* GPU flavour (-m gpu): the real path, HIP kernels through the C ABI.
+
+Tolerance 1e-4 on float features (north_star); integer outputs exact.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import golden_common as gc
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "capnet_cfg1.npz")
+ATOL, RTOL = 1e-4, 1e-4
+
+
+def build_model(device):
+    from scan2cap_amd.models import CapNet
+    vocabulary, embeddings = gc.vocab_and_embeddings(gc.GOLDEN_CFG["V"])
+    model = CapNet(vocabulary=vocabulary, embeddings=embeddings,
+                   mean_size_arr=gc.mean_size_arr(), **gc.CAPNET_KW)
+    sd = model.state_dict()
+    with torch.no_grad():
+        gc.det_fill_(sd)
+    model.load_state_dict(sd)
+    return model.to(device), sd
+
+
+def check(got, want, key):
+    g = got.detach().cpu().numpy()
+    assert g.shape == want.shape, (key, g.shape, want.shape)
+    if want.dtype.kind in "iub":
+        np.testing.assert_array_equal(g, want, err_msg=key)
+    else:
+        np.testing.assert_allclose(g.astype(np.float64), want.astype(np.float64),
+                                   rtol=RTOL, atol=ATOL, err_msg=key)
+
+
+def run_and_compare(device):
+    ref = np.load(GOLDEN)
+    inputs = {k[3:]: ref[k] for k in ref.files if k.startswith("in/")}
+    model, sd = build_model(device)
+
+    model.train()
+    with torch.no_grad():
+        dd = model(gc.to_torch(inputs, device), use_tf=True, is_eval=False)
+    for key, sl in gc.TRAIN_KEYS.items():
+        v = dd[key]
+        check(v[sl] if sl is not None else v, ref["train/" + key], "train/" + key)
+
+    model.load_state_dict(sd)
+    model.eval()
+    with torch.no_grad():
+        dd = model(gc.to_torch(inputs, device), use_tf=False, is_eval=True)
+    for key, sl in gc.EVAL_KEYS.items():
+        v = dd[key]
+        check(v[sl] if sl is not None else v, ref["eval/" + key], "eval/" + key)
+    # greedy tokens identical
+    np.testing.assert_array_equal(dd["lang_cap"].argmax(-1).cpu().numpy(),
+                                  ref["eval/lang_cap"].argmax(-1))
+
+
+def test_capnet_host_logic_cpu(monkeypatch):
+    from oracle import torch_ext
+    from scan2cap_amd.pointnet2 import _ext
+    for name in torch_ext.NAMES:
+        monkeypatch.setattr(_ext, name, getattr(torch_ext, name))
+    run_and_compare("cpu")
+
+
+@pytest.mark.gpu
+def test_capnet_gpu():
+    run_and_compare("cuda")
