@@ -35,6 +35,7 @@ def main():
     with torch.no_grad():
         gc.det_fill_(sd)
     model.load_state_dict(sd)
+    sd = {k: v.clone() for k, v in sd.items()}  # detached copy (no aliasing)
     inputs = gc.make_inputs(cfg)
 
     out = {}

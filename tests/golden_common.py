@@ -59,7 +59,11 @@ def det_fill_(state_dict):
             x = 0.1 * x
         else:
             fan_in = int(np.prod(shape[1:]))
-            x = x * np.sqrt(2.0 / max(fan_in, 1))
+            # the graph MLPs sum ~10 messages per node and are not normalised:
+            # a unit-gain init keeps activations O(1) (a kaiming gain grows them
+            # to ~1e3, which only amplifies rounding noise downstream)
+            gain = 0.5 if key.startswith("graph.") else 2.0
+            x = x * np.sqrt(gain / max(fan_in, 1))
         t.copy_(torch.from_numpy(x.astype(np.float32)).view(shape))
     # bias the objectness logit so most proposals are valid objects: the local
     # top-k then never has to choose among 1e30-tied entries
