@@ -1,0 +1,273 @@
+#!/usr/bin/env python
+"""bench.py -- scenes/s of the Scan2Cap hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over one batch of synthetic scenes:
+CapNet forward + get_scene_cap_loss + backward + Adam (the reference's train
+step, lib/solver.py:293-302) on the workload BASELINE.json's metric is quoted
+on: B=8 scenes per GPU, N=40000 points, XYZ + multiview(128) + normal + height,
+256 proposals, --use_topdown --use_relation --num_graph_steps 2 --num_locals 10
+(BASELINE.json configs[2]; configs[1] is the forward-only detection case,
+`--workload cfg2`).  Inputs are resident in HBM before the timed region.
+
+Scenes shard data-parallel: one process per GPU, B scenes each (weak scaling),
+one flat-bucket gradient all-reduce per step over RCCL (scan2cap_amd/parallel.py).
+
+Prints ONE JSON line (rank 0).  `roofline` describes the kernel with the largest
+share of the timed region (HIP events on the launch stream, live in this run);
+`cpu_baseline` is the same step run through the CPU oracle ops + torch CPU on a
+bounded sample (rank 0, N=1 only) -- a reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from scan2cap_amd import _C  # noqa: E402
+from scan2cap_amd.loss_helper import get_scene_cap_loss  # noqa: E402
+from scan2cap_amd.models import CapNet  # noqa: E402
+from scan2cap_amd.parallel import FlatGradAllReduce, init_from_env  # noqa: E402
+from scan2cap_amd.synthetic import scene_labels, scene_xyz  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3  # dense f32-input MFMA peak
+
+WORKLOADS = {
+    # name: (B, N, feature channels C, proposals K, vocab V, train?)
+    "cfg3": dict(B=8, N=40000, C=132, K=256, V=3500, train=True,
+                 desc="B=8 N=40000 XYZ+multiview(128)+normal+height, 256 proposals, "
+                      "topdown+relation graph(2 steps, 10 locals), train step"),
+    "cfg2": dict(B=8, N=40000, C=4, K=256, V=3500, train=False,
+                 desc="B=8 N=40000 XYZ+normal+height, VoteNet 256 proposals, forward only"),
+    "cfg1": dict(B=1, N=4096, C=1, K=32, V=3500, train=True,
+                 desc="1 scene XYZ+height N=4096, 32 proposals"),
+}
+
+
+class LossConfig(object):
+    def __init__(self, msa):
+        self.num_heading_bin, self.num_size_cluster, self.num_class = 1, 18, 18
+        self.mean_size_arr = msa
+
+
+def make_vocab(V, seed=0):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    words = ["pad_", "unk", "sos", "eos"] + ["w%d" % i for i in range(V - 4)]
+    vocabulary = {"word2idx": {w: i for i, w in enumerate(words)},
+                  "idx2word": {str(i): w for i, w in enumerate(words)}}
+    table = (rng.standard_normal((V, 300)) * 0.3).astype(np.float32)
+    embeddings = {w: table[i] for i, w in enumerate(words)}
+    return vocabulary, embeddings, table
+
+
+def make_batch(wl, B, seed, table, msa):
+    """Synthetic data_dict (numpy) with the reference's keys/dtypes."""
+    N, C, V = wl["N"], wl["C"], wl["V"]
+    rng = np.random.Generator(np.random.PCG64(seed))
+    xyz = scene_xyz(B, N, seed=seed, mode="volume", adversarial=True)
+    feats = []
+    if C >= 4:
+        nrm = rng.standard_normal((B, N, 3)).astype(np.float32)
+        nrm /= np.linalg.norm(nrm, axis=-1, keepdims=True) + 1e-9
+        feats.append(nrm)
+    if C >= 132:
+        mv = np.maximum(rng.standard_normal((B, N, 128)).astype(np.float32) * 0.5, 0)
+        feats.append(mv)
+    height = xyz[..., 2:3] - np.percentile(xyz[..., 2], 0.99)
+    feats.append(height.astype(np.float32))
+    pc = np.concatenate([xyz] + feats, -1).astype(np.float32)
+    assert pc.shape[-1] == 3 + C, pc.shape
+    T = 32
+    lang_len = rng.integers(8, T + 1, B).astype(np.int64)
+    lang_ids = np.zeros((B, T), np.int64)
+    for b in range(B):
+        toks = [2] + list(rng.integers(4, V, lang_len[b] - 2)) + [3]
+        lang_ids[b, :len(toks)] = toks
+    lang_feat = table[lang_ids] * (lang_ids != 0)[..., None]
+    out = dict(point_clouds=pc, lang_feat=lang_feat.astype(np.float32),
+               lang_len=lang_len, lang_ids=lang_ids)
+    labels = scene_labels(xyz, num_boxes=32, seed=seed, mean_size_arr=msa)
+    out.update(labels)
+    out["ref_box_corner_label"] = labels["gt_box_corner_label"][:, 0].copy()
+    return out
+
+
+def build_model(wl, vocabulary, embeddings, msa):
+    return CapNet(num_class=18, vocabulary=vocabulary, embeddings=embeddings,
+                  num_heading_bin=1, num_size_cluster=18, mean_size_arr=msa,
+                  input_feature_dim=wl["C"], num_proposal=wl["K"],
+                  num_locals=10 if wl["train"] else -1,
+                  no_caption=not wl["train"], use_topdown=True,
+                  query_mode="corner", graph_mode="edge_conv",
+                  num_graph_steps=2 if wl["train"] else 0,
+                  use_relation=wl["train"])
+
+
+def to_device(batch, device):
+    dd = {k: torch.from_numpy(v).to(device) for k, v in batch.items()}
+    dd["_num_words"] = int(batch["lang_len"].max())   # host-known: no device read
+    return dd
+
+
+def make_step(model, wl, cfg_loss, optimizer, ddp, device):
+    def train_step(dd):
+        dd = dict(dd)
+        if ddp is not None:
+            ddp.zero_grad()
+        else:
+            optimizer.zero_grad(set_to_none=False)
+        dd = model(dd, use_tf=True, is_eval=False)
+        dd = get_scene_cap_loss(dd, device, cfg_loss, None, detection=True,
+                                caption=True, orientation=False, distance=False)
+        dd["loss"].backward()
+        if ddp is not None:
+            ddp.reduce()
+        optimizer.step()
+        return dd["loss"]
+
+    def fwd_step(dd):
+        with torch.no_grad():
+            return model(dict(dd), use_tf=False, is_eval=True)["objectness_scores"]
+
+    return train_step if wl["train"] else fwd_step
+
+
+def cpu_baseline(wl, vocabulary, embeddings, table, msa, sample_B=1):
+    """The same step through the CPU oracle ops (oracle/s2c_oracle.c, OpenMP) +
+    torch CPU, on a bounded sample of the workload.  kind = "port"."""
+    from oracle import torch_ext
+    from scan2cap_amd.pointnet2 import _ext
+    saved = {n: getattr(_ext, n) for n in torch_ext.NAMES}
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    try:
+        for n in torch_ext.NAMES:
+            setattr(_ext, n, getattr(torch_ext, n))
+        torch.manual_seed(0)
+        model = build_model(wl, vocabulary, embeddings, msa)
+        cfg_loss = LossConfig(msa)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
+        model.train(wl["train"])
+        step = make_step(model, wl, cfg_loss, opt, None, torch.device("cpu"))
+        dd = to_device(make_batch(wl, sample_B, 4242, table, msa), "cpu")
+        t0 = time.time()
+        step(dd)
+        dt = time.time() - t0
+    finally:
+        for n, f in saved.items():
+            setattr(_ext, n, f)
+    return {"value": sample_B / dt, "unit": "scenes/s", "cores": cores,
+            "kind": "port",
+            "sample": "1 step of the same workload at B=%d (N=%d, C=%d, K=%d), "
+                      "%.1f s wall; oracle C ops (OpenMP) + torch CPU fp32"
+                      % (sample_B, wl["N"], wl["C"], wl["K"], dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-scenes", type=int, default=1)
+    args = ap.parse_args()
+
+    rank, world, local_rank = init_from_env()
+    assert world == args.gpus or world == 1 and args.gpus == 1, \
+        "--gpus must match the launched world size"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    _C.load()
+
+    wl = WORKLOADS[args.workload]
+    B = wl["B"]
+    vocabulary, embeddings, table = make_vocab(wl["V"])
+    msa = np.random.Generator(np.random.PCG64(5)).uniform(0.3, 1.5, size=(18, 3))
+
+    torch.manual_seed(0)
+    model = build_model(wl, vocabulary, embeddings, msa).to(device)
+    model.train(wl["train"])
+    cfg_loss = LossConfig(msa)
+    optimizer = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
+    ddp = FlatGradAllReduce(model) if (world > 1 and wl["train"]) else None
+    step = make_step(model, wl, cfg_loss, optimizer, ddp, device)
+    dd = to_device(make_batch(wl, B, 42 + rank, table, msa), device)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(dd)
+    barrier()
+    _C.TIMER.start()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(dd)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kern = _C.TIMER.stop()
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = B * world * args.steps / elapsed
+        # dominant hand-written kernel of the timed region
+        roof, table_k = None, []
+        for name, r in sorted(kern.items(), key=lambda kv: -kv[1]["total_ms"]):
+            avg_us = r["total_ms"] / max(r["calls"], 1) * 1e3
+            gbs = r["alg_bytes"] / max(r["total_ms"], 1e-9) / 1e6
+            table_k.append({"kernel": name, "calls_per_step": r["calls"] / args.steps,
+                            "ms_per_step": r["total_ms"] / args.steps,
+                            "avg_us": avg_us, "alg_GBps": gbs})
+        if table_k:
+            top = table_k[0]
+            roof = {"kernel": top["kernel"], "bound": "hbm",
+                    "achieved": top["alg_GBps"], "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": top["alg_GBps"] / HBM_PEAK_GBS,
+                    "traffic": None,
+                    "avg_launch_us": top["avg_us"],
+                    "share_of_step": top["ms_per_step"] / ms_per_step}
+        out = {
+            "metric": "scenes/sec forward+backward, B=8 N=40000 pts" if wl["train"]
+                      else "scenes/sec forward, B=8 N=40000 pts",
+            "value": value, "unit": "scenes/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %s" % (args.workload, wl["desc"]),
+                       "scenes_per_gpu": B, "global_batch": B * world,
+                       "parallelism": "dp%d" % world,
+                       "grad_allreduce_bytes": ddp.nbytes if ddp else 0},
+            "roofline": roof,
+            "kernels": table_k[:8],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl, vocabulary, embeddings, table, msa,
+                                               args.cpu_sample_scenes)
+            out["vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -181,6 +181,27 @@ def _install_pyg_shim():
         sys.modules[name] = m
 
 
+def _install_absent_stubs():
+    """Empty stand-ins for third-party packages the reference imports at module
+    scope but never touches on this path (utils/metric_util.py:17 `trimesh`,
+    pc_utils `plyfile`, ...).  Only installed when the real package is absent."""
+    import importlib.util
+    for name in ("trimesh", "plyfile", "h5py", "tensorboardX"):
+        if name in sys.modules:
+            continue
+        try:
+            found = importlib.util.find_spec(name) is not None
+        except (ImportError, ValueError):
+            found = False
+        if not found:
+            m = types.ModuleType(name)
+            m.__path__ = []
+            sys.modules[name] = m
+    if "plyfile" in sys.modules and not hasattr(sys.modules["plyfile"], "PlyData"):
+        sys.modules["plyfile"].PlyData = object
+        sys.modules["plyfile"].PlyElement = object
+
+
 def install():
     """Make `import models.capnet` etc. (the reference's modules) work here."""
     global _installed
@@ -192,6 +213,7 @@ def install():
     _install_ext()
     _install_cuda_noops()
     _install_pyg_shim()
+    _install_absent_stubs()
     os.chdir(REF_ROOT)
     for p in (REF_ROOT, os.path.join(REF_ROOT, "lib"),
               os.path.join(REF_ROOT, "lib", "pointnet2")):
@@ -217,5 +239,6 @@ def reference_modules():
     ns.caption = importlib.import_module("models.caption_module")
     ns.capnet = importlib.import_module("models.capnet")
     ns.box_util = importlib.import_module("utils.box_util")
+    ns.loss_helper = importlib.import_module("lib.loss_helper")
     ns.DC = ns.proposal.DC
     return ns

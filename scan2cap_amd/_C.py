@@ -74,9 +74,57 @@ def register(name, argtypes):
         fn.restype = _INT
 
 
+class KernelTimer(object):
+    """Optional per-entry-point timing with HIP events recorded on the stream the
+    kernels are launched on (torch's current stream).  Enabled by bench.py over
+    its timed region; zero cost when off."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = {}      # name -> list of (start_event, end_event, alg_bytes)
+        self.alg_bytes = 0     # set by the op wrapper right before call()
+
+    def start(self):
+        self.records = {}
+        self.enabled = True
+
+    def stop(self):
+        """Synchronise and return {name: {"calls", "total_ms", "alg_bytes",
+        "max_ms", "max_call_bytes"}}."""
+        import torch
+        self.enabled = False
+        torch.cuda.synchronize()
+        out = {}
+        for name, evs in self.records.items():
+            tot, nbytes, worst = 0.0, 0, (0.0, 0)
+            for s, e, ab in evs:
+                ms = s.elapsed_time(e)
+                tot += ms
+                nbytes += ab
+                if ms > worst[0]:
+                    worst = (ms, ab)
+            out[name] = {"calls": len(evs), "total_ms": tot, "alg_bytes": nbytes,
+                         "max_ms": worst[0], "max_call_bytes": worst[1]}
+        self.records = {}
+        return out
+
+
+TIMER = KernelTimer()
+
+
 def call(name, *args):
     lib = load()
-    rc = getattr(lib, name)(*args)
+    if TIMER.enabled:
+        import torch
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        rc = getattr(lib, name)(*args)
+        e.record()
+        TIMER.records.setdefault(name, []).append((s, e, TIMER.alg_bytes))
+        TIMER.alg_bytes = 0
+    else:
+        rc = getattr(lib, name)(*args)
     if rc != 0:
         raise S2CError("%s failed (rc=%d): %s" %
                        (name, rc, lib.s2c_last_error_string().decode()))

@@ -30,7 +30,12 @@ def _chk_i(x, name):
     _check(x.is_cuda, "%s must be a CUDA tensor" % name)
 
 
-def _run(name, ref, *args):
+def _run(name, ref, *args, alg_bytes=0):
+    """alg_bytes: algorithmic HBM bytes of this call under the op contract
+    (compulsory reads + writes), recorded only while bench.py's
+    kernel timer is on."""
+    if _C.TIMER.enabled:
+        _C.TIMER.alg_bytes = int(alg_bytes)
     with torch.cuda.device(ref.device):
         _C.call(name, *args, _C.stream_ptr())
 
@@ -43,7 +48,7 @@ def gather_points(points, idx):
     m = idx.shape[1]
     out = torch.empty((b, c, m), dtype=torch.float32, device=points.device)
     _run("s2c_gather_points", points, b, c, n, m, points.data_ptr(),
-         idx.data_ptr(), out.data_ptr())
+         idx.data_ptr(), out.data_ptr(), alg_bytes=4 * (2 * b * c * m + b * m))
     return out
 
 
@@ -54,7 +59,8 @@ def gather_points_grad(grad_out, idx, n):
     b, c, m = grad_out.shape
     out = torch.empty((b, c, n), dtype=torch.float32, device=grad_out.device)
     _run("s2c_gather_points_grad", grad_out, b, c, int(n), m,
-         grad_out.data_ptr(), idx.data_ptr(), out.data_ptr())
+         grad_out.data_ptr(), idx.data_ptr(), out.data_ptr(),
+         alg_bytes=4 * (b * c * m + b * m + b * c * n))
     return out
 
 
@@ -68,7 +74,7 @@ def furthest_point_sampling(points, nsamples):
         temp = torch.empty((b, n), dtype=torch.float32, device=points.device)
     _run("s2c_furthest_point_sampling", points, b, n, int(nsamples),
          points.data_ptr(), temp.data_ptr() if temp is not None else None,
-         out.data_ptr())
+         out.data_ptr(), alg_bytes=4 * (3 * b * n + b * nsamples))
     return out
 
 
@@ -81,7 +87,8 @@ def three_nn(unknowns, knows):
     dist2 = torch.empty((b, n, 3), dtype=torch.float32, device=unknowns.device)
     idx = torch.empty((b, n, 3), dtype=torch.int32, device=unknowns.device)
     _run("s2c_three_nn", unknowns, b, n, m, unknowns.data_ptr(),
-         knows.data_ptr(), dist2.data_ptr(), idx.data_ptr())
+         knows.data_ptr(), dist2.data_ptr(), idx.data_ptr(),
+         alg_bytes=4 * (3 * b * n + 3 * b * m + 6 * b * n))
     return [dist2, idx]
 
 
@@ -94,7 +101,8 @@ def three_interpolate(points, idx, weight):
     n = idx.shape[1]
     out = torch.empty((b, c, n), dtype=torch.float32, device=points.device)
     _run("s2c_three_interpolate", points, b, c, m, n, points.data_ptr(),
-         idx.data_ptr(), weight.data_ptr(), out.data_ptr())
+         idx.data_ptr(), weight.data_ptr(), out.data_ptr(),
+         alg_bytes=4 * (min(b * c * m, 3 * b * c * n) + 6 * b * n + b * c * n))
     return out
 
 
@@ -107,7 +115,7 @@ def three_interpolate_grad(grad_out, idx, weight, m):
     out = torch.empty((b, c, m), dtype=torch.float32, device=grad_out.device)
     _run("s2c_three_interpolate_grad", grad_out, b, c, n, int(m),
          grad_out.data_ptr(), idx.data_ptr(), weight.data_ptr(),
-         out.data_ptr())
+         out.data_ptr(), alg_bytes=4 * (b * c * n + 6 * b * n + b * c * m))
     return out
 
 
@@ -120,7 +128,8 @@ def ball_query(new_xyz, xyz, radius, nsample):
     n = xyz.shape[1]
     idx = torch.empty((b, m, nsample), dtype=torch.int32, device=new_xyz.device)
     _run("s2c_ball_query", new_xyz, b, n, m, float(radius), int(nsample),
-         new_xyz.data_ptr(), xyz.data_ptr(), idx.data_ptr())
+         new_xyz.data_ptr(), xyz.data_ptr(), idx.data_ptr(),
+         alg_bytes=4 * (3 * b * n + 3 * b * m + b * m * nsample))
     return idx
 
 
@@ -132,7 +141,8 @@ def group_points(points, idx):
     _, m, ns = idx.shape
     out = torch.empty((b, c, m, ns), dtype=torch.float32, device=points.device)
     _run("s2c_group_points", points, b, c, n, m, ns, points.data_ptr(),
-         idx.data_ptr(), out.data_ptr())
+         idx.data_ptr(), out.data_ptr(),
+         alg_bytes=4 * (min(b * c * n, b * c * m * ns) + b * m * ns + b * c * m * ns))
     return out
 
 
@@ -143,5 +153,6 @@ def group_points_grad(grad_out, idx, n):
     b, c, m, ns = grad_out.shape
     out = torch.empty((b, c, n), dtype=torch.float32, device=grad_out.device)
     _run("s2c_group_points_grad", grad_out, b, c, int(n), m, ns,
-         grad_out.data_ptr(), idx.data_ptr(), out.data_ptr())
+         grad_out.data_ptr(), idx.data_ptr(), out.data_ptr(),
+         alg_bytes=4 * (b * c * m * ns + b * m * ns + b * c * n))
     return out

@@ -57,3 +57,63 @@ def _surface(rng, n):
     q[np.arange(n_box), face] = sign
     parts.append(centers[which] + q * sizes[which])
     return np.concatenate(parts, 0)
+
+
+MAX_NUM_OBJ = 128  # lib/dataset.py (center_label etc. are padded to 128 objects)
+
+
+def scene_labels(xyz, num_boxes=32, seed=42, num_class=18, mean_size_arr=None):
+    """Detection / relation labels with the shapes and dtypes of the reference's
+    data_dict (lib/dataset.py:503-540): random axis-aligned
+    boxes, votes from box membership (a point inside up to GT_VOTE_FACTOR=3 boxes
+    votes for each centre; the first vote is repeated otherwise), identity
+    object rotations.  xyz: (B,N,3) float32 numpy."""
+    B, N, _ = xyz.shape
+    rng = np.random.Generator(np.random.PCG64(seed + 1))
+    if mean_size_arr is None:
+        mean_size_arr = np.ones((num_class, 3))
+    out = dict(
+        center_label=np.zeros((B, MAX_NUM_OBJ, 3), np.float32),
+        heading_class_label=np.zeros((B, MAX_NUM_OBJ), np.int64),
+        heading_residual_label=np.zeros((B, MAX_NUM_OBJ), np.float32),
+        size_class_label=np.zeros((B, MAX_NUM_OBJ), np.int64),
+        size_residual_label=np.zeros((B, MAX_NUM_OBJ, 3), np.float32),
+        sem_cls_label=np.zeros((B, MAX_NUM_OBJ), np.int64),
+        box_label_mask=np.zeros((B, MAX_NUM_OBJ), np.float32),
+        vote_label=np.zeros((B, N, 9), np.float32),
+        vote_label_mask=np.zeros((B, N), np.int64),
+        scene_object_rotations=np.tile(np.eye(3, dtype=np.float32),
+                                       (B, MAX_NUM_OBJ, 1, 1)),
+        scene_object_rotation_masks=np.ones((B, MAX_NUM_OBJ), np.int64),
+        gt_box_corner_label=np.zeros((B, MAX_NUM_OBJ, 8, 3), np.float64),
+    )
+    sx = np.array([1, 1, -1, -1, 1, 1, -1, -1])
+    sy = np.array([1, -1, -1, 1, 1, -1, -1, 1])
+    sz = np.array([1, 1, 1, 1, -1, -1, -1, -1])
+    sign = np.stack([sx, sy, sz], -1)
+    for b in range(B):
+        lo, hi = xyz[b].min(0), xyz[b].max(0)
+        centers = rng.uniform(lo + 0.3, hi - 0.3, size=(num_boxes, 3))
+        sizes = rng.uniform(0.4, 1.4, size=(num_boxes, 3))
+        cls = rng.integers(0, num_class, num_boxes)
+        out["center_label"][b, :num_boxes] = centers
+        out["size_class_label"][b, :num_boxes] = cls
+        out["size_residual_label"][b, :num_boxes] = sizes - mean_size_arr[cls]
+        out["sem_cls_label"][b, :num_boxes] = cls
+        out["box_label_mask"][b, :num_boxes] = 1
+        out["gt_box_corner_label"][b, :num_boxes] = \
+            centers[:, None, :] + 0.5 * sizes[:, None, :] * sign[None]
+        nvotes = np.zeros(N, np.int64)
+        for k in range(num_boxes):
+            inside = np.all(np.abs(xyz[b] - centers[k]) <= sizes[k] / 2, axis=1)
+            ids = np.nonzero(inside)[0]
+            votes = (centers[k] - xyz[b, ids]).astype(np.float32)
+            for i, v in zip(ids, votes):
+                j = nvotes[i]
+                if j == 0:
+                    out["vote_label"][b, i] = np.tile(v, 3)
+                elif j < 3:
+                    out["vote_label"][b, i, 3 * j:3 * j + 3] = v
+                nvotes[i] += 1
+            out["vote_label_mask"][b, ids] = 1
+    return out

@@ -38,10 +38,26 @@ def main():
     sd = {k: v.clone() for k, v in sd.items()}  # detached copy (no aliasing)
     inputs = gc.make_inputs(cfg)
 
-    out = {}
+    # caption target of scene 0 := the reference's own proposal 5 (IoU 1 => a
+    # "good" box that receives the caption loss); scene 1 keeps the random box
     model.train()
     with torch.no_grad():
-        dd = model(gc.to_torch(inputs), use_tf=True, is_eval=False)
+        dry = model(gc.to_torch(inputs), use_tf=True, is_eval=False)
+    inputs["ref_box_corner_label"][0] = dry["bbox_corner"][0, 5].numpy()
+    model.load_state_dict(sd)
+
+    out = {}
+    model.train()
+    model.zero_grad()
+    dd = model(gc.to_torch(inputs), use_tf=True, is_eval=False)
+    dd = ref.loss_helper.get_scene_cap_loss(
+        dd, torch.device("cpu"), gc.LossConfig(msa), None, **gc.LOSS_FLAGS)
+    dd["loss"].backward()
+    for k in gc.LOSS_KEYS:
+        out["loss/" + k] = np.asarray(dd[k].detach().cpu().numpy(), np.float64)
+    for k, v in gc.extract_grads(model).items():
+        out["grad/" + k] = v
+    print("loss terms:", {k: float(out["loss/" + k]) for k in ("loss", "cap_loss", "ori_loss", "dist_loss", "cap_acc")})
     for k, v in gc.extract(dd, gc.TRAIN_KEYS).items():
         out["train/" + k] = v
     # sanity: the local top-k never had to pick among 1e30 ties

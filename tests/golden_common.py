@@ -97,8 +97,12 @@ def make_inputs(cfg=GOLDEN_CFG):
     sy = np.array([1, -1, -1, 1, 1, -1, -1, 1])
     sz = np.array([1, 1, 1, 1, -1, -1, -1, -1])
     corners = centers[:, None, :] + 0.5 * sizes[:, None, :] * np.stack([sx, sy, sz], -1)[None]
-    return dict(point_clouds=pc, lang_feat=lang_feat, lang_len=lang_len,
-                lang_ids=lang_ids, ref_box_corner_label=corners.astype(np.float64))
+    out = dict(point_clouds=pc, lang_feat=lang_feat, lang_len=lang_len,
+               lang_ids=lang_ids, ref_box_corner_label=corners.astype(np.float64))
+    from scan2cap_amd.synthetic import scene_labels
+    out.update(scene_labels(xyz, num_boxes=12, seed=cfg["seed"],
+                            mean_size_arr=mean_size_arr()))
+    return out
 
 
 def to_torch(inputs, device="cpu"):
@@ -129,6 +133,49 @@ EVAL_KEYS = {
     "adjacent_mat": None, "valid_masks": None,
     "lang_cap": None, "topdown_attn": None,
 }
+
+
+LOSS_KEYS = ("loss", "vote_loss", "objectness_loss", "center_loss",
+             "heading_cls_loss", "heading_reg_loss", "size_cls_loss",
+             "size_reg_loss", "sem_cls_loss", "box_loss", "cap_loss", "cap_acc",
+             "ori_loss", "ori_acc", "dist_loss", "obj_acc", "pos_ratio",
+             "neg_ratio", "pred_ious")
+LOSS_FLAGS = dict(detection=True, caption=True, orientation=True, distance=True)
+
+# parameter gradients stored in the fixture (name -> sub-sampling)
+GRAD_KEYS = {
+    "backbone_net.sa1.mlp_module.layer0.conv.weight": None,
+    "backbone_net.sa1.mlp_module.layer2.bn.bn.weight": None,
+    "backbone_net.sa4.mlp_module.layer2.conv.weight": (slice(None, None, 8), slice(None, None, 8)),
+    "backbone_net.fp2.mlp.layer0.conv.weight": (slice(None, None, 16), slice(None, None, 16)),
+    "vgen.conv3.weight": (slice(None, None, 8), slice(None, None, 8)),
+    "vgen.conv1.bias": None,
+    "proposal.vote_aggregation.mlp_module.layer0.conv.weight": (slice(None, None, 8), slice(None, None, 8)),
+    "proposal.proposal.6.weight": (slice(None, None, 4), slice(None, None, 4)),
+    "graph.gc_layers.0.map_edge.0.weight": (slice(None, None, 8), slice(None, None, 8)),
+    "graph.edge_predict.weight": None,
+    "caption.classifier.weight": (slice(None), slice(None, None, 8)),
+    "caption.recurrent_cell_1.weight_hh": (slice(None, None, 32), slice(None, None, 16)),
+    "caption.map_feat.weight": (slice(None, None, 16), slice(None, None, 4)),
+}
+
+
+class LossConfig(object):
+    """What get_scene_cap_loss reads from the dataset config
+    (loss_helper.py:122-125)."""
+
+    def __init__(self, msa):
+        self.num_heading_bin, self.num_size_cluster, self.num_class = 1, 18, 18
+        self.mean_size_arr = msa
+
+
+def extract_grads(model):
+    out = {}
+    params = dict(model.named_parameters())
+    for k, sl in GRAD_KEYS.items():
+        g = params[k].grad.detach().cpu()
+        out[k] = (g[sl] if sl is not None else g).numpy()
+    return out
 
 
 def extract(data_dict, keys):

@@ -27,7 +27,8 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "capnet_cfg1.npz")
 # amplifies fp32 re-association noise between the CPU reference run and the GPU:
 # measured 3.5e-4 of scale on lang_cap; eval mode (running stats) stays < 1e-5.
 TOL = {("cpu", "train"): 1e-4, ("cpu", "eval"): 1e-4,
-       ("cuda", "train"): 1e-3, ("cuda", "eval"): 1e-4}
+       ("cuda", "train"): 1e-3, ("cuda", "eval"): 1e-4,
+       ("cpu", "grad"): 1e-4, ("cuda", "grad"): 2e-3}
 
 
 def build_model(device):
@@ -60,12 +61,23 @@ def run_and_compare(device):
     inputs = {k[3:]: ref[k] for k in ref.files if k.startswith("in/")}
     model, sd = build_model(device)
 
+    from scan2cap_amd.loss_helper import get_scene_cap_loss
     model.train()
-    with torch.no_grad():
-        dd = model(gc.to_torch(inputs, device), use_tf=True, is_eval=False)
+    model.zero_grad()
+    dd = model(gc.to_torch(inputs, device), use_tf=True, is_eval=False)
     for key, sl in gc.TRAIN_KEYS.items():
         v = dd[key]
         check(v[sl] if sl is not None else v, ref["train/" + key], "train/" + key, TOL[(device, "train")])
+    # loss restatement + backward (autograd through the custom grad kernels)
+    dd = get_scene_cap_loss(dd, torch.device(device), gc.LossConfig(gc.mean_size_arr()),
+                            None, **gc.LOSS_FLAGS)
+    dd["loss"].backward()
+    for key in gc.LOSS_KEYS:
+        check(dd[key].detach().reshape(()), ref["loss/" + key].reshape(()),
+              "loss/" + key, TOL[(device, "train")])
+    for key, g in gc.extract_grads(model).items():
+        check(torch.from_numpy(g), ref["grad/" + key], "grad/" + key,
+              TOL[(device, "grad")])
 
     model.load_state_dict(sd)
     model.eval()
