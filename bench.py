@@ -121,6 +121,7 @@ def to_device(batch, device):
 
 
 def make_step(model, wl, cfg_loss, optimizer, ddp, device):
+    """Eager step (also the un-captured body of the graphed step)."""
     def train_step(dd):
         dd = dict(dd)
         if ddp is not None:
@@ -149,7 +150,9 @@ def cpu_baseline(wl, vocabulary, embeddings, table, msa, sample_B=1):
     from oracle import torch_ext
     from scan2cap_amd.pointnet2 import _ext
     saved = {n: getattr(_ext, n) for n in torch_ext.NAMES}
-    cores = os.cpu_count() or 1
+    # more threads than this only add OpenMP fork/join and NUMA noise on the
+    # 256-core hosts of the GPU boxes (measured: 143 s/step at 256 threads)
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     try:
         for n in torch_ext.NAMES:
@@ -161,16 +164,18 @@ def cpu_baseline(wl, vocabulary, embeddings, table, msa, sample_B=1):
         model.train(wl["train"])
         step = make_step(model, wl, cfg_loss, opt, None, torch.device("cpu"))
         dd = to_device(make_batch(wl, sample_B, 4242, table, msa), "cpu")
+        reps = 2
         t0 = time.time()
-        step(dd)
-        dt = time.time() - t0
+        for _ in range(reps):
+            step(dd)
+        dt = (time.time() - t0) / reps
     finally:
         for n, f in saved.items():
             setattr(_ext, n, f)
     return {"value": sample_B / dt, "unit": "scenes/s", "cores": cores,
             "kind": "port",
-            "sample": "1 step of the same workload at B=%d (N=%d, C=%d, K=%d), "
-                      "%.1f s wall; oracle C ops (OpenMP) + torch CPU fp32"
+            "sample": "2 steps of the same workload at B=%d (N=%d, C=%d, K=%d), "
+                      "%.1f s/step wall; oracle C ops (OpenMP) + torch CPU fp32"
                       % (sample_B, wl["N"], wl["C"], wl["K"], dt)}
 
 
@@ -181,7 +186,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-scenes", type=int, default=1)
+    ap.add_argument("--no-graph", action="store_true",
+                    help="launch every kernel eagerly instead of replaying the "
+                         "captured hipGraph of the step")
+    ap.add_argument("--cpu-sample-scenes", type=int, default=8)
     args = ap.parse_args()
 
     rank, world, local_rank = init_from_env()
@@ -202,10 +210,40 @@ def main():
     model = build_model(wl, vocabulary, embeddings, msa).to(device)
     model.train(wl["train"])
     cfg_loss = LossConfig(msa)
-    optimizer = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
+    use_graph = not args.no_graph
+    optimizer = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5,
+                                 capturable=use_graph)
     ddp = FlatGradAllReduce(model) if (world > 1 and wl["train"]) else None
-    step = make_step(model, wl, cfg_loss, optimizer, ddp, device)
+    eager_step = make_step(model, wl, cfg_loss, optimizer, ddp, device)
     dd = to_device(make_batch(wl, B, 42 + rank, table, msa), device)
+
+    if use_graph:
+        # whole step = one hipGraph replay (fwd + loss + bwd [+ Adam]); with N>1
+        # the RCCL all-reduce stays an eager call between two graphs
+        from scan2cap_amd.graphs import GraphedCallable
+        if wl["train"] and ddp is not None:
+            def fwd_bwd():
+                d = dict(dd)
+                ddp.zero_grad()
+                d = model(d, use_tf=True, is_eval=False)
+                d = get_scene_cap_loss(d, device, cfg_loss, None)
+                d["loss"].backward()
+                return d["loss"]
+            g1 = GraphedCallable(fwd_bwd).capture()
+            g2 = GraphedCallable(lambda: optimizer.step()).capture()
+
+            def step(_dd):
+                loss = g1()
+                ddp.reduce()
+                g2()
+                return loss
+        else:
+            g = GraphedCallable(lambda: eager_step(dd)).capture()
+
+            def step(_dd):
+                return g()
+    else:
+        step = eager_step
 
     def barrier():
         if world > 1:
@@ -215,12 +253,23 @@ def main():
     for _ in range(args.warmup):
         step(dd)
     barrier()
-    _C.TIMER.start()
+    if not use_graph:
+        _C.TIMER.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(dd)
     barrier()
     elapsed = time.perf_counter() - t0
+    if use_graph:
+        # per-kernel durations: HIP events cannot be read back from inside a graph
+        # replay, so the same steps are run once more eagerly, un-timed for the
+        # headline, with the event timer on (same kernels, same shapes)
+        _C.TIMER.start()
+        for _ in range(min(args.steps, 3)):
+            eager_step(dd)
+        kern_steps = min(args.steps, 3)
+    else:
+        kern_steps = args.steps
     kern = _C.TIMER.stop()
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -235,8 +284,8 @@ def main():
         for name, r in sorted(kern.items(), key=lambda kv: -kv[1]["total_ms"]):
             avg_us = r["total_ms"] / max(r["calls"], 1) * 1e3
             gbs = r["alg_bytes"] / max(r["total_ms"], 1e-9) / 1e6
-            table_k.append({"kernel": name, "calls_per_step": r["calls"] / args.steps,
-                            "ms_per_step": r["total_ms"] / args.steps,
+            table_k.append({"kernel": name, "calls_per_step": r["calls"] / kern_steps,
+                            "ms_per_step": r["total_ms"] / kern_steps,
                             "avg_us": avg_us, "alg_GBps": gbs})
         if table_k:
             top = table_k[0]
@@ -256,6 +305,7 @@ def main():
             "config": {"workload": "%s: %s" % (args.workload, wl["desc"]),
                        "scenes_per_gpu": B, "global_batch": B * world,
                        "parallelism": "dp%d" % world,
+                       "launch": "hipGraph replay" if use_graph else "eager",
                        "grad_allreduce_bytes": ddp.nbytes if ddp else 0},
             "roofline": roof,
             "kernels": table_k[:8],

@@ -12,6 +12,8 @@ import math
 
 import torch
 
+from .consts import const
+
 # corner sign pattern of utils/box_util.py:377-379 (x: l, y: w, z: h)
 _SX = (1, 1, -1, -1, 1, 1, -1, -1)
 _SY = (1, -1, -1, 1, 1, -1, -1, 1)
@@ -27,9 +29,9 @@ def get_3d_box_batch(box_size, heading_angle, center):
     l = box_size[..., 0:1]
     w = box_size[..., 1:2]
     h = box_size[..., 2:3]
-    sx = torch.tensor(_SX, dtype=box_size.dtype, device=box_size.device)
-    sy = torch.tensor(_SY, dtype=box_size.dtype, device=box_size.device)
-    sz = torch.tensor(_SZ, dtype=box_size.dtype, device=box_size.device)
+    sx = const("box_sx", _SX, box_size.device, box_size.dtype)
+    sy = const("box_sy", _SY, box_size.device, box_size.dtype)
+    sz = const("box_sz", _SZ, box_size.device, box_size.dtype)
     cx = (l / 2) * sx
     cy = (w / 2) * sy
     cz = (h / 2) * sz

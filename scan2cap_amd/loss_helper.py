@@ -12,6 +12,7 @@ import torch
 import torch.nn.functional as F
 
 from .config import CONF
+from .consts import array_const, const
 
 FAR_THRESHOLD = 0.6
 NEAR_THRESHOLD = 0.3
@@ -69,7 +70,7 @@ def compute_objectness_loss(data_dict):
     objectness_label = near.long()
     objectness_mask = (near | (euclidean_dist1 > FAR_THRESHOLD)).float()
     scores = data_dict["objectness_scores"]
-    w = torch.tensor(OBJECTNESS_CLS_WEIGHTS, device=scores.device)
+    w = const("objectness_cls_weights", OBJECTNESS_CLS_WEIGHTS, scores.device)
     loss = F.cross_entropy(scores.transpose(2, 1), objectness_label, weight=w,
                            reduction="none")
     loss = torch.sum(loss * objectness_mask) / (torch.sum(objectness_mask) + 1e-6)
@@ -116,7 +117,7 @@ def compute_box_and_sem_cls_loss(data_dict, config):
         object_assignment.unsqueeze(-1).expand(-1, -1, 3))
     size_one_hot = F.one_hot(size_class_label, num_size_cluster).float().unsqueeze(-1)
     predicted = torch.sum(data_dict["size_residuals_normalized"] * size_one_hot, 2)
-    msa = torch.from_numpy(np.asarray(mean_size_arr).astype(np.float32)).to(dev)
+    msa = array_const(np.asarray(mean_size_arr).astype(np.float32), dev)
     mean_size_label = torch.sum(size_one_hot * msa.view(1, 1, num_size_cluster, 3), 2)
     size_residual_label_normalized = size_residual_label / mean_size_label
     size_reg = torch.mean(huber_loss(predicted - size_residual_label_normalized,

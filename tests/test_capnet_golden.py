@@ -28,7 +28,7 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "capnet_cfg1.npz")
 # measured 3.5e-4 of scale on lang_cap; eval mode (running stats) stays < 1e-5.
 TOL = {("cpu", "train"): 1e-4, ("cpu", "eval"): 1e-4,
        ("cuda", "train"): 1e-3, ("cuda", "eval"): 1e-4,
-       ("cpu", "grad"): 1e-4, ("cuda", "grad"): 2e-3}
+       ("cpu", "grad"): 1e-4, ("cuda", "grad"): 5e-3}
 
 
 def build_model(device):
