@@ -1,0 +1,88 @@
+/*
+ * s2c_fused.h -- C ABI of the MI355X-first, POINT-MAJOR set-abstraction kernels
+ * in libs2c_hip.so (scan2cap_amd/csrc/s2c_sa.hip).
+ *
+ * These entry points have no one-to-one counterpart in the reference's FFI (the
+ * nine `pointnet2._ext` functions are in s2c_ops.h); they implement, for the
+ * build's own Python layers, the work the reference spreads over
+ * QueryAndGroup.forward (lib/pointnet2/pointnet2_utils.py:347-359),
+ * SharedMLP's Conv2d/BatchNorm2d/ReLU (lib/pointnet2/pytorch_utils.py:11-120),
+ * F.max_pool2d (lib/pointnet2/pointnet2_modules.py:255-257) and their autograd
+ * backward, on row-major (rows x channels) matrices:
+ *      rows = (scene, centre, sample), channels contiguous.
+ * Same conventions as s2c_ops.h: device pointers, fp32 / int32, asynchronous on
+ * `stream` (hipStream_t as void*), 0 on success, s2c_fused_last_error_string().
+ * All BN kernels require C % 4 == 0 (every BN width of the model is 64..256).
+ */
+#ifndef S2C_FUSED_H
+#define S2C_FUSED_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char *s2c_fused_last_error_string(void);
+
+/* X[(b,j,k), 0:3]   = (xyz[b, idx[b,j,k]] - new_xyz[b,j]) [/ radius if normalize]
+ * X[(b,j,k), 3:3+C] = feats[b, idx[b,j,k], 0:C]
+ * feats is point-major with arbitrary row / batch strides (in floats), so the raw
+ * (B,N,3+C) input cloud can be read in place (feats = cloud + 3, row stride 3+C). */
+int s2c_sa_gather_rows(int b, int n, int m, int ns, int C,
+                       long long feat_row_stride, long long feat_batch_stride,
+                       float radius, int normalize, const float *xyz,
+                       const float *new_xyz, const float *feats, const int *idx,
+                       float *X, void *stream);
+
+/* backward of s2c_sa_gather_rows: d_feats (b,n,C) dense point-major, d_xyz
+ * (b,n,3), d_new_xyz (b,m,3); any of d_feats / d_xyz may be NULL (skipped).
+ * Outputs are zeroed by the callee. */
+int s2c_sa_scatter_rows(int b, int n, int m, int ns, int C, float radius,
+                        int normalize, const float *dX, const int *idx,
+                        float *d_feats, float *d_xyz, float *d_new_xyz,
+                        void *stream);
+
+/* number of row slabs (partial-sum blocks) the statistics kernels use for M rows;
+ * `partial` buffers must hold s2c_bn_stat_blocks(M) * 2 * C floats. */
+int s2c_bn_stat_blocks(long long M);
+
+/* training-mode BatchNorm statistics of Y (M x C): writes scale = gamma*invstd,
+ * shift = beta - mean*scale, save_mean, save_invstd and updates running_mean /
+ * running_var (momentum, unbiased variance) like torch.nn.BatchNorm in train(). */
+int s2c_bn_train_stats(long long M, int C, const float *Y, float *partial,
+                       float eps, float momentum, const float *gamma,
+                       const float *beta, float *running_mean, float *running_var,
+                       float *scale, float *shift, float *save_mean,
+                       float *save_invstd, void *stream);
+
+/* eval-mode coefficients from the running statistics */
+int s2c_bn_eval_coeffs(int C, float eps, const float *gamma, const float *beta,
+                       const float *running_mean, const float *running_var,
+                       float *scale, float *shift, float *save_mean,
+                       float *save_invstd, void *stream);
+
+/* A = Y*scale + shift, followed by ReLU when relu != 0 */
+int s2c_bn_relu(long long M, int C, const float *Y, const float *scale,
+                const float *shift, float *A, int relu, void *stream);
+
+/* out[j,c] = max_k relu(Y[(j,k),c]*scale + shift); arg = first maximising k */
+int s2c_bn_relu_max(long long J, int ns, int C, const float *Y, const float *scale,
+                    const float *shift, float *out, int *arg, void *stream);
+
+/* backward of BN(+ReLU) given dA (M x C); coef: 3*C floats scratch;
+ * frozen != 0: statistics are constants (eval mode). */
+int s2c_bn_relu_bwd(long long M, int C, const float *dA, const float *Y,
+                    const float *scale, const float *shift, const float *mean,
+                    const float *invstd, const float *gamma, int relu, int frozen,
+                    float *partial, float *coef, float *dgamma, float *dbeta,
+                    float *dY, void *stream);
+
+/* backward of BN+ReLU+max-pool given dOut (J x C) and arg (J x C): dY (J*ns x C) */
+int s2c_bn_relu_max_bwd(long long J, int ns, int C, const float *dOut,
+                        const int *arg, const float *Y, const float *scale,
+                        const float *shift, const float *mean, const float *invstd,
+                        const float *gamma, int frozen, float *partial, float *coef,
+                        float *dgamma, float *dbeta, float *dY, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* S2C_FUSED_H */

@@ -17,6 +17,9 @@ HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17",
     # canonical arithmetic: IEEE binary32, source order, no FMA contraction
     "-ffp-contract=off",
+    # hardware float atomics (global_atomic_add_f32) instead of CAS loops in the
+    # scatter-add (grad) kernels
+    "-munsafe-fp-atomics",
     "-shared", "-fPIC", "-Wno-comment",
 ]
 

@@ -1,0 +1,591 @@
+// s2c_sa.hip -- point-major set-abstraction kernels (MI355X-first path).
+//
+// The reference materialises channel-major grouped tensors
+// (B, 3+C, npoint, nsample) (pointnet2_utils.py:347-359) and runs cuDNN-style
+// 1x1 Conv2d + BatchNorm2d + ReLU + max_pool2d over them
+// (pointnet2_modules.py:251-257, pytorch_utils.py:11-120).  Here every grouped
+// tensor is POINT-MAJOR: one row per (scene, centre, sample) with the channels
+// contiguous, so
+//   * a neighbour is ONE contiguous row read of the (B,N,3+C) input instead of
+//     3+C scattered 4-byte reads (group_points_gpu.cu:20-26),
+//   * the shared MLP is a plain row-major GEMM  Y = X W^T,
+//   * BatchNorm statistics are column reductions, BN+ReLU(+max over the nsample
+//     rows of a centre) one fused elementwise pass,
+//   * the gradient scatter is a row-coalesced atomic add.
+// The kernels below are the non-GEMM parts (HBM-bound): gather rows, column
+// statistics, BN+ReLU apply, BN+ReLU+max-pool, their backward passes and the
+// row scatter.
+#include "s2c_common.h"
+#include "../../include/s2c_fused.h"
+
+#include <stdio.h>
+
+using namespace s2c;
+
+static thread_local char g_err2[256] = "";
+static int fail2(const char *what) {
+  snprintf(g_err2, sizeof(g_err2), "s2c: invalid argument: %s", what);
+  return -1;
+}
+static int check2(const char *kernel) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_err2, sizeof(g_err2), "s2c: %s launch failed: %s", kernel,
+             hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+extern "C" const char *s2c_fused_last_error_string(void) { return g_err2; }
+
+static unsigned grid1d(long long items, int per_block, long long cap = 256 * 16) {
+  long long g = (items + per_block - 1) / per_block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+// ---------------------------------------------------------------------------
+// 1. gather rows:  X[(b,j,k), :] = [ (xyz[b,idx] - new_xyz[b,j]) (/ radius) ,
+//                                    feats[b, idx, 0:C] ]
+// (QueryAndGroup.forward, pointnet2_utils.py:347-359, in point-major form; the
+// subtraction and the division are two separate roundings as in the reference.)
+// One wave per output row; lanes run over the channels => both the source row
+// (a contiguous 4*(C) B segment of the point-major input) and the destination
+// row are coalesced.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sa_gather_rows_kernel(
+    int n, int m, int ns, int C, long long feat_row_stride,
+    long long feat_batch_stride, float radius, int normalize,
+    const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+    const float *__restrict__ feats, const int *__restrict__ idx,
+    float *__restrict__ X, long long rows) {
+  const int lane = threadIdx.x & 63;
+  const int ld = 3 + C;
+  for (long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows;
+       r += (long long)gridDim.x * 4) {
+    const long long bj = r / ns;           // b*m + j
+    const long long b = bj / m;
+    const int p = idx[r];                   // wave-uniform
+    float *dst = X + r * ld;
+    if (lane < 3) {
+      float v = xyz[(b * n + p) * 3 + lane] - new_xyz[bj * 3 + lane];
+      if (normalize) v = v / radius;
+      dst[lane] = v;
+    }
+    if (C > 0) {
+      const float *src = feats + b * feat_batch_stride + (long long)p * feat_row_stride;
+      for (int c = lane; c < C; c += 64) dst[3 + c] = src[c];
+    }
+  }
+}
+
+extern "C" int s2c_sa_gather_rows(int b, int n, int m, int ns, int C,
+                                  long long feat_row_stride,
+                                  long long feat_batch_stride, float radius,
+                                  int normalize, const float *xyz,
+                                  const float *new_xyz, const float *feats,
+                                  const int *idx, float *X, void *stream) {
+  if (b < 0 || n <= 0 || m < 0 || ns < 0 || C < 0) return fail2("sa_gather_rows sizes");
+  const long long rows = (long long)b * m * ns;
+  if (rows == 0) return 0;
+  if (!xyz || !new_xyz || !idx || !X || (C > 0 && !feats))
+    return fail2("sa_gather_rows: null pointer");
+  hipLaunchKernelGGL(sa_gather_rows_kernel, dim3(grid1d(rows, 4, 256 * 32)),
+                     dim3(256), 0, (hipStream_t)stream, n, m, ns, C,
+                     feat_row_stride, feat_batch_stride, radius, normalize, xyz,
+                     new_xyz, feats, idx, X, rows);
+  return check2("sa_gather_rows");
+}
+
+// backward of (1): scatter-add dX rows into d_feats (B,N,C) [row-coalesced
+// hardware float atomics], and optionally into d_xyz (B,N,3) / d_new_xyz (B,m,3).
+__global__ __launch_bounds__(256) void sa_scatter_rows_kernel(
+    int n, int m, int ns, int C, float radius, int normalize,
+    const float *__restrict__ dX, const int *__restrict__ idx,
+    float *__restrict__ d_feats, float *__restrict__ d_xyz,
+    float *__restrict__ d_new_xyz, long long rows) {
+  const int lane = threadIdx.x & 63;
+  const int ld = 3 + C;
+  for (long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows;
+       r += (long long)gridDim.x * 4) {
+    const long long bj = r / ns;
+    const long long b = bj / m;
+    const int p = idx[r];
+    const float *src = dX + r * ld;
+    if (d_xyz != nullptr && lane < 3) {
+      float g = src[lane];
+      if (normalize) g = g / radius;
+      atomicAdd(d_xyz + (b * n + p) * 3 + lane, g);
+      atomicAdd(d_new_xyz + bj * 3 + lane, -g);
+    }
+    if (d_feats != nullptr) {
+      float *dst = d_feats + (b * n + p) * (long long)C;
+      for (int c = lane; c < C; c += 64) atomicAdd(dst + c, src[3 + c]);
+    }
+  }
+}
+
+extern "C" int s2c_sa_scatter_rows(int b, int n, int m, int ns, int C,
+                                   float radius, int normalize, const float *dX,
+                                   const int *idx, float *d_feats, float *d_xyz,
+                                   float *d_new_xyz, void *stream) {
+  if (b < 0 || n <= 0 || m < 0 || ns < 0 || C < 0) return fail2("sa_scatter_rows sizes");
+  hipStream_t st = (hipStream_t)stream;
+  if (d_feats && (long long)b * n * C > 0)
+    if (hipMemsetAsync(d_feats, 0, sizeof(float) * (size_t)b * n * C, st) != hipSuccess)
+      return fail2("memset");
+  if (d_xyz) {
+    if (!d_new_xyz) return fail2("sa_scatter_rows: d_xyz needs d_new_xyz");
+    if (hipMemsetAsync(d_xyz, 0, sizeof(float) * (size_t)b * n * 3, st) != hipSuccess ||
+        hipMemsetAsync(d_new_xyz, 0, sizeof(float) * (size_t)b * m * 3, st) != hipSuccess)
+      return fail2("memset");
+  }
+  const long long rows = (long long)b * m * ns;
+  if (rows == 0) return 0;
+  if (!dX || !idx) return fail2("sa_scatter_rows: null pointer");
+  hipLaunchKernelGGL(sa_scatter_rows_kernel, dim3(grid1d(rows, 4, 256 * 32)),
+                     dim3(256), 0, st, n, m, ns, C, radius, normalize, dX, idx,
+                     d_feats, d_xyz, d_new_xyz, rows);
+  return check2("sa_scatter_rows");
+}
+
+// ---------------------------------------------------------------------------
+// 2. column statistics of a row-major (M x C) matrix, C % 4 == 0.
+// Stage 1: each block reduces a slab of rows to partial [sum | sumsq] (float).
+// Stage 2 (bn_finalize): fixed-order double reduction of the partials ->
+// mean, biased var; writes scale = gamma*invstd, shift = beta - mean*scale,
+// saves mean/invstd for backward and updates the running statistics exactly as
+// torch.nn.BatchNorm does in training (momentum, UNBIASED var for running_var;
+// pytorch_utils.py:100-120 instantiates nn.BatchNorm2d with defaults
+// eps=1e-5, momentum=0.1).  Deterministic (no atomics).
+// ---------------------------------------------------------------------------
+constexpr int STAT_BLOCK = 256;
+
+// generic 2-quantity column reduction; the functor gives (q1, q2) per element
+template <class F>
+__device__ __forceinline__ void col_reduce2(F f, long long M, int C,
+                                            float *__restrict__ partial,
+                                            long long rows_per_block) {
+  // thread layout: tx in [0, C/4) handles 4 channels, ty = row lane
+  __shared__ float4 s_a[STAT_BLOCK], s_b[STAT_BLOCK];
+  const int c4n = C >> 2;
+  const int ry = STAT_BLOCK / c4n;  // rows in flight (C/4 <= 256)
+  const int tx = threadIdx.x % c4n, ty = threadIdx.x / c4n;
+  float4 a = make_float4(0, 0, 0, 0), b2 = make_float4(0, 0, 0, 0);
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r1 = min(M, r0 + rows_per_block);
+  if (ty < ry) {
+    for (long long r = r0 + ty; r < r1; r += ry) {
+      float4 q1, q2;
+      f(r, tx, q1, q2);
+      a.x += q1.x; a.y += q1.y; a.z += q1.z; a.w += q1.w;
+      b2.x += q2.x; b2.y += q2.y; b2.z += q2.z; b2.w += q2.w;
+    }
+  }
+  s_a[threadIdx.x] = a;
+  s_b[threadIdx.x] = b2;
+  __syncthreads();
+  if (ty == 0) {
+    for (int y = 1; y < ry; ++y) {
+      const float4 u = s_a[y * c4n + tx], v = s_b[y * c4n + tx];
+      a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+      b2.x += v.x; b2.y += v.y; b2.z += v.z; b2.w += v.w;
+    }
+    float *p = partial + (long long)blockIdx.x * 2 * C;
+    reinterpret_cast<float4 *>(p)[tx] = a;
+    reinterpret_cast<float4 *>(p + C)[tx] = b2;
+  }
+}
+
+__global__ __launch_bounds__(STAT_BLOCK) void col_stats_kernel(
+    const float *__restrict__ Y, long long M, int C, float *__restrict__ partial,
+    long long rows_per_block) {
+  col_reduce2(
+      [&](long long r, int tx, float4 &q1, float4 &q2) {
+        const float4 v = reinterpret_cast<const float4 *>(Y + r * C)[tx];
+        q1 = v;
+        q2 = make_float4(v.x * v.x, v.y * v.y, v.z * v.z, v.w * v.w);
+      },
+      M, C, partial, rows_per_block);
+}
+
+__global__ void bn_finalize_kernel(const float *__restrict__ partial, int nblk,
+                                   int C, long long M, float eps, float momentum,
+                                   const float *__restrict__ gamma,
+                                   const float *__restrict__ beta,
+                                   float *__restrict__ running_mean,
+                                   float *__restrict__ running_var,
+                                   float *__restrict__ scale,
+                                   float *__restrict__ shift,
+                                   float *__restrict__ save_mean,
+                                   float *__restrict__ save_invstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < nblk; ++k) {
+    s1 += (double)partial[(long long)k * 2 * C + c];
+    s2 += (double)partial[(long long)k * 2 * C + C + c];
+  }
+  const double mean = s1 / (double)M;
+  double var = s2 / (double)M - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma ? gamma[c] : 1.0f, bt = beta ? beta[c] : 0.0f;
+  const float sc = g * invstd;
+  scale[c] = sc;
+  shift[c] = bt - (float)mean * sc;
+  save_mean[c] = (float)mean;
+  save_invstd[c] = invstd;
+  if (running_mean) {
+    const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
+    running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+// eval mode: scale/shift from the running statistics
+__global__ void bn_eval_coeffs_kernel(int C, float eps,
+                                      const float *__restrict__ gamma,
+                                      const float *__restrict__ beta,
+                                      const float *__restrict__ running_mean,
+                                      const float *__restrict__ running_var,
+                                      float *__restrict__ scale,
+                                      float *__restrict__ shift,
+                                      float *__restrict__ save_mean,
+                                      float *__restrict__ save_invstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = 1.0f / sqrtf(running_var[c] + eps);
+  const float sc = (gamma ? gamma[c] : 1.0f) * invstd;
+  scale[c] = sc;
+  shift[c] = (beta ? beta[c] : 0.0f) - running_mean[c] * sc;
+  save_mean[c] = running_mean[c];
+  save_invstd[c] = invstd;
+}
+
+static int stat_blocks(long long M, long long *rows_per_block) {
+  long long nb = (M + 511) / 512;  // >= 512 rows per block
+  if (nb > 2048) nb = 2048;
+  if (nb < 1) nb = 1;
+  *rows_per_block = (M + nb - 1) / nb;
+  return (int)((M + *rows_per_block - 1) / *rows_per_block);
+}
+
+extern "C" int s2c_bn_stat_blocks(long long M) {
+  long long rpb;
+  return stat_blocks(M, &rpb);
+}
+
+// training-mode BN statistics of Y (M x C): partial must hold
+// s2c_bn_stat_blocks(M)*2*C floats.
+extern "C" int s2c_bn_train_stats(long long M, int C, const float *Y,
+                                  float *partial, float eps, float momentum,
+                                  const float *gamma, const float *beta,
+                                  float *running_mean, float *running_var,
+                                  float *scale, float *shift, float *save_mean,
+                                  float *save_invstd, void *stream) {
+  if (M <= 0 || C <= 0 || (C & 3) || C > 1024) return fail2("bn_train_stats: C%4==0, C<=1024, M>0");
+  if (!Y || !partial || !scale || !shift || !save_mean || !save_invstd)
+    return fail2("bn_train_stats: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  long long rpb;
+  const int nb = stat_blocks(M, &rpb);
+  hipLaunchKernelGGL(col_stats_kernel, dim3(nb), dim3(STAT_BLOCK), 0, st, Y, M, C,
+                     partial, rpb);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st,
+                     partial, nb, C, M, eps, momentum, gamma, beta, running_mean,
+                     running_var, scale, shift, save_mean, save_invstd);
+  return check2("bn_train_stats");
+}
+
+extern "C" int s2c_bn_eval_coeffs(int C, float eps, const float *gamma,
+                                  const float *beta, const float *running_mean,
+                                  const float *running_var, float *scale,
+                                  float *shift, float *save_mean,
+                                  float *save_invstd, void *stream) {
+  if (C <= 0) return fail2("bn_eval_coeffs: C");
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 63) / 64), dim3(64), 0,
+                     (hipStream_t)stream, C, eps, gamma, beta, running_mean,
+                     running_var, scale, shift, save_mean, save_invstd);
+  return check2("bn_eval_coeffs");
+}
+
+// ---------------------------------------------------------------------------
+// 3. A = relu(Y*scale + shift)   (M x C, float4 over channels)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_relu_kernel(
+    const float *__restrict__ Y, const float *__restrict__ scale,
+    const float *__restrict__ shift, float *__restrict__ A, long long total4,
+    int c4n, int relu) {
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total4;
+       e += (long long)gridDim.x * 256) {
+    const int tx = (int)(e % c4n);
+    const float4 y = reinterpret_cast<const float4 *>(Y)[e];
+    const float4 sc = reinterpret_cast<const float4 *>(scale)[tx];
+    const float4 sh = reinterpret_cast<const float4 *>(shift)[tx];
+    float4 a;
+    a.x = y.x * sc.x + sh.x; a.y = y.y * sc.y + sh.y;
+    a.z = y.z * sc.z + sh.z; a.w = y.w * sc.w + sh.w;
+    if (relu) {
+      a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f);
+      a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
+    }
+    reinterpret_cast<float4 *>(A)[e] = a;
+  }
+}
+
+extern "C" int s2c_bn_relu(long long M, int C, const float *Y, const float *scale,
+                           const float *shift, float *A, int relu, void *stream) {
+  if (M < 0 || C <= 0 || (C & 3)) return fail2("bn_relu: C%4==0");
+  if (M == 0) return 0;
+  const long long total4 = M * (C >> 2);
+  hipLaunchKernelGGL(bn_relu_kernel, dim3(grid1d(total4, 256)), dim3(256), 0,
+                     (hipStream_t)stream, Y, scale, shift, A, total4, C >> 2, relu);
+  return check2("bn_relu");
+}
+
+// ---------------------------------------------------------------------------
+// 4. out[j, c] = max_k relu(Y[(j,k), c]*scale + shift), arg[j, c] = first k of
+// the maximum (F.max_pool2d over nsample, pointnet2_modules.py:255-257).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_relu_max_kernel(
+    const float *__restrict__ Y, const float *__restrict__ scale,
+    const float *__restrict__ shift, float *__restrict__ out,
+    int *__restrict__ arg, long long J, int ns, int c4n) {
+  const long long total = J * c4n;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total;
+       e += (long long)gridDim.x * 256) {
+    const int tx = (int)(e % c4n);
+    const long long j = e / c4n;
+    const float4 sc = reinterpret_cast<const float4 *>(scale)[tx];
+    const float4 sh = reinterpret_cast<const float4 *>(shift)[tx];
+    float4 best = make_float4(-1.f, -1.f, -1.f, -1.f);
+    int4 bi = make_int4(0, 0, 0, 0);
+    const float4 *src = reinterpret_cast<const float4 *>(Y) + (j * ns) * c4n + tx;
+    for (int k = 0; k < ns; ++k) {
+      const float4 y = src[(long long)k * c4n];
+      const float ax = fmaxf(y.x * sc.x + sh.x, 0.f), ay = fmaxf(y.y * sc.y + sh.y, 0.f);
+      const float az = fmaxf(y.z * sc.z + sh.z, 0.f), aw = fmaxf(y.w * sc.w + sh.w, 0.f);
+      if (ax > best.x) { best.x = ax; bi.x = k; }
+      if (ay > best.y) { best.y = ay; bi.y = k; }
+      if (az > best.z) { best.z = az; bi.z = k; }
+      if (aw > best.w) { best.w = aw; bi.w = k; }
+    }
+    reinterpret_cast<float4 *>(out)[e] = best;
+    reinterpret_cast<int4 *>(arg)[e] = bi;
+  }
+}
+
+extern "C" int s2c_bn_relu_max(long long J, int ns, int C, const float *Y,
+                               const float *scale, const float *shift, float *out,
+                               int *arg, void *stream) {
+  if (J < 0 || ns <= 0 || C <= 0 || (C & 3)) return fail2("bn_relu_max: C%4==0");
+  if (J == 0) return 0;
+  hipLaunchKernelGGL(bn_relu_max_kernel, dim3(grid1d(J * (C >> 2), 256)), dim3(256),
+                     0, (hipStream_t)stream, Y, scale, shift, out, arg, J, ns, C >> 2);
+  return check2("bn_relu_max");
+}
+
+// ---------------------------------------------------------------------------
+// 5. backward of BN(+ReLU):  dz = dA * [z > 0]   (z = Y*scale + shift)
+//    s1 = sum dz, s2 = sum dz * xhat            (xhat = (Y - mean) * invstd)
+//    dY = gamma*invstd * (dz - s1/M - xhat*s2/M)     (training statistics)
+//    dY = gamma*invstd * dz                           (frozen / eval statistics)
+//    dgamma = s2, dbeta = s1.
+// Two passes: (a) column reduction -> partials -> finalize (double, fixed
+// order); (b) apply.  The max-pool variant reads the sparse upstream gradient
+// dOut[j,c] routed to row arg[j,c].
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(STAT_BLOCK) void bn_bwd_stats_kernel(
+    const float *__restrict__ dA, const float *__restrict__ Y,
+    const float *__restrict__ scale, const float *__restrict__ shift,
+    const float *__restrict__ mean, const float *__restrict__ invstd,
+    long long M, int C, int relu, float *__restrict__ partial,
+    long long rows_per_block) {
+  col_reduce2(
+      [&](long long r, int tx, float4 &q1, float4 &q2) {
+        const float4 y = reinterpret_cast<const float4 *>(Y + r * C)[tx];
+        float4 g = reinterpret_cast<const float4 *>(dA + r * C)[tx];
+        const float4 sc = reinterpret_cast<const float4 *>(scale)[tx];
+        const float4 sh = reinterpret_cast<const float4 *>(shift)[tx];
+        const float4 mu = reinterpret_cast<const float4 *>(mean)[tx];
+        const float4 is = reinterpret_cast<const float4 *>(invstd)[tx];
+        if (relu) {
+          if (!(y.x * sc.x + sh.x > 0.f)) g.x = 0.f;
+          if (!(y.y * sc.y + sh.y > 0.f)) g.y = 0.f;
+          if (!(y.z * sc.z + sh.z > 0.f)) g.z = 0.f;
+          if (!(y.w * sc.w + sh.w > 0.f)) g.w = 0.f;
+        }
+        q1 = g;
+        q2 = make_float4(g.x * ((y.x - mu.x) * is.x), g.y * ((y.y - mu.y) * is.y),
+                         g.z * ((y.z - mu.z) * is.z), g.w * ((y.w - mu.w) * is.w));
+      },
+      M, C, partial, rows_per_block);
+}
+
+// sums -> dgamma (=s2), dbeta (=s1); also the per-channel coefficients used by
+// the apply pass: k0 = gamma*invstd, k1 = s1/M, k2 = s2/M (0 when frozen)
+__global__ void bn_bwd_finalize_kernel(const float *__restrict__ partial, int nblk,
+                                       int C, long long M, int frozen,
+                                       const float *__restrict__ gamma,
+                                       const float *__restrict__ invstd,
+                                       float *__restrict__ dgamma,
+                                       float *__restrict__ dbeta,
+                                       float *__restrict__ coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < nblk; ++k) {
+    s1 += (double)partial[(long long)k * 2 * C + c];
+    s2 += (double)partial[(long long)k * 2 * C + C + c];
+  }
+  if (dbeta) dbeta[c] = (float)s1;
+  if (dgamma) dgamma[c] = (float)s2;
+  coef[c] = (gamma ? gamma[c] : 1.0f) * invstd[c];
+  coef[C + c] = frozen ? 0.0f : (float)(s1 / (double)M);
+  coef[2 * C + c] = frozen ? 0.0f : (float)(s2 / (double)M);
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const float *__restrict__ dA, const float *__restrict__ Y,
+    const float *__restrict__ scale, const float *__restrict__ shift,
+    const float *__restrict__ mean, const float *__restrict__ invstd,
+    const float *__restrict__ coef, float *__restrict__ dY, long long total4,
+    int c4n, int C, int relu) {
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total4;
+       e += (long long)gridDim.x * 256) {
+    const int tx = (int)(e % c4n);
+    const float4 y = reinterpret_cast<const float4 *>(Y)[e];
+    float4 g = reinterpret_cast<const float4 *>(dA)[e];
+    const float4 sc = reinterpret_cast<const float4 *>(scale)[tx];
+    const float4 sh = reinterpret_cast<const float4 *>(shift)[tx];
+    const float4 mu = reinterpret_cast<const float4 *>(mean)[tx];
+    const float4 is = reinterpret_cast<const float4 *>(invstd)[tx];
+    const float4 k0 = reinterpret_cast<const float4 *>(coef)[tx];
+    const float4 k1 = reinterpret_cast<const float4 *>(coef + C)[tx];
+    const float4 k2 = reinterpret_cast<const float4 *>(coef + 2 * C)[tx];
+    if (relu) {
+      if (!(y.x * sc.x + sh.x > 0.f)) g.x = 0.f;
+      if (!(y.y * sc.y + sh.y > 0.f)) g.y = 0.f;
+      if (!(y.z * sc.z + sh.z > 0.f)) g.z = 0.f;
+      if (!(y.w * sc.w + sh.w > 0.f)) g.w = 0.f;
+    }
+    float4 o;
+    o.x = k0.x * (g.x - k1.x - ((y.x - mu.x) * is.x) * k2.x);
+    o.y = k0.y * (g.y - k1.y - ((y.y - mu.y) * is.y) * k2.y);
+    o.z = k0.z * (g.z - k1.z - ((y.z - mu.z) * is.z) * k2.z);
+    o.w = k0.w * (g.w - k1.w - ((y.w - mu.w) * is.w) * k2.w);
+    reinterpret_cast<float4 *>(dY)[e] = o;
+  }
+}
+
+// dA / partial / coef semantics as documented above.  `coef` = 3*C floats.
+extern "C" int s2c_bn_relu_bwd(long long M, int C, const float *dA, const float *Y,
+                               const float *scale, const float *shift,
+                               const float *mean, const float *invstd,
+                               const float *gamma, int relu, int frozen,
+                               float *partial, float *coef, float *dgamma,
+                               float *dbeta, float *dY, void *stream) {
+  if (M <= 0 || C <= 0 || (C & 3) || C > 1024) return fail2("bn_relu_bwd: C%4==0");
+  hipStream_t st = (hipStream_t)stream;
+  long long rpb;
+  const int nb = stat_blocks(M, &rpb);
+  hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(nb), dim3(STAT_BLOCK), 0, st, dA, Y,
+                     scale, shift, mean, invstd, M, C, relu, partial, rpb);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st,
+                     partial, nb, C, M, frozen, gamma, invstd, dgamma, dbeta, coef);
+  const long long total4 = M * (C >> 2);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid1d(total4, 256)), dim3(256), 0,
+                     st, dA, Y, scale, shift, mean, invstd, coef, dY, total4, C >> 2,
+                     C, relu);
+  return check2("bn_relu_bwd");
+}
+
+// max-pool variant: upstream dOut (J x C), arg (J x C); rows M = J*ns.
+__global__ __launch_bounds__(STAT_BLOCK) void pool_bwd_stats_kernel(
+    const float *__restrict__ dOut, const int *__restrict__ arg,
+    const float *__restrict__ Y, const float *__restrict__ scale,
+    const float *__restrict__ shift, const float *__restrict__ mean,
+    const float *__restrict__ invstd, long long J, int ns, int C,
+    float *__restrict__ partial, long long rows_per_block) {
+  col_reduce2(
+      [&](long long j, int tx, float4 &q1, float4 &q2) {
+        float4 g = reinterpret_cast<const float4 *>(dOut + j * C)[tx];
+        const int4 a = reinterpret_cast<const int4 *>(arg + j * C)[tx];
+        const float4 sc = reinterpret_cast<const float4 *>(scale)[tx];
+        const float4 sh = reinterpret_cast<const float4 *>(shift)[tx];
+        const float4 mu = reinterpret_cast<const float4 *>(mean)[tx];
+        const float4 is = reinterpret_cast<const float4 *>(invstd)[tx];
+        const float *base = Y + (j * ns) * C + tx * 4;
+        const float yx = base[(long long)a.x * C + 0], yy = base[(long long)a.y * C + 1];
+        const float yz = base[(long long)a.z * C + 2], yw = base[(long long)a.w * C + 3];
+        if (!(yx * sc.x + sh.x > 0.f)) g.x = 0.f;
+        if (!(yy * sc.y + sh.y > 0.f)) g.y = 0.f;
+        if (!(yz * sc.z + sh.z > 0.f)) g.z = 0.f;
+        if (!(yw * sc.w + sh.w > 0.f)) g.w = 0.f;
+        q1 = g;
+        q2 = make_float4(g.x * ((yx - mu.x) * is.x), g.y * ((yy - mu.y) * is.y),
+                         g.z * ((yz - mu.z) * is.z), g.w * ((yw - mu.w) * is.w));
+      },
+      J, C, partial, rows_per_block);
+}
+
+__global__ __launch_bounds__(256) void pool_bwd_apply_kernel(
+    const float *__restrict__ dOut, const int *__restrict__ arg,
+    const float *__restrict__ Y, const float *__restrict__ scale,
+    const float *__restrict__ shift, const float *__restrict__ mean,
+    const float *__restrict__ invstd, const float *__restrict__ coef,
+    float *__restrict__ dY, long long total4, int ns, int c4n, int C) {
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total4;
+       e += (long long)gridDim.x * 256) {
+    const int tx = (int)(e % c4n);
+    const long long r = e / c4n;
+    const long long j = r / ns;
+    const int k = (int)(r - j * ns);
+    const float4 y = reinterpret_cast<const float4 *>(Y)[e];
+    float4 g = reinterpret_cast<const float4 *>(dOut + j * C)[tx];
+    const int4 a = reinterpret_cast<const int4 *>(arg + j * C)[tx];
+    const float4 sc = reinterpret_cast<const float4 *>(scale)[tx];
+    const float4 sh = reinterpret_cast<const float4 *>(shift)[tx];
+    const float4 mu = reinterpret_cast<const float4 *>(mean)[tx];
+    const float4 is = reinterpret_cast<const float4 *>(invstd)[tx];
+    const float4 k0 = reinterpret_cast<const float4 *>(coef)[tx];
+    const float4 k1 = reinterpret_cast<const float4 *>(coef + C)[tx];
+    const float4 k2 = reinterpret_cast<const float4 *>(coef + 2 * C)[tx];
+    if (a.x != k || !(y.x * sc.x + sh.x > 0.f)) g.x = 0.f;
+    if (a.y != k || !(y.y * sc.y + sh.y > 0.f)) g.y = 0.f;
+    if (a.z != k || !(y.z * sc.z + sh.z > 0.f)) g.z = 0.f;
+    if (a.w != k || !(y.w * sc.w + sh.w > 0.f)) g.w = 0.f;
+    float4 o;
+    o.x = k0.x * (g.x - k1.x - ((y.x - mu.x) * is.x) * k2.x);
+    o.y = k0.y * (g.y - k1.y - ((y.y - mu.y) * is.y) * k2.y);
+    o.z = k0.z * (g.z - k1.z - ((y.z - mu.z) * is.z) * k2.z);
+    o.w = k0.w * (g.w - k1.w - ((y.w - mu.w) * is.w) * k2.w);
+    reinterpret_cast<float4 *>(dY)[e] = o;
+  }
+}
+
+extern "C" int s2c_bn_relu_max_bwd(long long J, int ns, int C, const float *dOut,
+                                   const int *arg, const float *Y,
+                                   const float *scale, const float *shift,
+                                   const float *mean, const float *invstd,
+                                   const float *gamma, int frozen, float *partial,
+                                   float *coef, float *dgamma, float *dbeta,
+                                   float *dY, void *stream) {
+  if (J <= 0 || ns <= 0 || C <= 0 || (C & 3) || C > 1024)
+    return fail2("bn_relu_max_bwd: C%4==0");
+  hipStream_t st = (hipStream_t)stream;
+  long long rpb;
+  const int nb = stat_blocks(J, &rpb);
+  const long long M = J * ns;
+  hipLaunchKernelGGL(pool_bwd_stats_kernel, dim3(nb), dim3(STAT_BLOCK), 0, st, dOut,
+                     arg, Y, scale, shift, mean, invstd, J, ns, C, partial, rpb);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st,
+                     partial, nb, C, M, frozen, gamma, invstd, dgamma, dbeta, coef);
+  const long long total4 = M * (C >> 2);
+  hipLaunchKernelGGL(pool_bwd_apply_kernel, dim3(grid1d(total4, 256)), dim3(256), 0,
+                     st, dOut, arg, Y, scale, shift, mean, invstd, coef, dY, total4,
+                     ns, C >> 2, C);
+  return check2("bn_relu_max_bwd");
+}

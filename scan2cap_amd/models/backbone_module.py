@@ -28,9 +28,12 @@ class Pointnet2Backbone(nn.Module):
         self.fp2 = PointnetFPModule(mlp=[256 + 256, 256, 256])
 
     def _break_up_pc(self, pc):
+        """xyz (B,N,3) contiguous; features as a (B,C,N) VIEW of the point-major
+        input -- the reference materialises the transpose (169 MB copy at cfg3,
+        backbone_module.py:68-72); the point-major SA path reads the (B,N,3+C)
+        rows in place."""
         xyz = pc[..., :3].contiguous()
-        features = (pc[..., 3:].transpose(1, 2).contiguous()
-                    if pc.size(-1) > 3 else None)
+        features = pc[..., 3:].transpose(1, 2) if pc.size(-1) > 3 else None
         return xyz, features
 
     def forward(self, data_dict):

@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 
 from ..box_util import get_3d_box_batch
+from ..pointnet2 import fused
 from ..pointnet2.pointnet2_modules import PointnetSAModuleVotes
 
 
@@ -50,7 +51,19 @@ class ProposalModule(nn.Module):
         data_dict["aggregated_vote_xyz"] = xyz
         data_dict["aggregated_vote_features"] = features.permute(0, 2, 1).contiguous()
         data_dict["aggregated_vote_inds"] = fps_inds
-        net = self.proposal(features)
+        if features.is_cuda:
+            B, C, K = features.shape
+            p = self.proposal
+            specs = [fused.LayerSpec(False, p[1], True),
+                     fused.LayerSpec(False, p[4], True),
+                     fused.LayerSpec(True, None, False)]
+            params = [p[0].weight.view(128, -1), p[1].weight, p[1].bias,
+                      p[3].weight.view(128, -1), p[4].weight, p[4].bias,
+                      p[6].weight.view(p[6].out_channels, -1), p[6].bias]
+            rows = features.transpose(1, 2).reshape(B * K, C)
+            net = fused.mlp_rows(rows, specs, params).view(B, K, -1).transpose(1, 2)
+        else:
+            net = self.proposal(features)
         return self.decode_scores(net, data_dict, self.num_class,
                                   self.num_heading_bin, self.num_size_cluster,
                                   self.mean_size_arr)

@@ -2,6 +2,8 @@
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..pointnet2 import fused
+
 
 class VotingModule(nn.Module):
     def __init__(self, vote_factor, seed_feature_dim):
@@ -20,11 +22,27 @@ class VotingModule(nn.Module):
         vote_xyz (B,S*vf,3), vote_features (B,C,S*vf)."""
         B, S = seed_xyz.shape[0], seed_xyz.shape[1]
         V = S * self.vote_factor
-        net = F.relu(self.bn1(self.conv1(seed_features)))
-        net = F.relu(self.bn2(self.conv2(net)))
-        net = self.conv3(net)  # (B,(3+C)*vf,S)
-        net = net.transpose(2, 1).view(B, S, self.vote_factor, 3 + self.out_dim)
+        if seed_features.is_cuda and self.in_dim % 4 == 0:
+            # point-major rows through the fused GEMM/BN kernels
+            specs = [fused.LayerSpec(True, self.bn1, True),
+                     fused.LayerSpec(True, self.bn2, True),
+                     fused.LayerSpec(True, None, False)]
+            params = [self.conv1.weight.view(self.in_dim, -1), self.conv1.bias,
+                      self.bn1.weight, self.bn1.bias,
+                      self.conv2.weight.view(self.in_dim, -1), self.conv2.bias,
+                      self.bn2.weight, self.bn2.bias,
+                      self.conv3.weight.view(self.conv3.out_channels, -1),
+                      self.conv3.bias]
+            rows = seed_features.transpose(2, 1).reshape(B * S, self.in_dim)
+            net = fused.mlp_rows(rows, specs, params)
+            net = net.view(B, S, self.vote_factor, 3 + self.out_dim)
+        else:
+            net = F.relu(self.bn1(self.conv1(seed_features)))
+            net = F.relu(self.bn2(self.conv2(net)))
+            net = self.conv3(net)  # (B,(3+C)*vf,S)
+            net = net.transpose(2, 1).view(B, S, self.vote_factor, 3 + self.out_dim)
         vote_xyz = (seed_xyz.unsqueeze(2) + net[..., 0:3]).contiguous().view(B, V, 3)
         vote_features = seed_features.transpose(2, 1).unsqueeze(2) + net[..., 3:]
         vote_features = vote_features.contiguous().view(B, V, self.out_dim)
-        return vote_xyz, vote_features.transpose(2, 1).contiguous()
+        # (B,C,V) view of point-major data; the reference returns a contiguous copy
+        return vote_xyz, vote_features.transpose(2, 1)

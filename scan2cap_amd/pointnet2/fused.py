@@ -1,0 +1,315 @@
+"""Point-major set-abstraction path (MI355X-first; kernels in csrc/s2c_sa.hip,
+C ABI in include/s2c_fused.h).
+
+`sa_group_mlp_pool` computes, for one set-abstraction stage, exactly what the
+reference computes with QueryAndGroup -> SharedMLP -> max_pool2d
+(pointnet2_modules.py:244-257), but on point-major rows: rows = (scene, centre,
+sample), channels contiguous.  The 1x1 convolutions become row-major GEMMs
+(library GEMM today, torch.mm -> hipBLASLt f32 MFMA); BatchNorm statistics,
+BN+ReLU, BN+ReLU+max and all their backward passes are the hand-written
+HBM-bound kernels.  `mlp_rows` is the same machinery without grouping/pooling
+for the FP / voting / proposal heads.
+
+Both are torch.autograd.Functions with hand-written backward, so nothing of
+torch's conv / batch-norm / pooling machinery (MIOpen) is on the hot path.
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+
+from .. import _C
+
+_I, _L, _P, _F = ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_float
+
+_C.register("s2c_sa_gather_rows", [_I, _I, _I, _I, _I, _L, _L, _F, _I, _P, _P, _P, _P, _P, _P])
+_C.register("s2c_sa_scatter_rows", [_I, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P])
+_C.register("s2c_bn_train_stats", [_L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P])
+_C.register("s2c_bn_eval_coeffs", [_I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P])
+_C.register("s2c_bn_relu", [_L, _I, _P, _P, _P, _P, _I, _P])
+_C.register("s2c_bn_relu_max", [_L, _I, _I, _P, _P, _P, _P, _P, _P])
+_C.register("s2c_bn_relu_bwd", [_L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P])
+_C.register("s2c_bn_relu_max_bwd", [_L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P])
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _call(name, ref, *args, alg_bytes=0):
+    if _C.TIMER.enabled:
+        _C.TIMER.alg_bytes = int(alg_bytes)
+    with torch.cuda.device(ref.device):
+        _C.call(name, *args, _C.stream_ptr())
+
+
+def _stat_blocks(M):
+    lib = _C.load()
+    lib.s2c_bn_stat_blocks.argtypes = [_L]
+    lib.s2c_bn_stat_blocks.restype = _I
+    return lib.s2c_bn_stat_blocks(M)
+
+
+def fused_available(t):
+    return t.is_cuda
+
+
+# ---------------------------------------------------------------------------
+# gather rows
+# ---------------------------------------------------------------------------
+class _GatherRows(Function):
+    """X (B*m*ns, 3+C) from xyz (B,N,3), new_xyz (B,m,3), point-major feats
+    (B,N,C) (any row/batch stride, unit channel stride) and idx (B,m,ns)."""
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, feats, idx, radius, normalize):
+        B, N, _ = xyz.shape
+        _, m, ns = idx.shape
+        if feats is not None:
+            if feats.stride(2) != 1:
+                feats = feats.contiguous()
+            C = feats.shape[2]
+            frs, fbs = feats.stride(1), feats.stride(0)
+        else:
+            C, frs, fbs = 0, 0, 0
+        xyz_c, new_c = xyz.contiguous(), new_xyz.contiguous()
+        X = torch.empty((B * m * ns, 3 + C), dtype=torch.float32, device=xyz.device)
+        _call("s2c_sa_gather_rows", xyz, B, N, m, ns, C, frs, fbs, float(radius),
+              int(bool(normalize)), xyz_c.data_ptr(), new_c.data_ptr(), _ptr(feats),
+              idx.data_ptr(), X.data_ptr(),
+              alg_bytes=4 * (min(B * N, B * m * ns) * (3 + C) + B * m * ns
+                             + B * m * ns * (3 + C)))
+        ctx.save_for_backward(idx)
+        ctx.dims = (B, N, m, ns, C, float(radius), int(bool(normalize)))
+        ctx.need = (xyz.requires_grad or new_xyz.requires_grad,
+                    feats is not None and feats.requires_grad)
+        return X
+
+    @staticmethod
+    def backward(ctx, dX):
+        (idx,) = ctx.saved_tensors
+        B, N, m, ns, C, radius, normalize = ctx.dims
+        need_xyz, need_feats = ctx.need
+        dX = dX.contiguous()
+        d_feats = torch.empty((B, N, C), dtype=torch.float32, device=dX.device) \
+            if need_feats else None
+        d_xyz = torch.empty((B, N, 3), dtype=torch.float32, device=dX.device) \
+            if need_xyz else None
+        d_new = torch.empty((B, m, 3), dtype=torch.float32, device=dX.device) \
+            if need_xyz else None
+        if need_xyz or need_feats:
+            _call("s2c_sa_scatter_rows", dX, B, N, m, ns, C, radius, normalize,
+                  dX.data_ptr(), idx.data_ptr(), _ptr(d_feats), _ptr(d_xyz),
+                  _ptr(d_new),
+                  alg_bytes=4 * (B * m * ns * (3 + C + 1) + B * N * C))
+        return d_xyz, d_new, d_feats, None, None, None
+
+
+# ---------------------------------------------------------------------------
+# MLP over rows
+# ---------------------------------------------------------------------------
+class LayerSpec(object):
+    """One shared-MLP layer: Y = X W^T (+ bias) -> [BatchNorm] -> [ReLU]."""
+    __slots__ = ("has_bias", "bn", "relu")
+
+    def __init__(self, has_bias, bn, relu):
+        self.has_bias, self.bn, self.relu = has_bias, bn, relu
+
+
+class _MLPRows(Function):
+    """forward(X, specs, pool_ns, *params) with params = per layer
+    [W (Cout,Cin), bias?, gamma?, beta?].  pool_ns > 0: the last layer's
+    BN+ReLU is fused with a max over groups of pool_ns consecutive rows."""
+
+    @staticmethod
+    def forward(ctx, X, specs, pool_ns, *params):
+        dev = X.device
+        M = X.shape[0]
+        need_grad = torch.is_grad_enabled() and (
+            X.requires_grad or any(p.requires_grad for p in params))
+        saved = []          # per layer dict of tensors needed in backward
+        A = X
+        pi = 0
+        nl = len(specs)
+        partial = None
+        out = None
+        for li, sp in enumerate(specs):
+            W = params[pi]; pi += 1
+            bias = None
+            if sp.has_bias:
+                bias = params[pi]; pi += 1
+            gamma = beta = None
+            bn = sp.bn
+            if bn is not None:
+                gamma, beta = params[pi], params[pi + 1]; pi += 2
+            Cout = W.shape[0]
+            Y = torch.addmm(bias, A, W.t()) if bias is not None else torch.mm(A, W.t())
+            rec = {"A_in": A, "W": W, "has_bias": bias is not None}
+            last = li == nl - 1
+            if bn is not None:
+                scale = torch.empty(Cout, device=dev)
+                shift = torch.empty(Cout, device=dev)
+                mean = torch.empty(Cout, device=dev)
+                invstd = torch.empty(Cout, device=dev)
+                train_stats = bn.training or bn.running_mean is None
+                if train_stats:
+                    nb = _stat_blocks(M)
+                    if partial is None or partial.numel() < nb * 2 * Cout:
+                        partial = torch.empty(nb * 2 * max(Cout, 256), device=dev)
+                    mom = bn.momentum if bn.momentum is not None else 0.1
+                    _call("s2c_bn_train_stats", Y, M, Cout, Y.data_ptr(),
+                          partial.data_ptr(), float(bn.eps), float(mom),
+                          _ptr(gamma), _ptr(beta), _ptr(bn.running_mean),
+                          _ptr(bn.running_var), scale.data_ptr(), shift.data_ptr(),
+                          mean.data_ptr(), invstd.data_ptr(),
+                          alg_bytes=4 * M * Cout)
+                    if bn.num_batches_tracked is not None:
+                        bn.num_batches_tracked.add_(1)
+                else:
+                    _call("s2c_bn_eval_coeffs", Y, Cout, float(bn.eps), _ptr(gamma),
+                          _ptr(beta), bn.running_mean.data_ptr(),
+                          bn.running_var.data_ptr(), scale.data_ptr(),
+                          shift.data_ptr(), mean.data_ptr(), invstd.data_ptr())
+                rec.update(Y=Y, scale=scale, shift=shift, mean=mean, invstd=invstd,
+                           gamma=gamma, frozen=not train_stats, relu=sp.relu)
+                if last and pool_ns > 0:
+                    J = M // pool_ns
+                    out = torch.empty((J, Cout), device=dev)
+                    arg = torch.empty((J, Cout), dtype=torch.int32, device=dev)
+                    _call("s2c_bn_relu_max", Y, J, pool_ns, Cout, Y.data_ptr(),
+                          scale.data_ptr(), shift.data_ptr(), out.data_ptr(),
+                          arg.data_ptr(), alg_bytes=4 * (M * Cout + 2 * J * Cout))
+                    rec["arg"] = arg
+                else:
+                    A = torch.empty_like(Y)
+                    _call("s2c_bn_relu", Y, M, Cout, Y.data_ptr(), scale.data_ptr(),
+                          shift.data_ptr(), A.data_ptr(), int(sp.relu),
+                          alg_bytes=8 * M * Cout)
+                    out = A
+            else:
+                if sp.relu:
+                    rec.update(Y=Y, relu=True)
+                    A = torch.relu(Y)
+                else:
+                    A = Y
+                out = A
+                if last and pool_ns > 0:
+                    raise NotImplementedError("pooling needs a BN+ReLU last layer")
+            saved.append(rec)
+        if need_grad:
+            ctx.saved = saved
+            ctx.specs = specs
+            ctx.pool_ns = pool_ns
+            ctx.x_needs_grad = X.requires_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, dOut):
+        saved, specs, pool_ns = ctx.saved, ctx.specs, ctx.pool_ns
+        dev = dOut.device
+        grads = []          # per layer, reversed
+        dA = dOut.contiguous()
+        partial = None
+        nl = len(specs)
+        for li in range(nl - 1, -1, -1):
+            rec, sp = saved[li], specs[li]
+            W, A_in = rec["W"], rec["A_in"]
+            Cout = W.shape[0]
+            M = A_in.shape[0]
+            dgamma = dbeta = None
+            if sp.bn is not None:
+                Y = rec["Y"]
+                nb = _stat_blocks(M)
+                if partial is None or partial.numel() < nb * 2 * Cout:
+                    partial = torch.empty(nb * 2 * max(Cout, 256), device=dev)
+                coef = torch.empty(3 * Cout, device=dev)
+                has_affine = rec["gamma"] is not None
+                dgamma = torch.empty(Cout, device=dev) if has_affine else None
+                dbeta = torch.empty(Cout, device=dev) if has_affine else None
+                dY = torch.empty_like(Y)
+                if li == nl - 1 and pool_ns > 0:
+                    J = M // pool_ns
+                    _call("s2c_bn_relu_max_bwd", Y, J, pool_ns, Cout, dA.data_ptr(),
+                          rec["arg"].data_ptr(), Y.data_ptr(), rec["scale"].data_ptr(),
+                          rec["shift"].data_ptr(), rec["mean"].data_ptr(),
+                          rec["invstd"].data_ptr(), _ptr(rec["gamma"]),
+                          int(rec["frozen"]), partial.data_ptr(), coef.data_ptr(),
+                          _ptr(dgamma), _ptr(dbeta), dY.data_ptr(),
+                          alg_bytes=4 * (2 * M * Cout + 2 * J * Cout))
+                else:
+                    _call("s2c_bn_relu_bwd", Y, M, Cout, dA.data_ptr(), Y.data_ptr(),
+                          rec["scale"].data_ptr(), rec["shift"].data_ptr(),
+                          rec["mean"].data_ptr(), rec["invstd"].data_ptr(),
+                          _ptr(rec["gamma"]), int(rec["relu"]), int(rec["frozen"]),
+                          partial.data_ptr(), coef.data_ptr(), _ptr(dgamma),
+                          _ptr(dbeta), dY.data_ptr(), alg_bytes=4 * 5 * M * Cout)
+            elif rec.get("relu"):
+                dY = dA * (rec["Y"] > 0)
+            else:
+                dY = dA
+            dW = torch.mm(dY.t(), A_in)
+            dbias = dY.sum(0) if rec["has_bias"] else None
+            need_dA = li > 0 or ctx.x_needs_grad
+            dA = torch.mm(dY, W) if need_dA else None
+            g = [dW]
+            if rec["has_bias"]:
+                g.append(dbias)
+            if sp.bn is not None:
+                g += [dgamma, dbeta]
+            grads.append(g)
+        flat = []
+        for g in reversed(grads):
+            flat += g
+        ctx.saved = None
+        return (dA, None, None) + tuple(flat)
+
+
+def _layer_params(conv_w, conv_b, bn):
+    W = conv_w.view(conv_w.shape[0], -1)
+    p = [W]
+    if conv_b is not None:
+        p.append(conv_b)
+    if bn is not None:
+        p += [bn.weight, bn.bias]
+    return p
+
+
+def shared_mlp_specs(mlp):
+    """(specs, params) of a pointnet2 SharedMLP (layer{i}.conv / .bn.bn / ReLU)."""
+    specs, params = [], []
+    for layer in mlp.children():
+        conv = layer.conv
+        bn = layer.bn.bn if hasattr(layer, "bn") else None
+        relu = hasattr(layer, "activation")
+        specs.append(LayerSpec(conv.bias is not None, bn, relu))
+        params += _layer_params(conv.weight, conv.bias, bn)
+    return specs, params
+
+
+def mlp_supported(specs, params):
+    """BN kernels need channel counts that are multiples of 4."""
+    pi = 0
+    for sp in specs:
+        W = params[pi]
+        pi += 1 + (1 if sp.has_bias else 0) + (2 if sp.bn is not None else 0)
+        if sp.bn is not None and W.shape[0] % 4 != 0:
+            return False
+    return True
+
+
+def mlp_rows(X, specs, params, pool_ns=0):
+    """Apply the layer stack to row-major X (M, Cin) -> (M or M/pool_ns, Cout)."""
+    return _MLPRows.apply(X, specs, pool_ns, *params)
+
+
+def sa_group_mlp_pool(xyz, new_xyz, feats_pm, idx, radius, normalize, mlp):
+    """One set-abstraction stage on point-major data.
+
+    xyz (B,N,3), new_xyz (B,m,3), feats_pm (B,N,C) or None, idx (B,m,ns) int32,
+    mlp: pointnet2 SharedMLP.  Returns pooled features (B, m, Cout) point-major.
+    """
+    B, m, ns = idx.shape
+    specs, params = shared_mlp_specs(mlp)
+    X = _GatherRows.apply(xyz, new_xyz, feats_pm, idx, radius, normalize)
+    out = mlp_rows(X, specs, params, pool_ns=ns)
+    return out.view(B, m, -1)

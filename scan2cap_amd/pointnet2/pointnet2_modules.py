@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import fused
 from . import pointnet2_utils
 from . import pytorch_utils as pt_utils
 
@@ -41,9 +42,37 @@ class PointnetSAModuleVotes(nn.Module):
             mlp_spec[0] += 3  # in place, like the reference (:206-207)
         self.mlp_module = pt_utils.SharedMLP(mlp_spec, bn=bn)
 
+    def _fused_ok(self, xyz):
+        if not (xyz.is_cuda and self.npoint is not None and self.pooling == "max"):
+            return False
+        specs, params = fused.shared_mlp_specs(self.mlp_module)
+        return len(specs) > 0 and specs[-1].bn is not None and specs[-1].relu \
+            and fused.mlp_supported(specs, params)
+
+    def _forward_fused(self, xyz, features, inds):
+        """MI355X path: point-major rows, no (B,C,npoint,nsample) tensors, no
+        transposes (the reference flips xyz twice around gather_points,
+        pointnet2_modules.py:233-240).  `features` (B,C,N) is consumed through its
+        (B,N,C) transposed VIEW, so a point-major producer costs no copy; the
+        returned features are likewise a (B,C,npoint) view of point-major data."""
+        if inds is None:
+            inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
+        else:
+            assert inds.shape[1] == self.npoint
+        new_xyz = torch.gather(xyz, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3))
+        idx = pointnet2_utils.ball_query(self.radius, self.nsample, xyz, new_xyz)
+        feats_pm = features.transpose(1, 2) if features is not None else None
+        if not self.use_xyz:
+            raise NotImplementedError("use_xyz=False is not on the CapNet path")
+        out = fused.sa_group_mlp_pool(xyz, new_xyz, feats_pm, idx, self.radius,
+                                      self.normalize_xyz, self.mlp_module)
+        return new_xyz, out.transpose(1, 2), inds
+
     def forward(self, xyz, features=None, inds=None):
         """xyz (B,N,3), features (B,C,N) -> new_xyz (B,npoint,3),
         new_features (B,mlp[-1],npoint), inds (B,npoint) int32."""
+        if self._fused_ok(xyz):
+            return self._forward_fused(xyz, features, inds)
         xyz_flipped = xyz.transpose(1, 2).contiguous()
         if inds is None:
             inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
@@ -91,5 +120,12 @@ class PointnetFPModule(nn.Module):
                 *known_feats.size()[0:2], unknown.size(1))
         new_features = (torch.cat([interpolated, unknow_feats], dim=1)
                         if unknow_feats is not None else interpolated)
+        if new_features.is_cuda:
+            specs, params = fused.shared_mlp_specs(self.mlp)
+            if fused.mlp_supported(specs, params):
+                B, C, n = new_features.shape
+                rows = new_features.transpose(1, 2).reshape(B * n, C)
+                out = fused.mlp_rows(rows, specs, params)
+                return out.view(B, n, -1).transpose(1, 2)
         new_features = self.mlp(new_features.unsqueeze(-1))
         return new_features.squeeze(-1)

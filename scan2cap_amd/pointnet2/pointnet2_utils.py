@@ -135,7 +135,7 @@ class QueryAndGroup(nn.Module):
         if self.normalize_xyz:
             grouped_xyz = grouped_xyz / self.radius
         if features is not None:
-            grouped_features = grouping_operation(features, idx)
+            grouped_features = grouping_operation(features.contiguous(), idx)
             new_features = (torch.cat([grouped_xyz, grouped_features], dim=1)
                             if self.use_xyz else grouped_features)
         else:
