@@ -125,8 +125,7 @@ class _MLPRows(Function):
     def forward(ctx, X, specs, pool_ns, *params):
         dev = X.device
         M = X.shape[0]
-        need_grad = torch.is_grad_enabled() and (
-            X.requires_grad or any(p.requires_grad for p in params))
+        need_grad = any(ctx.needs_input_grad)
         saved = []          # per layer dict of tensors needed in backward
         A = X
         pi = 0

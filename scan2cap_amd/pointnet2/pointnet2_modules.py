@@ -114,7 +114,7 @@ class PointnetFPModule(nn.Module):
             norm = torch.sum(dist_recip, dim=2, keepdim=True)
             weight = dist_recip / norm
             interpolated = pointnet2_utils.three_interpolate(
-                known_feats, idx, weight)
+                known_feats.contiguous(), idx, weight)
         else:
             interpolated = known_feats.expand(
                 *known_feats.size()[0:2], unknown.size(1))
