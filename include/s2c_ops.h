@@ -56,6 +56,15 @@ int s2c_furthest_point_sampling(int b, int n, int m, const float *xyz,
                                 float *temp, int *idx, s2c_stream_t stream);
 int s2c_fps_resident_limit(void);
 
+/* Spatially-bucketed exact FPS (csrc/s2c_fps_bucket.hip): identical output to
+ * s2c_furthest_point_sampling for every input, for large point sets.  Needs a
+ * caller-owned, 16-byte aligned scratch of s2c_fps_workspace_bytes(b, n) bytes
+ * (sorted points + tie-break ranks); nothing is allocated inside the library. */
+long long s2c_fps_workspace_bytes(int b, int n);
+int s2c_furthest_point_sampling_bucketed(int b, int n, int m, const float *xyz,
+                                         void *workspace, int *idx,
+                                         s2c_stream_t stream);
+
 /* replaces gather_points_kernel_wrapper (sampling.cpp:5-7, sampling_gpu.cu:22-30).
  * points (b,c,n), idx (b,npoints) -> out (b,c,npoints) */
 int s2c_gather_points(int b, int c, int n, int npoints, const float *points,

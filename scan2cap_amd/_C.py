@@ -19,6 +19,7 @@ _FLT = ctypes.c_float
 # name -> argtypes (all return int)
 _SIGNATURES = {
     "s2c_furthest_point_sampling": [_INT, _INT, _INT, _PTR, _PTR, _PTR, _PTR],
+    "s2c_furthest_point_sampling_bucketed": [_INT, _INT, _INT, _PTR, _PTR, _PTR, _PTR],
     "s2c_gather_points": [_INT, _INT, _INT, _INT, _PTR, _PTR, _PTR, _PTR],
     "s2c_gather_points_grad": [_INT, _INT, _INT, _INT, _PTR, _PTR, _PTR, _PTR],
     "s2c_ball_query": [_INT, _INT, _INT, _FLT, _INT, _PTR, _PTR, _PTR, _PTR],
@@ -52,6 +53,8 @@ def load():
     lib.s2c_abi_version.restype = _INT
     lib.s2c_last_error_string.restype = ctypes.c_char_p
     lib.s2c_fps_resident_limit.restype = _INT
+    lib.s2c_fps_workspace_bytes.restype = ctypes.c_longlong
+    lib.s2c_fps_workspace_bytes.argtypes = [_INT, _INT]
     for name, argtypes in _SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
@@ -62,7 +65,7 @@ def load():
 
 def declared_symbols():
     return ["s2c_abi_version", "s2c_last_error_string",
-            "s2c_fps_resident_limit"] + list(_SIGNATURES)
+            "s2c_fps_resident_limit", "s2c_fps_workspace_bytes"] + list(_SIGNATURES)
 
 
 def register(name, argtypes):

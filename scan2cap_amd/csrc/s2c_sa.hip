@@ -210,23 +210,31 @@ __global__ __launch_bounds__(STAT_BLOCK) void col_stats_kernel(
       M, C, partial, rows_per_block);
 }
 
-__global__ void bn_finalize_kernel(const float *__restrict__ partial, int nblk,
-                                   int C, long long M, float eps, float momentum,
-                                   const float *__restrict__ gamma,
-                                   const float *__restrict__ beta,
-                                   float *__restrict__ running_mean,
-                                   float *__restrict__ running_var,
-                                   float *__restrict__ scale,
-                                   float *__restrict__ shift,
-                                   float *__restrict__ save_mean,
-                                   float *__restrict__ save_invstd) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// one wave per channel: lanes stride over the partial blocks (double
+// accumulation, fixed order => deterministic), DPP-free shuffle tree to lane 0
+__device__ __forceinline__ void wave_sum2(double &a, double &b) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    a += __shfl_down(a, off, 64);
+    b += __shfl_down(b, off, 64);
+  }
+}
+
+__global__ __launch_bounds__(64) void bn_finalize_kernel(
+    const float *__restrict__ partial, int nblk, int C, long long M, float eps,
+    float momentum, const float *__restrict__ gamma,
+    const float *__restrict__ beta, float *__restrict__ running_mean,
+    float *__restrict__ running_var, float *__restrict__ scale,
+    float *__restrict__ shift, float *__restrict__ save_mean,
+    float *__restrict__ save_invstd) {
+  const int c = blockIdx.x;
   double s1 = 0.0, s2 = 0.0;
-  for (int k = 0; k < nblk; ++k) {
+  for (int k = threadIdx.x; k < nblk; k += 64) {
     s1 += (double)partial[(long long)k * 2 * C + c];
     s2 += (double)partial[(long long)k * 2 * C + C + c];
   }
+  wave_sum2(s1, s2);
+  if (threadIdx.x != 0) return;
   const double mean = s1 / (double)M;
   double var = s2 / (double)M - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -266,7 +274,7 @@ __global__ void bn_eval_coeffs_kernel(int C, float eps,
 
 static int stat_blocks(long long M, long long *rows_per_block) {
   long long nb = (M + 511) / 512;  // >= 512 rows per block
-  if (nb > 2048) nb = 2048;
+  if (nb > 1024) nb = 1024;
   if (nb < 1) nb = 1;
   *rows_per_block = (M + nb - 1) / nb;
   return (int)((M + *rows_per_block - 1) / *rows_per_block);
@@ -293,7 +301,7 @@ extern "C" int s2c_bn_train_stats(long long M, int C, const float *Y,
   const int nb = stat_blocks(M, &rpb);
   hipLaunchKernelGGL(col_stats_kernel, dim3(nb), dim3(STAT_BLOCK), 0, st, Y, M, C,
                      partial, rpb);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, st,
                      partial, nb, C, M, eps, momentum, gamma, beta, running_mean,
                      running_var, scale, shift, save_mean, save_invstd);
   return check2("bn_train_stats");
@@ -426,20 +434,19 @@ __global__ __launch_bounds__(STAT_BLOCK) void bn_bwd_stats_kernel(
 
 // sums -> dgamma (=s2), dbeta (=s1); also the per-channel coefficients used by
 // the apply pass: k0 = gamma*invstd, k1 = s1/M, k2 = s2/M (0 when frozen)
-__global__ void bn_bwd_finalize_kernel(const float *__restrict__ partial, int nblk,
-                                       int C, long long M, int frozen,
-                                       const float *__restrict__ gamma,
-                                       const float *__restrict__ invstd,
-                                       float *__restrict__ dgamma,
-                                       float *__restrict__ dbeta,
-                                       float *__restrict__ coef) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(
+    const float *__restrict__ partial, int nblk, int C, long long M, int frozen,
+    const float *__restrict__ gamma, const float *__restrict__ invstd,
+    float *__restrict__ dgamma, float *__restrict__ dbeta,
+    float *__restrict__ coef) {
+  const int c = blockIdx.x;
   double s1 = 0.0, s2 = 0.0;
-  for (int k = 0; k < nblk; ++k) {
+  for (int k = threadIdx.x; k < nblk; k += 64) {
     s1 += (double)partial[(long long)k * 2 * C + c];
     s2 += (double)partial[(long long)k * 2 * C + C + c];
   }
+  wave_sum2(s1, s2);
+  if (threadIdx.x != 0) return;
   if (dbeta) dbeta[c] = (float)s1;
   if (dgamma) dgamma[c] = (float)s2;
   coef[c] = (gamma ? gamma[c] : 1.0f) * invstd[c];
@@ -493,7 +500,7 @@ extern "C" int s2c_bn_relu_bwd(long long M, int C, const float *dA, const float 
   const int nb = stat_blocks(M, &rpb);
   hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(nb), dim3(STAT_BLOCK), 0, st, dA, Y,
                      scale, shift, mean, invstd, M, C, relu, partial, rpb);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st,
                      partial, nb, C, M, frozen, gamma, invstd, dgamma, dbeta, coef);
   const long long total4 = M * (C >> 2);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid1d(total4, 256)), dim3(256), 0,
@@ -581,7 +588,7 @@ extern "C" int s2c_bn_relu_max_bwd(long long J, int ns, int C, const float *dOut
   const long long M = J * ns;
   hipLaunchKernelGGL(pool_bwd_stats_kernel, dim3(nb), dim3(STAT_BLOCK), 0, st, dOut,
                      arg, Y, scale, shift, mean, invstd, J, ns, C, partial, rpb);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st,
                      partial, nb, C, M, frozen, gamma, invstd, dgamma, dbeta, coef);
   const long long total4 = M * (C >> 2);
   hipLaunchKernelGGL(pool_bwd_apply_kernel, dim3(grid1d(total4, 256)), dim3(256), 0,

@@ -64,17 +64,41 @@ def gather_points_grad(grad_out, idx, n):
     return out
 
 
+# point sets at least this large take the spatially-bucketed exact kernel
+# (csrc/s2c_fps_bucket.hip); smaller ones stay register-resident (csrc/s2c_ops.hip)
+FPS_BUCKET_MIN_N = 8192
+
+
 def furthest_point_sampling(points, nsamples):
     """sampling.cpp:66-87.  (B,N,3) f32 -> (B,nsamples) i32"""
     _chk_f(points, "points")
     b, n, _ = points.shape
     out = torch.empty((b, nsamples), dtype=torch.int32, device=points.device)
+    ab = 4 * (3 * b * n + b * nsamples)
+    if n >= FPS_BUCKET_MIN_N:
+        ws = torch.empty(_C.load().s2c_fps_workspace_bytes(b, n), dtype=torch.uint8,
+                         device=points.device)
+        _run("s2c_furthest_point_sampling_bucketed", points, b, n, int(nsamples),
+             points.data_ptr(), ws.data_ptr(), out.data_ptr(), alg_bytes=ab)
+        return out
     temp = None
     if n > _C.load().s2c_fps_resident_limit():
         temp = torch.empty((b, n), dtype=torch.float32, device=points.device)
     _run("s2c_furthest_point_sampling", points, b, n, int(nsamples),
          points.data_ptr(), temp.data_ptr() if temp is not None else None,
-         out.data_ptr(), alg_bytes=4 * (3 * b * n + b * nsamples))
+         out.data_ptr(), alg_bytes=ab)
+    return out
+
+
+def furthest_point_sampling_bruteforce(points, nsamples):
+    """The register-resident / streaming brute-force kernel regardless of size
+    (kept callable for A/B parity tests against the bucketed kernel)."""
+    _chk_f(points, "points")
+    b, n, _ = points.shape
+    out = torch.empty((b, nsamples), dtype=torch.int32, device=points.device)
+    temp = torch.empty((b, n), dtype=torch.float32, device=points.device)
+    _run("s2c_furthest_point_sampling", points, b, n, int(nsamples),
+         points.data_ptr(), temp.data_ptr(), out.data_ptr())
     return out
 
 

@@ -246,7 +246,7 @@ class _MLPRows(Function):
                 dY = dA * (rec["Y"] > 0)
             else:
                 dY = dA
-            dW = torch.mm(dY.t(), A_in)
+            dW = _weight_grad(dY, A_in)
             dbias = dY.sum(0) if rec["has_bias"] else None
             need_dA = li > 0 or ctx.x_needs_grad
             dA = torch.mm(dY, W) if need_dA else None
@@ -261,6 +261,21 @@ class _MLPRows(Function):
             flat += g
         ctx.saved = None
         return (dA, None, None) + tuple(flat)
+
+
+def _weight_grad(dY, A):
+    """dW (Cout,Cin) = dY^T (Cout,M) @ A (M,Cin) with M up to ~1e6 and a tiny
+    output: a plain GEMM call gives the library ONE output tile and a million-deep
+    K loop (a single workgroup).  Split the row dimension into S independent
+    slabs (strided-batched GEMM fills the chip) and reduce the S partials."""
+    M = dY.shape[0]
+    S = 1
+    while S < 512 and M % (2 * S) == 0 and M // (2 * S) >= 1024:
+        S *= 2
+    if S == 1:
+        return torch.mm(dY.t(), A)
+    part = torch.bmm(dY.view(S, M // S, -1).transpose(1, 2), A.view(S, M // S, -1))
+    return part.sum(0)
 
 
 def _layer_params(conv_w, conv_b, bn):

@@ -26,7 +26,10 @@ FPS_CASES = [
     (2, 2048, 1024, "volume"),    # SA2 shape
     (4, 4096, 512, "surface"),    # cfg1-like
     (1, 20000, 256, "volume"),    # streaming path, PPT=24
-    (2, 40000, 2048, "volume"),   # SA1 shape (cfg2/cfg3)
+    (2, 40000, 2048, "volume"),   # SA1 shape (cfg2/cfg3) -> bucketed kernel
+    (2, 40000, 2048, "surface"),
+    (1, 80000, 2048, "volume"),   # cfg5 shape
+    (3, 9000, 700, "surface"),
 ]
 
 
@@ -37,6 +40,30 @@ def test_fps_bit_exact(ext, oracle, B, N, m, mode):
     got = ext.furthest_point_sampling(dev(xyz), m).cpu().numpy()
     assert got.dtype == np.int32
     np.testing.assert_array_equal(got, want)
+
+
+def test_fps_bucketed_adversarial(ext, oracle):
+    """Inputs built to stress the bucket pruning: tight clusters (many points per
+    cell), all points identical (one cell, ties everywhere), a regular lattice
+    (masses of bit-equal distances across cells), mostly-skipped scenes."""
+    rng = np.random.default_rng(0)
+    N = 12000
+    centers = rng.uniform(-3, 3, size=(6, 3))
+    clustered = (centers[rng.integers(0, 6, N)] +
+                 rng.normal(0, 0.02, size=(N, 3))).astype(np.float32)[None]
+    same = np.full((1, N, 3), 1.25, np.float32)
+    g = np.stack(np.meshgrid(np.arange(25), np.arange(24), np.arange(20),
+                             indexing="ij"), -1).reshape(1, -1, 3)
+    lattice = (g.astype(np.float32) * 0.125 + 0.5)
+    skipped = rng.uniform(-0.02, 0.02, size=(1, N, 3)).astype(np.float32)
+    skipped[0, 5000:5040] = rng.uniform(1, 2, size=(40, 3))
+    for name, xyz in (("clustered", clustered), ("same", same),
+                      ("lattice", lattice), ("skipped", skipped)):
+        want = oracle.furthest_point_sampling(xyz, 300)
+        got = ext.furthest_point_sampling(dev(xyz), 300).cpu().numpy()
+        np.testing.assert_array_equal(got, want, err_msg=name)
+        brute = ext.furthest_point_sampling_bruteforce(dev(xyz), 300).cpu().numpy()
+        np.testing.assert_array_equal(brute, want, err_msg=name + " (brute)")
 
 
 def test_fps_degenerate(ext, oracle):
