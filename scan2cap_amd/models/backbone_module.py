@@ -1,6 +1,7 @@
 """PointNet++ backbone (4 SA + 2 FP), drop-in for models/backbone_module.py:11-127.
 Same constructor, same `data_dict` keys, same state_dict names (sa1..sa4, fp1, fp2).
 """
+import torch
 import torch.nn as nn
 
 from ..pointnet2.pointnet2_modules import PointnetFPModule, PointnetSAModuleVotes
@@ -36,18 +37,40 @@ class Pointnet2Backbone(nn.Module):
         features = pc[..., 3:].transpose(1, 2) if pc.size(-1) > 3 else None
         return xyz, features
 
+    def compute_geometry(self, point_clouds):
+        """Everything in the backbone that depends on xyz only: the FPS chain, the
+        four ball queries and the two 3-NN searches.  No features, no weights, no
+        gradient -- so it can run one batch ahead on a side stream (8 CUs busy)
+        while the previous batch's GEMMs own the rest of the chip."""
+        with torch.no_grad():
+            xyz = point_clouds[..., :3].contiguous()
+            geo = {}
+            for i in (1, 2, 3, 4):
+                g = getattr(self, "sa%d" % i).geometry(xyz)
+                geo["sa%d" % i] = g
+                xyz = g[1]
+            geo["fp1"] = PointnetFPModule.geometry(geo["sa3"][1], geo["sa4"][1])
+            geo["fp2"] = PointnetFPModule.geometry(geo["sa2"][1], geo["sa3"][1])
+        return geo
+
     def forward(self, data_dict):
         xyz, features = self._break_up_pc(data_dict["point_clouds"])
+        geo = data_dict.get("_geometry")
+        if geo is None and xyz.is_cuda:
+            geo = self.compute_geometry(data_dict["point_clouds"])
         for i in (1, 2, 3, 4):
-            xyz, features, inds = getattr(self, "sa%d" % i)(xyz, features)
+            xyz, features, inds = getattr(self, "sa%d" % i)(
+                xyz, features, geom=None if geo is None else geo["sa%d" % i])
             if i <= 2:
                 data_dict["sa%d_inds" % i] = inds
             data_dict["sa%d_xyz" % i] = xyz
             data_dict["sa%d_features" % i] = features
         features = self.fp1(data_dict["sa3_xyz"], data_dict["sa4_xyz"],
-                            data_dict["sa3_features"], data_dict["sa4_features"])
+                            data_dict["sa3_features"], data_dict["sa4_features"],
+                            geom=None if geo is None else geo["fp1"])
         features = self.fp2(data_dict["sa2_xyz"], data_dict["sa3_xyz"],
-                            data_dict["sa2_features"], features)
+                            data_dict["sa2_features"], features,
+                            geom=None if geo is None else geo["fp2"])
         data_dict["fp2_features"] = features
         data_dict["fp2_xyz"] = data_dict["sa2_xyz"]
         num_seed = data_dict["fp2_xyz"].shape[1]

@@ -49,18 +49,28 @@ class PointnetSAModuleVotes(nn.Module):
         return len(specs) > 0 and specs[-1].bn is not None and specs[-1].relu \
             and fused.mlp_supported(specs, params)
 
-    def _forward_fused(self, xyz, features, inds):
+    def geometry(self, xyz, inds=None):
+        """The xyz-only part of the stage: FPS -> centres -> ball query.  It does
+        not depend on features or weights, so a pipeline can compute it ahead of
+        time on another stream (scan2cap_amd/pipeline.py)."""
+        if inds is None:
+            inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
+        new_xyz = torch.gather(xyz, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3))
+        idx = pointnet2_utils.ball_query(self.radius, self.nsample, xyz, new_xyz)
+        return inds, new_xyz, idx
+
+    def _forward_fused(self, xyz, features, inds, geom=None):
         """MI355X path: point-major rows, no (B,C,npoint,nsample) tensors, no
         transposes (the reference flips xyz twice around gather_points,
         pointnet2_modules.py:233-240).  `features` (B,C,N) is consumed through its
         (B,N,C) transposed VIEW, so a point-major producer costs no copy; the
         returned features are likewise a (B,C,npoint) view of point-major data."""
-        if inds is None:
-            inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
+        if geom is not None:
+            inds, new_xyz, idx = geom
         else:
-            assert inds.shape[1] == self.npoint
-        new_xyz = torch.gather(xyz, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3))
-        idx = pointnet2_utils.ball_query(self.radius, self.nsample, xyz, new_xyz)
+            if inds is not None:
+                assert inds.shape[1] == self.npoint
+            inds, new_xyz, idx = self.geometry(xyz, inds)
         feats_pm = features.transpose(1, 2) if features is not None else None
         if not self.use_xyz:
             raise NotImplementedError("use_xyz=False is not on the CapNet path")
@@ -68,11 +78,14 @@ class PointnetSAModuleVotes(nn.Module):
                                       self.normalize_xyz, self.mlp_module)
         return new_xyz, out.transpose(1, 2), inds
 
-    def forward(self, xyz, features=None, inds=None):
+    def forward(self, xyz, features=None, inds=None, geom=None):
         """xyz (B,N,3), features (B,C,N) -> new_xyz (B,npoint,3),
-        new_features (B,mlp[-1],npoint), inds (B,npoint) int32."""
+        new_features (B,mlp[-1],npoint), inds (B,npoint) int32.
+        `geom` = precomputed (inds, new_xyz, idx) from `geometry()` (optional)."""
         if self._fused_ok(xyz):
-            return self._forward_fused(xyz, features, inds)
+            return self._forward_fused(xyz, features, inds, geom)
+        if geom is not None:
+            inds = geom[0]
         xyz_flipped = xyz.transpose(1, 2).contiguous()
         if inds is None:
             inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
@@ -107,12 +120,18 @@ class PointnetFPModule(nn.Module):
         super().__init__()
         self.mlp = pt_utils.SharedMLP(mlp, bn=bn)
 
-    def forward(self, unknown, known, unknow_feats, known_feats):
+    @staticmethod
+    def geometry(unknown, known):
+        """xyz-only part: 3-NN indices and inverse-distance weights
+        (pointnet2_modules.py:394-397)."""
+        dist, idx = pointnet2_utils.three_nn(unknown, known)
+        dist_recip = 1.0 / (dist + 1e-8)
+        norm = torch.sum(dist_recip, dim=2, keepdim=True)
+        return idx, dist_recip / norm
+
+    def forward(self, unknown, known, unknow_feats, known_feats, geom=None):
         if known is not None:
-            dist, idx = pointnet2_utils.three_nn(unknown, known)
-            dist_recip = 1.0 / (dist + 1e-8)
-            norm = torch.sum(dist_recip, dim=2, keepdim=True)
-            weight = dist_recip / norm
+            idx, weight = geom if geom is not None else self.geometry(unknown, known)
             interpolated = pointnet2_utils.three_interpolate(
                 known_feats.contiguous(), idx, weight)
         else:

@@ -85,3 +85,20 @@ def test_mlp_rows_with_bias_and_linear_tail():
     assert _rel(conv1.weight.grad, gw_ref) < 1e-4
     assert _rel(x.grad, gx_ref) < 1e-4
     assert _rel(bn1.running_var, bn2.running_var) < 1e-5
+
+
+def test_geometry_pipeline_matches_inline():
+    """Geometry computed ahead on a side stream == geometry computed in-line."""
+    from scan2cap_amd.models.backbone_module import Pointnet2Backbone
+    from scan2cap_amd.pipeline import GeometryPipeline
+    torch.manual_seed(0)
+    net = Pointnet2Backbone(input_feature_dim=4).cuda().eval()
+    pc = torch.cat([torch.from_numpy(scene_xyz(2, 8192, seed=4)).cuda(),
+                    torch.randn(2, 8192, 4, device="cuda")], -1)
+    with torch.no_grad():
+        want = net({"point_clouds": pc})
+        pipe = GeometryPipeline(net)
+        dd = pipe.attach({"point_clouds": pc}, pipe.submit(pc))
+        got = net(dd)
+    for k in ("sa1_inds", "sa2_inds", "sa4_xyz", "fp2_features", "sa1_features"):
+        assert torch.equal(got[k], want[k]), k
