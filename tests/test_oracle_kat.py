@@ -1,0 +1,246 @@
+"""Pins the CPU oracle (oracle/s2c_oracle.c) WITHOUT a GPU:
+  * the one vector the reference's own tests hold on this path
+    (lib/pointnet2/pointnet2_test.py:18-30, three_interpolate + its gradient);
+  * hand-derived known answers for every tie / padding / skip rule;
+  * an independent pure-Python/numpy restatement written from the .cu sources
+    (thread-by-thread emulation, no shared code with the C oracle).
+Also checks that libs2c_hip.so loads and exports every symbol include/*.h declares.
+"""
+import glob
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+f32 = np.float32
+
+
+# ---------------------------------------------------------------------------
+# independent restatement (python loops, per-thread emulation)
+# ---------------------------------------------------------------------------
+def py_opt_n_threads(n):
+    import math
+    p = int(math.log(float(n)) / math.log(2.0))
+    return max(min(1 << p, 512), 1)
+
+
+def sq(a):
+    return f32(a) * f32(a)
+
+
+def py_fps(xyz, m):
+    """sampling_gpu.cu:69-173 emulated thread by thread."""
+    n = len(xyz)
+    bs = py_opt_n_threads(n)
+    temp = np.full(n, 1e10, f32)
+    out = [0]
+    old = 0
+    for _ in range(1, m):
+        dists = np.full(bs, -1.0, f32)
+        dists_i = np.zeros(bs, np.int64)
+        x1, y1, z1 = xyz[old]
+        for t in range(bs):
+            best, besti = f32(-1.0), 0
+            for k in range(t, n, bs):
+                x2, y2, z2 = xyz[k]
+                mag = f32(f32(sq(x2) + sq(y2)) + sq(z2))
+                if float(mag) <= 1e-3:
+                    continue
+                d = f32(f32(sq(f32(x2 - x1)) + sq(f32(y2 - y1))) + sq(f32(z2 - z1)))
+                d2 = min(d, temp[k])
+                temp[k] = d2
+                if d2 > best:
+                    best, besti = d2, k
+            dists[t], dists_i[t] = best, besti
+        h = bs // 2
+        while h >= 1:
+            for t in range(h):
+                v1, v2 = dists[t], dists[t + h]
+                i1, i2 = dists_i[t], dists_i[t + h]
+                dists[t] = max(v1, v2)
+                dists_i[t] = i2 if v2 > v1 else i1
+            h //= 2
+        old = int(dists_i[0])
+        out.append(old)
+    return np.array(out, np.int32)
+
+
+def py_ball_query(new_xyz, xyz, radius, ns):
+    r2 = f32(radius) * f32(radius)
+    out = np.zeros((len(new_xyz), ns), np.int32)
+    for j, c in enumerate(new_xyz):
+        cnt = 0
+        for k, p in enumerate(xyz):
+            if cnt >= ns:
+                break
+            d2 = f32(f32(sq(f32(c[0] - p[0])) + sq(f32(c[1] - p[1]))) + sq(f32(c[2] - p[2])))
+            if d2 < r2:
+                if cnt == 0:
+                    out[j, :] = k
+                out[j, cnt] = k
+                cnt += 1
+    return out
+
+
+def py_three_nn(unknown, known):
+    d_out = np.zeros((len(unknown), 3), f32)
+    i_out = np.zeros((len(unknown), 3), np.int32)
+    for j, u in enumerate(unknown):
+        best = [1e40, 1e40, 1e40]
+        bi = [0, 0, 0]
+        for k, p in enumerate(known):
+            d = float(f32(f32(sq(f32(u[0] - p[0])) + sq(f32(u[1] - p[1]))) + sq(f32(u[2] - p[2]))))
+            if d < best[0]:
+                best = [d, best[0], best[1]]; bi = [k, bi[0], bi[1]]
+            elif d < best[1]:
+                best = [best[0], d, best[1]]; bi = [bi[0], k, bi[1]]
+            elif d < best[2]:
+                best[2] = d; bi[2] = k
+        d_out[j] = np.array(best, np.float64).astype(f32)
+        i_out[j] = bi
+    return d_out, i_out
+
+
+# ---------------------------------------------------------------------------
+def test_reference_kat_three_interpolate(oracle):
+    """lib/pointnet2/pointnet2_test.py:18-30."""
+    feats = np.arange(8, dtype=f32).reshape(1, 2, 4)
+    idx = np.array([[[0, 1, 2], [1, 2, 3]]], np.int32)
+    w = np.array([[[1, 1, 1], [2, 2, 2]]], f32)
+    out = oracle.three_interpolate(feats, idx, w)
+    want = np.stack([feats[:, :, 0] + feats[:, :, 1] + feats[:, :, 2],
+                     2 * (feats[:, :, 1] + feats[:, :, 2] + feats[:, :, 3])], -1)
+    np.testing.assert_array_equal(out, want)
+    g = oracle.three_interpolate_grad(np.ones((1, 2, 2), f32), idx, w, 4)
+    np.testing.assert_array_equal(g, np.array([[[1, 3, 3, 2]] * 2], f32))
+
+
+def test_fps_known_answers(oracle):
+    # points on a line 1..16: start at idx 0, then the far end, then the middle ...
+    x = np.arange(1, 17, dtype=f32)
+    xyz = np.stack([x, np.zeros_like(x), np.zeros_like(x)], -1)[None]
+    got = oracle.furthest_point_sampling(xyz, 5)[0]
+    assert got[0] == 0 and got[1] == 15
+    assert got[2] in (7, 8)   # equidistant pair: decided by the tree tie rule below
+    np.testing.assert_array_equal(got, py_fps(xyz[0], 5))
+    # skip rule: |p|^2 <= 1e-3 points are never selected, never updated
+    xyz = np.array([[[1, 0, 0], [0.01, 0.01, 0.01], [5, 0, 0], [0, 0, 0], [3, 0, 0]]], f32)
+    got = oracle.furthest_point_sampling(xyz, 4)[0]
+    assert set(got.tolist()) == {0, 2, 4} or got.tolist() == [0, 2, 4, 0]
+    assert 1 not in got and 3 not in got
+    # every point skipped -> index 0 forever (besti initialised to 0, :90)
+    assert (oracle.furthest_point_sampling(np.zeros((1, 40, 3), f32), 6) == 0).all()
+
+
+@pytest.mark.parametrize("n,m,seed", [(37, 12, 0), (64, 20, 1), (300, 25, 2), (700, 18, 3)])
+def test_fps_matches_thread_emulation(oracle, n, m, seed):
+    rng = np.random.default_rng(seed)
+    xyz = rng.uniform(-2, 2, size=(n, 3)).astype(f32)
+    xyz[rng.integers(0, n, 5)] = xyz[rng.integers(0, n, 5)]      # exact duplicates
+    xyz[3] = 0.0
+    np.testing.assert_array_equal(oracle.furthest_point_sampling(xyz[None], m)[0],
+                                  py_fps(xyz, m))
+
+
+def test_fps_tie_rule_bit_reversal(oracle):
+    """All points identical: every candidate ties; the reference tree keeps the
+    lower slot at each level, i.e. thread 0's first point -> always index 0;
+    with point 0 skipped the winner is the thread with the smallest bit-reversed
+    id among the rest."""
+    xyz = np.ones((1, 16, 3), f32)
+    assert (oracle.furthest_point_sampling(xyz, 5) == 0).all()
+    xyz[0, 0] = 0.0    # skipped
+    got = oracle.furthest_point_sampling(xyz, 3)[0]
+    # bs=16: bit-reversed ids 1..15 -> smallest is thread 8 (1000b -> 0001b)
+    assert got.tolist() == [0, 8, 8]
+    np.testing.assert_array_equal(got, py_fps(xyz[0], 3))
+
+
+def test_ball_query_known_answers(oracle):
+    g = np.stack(np.meshgrid(np.arange(4), np.arange(4), np.arange(4), indexing="ij"),
+                 -1).reshape(-1, 3).astype(f32)
+    c = np.array([[1, 1, 1]], f32)
+    # radius 1.0 is strict: only the centre itself (d2 = 0 < 1) -> row padded with it
+    idx = oracle.ball_query(c[None], g[None], 1.0, 5)[0, 0]
+    centre = int(np.where((g == c[0]).all(1))[0][0])
+    assert idx.tolist() == [centre] * 5
+    # radius just above 1: centre + 6 face neighbours, ascending index, padded with first hit
+    idx = oracle.ball_query(c[None], g[None], 1.0001, 9)[0, 0]
+    d2 = ((g - c[0]) ** 2).sum(1)
+    hits = np.nonzero(d2 < 1.0001 ** 2)[0]
+    assert len(hits) == 7
+    assert idx.tolist() == hits.tolist() + [hits[0]] * 2
+    # early exit at nsample
+    idx = oracle.ball_query(c[None], g[None], 10.0, 3)[0, 0]
+    assert idx.tolist() == [0, 1, 2]
+    # no hit: zeros
+    assert (oracle.ball_query(np.full((1, 1, 3), 99, f32), g[None], 0.5, 4) == 0).all()
+    rng = np.random.default_rng(0)
+    xyz = rng.uniform(0, 1, (200, 3)).astype(f32)
+    q = xyz[rng.integers(0, 200, 20)]
+    np.testing.assert_array_equal(oracle.ball_query(q[None], xyz[None], 0.25, 8)[0],
+                                  py_ball_query(q, xyz, 0.25, 8))
+
+
+def test_three_nn_ties_and_restatement(oracle):
+    known = np.array([[0, 0, 0], [1, 0, 0], [1, 0, 0], [2, 0, 0], [-1, 0, 0]], f32)
+    unknown = np.array([[1, 0, 0], [0.5, 0, 0]], f32)
+    d, i = oracle.three_nn(unknown[None], known[None])
+    assert i[0, 0].tolist() == [1, 2, 0]          # duplicates keep the earlier index first
+    assert i[0, 1].tolist() == [0, 1, 2]          # d=0.25 ties: strict '<' keeps order
+    rng = np.random.default_rng(1)
+    u = rng.uniform(-1, 1, (50, 3)).astype(f32)
+    k = rng.uniform(-1, 1, (30, 3)).astype(f32)
+    d, i = oracle.three_nn(u[None], k[None])
+    dw, iw = py_three_nn(u, k)
+    np.testing.assert_array_equal(i[0], iw)
+    np.testing.assert_array_equal(d[0], dw)
+    # fewer than 3 known points: +inf distances, index 0 (1e40 sentinel -> float inf)
+    d, i = oracle.three_nn(u[None, :2], k[None, :1])
+    assert np.isinf(d[0, :, 1:]).all() and (i[0, :, 1:] == 0).all()
+
+
+def test_gather_group_and_grads(oracle):
+    rng = np.random.default_rng(2)
+    pts = rng.standard_normal((2, 3, 10)).astype(f32)
+    idx = rng.integers(0, 10, (2, 4)).astype(np.int32)
+    np.testing.assert_array_equal(oracle.gather_points(pts, idx),
+                                  np.take_along_axis(pts, idx[:, None, :].repeat(3, 1), 2))
+    idx2 = rng.integers(0, 10, (2, 4, 5)).astype(np.int32)
+    want = np.stack([pts[b][:, idx2[b]] for b in range(2)])
+    np.testing.assert_array_equal(oracle.group_points(pts, idx2), want)
+    g = rng.standard_normal((2, 3, 4, 5)).astype(f32)
+    want = np.zeros((2, 3, 10), np.float64)
+    for b in range(2):
+        for j in range(4):
+            for k in range(5):
+                want[b, :, idx2[b, j, k]] += g[b, :, j, k]
+    np.testing.assert_allclose(oracle.group_points_grad(g, idx2, 10), want, atol=1e-5)
+    g1 = rng.standard_normal((2, 3, 4)).astype(f32)
+    want = np.zeros((2, 3, 10), np.float64)
+    for b in range(2):
+        for j in range(4):
+            want[b, :, idx[b, j]] += g1[b, :, j]
+    np.testing.assert_allclose(oracle.gather_points_grad(g1, idx, 10), want, atol=1e-5)
+
+
+def test_opt_n_threads(oracle):
+    for n in (1, 2, 3, 7, 8, 31, 32, 33, 511, 512, 513, 4096, 40000, 80000):
+        assert oracle.opt_n_threads(n) == py_opt_n_threads(n)
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    """libs2c_hip.so loads without a GPU and exports everything include/*.h declares."""
+    from scan2cap_amd import _C, build
+    build.build()
+    lib = _C.load()
+    declared = set()
+    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        txt = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        declared |= set(re.findall(r"\b(s2c_[a-z0-9_]+)\s*\(", txt))
+    assert len(declared) >= 20
+    for sym in sorted(declared):
+        assert hasattr(lib, sym), "missing export: " + sym
+    assert lib.s2c_abi_version() == 1
