@@ -82,6 +82,44 @@ int s2c_bn_relu_max_bwd(long long J, int ns, int C, const float *dOut,
                         const float *gamma, int frozen, float *partial, float *coef,
                         float *dgamma, float *dbeta, float *dY, void *stream);
 
+/* ---- teacher-forced top-down caption decoder (csrc/s2c_decoder.hip) -------
+ * Small-batch (R <= a few dozen rows) building blocks of one recurrent step of
+ * TopDownSceneCaptionModule._step (models/caption_module.py:250-292) and of its
+ * back-propagation through time.  All matrices row-major fp32; feature counts
+ * and leading dimensions multiples of 4. */
+
+/* out[r,o] = epi( W[o,:I] . x[r,:I] + bias[o] + add1[r,o] + add2[r,o] );
+ * epi: 0 none, 1 ReLU, 2 multiply by (gate[r,o] > 0).  Null pointers skip a term. */
+int s2c_small_linear(int R, int O, int I, const float *W, int ldw, const float *x,
+                     int ldx, const float *bias, const float *add1, int ld1,
+                     const float *add2, int ld2, const float *gate, int ldg, int epi,
+                     float *out, int ldo, void *stream);
+
+/* torch.nn.GRUCell forward; saves r, z, n and gh_n (R x H each) for backward */
+int s2c_gru_fwd(int R, int H, int I, const float *Wih, const float *Whh,
+                const float *bih, const float *bhh, const float *x, int ldx,
+                const float *h, float *hnew, float *sr, float *sz, float *sn,
+                float *sghn, void *stream);
+
+/* gate part of GRUCell backward: dh' = dh1 (+ dh2) -> dgi, dgh (R x 3H),
+ * dh_direct = dh' * z */
+int s2c_gru_gates_bwd(int R, int H, const float *dh1, const float *dh2,
+                      const float *sr, const float *sz, const float *sn,
+                      const float *sghn, const float *hprev, float *dgi, float *dgh,
+                      float *dh_direct, void *stream);
+
+/* additive attention: scores -> masked softmax alpha (R x K) -> att (R x F) */
+int s2c_attn_fwd(int R, int K, int H, int F, const float *M, const float *q, int ldq,
+                 const float *wa, const float *mask, const float *O, float *scores,
+                 float *alpha, float *att, int lda, void *stream);
+
+/* its backward from datt (R x F): ds scratch (R x K); dq (R x H) overwritten;
+ * dO (R x K x F), dM (R x K x H) and dwa (H) ACCUMULATE */
+int s2c_attn_bwd(int R, int K, int H, int F, const float *datt, int ldd,
+                 const float *alpha, const float *O, const float *M, const float *q,
+                 int ldq, const float *wa, float *ds, float *dO, float *dM, float *dq,
+                 float *dwa, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

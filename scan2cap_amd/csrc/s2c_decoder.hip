@@ -1,0 +1,360 @@
+// s2c_decoder.hip -- kernels for the teacher-forced top-down caption decoder
+// (models/caption_module.py:250-292 `_step`, :428-500 `_forward_sample_batch`).
+//
+// In training the decoder advances R = batch-size rows (8 at the benchmark
+// configuration) through T <= 31 strictly sequential steps.  Each step is ~10
+// MFLOP per row: far too little for library GEMMs -- the reference (and a naive
+// port) spends it in ~25 forward + ~50 backward micro-kernels per step whose cost
+// is launch latency, not work.  Here a step is 7 forward / 11 backward launches of
+// purpose-built kernels, the step-invariant pieces are hoisted into a few large
+// GEMMs outside the loop (word / target projections, classifier, every weight
+// gradient), and the whole sequence replays from a hipGraph.
+//
+// Lane layout of the small-batch matrix-vector kernels: a wave owns one output
+// feature; lane = (row r = lane & 7, chunk c = lane >> 3).  The 8 chunk lanes of a
+// row read consecutive float4s of the weight row (128 B per load instruction, the
+// 8 row lanes of a chunk share the address), each lane accumulates its row's
+// partial dot product, and 3 xor-shuffles fold the chunks.  R <= 8 rows per pass.
+#include "s2c_common.h"
+#include "../../include/s2c_fused.h"
+
+#include <stdio.h>
+
+using namespace s2c;
+
+namespace {
+
+constexpr int RB = 8;  // rows per pass
+
+__device__ __forceinline__ float fold_chunks(float v) {
+  v += __shfl_xor(v, 8, 64);
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// partial dot product of one weight row with this lane's input row
+__device__ __forceinline__ float dot_row(const float *__restrict__ w,
+                                         const float *__restrict__ x, int n4,
+                                         int chunk) {
+  float acc = 0.0f;
+  for (int j = chunk; j < n4; j += 8) {
+    const float4 a = reinterpret_cast<const float4 *>(w)[j];
+    const float4 b = reinterpret_cast<const float4 *>(x)[j];
+    acc += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+  }
+  return acc;
+}
+
+// ---------------------------------------------------------------------------
+// out[r, o] = epi( sum_i W[o, i] * x[r, i] + bias[o] + add1[r, o] + add2[r, o] )
+// epi: 0 none, 1 relu, 2 multiply by (gate[r, o] > 0)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void small_linear_kernel(
+    int R, int O, int I, const float *__restrict__ W, int ldw,
+    const float *__restrict__ x, int ldx, const float *__restrict__ bias,
+    const float *__restrict__ add1, int ld1, const float *__restrict__ add2,
+    int ld2, const float *__restrict__ gate, int ldg, int epi,
+    float *__restrict__ out, int ldo) {
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 7, chunk = lane >> 3;
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int rbase = blockIdx.y * RB;
+  const int row = rbase + r;
+  if (o >= O) return;
+  const int rowc = row < R ? row : R - 1;
+  float acc = dot_row(W + (size_t)o * ldw, x + (size_t)rowc * ldx, I >> 2, chunk);
+  acc = fold_chunks(acc);
+  if (chunk == 0 && row < R) {
+    if (bias) acc += bias[o];
+    if (add1) acc += add1[(size_t)row * ld1 + o];
+    if (add2) acc += add2[(size_t)row * ld2 + o];
+    if (epi == 1) acc = fmaxf(acc, 0.0f);
+    else if (epi == 2) acc = gate[(size_t)row * ldg + o] > 0.0f ? acc : 0.0f;
+    out[(size_t)row * ldo + o] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// GRUCell forward (torch.nn.GRUCell semantics):
+//   gi = W_ih x + b_ih ; gh = W_hh h + b_hh          (gate order r, z, n)
+//   r = sig(gi_r + gh_r) ; z = sig(gi_z + gh_z) ; n = tanh(gi_n + r * gh_n)
+//   h' = (1 - z) * n + z * h
+// One wave per hidden unit; saves r, z, n and gh_n (bias included) for BPTT.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gru_fwd_kernel(
+    int R, int H, int I, const float *__restrict__ Wih,
+    const float *__restrict__ Whh, const float *__restrict__ bih,
+    const float *__restrict__ bhh, const float *__restrict__ x, int ldx,
+    const float *__restrict__ h, float *__restrict__ hnew,
+    float *__restrict__ sr, float *__restrict__ sz, float *__restrict__ sn,
+    float *__restrict__ sghn) {
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 7, chunk = lane >> 3;
+  const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int row = blockIdx.y * RB + r;
+  if (u >= H) return;
+  const int rowc = row < R ? row : R - 1;
+  const float *xr = x + (size_t)rowc * ldx;
+  const float *hr = h + (size_t)rowc * H;
+  float g[6];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    g[k] = dot_row(Wih + (size_t)(k * H + u) * I, xr, I >> 2, chunk);
+    g[3 + k] = dot_row(Whh + (size_t)(k * H + u) * H, hr, H >> 2, chunk);
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) g[k] = fold_chunks(g[k]);
+  if (chunk == 0 && row < R) {
+    const float gir = g[0] + bih[u], giz = g[1] + bih[H + u], gin = g[2] + bih[2 * H + u];
+    const float ghr = g[3] + bhh[u], ghz = g[4] + bhh[H + u], ghn = g[5] + bhh[2 * H + u];
+    const float rr = sigmoidf_(gir + ghr);
+    const float zz = sigmoidf_(giz + ghz);
+    const float nn = tanhf(gin + rr * ghn);
+    const float hp = hr[u];
+    const size_t e = (size_t)row * H + u;
+    hnew[e] = (1.0f - zz) * nn + zz * hp;
+    sr[e] = rr; sz[e] = zz; sn[e] = nn; sghn[e] = ghn;
+  }
+}
+
+// GRUCell backward, gate part (elementwise over R x H):
+//   dgi = [dpre_r, dpre_z, dpre_n] ; dgh = [dpre_r, dpre_z, dpre_n * r]
+//   dh_direct = dh' * z
+__global__ __launch_bounds__(256) void gru_gates_bwd_kernel(
+    int R, int H, const float *__restrict__ dh1, const float *__restrict__ dh2,
+    const float *__restrict__ sr, const float *__restrict__ sz,
+    const float *__restrict__ sn, const float *__restrict__ sghn,
+    const float *__restrict__ hprev, float *__restrict__ dgi,
+    float *__restrict__ dgh, float *__restrict__ dh_direct) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= R * H) return;
+  const int row = e / H, u = e - row * H;
+  float dh = dh1[e];
+  if (dh2) dh += dh2[e];
+  const float r = sr[e], z = sz[e], n = sn[e];
+  const float dz = dh * (hprev[e] - n);
+  const float dn = dh * (1.0f - z);
+  const float dpn = dn * (1.0f - n * n);
+  const float dr = dpn * sghn[e];
+  const float dpr = dr * r * (1.0f - r);
+  const float dpz = dz * z * (1.0f - z);
+  float *gi = dgi + (size_t)row * 3 * H;
+  float *gh = dgh + (size_t)row * 3 * H;
+  gi[u] = dpr; gi[H + u] = dpz; gi[2 * H + u] = dpn;
+  gh[u] = dpr; gh[H + u] = dpz; gh[2 * H + u] = dpn * r;
+  dh_direct[e] = dh * z;
+}
+
+// ---------------------------------------------------------------------------
+// Additive attention (caption_module.py:274-283).
+//   s[r,k] = sum_h wa[h] * tanh(M[r,k,h] + q[r,h]) ; masked -> -1e30
+// One wave per (row, k): 64 lanes over H.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_scores_kernel(
+    int R, int K, int H, const float *__restrict__ M, const float *__restrict__ q,
+    int ldq, const float *__restrict__ wa, const float *__restrict__ mask,
+    float *__restrict__ scores) {
+  const int lane = threadIdx.x & 63;
+  const long long rk = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (rk >= (long long)R * K) return;
+  const int row = (int)(rk / K);
+  const float *m = M + rk * H;
+  const float *qq = q + (size_t)row * ldq;
+  float acc = 0.0f;
+  for (int h4 = lane; h4 < (H >> 2); h4 += 64) {
+    const float4 a = reinterpret_cast<const float4 *>(m)[h4];
+    const float4 b = reinterpret_cast<const float4 *>(qq)[h4];
+    const float4 w = reinterpret_cast<const float4 *>(wa)[h4];
+    acc += w.x * tanhf(a.x + b.x) + w.y * tanhf(a.y + b.y) +
+           w.z * tanhf(a.z + b.z) + w.w * tanhf(a.w + b.w);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (lane == 0) scores[rk] = mask[rk] == 0.0f ? -1e30f : acc;
+}
+
+// softmax over K and att[r,:] = sum_k alpha[r,k] * O[r,k,:]; one block per row
+__global__ __launch_bounds__(256) void attn_softmax_kernel(
+    int K, int F, const float *__restrict__ scores, const float *__restrict__ O,
+    float *__restrict__ alpha, float *__restrict__ att, int lda) {
+  __shared__ float s_red[4];
+  __shared__ float s_alpha[1024];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float *s = scores + (size_t)row * K;
+  float mx = -INFINITY;
+  for (int k = tid; k < K; k += 256) mx = fmaxf(mx, s[k]);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  if (lane == 0) s_red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+  __syncthreads();
+  float sum = 0.0f;
+  for (int k = tid; k < K; k += 256) {
+    const float e = expf(s[k] - mx);
+    s_alpha[k] = e;
+    sum += e;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+  if (lane == 0) s_red[wave] = sum;
+  __syncthreads();
+  sum = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+  const float inv = 1.0f / sum;
+  for (int k = tid; k < K; k += 256) {
+    const float a = s_alpha[k] * inv;
+    s_alpha[k] = a;
+    alpha[(size_t)row * K + k] = a;
+  }
+  __syncthreads();
+  const float *o = O + (size_t)row * K * F;
+  for (int f = tid; f < F; f += 256) {
+    float acc = 0.0f;
+    for (int k = 0; k < K; ++k) acc += s_alpha[k] * o[(size_t)k * F + f];
+    att[(size_t)row * lda + f] = acc;
+  }
+}
+
+// attention backward, stage 1 (one block per row): ds[r,k] from datt, and the
+// dO accumulation  dO[r,k,:] += alpha[r,k] * datt[r,:]
+__global__ __launch_bounds__(256) void attn_bwd_ds_kernel(
+    int K, int F, const float *__restrict__ datt, int ldd,
+    const float *__restrict__ alpha, const float *__restrict__ O,
+    float *__restrict__ ds, float *__restrict__ dO) {
+  __shared__ float s_datt[512];
+  __shared__ float s_red[4];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int f = tid; f < F; f += 256) s_datt[f] = datt[(size_t)row * ldd + f];
+  __syncthreads();
+  const float *o = O + (size_t)row * K * F;
+  float *dor = dO + (size_t)row * K * F;
+  float part = 0.0f;
+  // thread per k (K <= 1024 handled in strides)
+  for (int k = tid; k < K; k += 256) {
+    float da = 0.0f;
+    for (int f = 0; f < F; ++f) da += s_datt[f] * o[(size_t)k * F + f];
+    const float a = alpha[(size_t)row * K + k];
+    ds[(size_t)row * K + k] = da;      // temporarily d(alpha)
+    part += a * da;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+  if (lane == 0) s_red[wave] = part;
+  __syncthreads();
+  const float dot = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+  for (int k = tid; k < K; k += 256) {
+    const float a = alpha[(size_t)row * K + k];
+    ds[(size_t)row * K + k] = a * (ds[(size_t)row * K + k] - dot);
+  }
+  // dO += alpha (outer) datt : coalesced over f
+  for (int e = tid; e < K * F; e += 256) {
+    const int k = e / F, f = e - k * F;
+    dor[e] += alpha[(size_t)row * K + k] * s_datt[f];
+  }
+}
+
+// stage 2: dpre = ds * wa * (1 - c^2), c = tanh(M + q);
+//   dM[r,k,:] += dpre ; dq[r,:] += sum_k dpre ; dwa[:] += sum_k ds * c
+// Block = (row, chunk of KC keys), thread = hidden unit(s): the k loop keeps the
+// dq / dwa partial sums in registers, so only one atomic per (block, h) is issued.
+constexpr int ATT_KC = 16;
+__global__ __launch_bounds__(256) void attn_bwd_pre_kernel(
+    int K, int H, const float *__restrict__ M, const float *__restrict__ q, int ldq,
+    const float *__restrict__ wa, const float *__restrict__ ds,
+    float *__restrict__ dM, float *__restrict__ dq, float *__restrict__ dwa) {
+  const int row = blockIdx.y;
+  const int k0 = blockIdx.x * ATT_KC;
+  const int k1 = min(K, k0 + ATT_KC);
+  for (int h = threadIdx.x; h < H; h += 256) {
+    const float qh = q[(size_t)row * ldq + h], wh = wa[h];
+    float sq = 0.0f, sw = 0.0f;
+    for (int k = k0; k < k1; ++k) {
+      const float d = ds[(size_t)row * K + k];   // block-uniform
+      if (d == 0.0f) continue;                   // masked (alpha == 0)
+      const size_t e = ((size_t)row * K + k) * H + h;
+      const float c = tanhf(M[e] + qh);
+      const float dp = d * wh * (1.0f - c * c);
+      dM[e] += dp;
+      sq += dp;
+      sw += d * c;
+    }
+    atomicAdd(dq + (size_t)row * H + h, sq);
+    atomicAdd(dwa + h, sw);
+  }
+}
+
+}  // namespace
+
+static int chk(const char *k) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    fprintf(stderr, "s2c: %s launch failed: %s\n", k, hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
+extern "C" int s2c_small_linear(int R, int O, int I, const float *W, int ldw,
+                                const float *x, int ldx, const float *bias,
+                                const float *add1, int ld1, const float *add2,
+                                int ld2, const float *gate, int ldg, int epi,
+                                float *out, int ldo, void *stream) {
+  if (R <= 0 || O <= 0 || I <= 0 || (I & 3) || (ldw & 3) || (ldx & 3)) return -1;
+  hipLaunchKernelGGL(small_linear_kernel, dim3((O + 3) / 4, (R + RB - 1) / RB),
+                     dim3(256), 0, (hipStream_t)stream, R, O, I, W, ldw, x, ldx,
+                     bias, add1, ld1, add2, ld2, gate, ldg, epi, out, ldo);
+  return chk("small_linear");
+}
+
+extern "C" int s2c_gru_fwd(int R, int H, int I, const float *Wih, const float *Whh,
+                           const float *bih, const float *bhh, const float *x,
+                           int ldx, const float *h, float *hnew, float *sr,
+                           float *sz, float *sn, float *sghn, void *stream) {
+  if (R <= 0 || (H & 3) || (I & 3) || (ldx & 3)) return -1;
+  hipLaunchKernelGGL(gru_fwd_kernel, dim3((H + 3) / 4, (R + RB - 1) / RB), dim3(256),
+                     0, (hipStream_t)stream, R, H, I, Wih, Whh, bih, bhh, x, ldx, h,
+                     hnew, sr, sz, sn, sghn);
+  return chk("gru_fwd");
+}
+
+extern "C" int s2c_gru_gates_bwd(int R, int H, const float *dh1, const float *dh2,
+                                 const float *sr, const float *sz, const float *sn,
+                                 const float *sghn, const float *hprev, float *dgi,
+                                 float *dgh, float *dh_direct, void *stream) {
+  if (R <= 0 || H <= 0) return -1;
+  hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3((R * H + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, R, H, dh1, dh2, sr, sz, sn, sghn, hprev,
+                     dgi, dgh, dh_direct);
+  return chk("gru_gates_bwd");
+}
+
+extern "C" int s2c_attn_fwd(int R, int K, int H, int F, const float *M,
+                            const float *q, int ldq, const float *wa,
+                            const float *mask, const float *O, float *scores,
+                            float *alpha, float *att, int lda, void *stream) {
+  if (R <= 0 || K <= 0 || K > 1024 || (H & 3) || (ldq & 3)) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(attn_scores_kernel, dim3((unsigned)(((long long)R * K + 3) / 4)),
+                     dim3(256), 0, st, R, K, H, M, q, ldq, wa, mask, scores);
+  hipLaunchKernelGGL(attn_softmax_kernel, dim3(R), dim3(256), 0, st, K, F, scores, O,
+                     alpha, att, lda);
+  return chk("attn_fwd");
+}
+
+// dq must be zeroed by the callee (done here); dM, dO, dwa accumulate.
+extern "C" int s2c_attn_bwd(int R, int K, int H, int F, const float *datt, int ldd,
+                            const float *alpha, const float *O, const float *M,
+                            const float *q, int ldq, const float *wa, float *ds,
+                            float *dO, float *dM, float *dq, float *dwa,
+                            void *stream) {
+  if (R <= 0 || K <= 0 || K > 1024 || F > 512 || (H & 3)) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(dq, 0, sizeof(float) * (size_t)R * H, st) != hipSuccess) return -1;
+  hipLaunchKernelGGL(attn_bwd_ds_kernel, dim3(R), dim3(256), 0, st, K, F, datt, ldd,
+                     alpha, O, ds, dO);
+  hipLaunchKernelGGL(attn_bwd_pre_kernel, dim3((K + ATT_KC - 1) / ATT_KC, R),
+                     dim3(256), 0, st, K, H, M, q, ldq, wa, ds, dM, dq, dwa);
+  return chk("attn_bwd");
+}

@@ -20,6 +20,7 @@ import torch.nn.functional as F
 
 from ..box_util import box3d_iou_batch_tensor
 from ..config import CONF
+from . import decoder_fused
 from .graph_module import query_locals
 
 
@@ -241,6 +242,19 @@ class TopDownSceneCaptionModule(nn.Module):
         if self.use_relation:
             obj_feats = self._add_relation_feat(
                 data_dict, obj_feats, target_ids.view(B, 1)).squeeze(1)
+
+        if obj_feats.is_cuda and decoder_fused.supported(
+                self.emb_size, self.hidden_size, self.feat_size, self.num_proposals):
+            # hand-written recurrent kernels + hoisted GEMMs (decoder_fused.py)
+            lang_cap, attn = decoder_fused.decode(
+                self, word_embs, target_feats, obj_feats, valid_masks, steps)
+            good, mean_iou = _good_bbox_stats(target_ious, min_iou)
+            data_dict["lang_cap"] = lang_cap
+            data_dict["pred_ious"] = mean_iou
+            data_dict["topdown_attn"] = attn
+            data_dict["valid_masks"] = valid_masks
+            data_dict["good_bbox_masks"] = good
+            return data_dict
 
         mapped = self.map_feat(obj_feats)           # hoisted out of the loop
         step_masks = valid_masks.unsqueeze(-1)

@@ -1,0 +1,208 @@
+"""Teacher-forced top-down decoder as ONE autograd Function over the hand-written
+small-batch kernels of csrc/s2c_decoder.hip (C ABI: include/s2c_fused.h).
+
+Computes exactly TopDownSceneCaptionModule._step (models/caption_module.py:250-292)
+for `steps` sequential steps and its back-propagation through time, but:
+  * per step: 7 forward / 11 backward kernel launches instead of ~25 / ~50;
+  * everything that does not depend on the recurrence is hoisted into a handful of
+    large GEMMs outside the loop: the word and target-feature columns of
+    `map_topdown`, `map_feat(obj_feats)`, the classifier over all steps, and EVERY
+    weight gradient (sum_t delta_t^T a_t == one stacked GEMM);
+  * no host synchronisation, fixed shapes => hipGraph-capturable.
+Splitting `map_topdown` / `map_lang` by column blocks changes the fp32 summation
+order only (|diff| ~1e-6, tolerance 1e-4).
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+
+from .. import _C
+
+_I, _P = ctypes.c_int, ctypes.c_void_p
+_C.register("s2c_small_linear", [_I, _I, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _P, _I, _P])
+_C.register("s2c_gru_fwd", [_I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P])
+_C.register("s2c_gru_gates_bwd", [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P])
+_C.register("s2c_attn_fwd", [_I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P])
+_C.register("s2c_attn_bwd", [_I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P])
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _call(name, *args):
+    _C.call(name, *args, _C.stream_ptr())
+
+
+def _lin(R, O, I, W, ldw, x, ldx, out, ldo, bias=None, add1=None, ld1=0, add2=None,
+         ld2=0, gate=None, ldg=0, epi=0):
+    _call("s2c_small_linear", R, O, I, _p(W), ldw, _p(x), ldx, _p(bias), _p(add1), ld1,
+          _p(add2), ld2, _p(gate), ldg, epi, _p(out), ldo)
+
+
+def supported(emb, hid, feat, K):
+    return emb % 4 == 0 and hid % 4 == 0 and feat % 4 == 0 and K <= 1024 and feat <= 512
+
+
+class TopDownDecode(Function):
+    """forward(word_embs (R,Tw,E), target_feats (R,F), obj_feats (R,K,F),
+    masks (R,K) float, steps, *params) -> logits (R,steps,V), attn (R,K,steps).
+
+    params (order): W_td, b_td, W_ih1, W_hh1, b_ih1, b_hh1, W_f, W_h, w_a, W_lang,
+    b_lang, W_ih2, W_hh2, b_ih2, b_hh2, W_cls, b_cls."""
+
+    @staticmethod
+    def forward(ctx, word_embs, target_feats, obj_feats, masks, steps, *params):
+        (W_td, b_td, W_ih1, W_hh1, b_ih1, b_hh1, W_f, W_h, w_a, W_lang, b_lang,
+         W_ih2, W_hh2, b_ih2, b_hh2, W_cls, b_cls) = params
+        dev = obj_feats.device
+        R, K, F = obj_feats.shape
+        E = W_td.shape[0]
+        H = W_hh1.shape[1]
+        T = int(steps)
+        words = word_embs[:, :T].contiguous()                       # (R,T,E)
+        O = obj_feats.contiguous()
+        tf = target_feats.contiguous()
+        mask = masks.to(torch.float32).contiguous()
+        with torch.cuda.device(dev):
+            # ---- hoisted, recurrence-free GEMMs -----------------------------
+            Pw = torch.matmul(words, W_td[:, :E].t())               # (R,T,E)
+            Ptf = torch.addmm(b_td, tf, W_td[:, E + H:].t())        # (R,E)
+            M = torch.matmul(O, W_f.t())                            # (R,K,H)
+            Wqh = torch.cat([W_h, W_lang[:, F:]], 0).contiguous()   # (H+E, H)
+            wa = w_a.reshape(-1).contiguous()
+            z = lambda *s: torch.zeros(*s, device=dev)
+            e = lambda *s: torch.empty(*s, device=dev)
+            H1, H2 = z(T + 1, R, H), z(T + 1, R, H)
+            X1, X2 = e(T, R, E), e(T, R, E)
+            S1 = [e(T, R, H) for _ in range(4)]   # r, z, n, gh_n of GRU 1
+            S2 = [e(T, R, H) for _ in range(4)]
+            QL = e(T, R, H + E)
+            ALPHA, SC = e(T, R, K), e(R, K)
+            ATT = e(T, R, F)
+            ldtd, ldlang = W_td.shape[1], W_lang.shape[1]
+            td_h2 = W_td[:, E:E + H]          # column block, row stride ldtd
+            for t in range(T):
+                _lin(R, E, H, td_h2, ldtd, H2[t], H, X1[t], E, add1=Pw[:, t],
+                     ld1=T * E, add2=Ptf, ld2=E, epi=1)
+                _call("s2c_gru_fwd", R, H, E, _p(W_ih1), _p(W_hh1), _p(b_ih1),
+                      _p(b_hh1), _p(X1[t]), E, _p(H1[t]), _p(H1[t + 1]),
+                      _p(S1[0][t]), _p(S1[1][t]), _p(S1[2][t]), _p(S1[3][t]))
+                _lin(R, H + E, H, Wqh, H, H1[t + 1], H, QL[t], H + E)
+                _call("s2c_attn_fwd", R, K, H, F, _p(M), _p(QL[t]), H + E, _p(wa),
+                      _p(mask), _p(O), _p(SC), _p(ALPHA[t]), _p(ATT[t]), F)
+                _lin(R, E, F, W_lang, ldlang, ATT[t], F, X2[t], E, bias=b_lang,
+                     add1=QL[t][:, H:], ld1=H + E, epi=1)
+                _call("s2c_gru_fwd", R, H, E, _p(W_ih2), _p(W_hh2), _p(b_ih2),
+                      _p(b_hh2), _p(X2[t]), E, _p(H2[t]), _p(H2[t + 1]),
+                      _p(S2[0][t]), _p(S2[1][t]), _p(S2[2][t]), _p(S2[3][t]))
+            H2n = H2[1:].permute(1, 0, 2).contiguous()              # (R,T,H)
+            logits = torch.addmm(b_cls, H2n.view(R * T, H), W_cls.t()).view(R, T, -1)
+            attn = ALPHA.permute(1, 2, 0).contiguous()              # (R,K,T)
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(*params)
+            ctx.stash = (words, tf, O, M, wa, H1, H2, X1, X2, S1, S2, QL, ALPHA, ATT, H2n)
+            ctx.dims = (R, K, F, E, H, T)
+            ctx.words_need_grad = ctx.needs_input_grad[0]
+        ctx.mark_non_differentiable(attn)
+        return logits, attn
+
+    @staticmethod
+    def backward(ctx, dlogits, _dattn):
+        (W_td, b_td, W_ih1, W_hh1, b_ih1, b_hh1, W_f, W_h, w_a, W_lang, b_lang,
+         W_ih2, W_hh2, b_ih2, b_hh2, W_cls, b_cls) = ctx.saved_tensors
+        words, tf, O, M, wa, H1, H2, X1, X2, S1, S2, QL, ALPHA, ATT, H2n = ctx.stash
+        R, K, F, E, H, T = ctx.dims
+        dev = dlogits.device
+        with torch.cuda.device(dev):
+            dl = dlogits.contiguous().view(R * T, -1)
+            dW_cls = torch.mm(dl.t(), H2n.view(R * T, H))
+            db_cls = dl.sum(0)
+            dH2 = torch.mm(dl, W_cls).view(R, T, H).permute(1, 0, 2).contiguous()
+            # transposed weights: the same small_linear kernel serves W^T products
+            WT_ih2, WT_hh2 = W_ih2.t().contiguous(), W_hh2.t().contiguous()
+            WT_lang, WT_h = W_lang.t().contiguous(), W_h.t().contiguous()
+            WT_ih1, WT_hh1 = W_ih1.t().contiguous(), W_hh1.t().contiguous()
+            WT_td_h2 = W_td[:, E:E + H].t().contiguous()            # (H,E)
+            WT_td_tf = W_td[:, E + H:].t().contiguous()             # (F,E)
+            z = lambda *s: torch.zeros(*s, device=dev)
+            e = lambda *s: torch.empty(*s, device=dev)
+            dM, dO, dwa, dtf = z(R, K, H), z(R, K, F), z(H), z(R, F)
+            dh1c, dh2c = z(R, H), z(R, H)
+            DA1, DA2 = e(T, R, E), e(T, R, E)
+            DGI1, DGH1 = e(T, R, 3 * H), e(T, R, 3 * H)
+            DGI2, DGH2 = e(T, R, 3 * H), e(T, R, 3 * H)
+            DQ = e(T, R, H)
+            dh2_direct, dh1_direct = e(R, H), e(R, H)
+            dh2_part, dh1_total, dv, ds = e(R, H), e(R, H), e(R, F + H), e(R, K)
+            for t in range(T - 1, -1, -1):
+                _call("s2c_gru_gates_bwd", R, H, _p(dH2[t]), _p(dh2c), _p(S2[0][t]),
+                      _p(S2[1][t]), _p(S2[2][t]), _p(S2[3][t]), _p(H2[t]),
+                      _p(DGI2[t]), _p(DGH2[t]), _p(dh2_direct))
+                _lin(R, E, 3 * H, WT_ih2, 3 * H, DGI2[t], 3 * H, DA2[t], E,
+                     gate=X2[t], ldg=E, epi=2)
+                _lin(R, H, 3 * H, WT_hh2, 3 * H, DGH2[t], 3 * H, dh2_part, H,
+                     add1=dh2_direct, ld1=H)
+                _lin(R, F + H, E, WT_lang, E, DA2[t], E, dv, F + H)
+                _call("s2c_attn_bwd", R, K, H, F, _p(dv), F + H, _p(ALPHA[t]), _p(O),
+                      _p(M), _p(QL[t]), H + E, _p(wa), _p(ds), _p(dO), _p(dM),
+                      _p(DQ[t]), _p(dwa))
+                _lin(R, H, H, WT_h, H, DQ[t], H, dh1_total, H, add1=dv[:, F:],
+                     ld1=F + H, add2=dh1c, ld2=H)
+                _call("s2c_gru_gates_bwd", R, H, _p(dh1_total), None, _p(S1[0][t]),
+                      _p(S1[1][t]), _p(S1[2][t]), _p(S1[3][t]), _p(H1[t]),
+                      _p(DGI1[t]), _p(DGH1[t]), _p(dh1_direct))
+                _lin(R, E, 3 * H, WT_ih1, 3 * H, DGI1[t], 3 * H, DA1[t], E,
+                     gate=X1[t], ldg=E, epi=2)
+                _lin(R, H, 3 * H, WT_hh1, 3 * H, DGH1[t], 3 * H, dh1c, H,
+                     add1=dh1_direct, ld1=H)
+                _lin(R, H, E, WT_td_h2, E, DA1[t], E, dh2c, H, add1=dh2_part, ld1=H)
+                _lin(R, F, E, WT_td_tf, E, DA1[t], E, dtf, F, add1=dtf, ld1=F)
+            # ---- every weight gradient: one stacked GEMM each ------------------
+            TR = T * R
+            da1 = DA1.view(TR, E)
+            dW_td = torch.empty_like(W_td)
+            dW_td[:, :E] = torch.mm(da1.t(), words.permute(1, 0, 2).reshape(TR, E))
+            dW_td[:, E:E + H] = torch.mm(da1.t(), H2[:-1].reshape(TR, H))
+            dW_td[:, E + H:] = torch.mm(DA1.sum(0).t(), tf)
+            db_td = da1.sum(0)
+            gi1, gh1 = DGI1.view(TR, 3 * H), DGH1.view(TR, 3 * H)
+            dW_ih1 = torch.mm(gi1.t(), X1.view(TR, E))
+            dW_hh1 = torch.mm(gh1.t(), H1[:-1].reshape(TR, H))
+            db_ih1, db_hh1 = gi1.sum(0), gh1.sum(0)
+            h1n = H1[1:].reshape(TR, H)
+            dW_h = torch.mm(DQ.view(TR, H).t(), h1n)
+            da2 = DA2.view(TR, E)
+            dW_lang = torch.empty_like(W_lang)
+            dW_lang[:, :F] = torch.mm(da2.t(), ATT.view(TR, F))
+            dW_lang[:, F:] = torch.mm(da2.t(), h1n)
+            db_lang = da2.sum(0)
+            gi2, gh2 = DGI2.view(TR, 3 * H), DGH2.view(TR, 3 * H)
+            dW_ih2 = torch.mm(gi2.t(), X2.view(TR, E))
+            dW_hh2 = torch.mm(gh2.t(), H2[:-1].reshape(TR, H))
+            db_ih2, db_hh2 = gi2.sum(0), gh2.sum(0)
+            dMf = dM.view(R * K, H)
+            dW_f = torch.mm(dMf.t(), O.view(R * K, F))
+            dO = dO + torch.mm(dMf, W_f).view(R, K, F)
+            dwords = None
+            if ctx.words_need_grad:
+                dwords = torch.matmul(DA1.permute(1, 0, 2), W_td[:, :E])
+        ctx.stash = None
+        return (dwords, dtf, dO, None, None, dW_td, db_td, dW_ih1, dW_hh1, db_ih1,
+                db_hh1, dW_f, dW_h, dwa.view_as(w_a), dW_lang, db_lang, dW_ih2, dW_hh2,
+                db_ih2, db_hh2, dW_cls, db_cls)
+
+
+def decode(module, word_embs, target_feats, obj_feats, masks, steps):
+    """Run the fused decoder with the parameters of a TopDownSceneCaptionModule."""
+    m = module
+    params = (m.map_topdown[0].weight, m.map_topdown[0].bias,
+              m.recurrent_cell_1.weight_ih, m.recurrent_cell_1.weight_hh,
+              m.recurrent_cell_1.bias_ih, m.recurrent_cell_1.bias_hh,
+              m.map_feat.weight, m.map_hidd.weight, m.attend.weight,
+              m.map_lang[0].weight, m.map_lang[0].bias,
+              m.recurrent_cell_2.weight_ih, m.recurrent_cell_2.weight_hh,
+              m.recurrent_cell_2.bias_ih, m.recurrent_cell_2.bias_hh,
+              m.classifier.weight, m.classifier.bias)
+    return TopDownDecode.apply(word_embs, target_feats, obj_feats, masks, steps, *params)
