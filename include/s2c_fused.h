@@ -82,6 +82,22 @@ int s2c_bn_relu_max_bwd(long long J, int ns, int C, const float *dOut,
                         const float *gamma, int frozen, float *partial, float *coef,
                         float *dgamma, float *dbeta, float *dY, void *stream);
 
+/* ---- hand-written fp32 MFMA GEMM for the shared-MLP layers (csrc/s2c_gemm.hip)
+ * Y[M x N] = pro(A)[M x K] * W^T, W (N x K) row-major.  pro = identity when
+ * pscale == NULL, else relu(A*pscale[k] + pshift[k]) (previous layer's BN+ReLU
+ * fused into the tile staging).  partial != NULL: per-row-block column
+ * [sum | sumsq] of Y, s2c_rows_gemm_blocks(M,N) * 2N floats, to be reduced by
+ * s2c_bn_finalize_partials (BN batch statistics without another pass over Y). */
+int s2c_rows_gemm_blocks(long long M, int N);
+int s2c_rows_gemm(long long M, int N, int K, const float *A, int lda, const float *W,
+                  int ldw, const float *pscale, const float *pshift, float *Y,
+                  int ldy, float *partial, void *stream);
+int s2c_bn_finalize_partials(int nblk, long long M, int C, const float *partial,
+                             float eps, float momentum, const float *gamma,
+                             const float *beta, float *running_mean,
+                             float *running_var, float *scale, float *shift,
+                             float *save_mean, float *save_invstd, void *stream);
+
 /* ---- teacher-forced top-down caption decoder (csrc/s2c_decoder.hip) -------
  * Small-batch (R <= a few dozen rows) building blocks of one recurrent step of
  * TopDownSceneCaptionModule._step (models/caption_module.py:250-292) and of its

@@ -34,17 +34,49 @@ __device__ __forceinline__ float fold_chunks(float v) {
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// partial dot product of one weight row with this lane's input row
+// partial dot product of one weight row with this lane's input row; the 32 chunk
+// lanes of a row (8 per wave x 4 waves of the block) stride over the float4s.
+// Two independent accumulators / unroll 4 keep several 16-byte loads in flight
+// (these kernels are pure latency: ~1 wave per SIMD, a few KB per wave).
+constexpr int NCHUNK = 32;
 __device__ __forceinline__ float dot_row(const float *__restrict__ w,
                                          const float *__restrict__ x, int n4,
                                          int chunk) {
-  float acc = 0.0f;
-  for (int j = chunk; j < n4; j += 8) {
-    const float4 a = reinterpret_cast<const float4 *>(w)[j];
-    const float4 b = reinterpret_cast<const float4 *>(x)[j];
-    acc += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+  float acc0 = 0.0f, acc1 = 0.0f;
+  int j = chunk;
+#pragma unroll 2
+  for (; j + NCHUNK < n4; j += 2 * NCHUNK) {
+    const float4 a0 = reinterpret_cast<const float4 *>(w)[j];
+    const float4 a1 = reinterpret_cast<const float4 *>(w)[j + NCHUNK];
+    const float4 b0 = reinterpret_cast<const float4 *>(x)[j];
+    const float4 b1 = reinterpret_cast<const float4 *>(x)[j + NCHUNK];
+    acc0 += a0.x * b0.x + a0.y * b0.y + a0.z * b0.z + a0.w * b0.w;
+    acc1 += a1.x * b1.x + a1.y * b1.y + a1.z * b1.z + a1.w * b1.w;
   }
-  return acc;
+  if (j < n4) {
+    const float4 a0 = reinterpret_cast<const float4 *>(w)[j];
+    const float4 b0 = reinterpret_cast<const float4 *>(x)[j];
+    acc0 += a0.x * b0.x + a0.y * b0.y + a0.z * b0.z + a0.w * b0.w;
+  }
+  return acc0 + acc1;
+}
+
+// block-wide fold of per-lane partials: result valid in threads 0..7 (row = tid)
+template <int NV>
+__device__ __forceinline__ void block_fold(float (&v)[NV], float (*s_part)[4][RB]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    v[k] = fold_chunks(v[k]);
+    if (lane < RB) s_part[k][wave][lane] = v[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < RB) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+      v[k] = (s_part[k][0][threadIdx.x] + s_part[k][1][threadIdx.x]) +
+             (s_part[k][2][threadIdx.x] + s_part[k][3][threadIdx.x]);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -57,16 +89,16 @@ __global__ __launch_bounds__(256) void small_linear_kernel(
     const float *__restrict__ add1, int ld1, const float *__restrict__ add2,
     int ld2, const float *__restrict__ gate, int ldg, int epi,
     float *__restrict__ out, int ldo) {
-  const int lane = threadIdx.x & 63;
-  const int r = lane & 7, chunk = lane >> 3;
-  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int rbase = blockIdx.y * RB;
-  const int row = rbase + r;
-  if (o >= O) return;
+  __shared__ float s_part[1][4][RB];
+  const int r = threadIdx.x & 7, chunk = threadIdx.x >> 3;   // 32 chunks
+  const int o = blockIdx.x;
+  const int row = blockIdx.y * RB + r;
   const int rowc = row < R ? row : R - 1;
-  float acc = dot_row(W + (size_t)o * ldw, x + (size_t)rowc * ldx, I >> 2, chunk);
-  acc = fold_chunks(acc);
-  if (chunk == 0 && row < R) {
+  float v[1];
+  v[0] = dot_row(W + (size_t)o * ldw, x + (size_t)rowc * ldx, I >> 2, chunk);
+  block_fold<1>(v, s_part);
+  if (threadIdx.x < RB && row < R) {
+    float acc = v[0];
     if (bias) acc += bias[o];
     if (add1) acc += add1[(size_t)row * ld1 + o];
     if (add2) acc += add2[(size_t)row * ld2 + o];
@@ -90,11 +122,10 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(
     const float *__restrict__ h, float *__restrict__ hnew,
     float *__restrict__ sr, float *__restrict__ sz, float *__restrict__ sn,
     float *__restrict__ sghn) {
-  const int lane = threadIdx.x & 63;
-  const int r = lane & 7, chunk = lane >> 3;
-  const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+  __shared__ float s_part[6][4][RB];
+  const int r = threadIdx.x & 7, chunk = threadIdx.x >> 3;
+  const int u = blockIdx.x;                      // one block per hidden unit
   const int row = blockIdx.y * RB + r;
-  if (u >= H) return;
   const int rowc = row < R ? row : R - 1;
   const float *xr = x + (size_t)rowc * ldx;
   const float *hr = h + (size_t)rowc * H;
@@ -104,9 +135,8 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(
     g[k] = dot_row(Wih + (size_t)(k * H + u) * I, xr, I >> 2, chunk);
     g[3 + k] = dot_row(Whh + (size_t)(k * H + u) * H, hr, H >> 2, chunk);
   }
-#pragma unroll
-  for (int k = 0; k < 6; ++k) g[k] = fold_chunks(g[k]);
-  if (chunk == 0 && row < R) {
+  block_fold<6>(g, s_part);
+  if (threadIdx.x < RB && row < R) {
     const float gir = g[0] + bih[u], giz = g[1] + bih[H + u], gin = g[2] + bih[2 * H + u];
     const float ghr = g[3] + bhh[u], ghz = g[4] + bhh[H + u], ghn = g[5] + bhh[2 * H + u];
     const float rr = sigmoidf_(gir + ghr);
@@ -302,7 +332,7 @@ extern "C" int s2c_small_linear(int R, int O, int I, const float *W, int ldw,
                                 int ld2, const float *gate, int ldg, int epi,
                                 float *out, int ldo, void *stream) {
   if (R <= 0 || O <= 0 || I <= 0 || (I & 3) || (ldw & 3) || (ldx & 3)) return -1;
-  hipLaunchKernelGGL(small_linear_kernel, dim3((O + 3) / 4, (R + RB - 1) / RB),
+  hipLaunchKernelGGL(small_linear_kernel, dim3(O, (R + RB - 1) / RB),
                      dim3(256), 0, (hipStream_t)stream, R, O, I, W, ldw, x, ldx,
                      bias, add1, ld1, add2, ld2, gate, ldg, epi, out, ldo);
   return chk("small_linear");
@@ -313,7 +343,7 @@ extern "C" int s2c_gru_fwd(int R, int H, int I, const float *Wih, const float *W
                            int ldx, const float *h, float *hnew, float *sr,
                            float *sz, float *sn, float *sghn, void *stream) {
   if (R <= 0 || (H & 3) || (I & 3) || (ldx & 3)) return -1;
-  hipLaunchKernelGGL(gru_fwd_kernel, dim3((H + 3) / 4, (R + RB - 1) / RB), dim3(256),
+  hipLaunchKernelGGL(gru_fwd_kernel, dim3(H, (R + RB - 1) / RB), dim3(256),
                      0, (hipStream_t)stream, R, H, I, Wih, Whh, bih, bhh, x, ldx, h,
                      hnew, sr, sz, sn, sghn);
   return chk("gru_fwd");

@@ -307,6 +307,22 @@ extern "C" int s2c_bn_train_stats(long long M, int C, const float *Y,
   return check2("bn_train_stats");
 }
 
+// finalize from partials produced elsewhere (the MFMA GEMM epilogue,
+// csrc/s2c_gemm.hip): same layout [nblk][sum(C) | sumsq(C)]
+extern "C" int s2c_bn_finalize_partials(int nblk, long long M, int C,
+                                        const float *partial, float eps,
+                                        float momentum, const float *gamma,
+                                        const float *beta, float *running_mean,
+                                        float *running_var, float *scale,
+                                        float *shift, float *save_mean,
+                                        float *save_invstd, void *stream) {
+  if (nblk <= 0 || M <= 0 || C <= 0) return fail2("bn_finalize_partials sizes");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream,
+                     partial, nblk, C, M, eps, momentum, gamma, beta, running_mean,
+                     running_var, scale, shift, save_mean, save_invstd);
+  return check2("bn_finalize_partials");
+}
+
 extern "C" int s2c_bn_eval_coeffs(int C, float eps, const float *gamma,
                                   const float *beta, const float *running_mean,
                                   const float *running_var, float *scale,

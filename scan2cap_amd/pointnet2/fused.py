@@ -29,6 +29,8 @@ _C.register("s2c_bn_eval_coeffs", [_I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_bn_relu", [_L, _I, _P, _P, _P, _P, _I, _P])
 _C.register("s2c_bn_relu_max", [_L, _I, _I, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_bn_relu_bwd", [_L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P])
+_C.register("s2c_rows_gemm", [_L, _I, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _P])
+_C.register("s2c_bn_finalize_partials", [_I, _L, _I, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_bn_relu_max_bwd", [_L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P])
 
 
@@ -48,6 +50,17 @@ def _stat_blocks(M):
     lib.s2c_bn_stat_blocks.argtypes = [_L]
     lib.s2c_bn_stat_blocks.restype = _I
     return lib.s2c_bn_stat_blocks(M)
+
+
+def _gemm_blocks(M, N):
+    lib = _C.load()
+    lib.s2c_rows_gemm_blocks.argtypes = [_L, _I]
+    lib.s2c_rows_gemm_blocks.restype = _I
+    return lib.s2c_rows_gemm_blocks(M, N)
+
+
+# use the hand-written MFMA GEMM (statistics in its epilogue) for BN layers
+USE_MFMA_GEMM = True
 
 
 def fused_available(t):
@@ -142,7 +155,21 @@ class _MLPRows(Function):
             if bn is not None:
                 gamma, beta = params[pi], params[pi + 1]; pi += 2
             Cout = W.shape[0]
-            Y = torch.addmm(bias, A, W.t()) if bias is not None else torch.mm(A, W.t())
+            train_stats = bn is not None and (bn.training or bn.running_mean is None)
+            gemm_stats = (USE_MFMA_GEMM and train_stats and bias is None
+                          and A.stride(1) == 1 and W.stride(1) == 1)
+            if gemm_stats:
+                # hand-written f32 MFMA GEMM; BN batch statistics come out of its
+                # epilogue as per-row-block partials (no extra pass over Y)
+                nbg = _gemm_blocks(M, Cout)
+                gpart = torch.empty(nbg * 2 * Cout, device=dev)
+                Y = torch.empty((M, Cout), device=dev)
+                K_in = A.shape[1]
+                _call("s2c_rows_gemm", Y, M, Cout, K_in, A.data_ptr(), A.stride(0),
+                      W.data_ptr(), W.stride(0), None, None, Y.data_ptr(), Cout,
+                      gpart.data_ptr(), alg_bytes=4 * (M * K_in + M * Cout))
+            else:
+                Y = torch.addmm(bias, A, W.t()) if bias is not None else torch.mm(A, W.t())
             rec = {"A_in": A, "W": W, "has_bias": bias is not None}
             last = li == nl - 1
             if bn is not None:
@@ -150,8 +177,16 @@ class _MLPRows(Function):
                 shift = torch.empty(Cout, device=dev)
                 mean = torch.empty(Cout, device=dev)
                 invstd = torch.empty(Cout, device=dev)
-                train_stats = bn.training or bn.running_mean is None
-                if train_stats:
+                if gemm_stats:
+                    mom = bn.momentum if bn.momentum is not None else 0.1
+                    _call("s2c_bn_finalize_partials", Y, nbg, M, Cout, gpart.data_ptr(),
+                          float(bn.eps), float(mom), _ptr(gamma), _ptr(beta),
+                          _ptr(bn.running_mean), _ptr(bn.running_var),
+                          scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+                          invstd.data_ptr())
+                    if bn.num_batches_tracked is not None:
+                        bn.num_batches_tracked.add_(1)
+                elif train_stats:
                     nb = _stat_blocks(M)
                     if partial is None or partial.numel() < nb * 2 * Cout:
                         partial = torch.empty(nb * 2 * max(Cout, 256), device=dev)

@@ -1,0 +1,46 @@
+"""rows_gemm (hand-written fp32 MFMA) vs torch.mm on the SA layer shapes."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from scan2cap_amd import _C
+from scan2cap_amd.pointnet2 import fused  # registers signatures
+from tools.bench_ops import timeit
+
+_I, _L, _P = ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p
+_C.register("s2c_rows_gemm", [_L, _I, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _P])
+lib = _C.load()
+lib.s2c_rows_gemm_blocks.argtypes = [_L, _I]; lib.s2c_rows_gemm_blocks.restype = _I
+
+def run(M, N, K, stats=True, pro=False):
+    A = torch.randn(M, K, device="cuda"); W = torch.randn(N, K, device="cuda") * 0.1
+    Y = torch.empty(M, N, device="cuda")
+    nb = lib.s2c_rows_gemm_blocks(M, N)
+    part = torch.empty(nb * 2 * N, device="cuda") if stats else None
+    sc = torch.rand(K, device="cuda") + 0.5 if pro else None
+    sh = torch.randn(K, device="cuda") * 0.1 if pro else None
+    def f():
+        _C.call("s2c_rows_gemm", M, N, K, A.data_ptr(), K, W.data_ptr(), K,
+                sc.data_ptr() if pro else None, sh.data_ptr() if pro else None,
+                Y.data_ptr(), N, part.data_ptr() if stats else None, _C.stream_ptr())
+    f(); torch.cuda.synchronize()
+    Ain = torch.relu(A * sc + sh) if pro else A
+    ref = Ain.double() @ W.double().t()
+    err = (Y.double() - ref).abs().max().item() / ref.abs().max().item()
+    if stats:
+        p = part.view(nb, 2, N).double().sum(0)
+        e1 = (p[0] - ref.sum(0)).abs().max().item() / ref.sum(0).abs().max().item()
+        e2 = (p[1] - (ref * ref).sum(0)).abs().max().item() / (ref * ref).sum(0).abs().max().item()
+    else:
+        e1 = e2 = 0
+    t1 = timeit(f, iters=20)
+    t2 = timeit(lambda: torch.mm(Ain, W.t()), iters=20)
+    gf = 2.0 * M * N * K / 1e9
+    byt = 4.0 * (M * K + M * N) / 1e9
+    print(f"M={M:8d} N={N:4d} K={K:4d} pro={int(pro)}: mine {t1:8.1f} us ({gf/t1*1e3:6.1f} TF, {byt/t1*1e3:5.2f} TB/s)  torch.mm {t2:8.1f} us  relerr {err:.1e} stats {e1:.1e} {e2:.1e}")
+
+for (M, N, K) in [(1048576, 64, 135), (1048576, 64, 64), (1048576, 128, 64), (262144, 128, 131),
+                  (262144, 128, 128), (262144, 256, 128), (65536, 128, 259), (65536, 256, 128),
+                  (32768, 128, 259), (8192, 256, 512), (1000, 64, 135)]:
+    run(M, N, K)
+run(1048576, 64, 64, pro=True)
+run(262144, 256, 128, pro=True)
