@@ -217,7 +217,16 @@ def main():
     use_graph = not args.no_graph
     optimizer = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5,
                                  capturable=use_graph)
-    ddp = FlatGradAllReduce(model) if (world > 1 and wl["train"]) else None
+    # S2C_FORCE_DDP=1 exercises the multi-GPU code path (flat gradient bucket,
+    # fwd/bwd graph + eager all-reduce + optimizer graph) on a single rank
+    force_ddp = os.environ.get("S2C_FORCE_DDP") == "1"
+    if force_ddp and world == 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    ddp = FlatGradAllReduce(model) if ((world > 1 or force_ddp) and wl["train"]) else None
+    if ddp is not None and force_ddp:
+        ddp.world = 2          # make reduce() issue the collective
     eager_step = make_step(model, wl, cfg_loss, optimizer, ddp, device)
     dd = to_device(make_batch(wl, B, 42 + rank, table, msa), device)
 
@@ -348,7 +357,7 @@ def main():
                                                args.cpu_sample_scenes)
             out["vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
