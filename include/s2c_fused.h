@@ -92,6 +92,14 @@ int s2c_rows_gemm_blocks(long long M, int N);
 int s2c_rows_gemm(long long M, int N, int K, const float *A, int lda, const float *W,
                   int ldw, const float *pscale, const float *pshift, float *Y,
                   int ldy, float *partial, void *stream);
+/* first SA layer with the grouping fused into the operand load:
+ * Y[(b,j,s),:] = [ (xyz[b,idx]-new_xyz[b,j]) (/radius) | feats[b,idx,:] ] W^T,
+ * K = 3 + C; same arguments as s2c_sa_gather_rows, same partials as s2c_rows_gemm. */
+int s2c_sa_gather_gemm(int b, int n, int m, int ns, int C, long long feat_row_stride,
+                       long long feat_batch_stride, float radius, int normalize,
+                       const float *xyz, const float *new_xyz, const float *feats,
+                       const int *idx, int N, const float *W, int ldw, float *Y,
+                       int ldy, float *partial, void *stream);
 int s2c_bn_finalize_partials(int nblk, long long M, int C, const float *partial,
                              float eps, float momentum, const float *gamma,
                              const float *beta, float *running_mean,

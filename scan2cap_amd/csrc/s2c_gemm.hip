@@ -3,24 +3,33 @@
 //
 //     Y[M x N] = pro(A)[M x K] * W^T            W is (N x K) row-major (conv weight)
 //
-// * pro(A) = A, or relu(A * scale[k] + shift[k]) -- the previous layer's
-//   BatchNorm + ReLU applied while the A tile is staged into LDS, so the
-//   activation tensor between two layers is never materialised;
-// * epilogue: per-column sum and sum-of-squares of the Y tile written as partials
-//   (one row of [sum | sumsq] per row-block) -- the BatchNorm batch statistics of
-//   THIS layer without another pass over Y.
+// Prologue (applied while the A tile is staged into LDS, so the operand is never
+// materialised in HBM):
+//   PRO_NONE    A as is;
+//   PRO_BNRELU  relu(A * scale[k] + shift[k]) -- the previous layer's BatchNorm +
+//               ReLU (pytorch_utils.py:100-120) fused into this layer's load;
+//   PRO_GATHER  A row r = (scene b, centre j, sample s) is GATHERED on the fly:
+//               channels 0..2 = (xyz[b, idx[r]] - new_xyz[b, j]) (/ radius),
+//               channels 3..  = feats[b, idx[r], :]  -- ball-query grouping
+//               (pointnet2_utils.py:347-359) fused into the first layer, the
+//               (B, 3+C, npoint, nsample) tensor of the reference never exists.
+// Epilogue: per-column sum / sum-of-squares of the Y tile as partials (one
+// [sum | sumsq] row per row-block) = this layer's BatchNorm batch statistics
+// without another pass over Y.
+//
 // fp32-in / fp32-accumulate `v_mfma_f32_32x32x2_f32` (exact f32 FMA chain, 157 TF
-// peak on gfx950) keeps the 1e-4 parity budget; there is no TF32-like fast path on
-// CDNA4 and bf16 is not parity-safe.
+// peak on gfx950) keeps the 1e-4 parity budget; CDNA4 has no TF32-like fast path
+// and bf16 is not parity-safe.
 //
 // Geometry: 256 threads = 4 waves, each wave owns a 64x64 tile (2x2 MFMA tiles,
 // 64 accumulator registers).  N <= 64: waves stacked 4x1 (block = 256 rows x 64
 // cols); otherwise 2x2 (block = 128 x 128).  K is walked in slices of 32 through
-// LDS; tiles are stored K-major ([k][row], row stride +1) so that the transposing
-// store and the MFMA operand reads (lane -> consecutive rows) are both
-// bank-conflict free; the next slice is prefetched into registers while the
-// current one feeds the matrix cores.  M is huge (up to 1e6 rows), so the grid has
-// thousands of workgroups.
+// LDS.  A slice is stored [row][32] with the k order permuted to
+// pos(k) = (k & 1) * 16 + (k >> 1): the 16 values lane (i, k&1) feeds to the 16
+// MFMAs of a slice are then contiguous, i.e. 4 x ds_read_b128 per operand tile
+// instead of 16 x ds_read_b32, and a 36-float row stride makes those reads
+// conflict-free across 16 consecutive rows.  The next slice is prefetched into
+// registers while the current one feeds the matrix cores.
 #include "s2c_common.h"
 #include "../../include/s2c_fused.h"
 
@@ -33,17 +42,36 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 32;
+constexpr int LDS_LD = 36;  // floats per LDS row (32 + 4 pad, 16-byte aligned)
 
-template <int WM, int WN>  // waves along M / N; block tile = (64*WM) x (64*WN)
+enum { PRO_NONE = 0, PRO_BNRELU = 1, PRO_GATHER = 2 };
+
+struct GatherArgs {
+  const float *xyz;       // (b, n, 3)
+  const float *new_xyz;   // (b, m, 3)
+  const float *feats;     // point-major, row stride frs, batch stride fbs (floats)
+  const int *idx;         // (b, m, ns) flattened = one entry per A row
+  long long frs, fbs;
+  int n, m, ns;
+  float radius;
+  int normalize;
+};
+
+__device__ __forceinline__ void lds_store_quad(float *row, int sq, float4 v) {
+  // k = 4sq .. 4sq+3 -> even ks at [2sq, 2sq+1], odd ks at 16 + [2sq, 2sq+1]
+  *reinterpret_cast<float2 *>(row + 2 * sq) = make_float2(v.x, v.z);
+  *reinterpret_cast<float2 *>(row + 16 + 2 * sq) = make_float2(v.y, v.w);
+}
+
+template <int WM, int WN, int PRO>
 __global__ __launch_bounds__(256) void rows_gemm_kernel(
-    int M, int N, int K, const float *__restrict__ A, int lda,
+    long long M, int N, int K, const float *__restrict__ A, int lda,
     const float *__restrict__ W, int ldw, const float *__restrict__ pscale,
-    const float *__restrict__ pshift, float *__restrict__ Y, int ldy,
+    const float *__restrict__ pshift, GatherArgs ga, float *__restrict__ Y, int ldy,
     float *__restrict__ partial, int avec, int wvec) {
   constexpr int BM = 64 * WM, BN = 64 * WN;
-  constexpr int LDA_S = BM + 1, LDW_S = BN + 1;
-  __shared__ float As[BK][LDA_S];
-  __shared__ float Ws[BK][LDW_S];
+  __shared__ __attribute__((aligned(16))) float As[BM * LDS_LD];
+  __shared__ __attribute__((aligned(16))) float Ws[BN * LDS_LD];
   __shared__ float s_stat[2][WM][BN];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -56,27 +84,79 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(
   constexpr int AI = BM / 32, WI = BN / 32;
   float4 ra[AI], rw[WI];
 
+  // PRO_GATHER: per staged row, the source-row offsets (computed once)
+  long long g_src[PRO == PRO_GATHER ? AI : 1];
+  int g_pt[PRO == PRO_GATHER ? AI : 1], g_ctr[PRO == PRO_GATHER ? AI : 1];
+  if (PRO == PRO_GATHER) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const long long row = m0 + sr + 32 * i;
+      const long long rc = row < M ? row : M - 1;
+      const long long bj = rc / ga.ns;
+      const long long b = bj / ga.m;
+      const int p = ga.idx[rc];
+      g_src[i] = b * ga.fbs + (long long)p * ga.frs;
+      g_pt[i] = (int)((b * ga.n + p) * 3);
+      g_ctr[i] = (int)(bj * 3);
+    }
+  }
+
   auto load_slice = [&](int k0) {
     const int k = k0 + sq * 4;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (PRO == PRO_BNRELU) {
+      if (k + 3 < K) {
+        sc = *reinterpret_cast<const float4 *>(pscale + k);
+        sh = *reinterpret_cast<const float4 *>(pshift + k);
+      } else {
+        if (k < K) { sc.x = pscale[k]; sh.x = pshift[k]; }
+        if (k + 1 < K) { sc.y = pscale[k + 1]; sh.y = pshift[k + 1]; }
+        if (k + 2 < K) { sc.z = pscale[k + 2]; sh.z = pshift[k + 2]; }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       const long long row = m0 + sr + 32 * i;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (row < M) {
-        const float *p = A + row * lda + k;
-        if (k + 3 < K) {
-          if (avec) v = *reinterpret_cast<const float4 *>(p);
-          else { v.x = p[0]; v.y = p[1]; v.z = p[2]; v.w = p[3]; }
+        if (PRO == PRO_GATHER) {
+          float e[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int kc = k + c;
+            float x = 0.f;
+            if (kc < K) {
+              if (kc < 3) {
+                x = ga.xyz[g_pt[i] + kc] - ga.new_xyz[g_ctr[i] + kc];
+                if (ga.normalize) x = x / ga.radius;
+              } else {
+                x = ga.feats[g_src[i] + (kc - 3)];
+              }
+            }
+            e[c] = x;
+          }
+          v = make_float4(e[0], e[1], e[2], e[3]);
         } else {
-          if (k < K) v.x = p[0];
-          if (k + 1 < K) v.y = p[1];
-          if (k + 2 < K) v.z = p[2];
-        }
-        if (pscale != nullptr) {
-          if (k < K) v.x = fmaxf(v.x * pscale[k] + pshift[k], 0.f);
-          if (k + 1 < K) v.y = fmaxf(v.y * pscale[k + 1] + pshift[k + 1], 0.f);
-          if (k + 2 < K) v.z = fmaxf(v.z * pscale[k + 2] + pshift[k + 2], 0.f);
-          if (k + 3 < K) v.w = fmaxf(v.w * pscale[k + 3] + pshift[k + 3], 0.f);
+          const float *p = A + row * lda + k;
+          if (k + 3 < K) {
+            if (avec) v = *reinterpret_cast<const float4 *>(p);
+            else { v.x = p[0]; v.y = p[1]; v.z = p[2]; v.w = p[3]; }
+          } else {
+            if (k < K) v.x = p[0];
+            if (k + 1 < K) v.y = p[1];
+            if (k + 2 < K) v.z = p[2];
+          }
+          if (PRO == PRO_BNRELU) {
+            // columns >= K keep scale 1 / shift 0 on a zero operand
+            v.x = fmaxf(v.x * sc.x + sh.x, 0.f); v.y = fmaxf(v.y * sc.y + sh.y, 0.f);
+            v.z = fmaxf(v.z * sc.z + sh.z, 0.f); v.w = fmaxf(v.w * sc.w + sh.w, 0.f);
+            if (k + 3 >= K) {
+              if (k >= K) v.x = 0.f;
+              if (k + 1 >= K) v.y = 0.f;
+              if (k + 2 >= K) v.z = 0.f;
+              v.w = 0.f;
+            }
+          }
         }
       }
       ra[i] = v;
@@ -101,17 +181,9 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(
   };
   auto store_slice = [&]() {
 #pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      const int r = sr + 32 * i;
-      As[sq * 4 + 0][r] = ra[i].x; As[sq * 4 + 1][r] = ra[i].y;
-      As[sq * 4 + 2][r] = ra[i].z; As[sq * 4 + 3][r] = ra[i].w;
-    }
+    for (int i = 0; i < AI; ++i) lds_store_quad(As + (sr + 32 * i) * LDS_LD, sq, ra[i]);
 #pragma unroll
-    for (int i = 0; i < WI; ++i) {
-      const int r = sr + 32 * i;
-      Ws[sq * 4 + 0][r] = rw[i].x; Ws[sq * 4 + 1][r] = rw[i].y;
-      Ws[sq * 4 + 2][r] = rw[i].z; Ws[sq * 4 + 3][r] = rw[i].w;
-    }
+    for (int i = 0; i < WI; ++i) lds_store_quad(Ws + (sr + 32 * i) * LDS_LD, sq, rw[i]);
   };
 
   f32x16 acc[2][2];
@@ -123,7 +195,10 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int li = lane & 31, lk = lane >> 5;
-  const int arow = wm * 64 + li, wcol = wn * 64 + li;
+  const float *a_base0 = As + (wm * 64 + li) * LDS_LD + lk * 16;
+  const float *a_base1 = a_base0 + 32 * LDS_LD;
+  const float *w_base0 = Ws + (wn * 64 + li) * LDS_LD + lk * 16;
+  const float *w_base1 = w_base0 + 32 * LDS_LD;
 
   load_slice(0);
   for (int k0 = 0; k0 < K; k0 += BK) {
@@ -132,13 +207,20 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(
     __syncthreads();
     if (k0 + BK < K) load_slice(k0 + BK);   // prefetch under the MFMAs
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      const float a0 = As[kk + lk][arow], a1 = As[kk + lk][arow + 32];
-      const float b0 = Ws[kk + lk][wcol], b1 = Ws[kk + lk][wcol + 32];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    for (int q = 0; q < 4; ++q) {
+      const float4 a0 = *reinterpret_cast<const float4 *>(a_base0 + 4 * q);
+      const float4 a1 = *reinterpret_cast<const float4 *>(a_base1 + 4 * q);
+      const float4 b0 = *reinterpret_cast<const float4 *>(w_base0 + 4 * q);
+      const float4 b1 = *reinterpret_cast<const float4 *>(w_base1 + 4 * q);
+      const float a0v[4] = {a0.x, a0.y, a0.z, a0.w}, a1v[4] = {a1.x, a1.y, a1.z, a1.w};
+      const float b0v[4] = {b0.x, b0.y, b0.z, b0.w}, b1v[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v[s], b0v[s], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v[s], b1v[s], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v[s], b0v[s], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v[s], b1v[s], acc[1][1], 0, 0, 0);
+      }
     }
   }
 
@@ -185,37 +267,20 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(
   }
 }
 
-}  // namespace
-
-extern "C" int s2c_rows_gemm_blocks(long long M, int N) {
-  const int BM = N <= 64 ? 256 : 128;
-  return (int)((M + BM - 1) / BM);
-}
-
-// Y = pro(A) W^T (+ column-statistics partials).  pscale/pshift NULL: pro = id.
-// partial NULL: no statistics; else s2c_rows_gemm_blocks(M,N) * 2N floats,
-// laid out exactly like the partials of s2c_bn_train_stats (see
-// s2c_bn_finalize_partials).
-extern "C" int s2c_rows_gemm(long long M, int N, int K, const float *A, int lda,
-                             const float *W, int ldw, const float *pscale,
-                             const float *pshift, float *Y, int ldy,
-                             float *partial, void *stream) {
-  if (M <= 0 || N <= 0 || K <= 0 || lda < K || ldw < K) {
-    fprintf(stderr, "s2c_rows_gemm: bad arguments\n");
-    return -1;
-  }
-  // 16-byte row loads need aligned rows; otherwise four 4-byte loads per quad
-  const int avec = ((lda & 3) == 0) && (((uintptr_t)A & 15) == 0);
+template <int PRO>
+int launch(long long M, int N, int K, const float *A, int lda, const float *W, int ldw,
+           const float *pscale, const float *pshift, const GatherArgs &ga, float *Y,
+           int ldy, float *partial, hipStream_t st) {
+  const int avec = A && ((lda & 3) == 0) && (((uintptr_t)A & 15) == 0);
   const int wvec = ((ldw & 3) == 0) && (((uintptr_t)W & 15) == 0);
-  hipStream_t st = (hipStream_t)stream;
   if (N <= 64) {
     dim3 grid((unsigned)((M + 255) / 256), 1);
-    hipLaunchKernelGGL((rows_gemm_kernel<4, 1>), grid, dim3(256), 0, st, (int)M, N, K, A,
-                       lda, W, ldw, pscale, pshift, Y, ldy, partial, avec, wvec);
+    hipLaunchKernelGGL((rows_gemm_kernel<4, 1, PRO>), grid, dim3(256), 0, st, M, N, K, A,
+                       lda, W, ldw, pscale, pshift, ga, Y, ldy, partial, avec, wvec);
   } else {
     dim3 grid((unsigned)((M + 127) / 128), (unsigned)((N + 127) / 128));
-    hipLaunchKernelGGL((rows_gemm_kernel<2, 2>), grid, dim3(256), 0, st, (int)M, N, K, A,
-                       lda, W, ldw, pscale, pshift, Y, ldy, partial, avec, wvec);
+    hipLaunchKernelGGL((rows_gemm_kernel<2, 2, PRO>), grid, dim3(256), 0, st, M, N, K, A,
+                       lda, W, ldw, pscale, pshift, ga, Y, ldy, partial, avec, wvec);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -223,4 +288,57 @@ extern "C" int s2c_rows_gemm(long long M, int N, int K, const float *A, int lda,
     return (int)e;
   }
   return 0;
+}
+
+}  // namespace
+
+extern "C" int s2c_rows_gemm_blocks(long long M, int N) {
+  const int BM = N <= 64 ? 256 : 128;
+  return (int)((M + BM - 1) / BM);
+}
+
+// Y = pro(A) W^T (+ column-statistics partials).  pscale/pshift NULL: pro = id,
+// else BN+ReLU of the operand.  partial NULL: no statistics; else
+// s2c_rows_gemm_blocks(M,N) * 2N floats (reduce with s2c_bn_finalize_partials).
+extern "C" int s2c_rows_gemm(long long M, int N, int K, const float *A, int lda,
+                             const float *W, int ldw, const float *pscale,
+                             const float *pshift, float *Y, int ldy,
+                             float *partial, void *stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || !A || !W || !Y || lda < K || ldw < K) {
+    fprintf(stderr, "s2c_rows_gemm: bad arguments\n");
+    return -1;
+  }
+  GatherArgs ga = {};
+  if (pscale != nullptr) {
+    if (((uintptr_t)pscale & 15) || ((uintptr_t)pshift & 15)) return -1;
+    return launch<PRO_BNRELU>(M, N, K, A, lda, W, ldw, pscale, pshift, ga, Y, ldy,
+                              partial, (hipStream_t)stream);
+  }
+  return launch<PRO_NONE>(M, N, K, A, lda, W, ldw, nullptr, nullptr, ga, Y, ldy, partial,
+                          (hipStream_t)stream);
+}
+
+// First set-abstraction layer with the ball-query grouping fused into the operand
+// load: Y[(b,j,s), :] = [ (xyz[b,idx]-new_xyz[b,j]) (/radius) | feats[b,idx,:] ] W^T.
+// K = 3 + C.  feats may be NULL when C == 0.
+extern "C" int s2c_sa_gather_gemm(int b, int n, int m, int ns, int C,
+                                  long long feat_row_stride,
+                                  long long feat_batch_stride, float radius,
+                                  int normalize, const float *xyz,
+                                  const float *new_xyz, const float *feats,
+                                  const int *idx, int N, const float *W, int ldw,
+                                  float *Y, int ldy, float *partial, void *stream) {
+  const long long M = (long long)b * m * ns;
+  const int K = 3 + C;
+  if (M <= 0 || N <= 0 || !xyz || !new_xyz || !idx || !W || !Y || ldw < K ||
+      (C > 0 && !feats)) {
+    fprintf(stderr, "s2c_sa_gather_gemm: bad arguments\n");
+    return -1;
+  }
+  GatherArgs ga;
+  ga.xyz = xyz; ga.new_xyz = new_xyz; ga.feats = feats; ga.idx = idx;
+  ga.frs = feat_row_stride; ga.fbs = feat_batch_stride;
+  ga.n = n; ga.m = m; ga.ns = ns; ga.radius = radius; ga.normalize = normalize;
+  return launch<PRO_GATHER>(M, N, K, nullptr, K, W, ldw, nullptr, nullptr, ga, Y, ldy,
+                            partial, (hipStream_t)stream);
 }

@@ -30,6 +30,7 @@ _C.register("s2c_bn_relu", [_L, _I, _P, _P, _P, _P, _I, _P])
 _C.register("s2c_bn_relu_max", [_L, _I, _I, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_bn_relu_bwd", [_L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_rows_gemm", [_L, _I, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _P])
+_C.register("s2c_sa_gather_gemm", [_I, _I, _I, _I, _I, _L, _L, _F, _I, _P, _P, _P, _P, _I, _P, _I, _P, _I, _P, _P])
 _C.register("s2c_bn_finalize_partials", [_I, _L, _I, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_bn_relu_max_bwd", [_L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P])
 
@@ -135,9 +136,19 @@ class _MLPRows(Function):
     BN+ReLU is fused with a max over groups of pool_ns consecutive rows."""
 
     @staticmethod
-    def forward(ctx, X, specs, pool_ns, *params):
-        dev = X.device
-        M = X.shape[0]
+    def forward(ctx, X, xyz, new_xyz, feats, gcfg, specs, pool_ns, *params):
+        # Operand: either X (M, Cin), or -- X is None -- the gathered rows described
+        # by (xyz, new_xyz, feats, gcfg=(idx, radius, normalize)); the first layer
+        # then gathers on the fly (s2c_sa_gather_gemm) and X is never built.
+        gather = None
+        if X is None:
+            gather = GatherSpec(xyz, new_xyz, feats, gcfg[0], gcfg[1], gcfg[2])
+            gather.needs_grad = any(ctx.needs_input_grad[1:4])
+            gather.need_xyz = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+            gather.need_feats = bool(ctx.needs_input_grad[3])
+            dev, M = gather.xyz.device, gather.rows
+        else:
+            dev, M = X.device, X.shape[0]
         need_grad = any(ctx.needs_input_grad)
         saved = []          # per layer dict of tensors needed in backward
         A = X
@@ -156,9 +167,21 @@ class _MLPRows(Function):
                 gamma, beta = params[pi], params[pi + 1]; pi += 2
             Cout = W.shape[0]
             train_stats = bn is not None and (bn.training or bn.running_mean is None)
+            from_gather = gather is not None and li == 0
             gemm_stats = (USE_MFMA_GEMM and train_stats and bias is None
-                          and A.stride(1) == 1 and W.stride(1) == 1)
-            if gemm_stats:
+                          and W.stride(1) == 1 and (from_gather or A.stride(1) == 1))
+            if from_gather:
+                assert bias is None and W.stride(1) == 1
+                g = gather
+                nbg = _gemm_blocks(M, Cout)
+                gpart = torch.empty(nbg * 2 * Cout, device=dev) if gemm_stats else None
+                Y = torch.empty((M, Cout), device=dev)
+                _call("s2c_sa_gather_gemm", Y, g.B, g.N, g.m, g.ns, g.C, g.frs, g.fbs,
+                      g.radius, g.normalize, g.xyz.data_ptr(), g.new_xyz.data_ptr(),
+                      _ptr(g.feats), g.idx.data_ptr(), Cout, W.data_ptr(), W.stride(0),
+                      Y.data_ptr(), Cout, _ptr(gpart),
+                      alg_bytes=4 * (min(g.B * g.N, M) * (3 + g.C) + M + M * Cout))
+            elif gemm_stats:
                 # hand-written f32 MFMA GEMM; BN batch statistics come out of its
                 # epilogue as per-row-block partials (no extra pass over Y)
                 nbg = _gemm_blocks(M, Cout)
@@ -170,14 +193,15 @@ class _MLPRows(Function):
                       gpart.data_ptr(), alg_bytes=4 * (M * K_in + M * Cout))
             else:
                 Y = torch.addmm(bias, A, W.t()) if bias is not None else torch.mm(A, W.t())
-            rec = {"A_in": A, "W": W, "has_bias": bias is not None}
+            rec = {"A_in": None if from_gather else A, "W": W,
+                   "has_bias": bias is not None}
             last = li == nl - 1
             if bn is not None:
                 scale = torch.empty(Cout, device=dev)
                 shift = torch.empty(Cout, device=dev)
                 mean = torch.empty(Cout, device=dev)
                 invstd = torch.empty(Cout, device=dev)
-                if gemm_stats:
+                if gemm_stats and gpart is not None:
                     mom = bn.momentum if bn.momentum is not None else 0.1
                     _call("s2c_bn_finalize_partials", Y, nbg, M, Cout, gpart.data_ptr(),
                           float(bn.eps), float(mom), _ptr(gamma), _ptr(beta),
@@ -234,7 +258,9 @@ class _MLPRows(Function):
             ctx.saved = saved
             ctx.specs = specs
             ctx.pool_ns = pool_ns
-            ctx.x_needs_grad = X.requires_grad
+            ctx.gather = gather
+            ctx.x_needs_grad = (gather.needs_grad if gather is not None
+                                else X.requires_grad)
         return out
 
     @staticmethod
@@ -245,9 +271,13 @@ class _MLPRows(Function):
         dA = dOut.contiguous()
         partial = None
         nl = len(specs)
+        gather = ctx.gather
         for li in range(nl - 1, -1, -1):
             rec, sp = saved[li], specs[li]
             W, A_in = rec["W"], rec["A_in"]
+            if A_in is None:
+                # first layer of a gather-fused stack: rebuild its operand now
+                A_in = gather.materialise()
             Cout = W.shape[0]
             M = A_in.shape[0]
             dgamma = dbeta = None
@@ -295,7 +325,12 @@ class _MLPRows(Function):
         for g in reversed(grads):
             flat += g
         ctx.saved = None
-        return (dA, None, None) + tuple(flat)
+        d_xyz = d_new = d_feats = None
+        if gather is not None:
+            if dA is not None:
+                d_xyz, d_new, d_feats = gather.scatter(dA)
+            dA = None
+        return (dA, d_xyz, d_new, d_feats, None, None, None) + tuple(flat)
 
 
 def _weight_grad(dY, A):
@@ -311,6 +346,52 @@ def _weight_grad(dY, A):
         return torch.mm(dY.t(), A)
     part = torch.bmm(dY.view(S, M // S, -1).transpose(1, 2), A.view(S, M // S, -1))
     return part.sum(0)
+
+
+class GatherSpec(object):
+    """Describes the operand of a set-abstraction stack without building it:
+    row (b, j, s) = [ (xyz[b, idx] - new_xyz[b, j]) (/radius) | feats[b, idx, :] ]."""
+
+    def __init__(self, xyz, new_xyz, feats, idx, radius, normalize):
+        self.xyz, self.new_xyz = xyz.contiguous(), new_xyz.contiguous()
+        if feats is not None and feats.stride(2) != 1:
+            feats = feats.contiguous()
+        self.feats, self.idx = feats, idx
+        self.B, self.N = xyz.shape[0], xyz.shape[1]
+        self.m, self.ns = idx.shape[1], idx.shape[2]
+        self.C = feats.shape[2] if feats is not None else 0
+        self.frs = feats.stride(1) if feats is not None else 0
+        self.fbs = feats.stride(0) if feats is not None else 0
+        self.radius, self.normalize = float(radius), int(bool(normalize))
+        self.rows = self.B * self.m * self.ns
+        self.needs_grad = self.need_xyz = self.need_feats = False
+
+    def materialise(self):
+        X = torch.empty((self.rows, 3 + self.C), dtype=torch.float32,
+                        device=self.xyz.device)
+        _call("s2c_sa_gather_rows", X, self.B, self.N, self.m, self.ns, self.C,
+              self.frs, self.fbs, self.radius, self.normalize, self.xyz.data_ptr(),
+              self.new_xyz.data_ptr(), _ptr(self.feats), self.idx.data_ptr(),
+              X.data_ptr(),
+              alg_bytes=4 * (min(self.B * self.N, self.rows) * (3 + self.C)
+                             + self.rows + self.rows * (3 + self.C)))
+        return X
+
+    def scatter(self, dX):
+        """Row gradients (rows, 3+C) -> d_xyz (B,N,3), d_new_xyz (B,m,3),
+        d_feats (B,N,C) (None where not needed)."""
+        dev = dX.device
+        dX = dX.contiguous()
+        d_feats = torch.empty((self.B, self.N, self.C), device=dev) \
+            if (self.need_feats and self.C > 0) else None
+        d_xyz = torch.empty((self.B, self.N, 3), device=dev) if self.need_xyz else None
+        d_new = torch.empty((self.B, self.m, 3), device=dev) if self.need_xyz else None
+        if d_feats is not None or d_xyz is not None:
+            _call("s2c_sa_scatter_rows", dX, self.B, self.N, self.m, self.ns, self.C,
+                  self.radius, self.normalize, dX.data_ptr(), self.idx.data_ptr(),
+                  _ptr(d_feats), _ptr(d_xyz), _ptr(d_new),
+                  alg_bytes=4 * (self.rows * (3 + self.C + 1) + self.B * self.N * self.C))
+        return d_xyz, d_new, d_feats
 
 
 def _layer_params(conv_w, conv_b, bn):
@@ -348,7 +429,11 @@ def mlp_supported(specs, params):
 
 def mlp_rows(X, specs, params, pool_ns=0):
     """Apply the layer stack to row-major X (M, Cin) -> (M or M/pool_ns, Cout)."""
-    return _MLPRows.apply(X, specs, pool_ns, *params)
+    return _MLPRows.apply(X, None, None, None, None, specs, pool_ns, *params)
+
+
+# fuse the grouping into the first layer's MFMA GEMM (no (rows, 3+C) tensor)
+FUSE_GATHER = True
 
 
 def sa_group_mlp_pool(xyz, new_xyz, feats_pm, idx, radius, normalize, mlp):
@@ -359,6 +444,12 @@ def sa_group_mlp_pool(xyz, new_xyz, feats_pm, idx, radius, normalize, mlp):
     """
     B, m, ns = idx.shape
     specs, params = shared_mlp_specs(mlp)
-    X = _GatherRows.apply(xyz, new_xyz, feats_pm, idx, radius, normalize)
-    out = mlp_rows(X, specs, params, pool_ns=ns)
+    first_bn = specs[0].bn
+    if (FUSE_GATHER and USE_MFMA_GEMM and not specs[0].has_bias
+            and params[0].stride(1) == 1):
+        out = _MLPRows.apply(None, xyz, new_xyz, feats_pm, (idx, radius, normalize),
+                             specs, ns, *params)
+    else:
+        X = _GatherRows.apply(xyz, new_xyz, feats_pm, idx, radius, normalize)
+        out = mlp_rows(X, specs, params, pool_ns=ns)
     return out.view(B, m, -1)
