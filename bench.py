@@ -124,15 +124,18 @@ def make_step(model, wl, cfg_loss, optimizer, ddp, device):
     """Eager step (also the un-captured body of the graphed step)."""
     def train_step(dd):
         dd = dict(dd)
+        # fresh gradient tensors every step: no zero-fill and no accumulate
+        # kernels (2 launches per parameter with preallocated .grad)
         if ddp is not None:
-            ddp.zero_grad()
+            ddp.drop_grads()
         else:
-            optimizer.zero_grad(set_to_none=False)
+            optimizer.zero_grad(set_to_none=True)
         dd = model(dd, use_tf=True, is_eval=False)
         dd = get_scene_cap_loss(dd, device, cfg_loss, None, detection=True,
                                 caption=True, orientation=False, distance=False)
         dd["loss"].backward()
         if ddp is not None:
+            ddp.pack_grads()
             ddp.reduce()
         optimizer.step()
         return dd["loss"]
@@ -251,10 +254,11 @@ def main():
         if wl["train"] and ddp is not None:
             def fwd_bwd():
                 d = dict(dd)
-                ddp.zero_grad()
+                ddp.drop_grads()
                 d = model(d, use_tf=True, is_eval=False)
                 d = get_scene_cap_loss(d, device, cfg_loss, None)
                 d["loss"].backward()
+                ddp.pack_grads()      # one multi-tensor copy into the flat bucket
                 return d["loss"]
             g1 = GraphedCallable(fwd_bwd).capture()
             g2 = GraphedCallable(lambda: optimizer.step()).capture()

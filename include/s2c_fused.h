@@ -63,9 +63,11 @@ int s2c_bn_eval_coeffs(int C, float eps, const float *gamma, const float *beta,
 int s2c_bn_relu(long long M, int C, const float *Y, const float *scale,
                 const float *shift, float *A, int relu, void *stream);
 
-/* out[j,c] = max_k relu(Y[(j,k),c]*scale + shift); arg = first maximising k */
+/* out[j,c] = max_k relu(Y[(j,k),c]*scale + shift); arg = first maximising k;
+ * ymax (optional) = Y at that k (raw, pre-BN) for the backward statistics */
 int s2c_bn_relu_max(long long J, int ns, int C, const float *Y, const float *scale,
-                    const float *shift, float *out, int *arg, void *stream);
+                    const float *shift, float *out, int *arg, float *ymax,
+                    void *stream);
 
 /* backward of BN(+ReLU) given dA (M x C); coef: 3*C floats scratch;
  * frozen != 0: statistics are constants (eval mode). */
@@ -77,7 +79,8 @@ int s2c_bn_relu_bwd(long long M, int C, const float *dA, const float *Y,
 
 /* backward of BN+ReLU+max-pool given dOut (J x C) and arg (J x C): dY (J*ns x C) */
 int s2c_bn_relu_max_bwd(long long J, int ns, int C, const float *dOut,
-                        const int *arg, const float *Y, const float *scale,
+                        const int *arg, const float *ymax, const float *Y,
+                        const float *scale,
                         const float *shift, const float *mean, const float *invstd,
                         const float *gamma, int frozen, float *partial, float *coef,
                         float *dgamma, float *dbeta, float *dY, void *stream);

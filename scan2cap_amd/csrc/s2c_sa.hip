@@ -376,7 +376,7 @@ extern "C" int s2c_bn_relu(long long M, int C, const float *Y, const float *scal
 __global__ __launch_bounds__(256) void bn_relu_max_kernel(
     const float *__restrict__ Y, const float *__restrict__ scale,
     const float *__restrict__ shift, float *__restrict__ out,
-    int *__restrict__ arg, long long J, int ns, int c4n) {
+    int *__restrict__ arg, float *__restrict__ ymax, long long J, int ns, int c4n) {
   const long long total = J * c4n;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total;
        e += (long long)gridDim.x * 256) {
@@ -385,29 +385,33 @@ __global__ __launch_bounds__(256) void bn_relu_max_kernel(
     const float4 sc = reinterpret_cast<const float4 *>(scale)[tx];
     const float4 sh = reinterpret_cast<const float4 *>(shift)[tx];
     float4 best = make_float4(-1.f, -1.f, -1.f, -1.f);
+    float4 ybest = make_float4(0.f, 0.f, 0.f, 0.f);
     int4 bi = make_int4(0, 0, 0, 0);
     const float4 *src = reinterpret_cast<const float4 *>(Y) + (j * ns) * c4n + tx;
     for (int k = 0; k < ns; ++k) {
       const float4 y = src[(long long)k * c4n];
       const float ax = fmaxf(y.x * sc.x + sh.x, 0.f), ay = fmaxf(y.y * sc.y + sh.y, 0.f);
       const float az = fmaxf(y.z * sc.z + sh.z, 0.f), aw = fmaxf(y.w * sc.w + sh.w, 0.f);
-      if (ax > best.x) { best.x = ax; bi.x = k; }
-      if (ay > best.y) { best.y = ay; bi.y = k; }
-      if (az > best.z) { best.z = az; bi.z = k; }
-      if (aw > best.w) { best.w = aw; bi.w = k; }
+      if (ax > best.x) { best.x = ax; bi.x = k; ybest.x = y.x; }
+      if (ay > best.y) { best.y = ay; bi.y = k; ybest.y = y.y; }
+      if (az > best.z) { best.z = az; bi.z = k; ybest.z = y.z; }
+      if (aw > best.w) { best.w = aw; bi.w = k; ybest.w = y.w; }
     }
     reinterpret_cast<float4 *>(out)[e] = best;
     reinterpret_cast<int4 *>(arg)[e] = bi;
+    // raw pre-BN value at the arg-max: lets the backward statistics run on
+    // (J x C) data instead of gathering from the (J*ns x C) tensor
+    if (ymax != nullptr) reinterpret_cast<float4 *>(ymax)[e] = ybest;
   }
 }
 
 extern "C" int s2c_bn_relu_max(long long J, int ns, int C, const float *Y,
                                const float *scale, const float *shift, float *out,
-                               int *arg, void *stream) {
+                               int *arg, float *ymax, void *stream) {
   if (J < 0 || ns <= 0 || C <= 0 || (C & 3)) return fail2("bn_relu_max: C%4==0");
   if (J == 0) return 0;
   hipLaunchKernelGGL(bn_relu_max_kernel, dim3(grid1d(J * (C >> 2), 256)), dim3(256),
-                     0, (hipStream_t)stream, Y, scale, shift, out, arg, J, ns, C >> 2);
+                     0, (hipStream_t)stream, Y, scale, shift, out, arg, ymax, J, ns, C >> 2);
   return check2("bn_relu_max");
 }
 
@@ -527,29 +531,25 @@ extern "C" int s2c_bn_relu_bwd(long long M, int C, const float *dA, const float 
 
 // max-pool variant: upstream dOut (J x C), arg (J x C); rows M = J*ns.
 __global__ __launch_bounds__(STAT_BLOCK) void pool_bwd_stats_kernel(
-    const float *__restrict__ dOut, const int *__restrict__ arg,
-    const float *__restrict__ Y, const float *__restrict__ scale,
-    const float *__restrict__ shift, const float *__restrict__ mean,
-    const float *__restrict__ invstd, long long J, int ns, int C,
-    float *__restrict__ partial, long long rows_per_block) {
+    const float *__restrict__ dOut, const float *__restrict__ ymax,
+    const float *__restrict__ scale, const float *__restrict__ shift,
+    const float *__restrict__ mean, const float *__restrict__ invstd, long long J,
+    int C, float *__restrict__ partial, long long rows_per_block) {
   col_reduce2(
       [&](long long j, int tx, float4 &q1, float4 &q2) {
         float4 g = reinterpret_cast<const float4 *>(dOut + j * C)[tx];
-        const int4 a = reinterpret_cast<const int4 *>(arg + j * C)[tx];
+        const float4 y = reinterpret_cast<const float4 *>(ymax + j * C)[tx];
         const float4 sc = reinterpret_cast<const float4 *>(scale)[tx];
         const float4 sh = reinterpret_cast<const float4 *>(shift)[tx];
         const float4 mu = reinterpret_cast<const float4 *>(mean)[tx];
         const float4 is = reinterpret_cast<const float4 *>(invstd)[tx];
-        const float *base = Y + (j * ns) * C + tx * 4;
-        const float yx = base[(long long)a.x * C + 0], yy = base[(long long)a.y * C + 1];
-        const float yz = base[(long long)a.z * C + 2], yw = base[(long long)a.w * C + 3];
-        if (!(yx * sc.x + sh.x > 0.f)) g.x = 0.f;
-        if (!(yy * sc.y + sh.y > 0.f)) g.y = 0.f;
-        if (!(yz * sc.z + sh.z > 0.f)) g.z = 0.f;
-        if (!(yw * sc.w + sh.w > 0.f)) g.w = 0.f;
+        if (!(y.x * sc.x + sh.x > 0.f)) g.x = 0.f;
+        if (!(y.y * sc.y + sh.y > 0.f)) g.y = 0.f;
+        if (!(y.z * sc.z + sh.z > 0.f)) g.z = 0.f;
+        if (!(y.w * sc.w + sh.w > 0.f)) g.w = 0.f;
         q1 = g;
-        q2 = make_float4(g.x * ((yx - mu.x) * is.x), g.y * ((yy - mu.y) * is.y),
-                         g.z * ((yz - mu.z) * is.z), g.w * ((yw - mu.w) * is.w));
+        q2 = make_float4(g.x * ((y.x - mu.x) * is.x), g.y * ((y.y - mu.y) * is.y),
+                         g.z * ((y.z - mu.z) * is.z), g.w * ((y.w - mu.w) * is.w));
       },
       J, C, partial, rows_per_block);
 }
@@ -559,16 +559,16 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(
     const float *__restrict__ Y, const float *__restrict__ scale,
     const float *__restrict__ shift, const float *__restrict__ mean,
     const float *__restrict__ invstd, const float *__restrict__ coef,
-    float *__restrict__ dY, long long total4, int ns, int c4n, int C) {
-  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total4;
+    float *__restrict__ dY, long long J, int ns, int c4n, int C) {
+  // thread = (centre j, channel quad): per-centre operands are read once, the ns
+  // rows of the centre are streamed (same access shape as the forward max kernel)
+  const long long total = J * c4n;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total;
        e += (long long)gridDim.x * 256) {
     const int tx = (int)(e % c4n);
-    const long long r = e / c4n;
-    const long long j = r / ns;
-    const int k = (int)(r - j * ns);
-    const float4 y = reinterpret_cast<const float4 *>(Y)[e];
-    float4 g = reinterpret_cast<const float4 *>(dOut + j * C)[tx];
-    const int4 a = reinterpret_cast<const int4 *>(arg + j * C)[tx];
+    const long long j = e / c4n;
+    float4 g = reinterpret_cast<const float4 *>(dOut)[e];
+    const int4 a = reinterpret_cast<const int4 *>(arg)[e];
     const float4 sc = reinterpret_cast<const float4 *>(scale)[tx];
     const float4 sh = reinterpret_cast<const float4 *>(shift)[tx];
     const float4 mu = reinterpret_cast<const float4 *>(mean)[tx];
@@ -576,21 +576,26 @@ __global__ __launch_bounds__(256) void pool_bwd_apply_kernel(
     const float4 k0 = reinterpret_cast<const float4 *>(coef)[tx];
     const float4 k1 = reinterpret_cast<const float4 *>(coef + C)[tx];
     const float4 k2 = reinterpret_cast<const float4 *>(coef + 2 * C)[tx];
-    if (a.x != k || !(y.x * sc.x + sh.x > 0.f)) g.x = 0.f;
-    if (a.y != k || !(y.y * sc.y + sh.y > 0.f)) g.y = 0.f;
-    if (a.z != k || !(y.z * sc.z + sh.z > 0.f)) g.z = 0.f;
-    if (a.w != k || !(y.w * sc.w + sh.w > 0.f)) g.w = 0.f;
-    float4 o;
-    o.x = k0.x * (g.x - k1.x - ((y.x - mu.x) * is.x) * k2.x);
-    o.y = k0.y * (g.y - k1.y - ((y.y - mu.y) * is.y) * k2.y);
-    o.z = k0.z * (g.z - k1.z - ((y.z - mu.z) * is.z) * k2.z);
-    o.w = k0.w * (g.w - k1.w - ((y.w - mu.w) * is.w) * k2.w);
-    reinterpret_cast<float4 *>(dY)[e] = o;
+    const float4 *src = reinterpret_cast<const float4 *>(Y) + (j * ns) * c4n + tx;
+    float4 *dst = reinterpret_cast<float4 *>(dY) + (j * ns) * c4n + tx;
+    for (int k = 0; k < ns; ++k) {
+      const float4 y = src[(long long)k * c4n];
+      const float gx = (a.x == k && (y.x * sc.x + sh.x > 0.f)) ? g.x : 0.f;
+      const float gy = (a.y == k && (y.y * sc.y + sh.y > 0.f)) ? g.y : 0.f;
+      const float gz = (a.z == k && (y.z * sc.z + sh.z > 0.f)) ? g.z : 0.f;
+      const float gw = (a.w == k && (y.w * sc.w + sh.w > 0.f)) ? g.w : 0.f;
+      float4 o;
+      o.x = k0.x * (gx - k1.x - ((y.x - mu.x) * is.x) * k2.x);
+      o.y = k0.y * (gy - k1.y - ((y.y - mu.y) * is.y) * k2.y);
+      o.z = k0.z * (gz - k1.z - ((y.z - mu.z) * is.z) * k2.z);
+      o.w = k0.w * (gw - k1.w - ((y.w - mu.w) * is.w) * k2.w);
+      dst[(long long)k * c4n] = o;
+    }
   }
 }
 
 extern "C" int s2c_bn_relu_max_bwd(long long J, int ns, int C, const float *dOut,
-                                   const int *arg, const float *Y,
+                                   const int *arg, const float *ymax, const float *Y,
                                    const float *scale, const float *shift,
                                    const float *mean, const float *invstd,
                                    const float *gamma, int frozen, float *partial,
@@ -603,12 +608,11 @@ extern "C" int s2c_bn_relu_max_bwd(long long J, int ns, int C, const float *dOut
   const int nb = stat_blocks(J, &rpb);
   const long long M = J * ns;
   hipLaunchKernelGGL(pool_bwd_stats_kernel, dim3(nb), dim3(STAT_BLOCK), 0, st, dOut,
-                     arg, Y, scale, shift, mean, invstd, J, ns, C, partial, rpb);
+                     ymax, scale, shift, mean, invstd, J, C, partial, rpb);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st,
                      partial, nb, C, M, frozen, gamma, invstd, dgamma, dbeta, coef);
-  const long long total4 = M * (C >> 2);
-  hipLaunchKernelGGL(pool_bwd_apply_kernel, dim3(grid1d(total4, 256)), dim3(256), 0,
-                     st, dOut, arg, Y, scale, shift, mean, invstd, coef, dY, total4,
-                     ns, C >> 2, C);
+  hipLaunchKernelGGL(pool_bwd_apply_kernel, dim3(grid1d(J * (C >> 2), 256)), dim3(256),
+                     0, st, dOut, arg, Y, scale, shift, mean, invstd, coef, dY, J, ns,
+                     C >> 2, C);
   return check2("bn_relu_max_bwd");
 }

@@ -64,8 +64,34 @@ class FlatGradAllReduce(object):
                     dist.broadcast(t, src=0, group=self.group)
 
     def zero_grad(self):
-        """Keep the views alive: zero the bucket instead of dropping .grad."""
+        """Keep the views alive: zero the bucket instead of dropping .grad
+        (autograd then ACCUMULATES into the views: one add_ per parameter)."""
         self.flat.zero_()
+
+    def drop_grads(self):
+        """Alternative to zero_grad(): let autograd produce fresh gradient tensors
+        (no zero-fill, no accumulate kernels -- ~2 launches per parameter saved)
+        and move them into the bucket afterwards with pack_grads()."""
+        for p in self.params:
+            p.grad = None
+
+    def pack_grads(self):
+        """Copy the freshly produced gradients into the flat bucket with one
+        multi-tensor copy and re-bind p.grad to the bucket views."""
+        views, grads = [], []
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            v = self.flat[off:off + n].view_as(p)
+            off += n
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                views.append(v)
+                grads.append(p.grad)
+            p.grad = v
+        if views:
+            torch._foreach_copy_(views, grads)
 
     def reattach(self):
         """(Re)bind p.grad to the bucket, e.g. after optimizer.zero_grad(set_to_none=True)."""

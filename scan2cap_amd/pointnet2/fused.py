@@ -27,12 +27,12 @@ _C.register("s2c_sa_scatter_rows", [_I, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, 
 _C.register("s2c_bn_train_stats", [_L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_bn_eval_coeffs", [_I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_bn_relu", [_L, _I, _P, _P, _P, _P, _I, _P])
-_C.register("s2c_bn_relu_max", [_L, _I, _I, _P, _P, _P, _P, _P, _P])
+_C.register("s2c_bn_relu_max", [_L, _I, _I, _P, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_bn_relu_bwd", [_L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_rows_gemm", [_L, _I, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _P])
 _C.register("s2c_sa_gather_gemm", [_I, _I, _I, _I, _I, _L, _L, _F, _I, _P, _P, _P, _P, _I, _P, _I, _P, _I, _P, _P])
 _C.register("s2c_bn_finalize_partials", [_I, _L, _I, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P])
-_C.register("s2c_bn_relu_max_bwd", [_L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P])
+_C.register("s2c_bn_relu_max_bwd", [_L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P])
 
 
 def _ptr(t):
@@ -234,10 +234,13 @@ class _MLPRows(Function):
                     J = M // pool_ns
                     out = torch.empty((J, Cout), device=dev)
                     arg = torch.empty((J, Cout), dtype=torch.int32, device=dev)
+                    ymax = torch.empty((J, Cout), device=dev) if need_grad else None
                     _call("s2c_bn_relu_max", Y, J, pool_ns, Cout, Y.data_ptr(),
                           scale.data_ptr(), shift.data_ptr(), out.data_ptr(),
-                          arg.data_ptr(), alg_bytes=4 * (M * Cout + 2 * J * Cout))
+                          arg.data_ptr(), _ptr(ymax),
+                          alg_bytes=4 * (M * Cout + 2 * J * Cout))
                     rec["arg"] = arg
+                    rec["ymax"] = ymax
                 else:
                     A = torch.empty_like(Y)
                     _call("s2c_bn_relu", Y, M, Cout, Y.data_ptr(), scale.data_ptr(),
@@ -294,7 +297,8 @@ class _MLPRows(Function):
                 if li == nl - 1 and pool_ns > 0:
                     J = M // pool_ns
                     _call("s2c_bn_relu_max_bwd", Y, J, pool_ns, Cout, dA.data_ptr(),
-                          rec["arg"].data_ptr(), Y.data_ptr(), rec["scale"].data_ptr(),
+                          rec["arg"].data_ptr(), rec["ymax"].data_ptr(), Y.data_ptr(),
+                          rec["scale"].data_ptr(),
                           rec["shift"].data_ptr(), rec["mean"].data_ptr(),
                           rec["invstd"].data_ptr(), _ptr(rec["gamma"]),
                           int(rec["frozen"]), partial.data_ptr(), coef.data_ptr(),

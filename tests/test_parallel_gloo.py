@@ -34,6 +34,11 @@ def _worker(rank, world, port, out):
     ddp.zero_grad()
     net(data[lo:hi]).pow(2).sum().backward()
     local = ddp.flat.clone()
+    # the drop/pack flavour (fresh grads + one multi-tensor copy) must agree
+    ddp.drop_grads()
+    net(data[lo:hi]).pow(2).sum().backward()
+    ddp.pack_grads()
+    assert torch.allclose(ddp.flat, local, atol=1e-6)
     ddp.reduce()
     out[rank] = dict(w0=w0, local=local, reduced=ddp.flat.clone(), shard=(lo, hi),
                      views=all(p.grad.data_ptr() >= ddp.flat.data_ptr()
