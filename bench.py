@@ -240,7 +240,10 @@ def main():
         # while step i runs; the captured step reads it from static buffers
         from scan2cap_amd.pipeline import (GeometryPipeline, flatten_geometry,
                                            unflatten_geometry)
-        pipe = GeometryPipeline(model.backbone_net)
+        # a forward-only step is shorter than one FPS chain: keep 3 batches of
+        # geometry in flight; a train step (~18 ms) hides one chain (~6.5 ms)
+        depth = 1 if wl["train"] else 3
+        pipe = GeometryPipeline(model.backbone_net, depth=depth)
         geo0 = model.backbone_net.compute_geometry(dd["point_clouds"])
         static_geo = [torch.empty_like(t) for t in flatten_geometry(geo0)]
         for d_, s_ in zip(static_geo, flatten_geometry(geo0)):
@@ -272,11 +275,12 @@ def main():
             g = GraphedCallable(lambda: eager_step(dd)).capture()
             replay = g
         if overlap:
-            state = {"h": pipe.submit(dd["point_clouds"])}
+            from collections import deque
+            queue = deque(pipe.submit(dd["point_clouds"]) for _ in range(depth))
 
             def step(_dd):
-                cur = state["h"]
-                state["h"] = pipe.submit(dd["point_clouds"])   # geometry of step i+1
+                cur = queue.popleft()
+                queue.append(pipe.submit(dd["point_clouds"]))  # geometry of step i+depth
                 geo, done = cur
                 torch.cuda.current_stream().wait_event(done)
                 for d_, s_ in zip(static_geo, flatten_geometry(geo)):
@@ -350,8 +354,8 @@ def main():
                        "scenes_per_gpu": B, "global_batch": B * world,
                        "parallelism": "dp%d" % world,
                        "launch": "hipGraph replay" if use_graph else "eager",
-                       "geometry": "one batch ahead on a side stream" if overlap
-                                   else "in-line",
+                       "geometry": ("%d batch(es) ahead on side stream(s)" % depth)
+                                   if overlap else "in-line",
                        "grad_allreduce_bytes": ddp.nbytes if ddp else 0},
             "roofline": roof,
             "kernels": table_k[:8],

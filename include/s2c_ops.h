@@ -65,6 +65,12 @@ int s2c_furthest_point_sampling_bucketed(int b, int n, int m, const float *xyz,
                                          void *workspace, int *idx,
                                          s2c_stream_t stream);
 
+/* Latency-optimised register-resident FPS for n <= s2c_fps_small_limit() points
+ * (csrc/s2c_fps_small.hip); identical output.  threads = 0 picks the geometry. */
+int s2c_fps_small_limit(void);
+int s2c_furthest_point_sampling_small(int b, int n, int m, const float *xyz, int *idx,
+                                      int threads, s2c_stream_t stream);
+
 /* replaces gather_points_kernel_wrapper (sampling.cpp:5-7, sampling_gpu.cu:22-30).
  * points (b,c,n), idx (b,npoints) -> out (b,c,npoints) */
 int s2c_gather_points(int b, int c, int n, int npoints, const float *points,

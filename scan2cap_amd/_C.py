@@ -20,6 +20,7 @@ _FLT = ctypes.c_float
 _SIGNATURES = {
     "s2c_furthest_point_sampling": [_INT, _INT, _INT, _PTR, _PTR, _PTR, _PTR],
     "s2c_furthest_point_sampling_bucketed": [_INT, _INT, _INT, _PTR, _PTR, _PTR, _PTR],
+    "s2c_furthest_point_sampling_small": [_INT, _INT, _INT, _PTR, _PTR, _INT, _PTR],
     "s2c_gather_points": [_INT, _INT, _INT, _INT, _PTR, _PTR, _PTR, _PTR],
     "s2c_gather_points_grad": [_INT, _INT, _INT, _INT, _PTR, _PTR, _PTR, _PTR],
     "s2c_ball_query": [_INT, _INT, _INT, _FLT, _INT, _PTR, _PTR, _PTR, _PTR],
@@ -65,7 +66,8 @@ def load():
 
 def declared_symbols():
     return ["s2c_abi_version", "s2c_last_error_string",
-            "s2c_fps_resident_limit", "s2c_fps_workspace_bytes"] + list(_SIGNATURES)
+            "s2c_fps_resident_limit", "s2c_fps_workspace_bytes",
+            "s2c_fps_small_limit"] + list(_SIGNATURES)
 
 
 def register(name, argtypes):

@@ -17,19 +17,88 @@ all work of every batch is still executed, none is cached or skipped.
 import torch
 
 
+def _shares_queue(a, b, probe):
+    """True if work on stream `b` is held up by earlier work on stream `a` (HIP
+    maps streams onto a small number of in-order hardware queues: two streams on
+    the same queue cannot overlap).  Timed with a ~1 ms probe kernel."""
+    torch.cuda.synchronize()
+    with torch.cuda.stream(b):
+        t0 = torch.cuda.Event(enable_timing=True)
+        t1 = torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(a):
+        busy0 = torch.cuda.Event(enable_timing=True)
+        busy1 = torch.cuda.Event(enable_timing=True)
+        busy0.record(a)
+        probe()
+        busy1.record(a)
+    with torch.cuda.stream(b):
+        t0.record(b)
+        torch.empty(1, device="cuda").fill_(0)
+        t1.record(b)
+    torch.cuda.synchronize()
+    # b's trivial kernel finished only after a's probe => same queue
+    return busy0.elapsed_time(t1) > 0.8 * busy0.elapsed_time(busy1)
+
+
+def independent_streams(n, candidates=12):
+    """`n` side streams that share a hardware queue neither with the current
+    stream nor with each other (best effort: falls back to plain new streams)."""
+    if not torch.cuda.is_available():
+        return [torch.cuda.Stream() for _ in range(n)]
+    main = torch.cuda.current_stream()
+    x = torch.randn(2048, 2048, device="cuda")
+
+    def probe():
+        y = x
+        for _ in range(8):
+            y = torch.mm(y, x) * 1e-3
+        return y
+
+    for s in (main,):
+        with torch.cuda.stream(s):
+            probe()
+    picked, pool = [], [torch.cuda.Stream() for _ in range(candidates)]
+    for c in pool:
+        with torch.cuda.stream(c):
+            probe()                       # warm the library on this stream
+    for c in pool:
+        if len(picked) == n:
+            break
+        if _shares_queue(c, main, probe) or _shares_queue(main, c, probe):
+            continue
+        if any(_shares_queue(c, p, probe) for p in picked):
+            continue
+        picked.append(c)
+    while len(picked) < n:
+        picked.append(torch.cuda.Stream())
+    return picked
+
+
 class GeometryPipeline(object):
-    def __init__(self, backbone, stream=None):
+    """`depth` side streams used round-robin: with depth d the geometry of d
+    batches is in flight at once (each FPS chain occupies only B CUs), which is
+    what a forward-only pipeline needs when a step is shorter than one FPS chain."""
+
+    def __init__(self, backbone, stream=None, depth=1):
         self.backbone = backbone
-        self.stream = stream if stream is not None else torch.cuda.Stream()
+        self.streams = [stream] if stream is not None else \
+            independent_streams(max(1, depth))
+        self._next = 0
+
+    @property
+    def stream(self):
+        return self.streams[0]
 
     def submit(self, point_clouds):
-        """Launch the geometry stage of `point_clouds` on the side stream."""
+        """Launch the geometry stage of `point_clouds` on the next side stream."""
+        side = self.streams[self._next % len(self.streams)]
+        self._next += 1
         main = torch.cuda.current_stream()
-        self.stream.wait_stream(main)          # inputs were produced on `main`
-        with torch.cuda.stream(self.stream):
+        side.wait_stream(main)                 # inputs were produced on `main`
+        with torch.cuda.stream(side):
             geo = self.backbone.compute_geometry(point_clouds)
             done = torch.cuda.Event()
-            done.record(self.stream)
+            done.record(side)
         return geo, done
 
     def attach(self, data_dict, handle):

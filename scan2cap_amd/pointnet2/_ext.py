@@ -81,13 +81,12 @@ def furthest_point_sampling(points, nsamples):
         _run("s2c_furthest_point_sampling_bucketed", points, b, n, int(nsamples),
              points.data_ptr(), ws.data_ptr(), out.data_ptr(), alg_bytes=ab)
         return out
-    temp = None
-    if n > _C.load().s2c_fps_resident_limit():
-        temp = torch.empty((b, n), dtype=torch.float32, device=points.device)
-    _run("s2c_furthest_point_sampling", points, b, n, int(nsamples),
-         points.data_ptr(), temp.data_ptr() if temp is not None else None,
-         out.data_ptr(), alg_bytes=ab)
+    _run("s2c_furthest_point_sampling_small", points, b, n, int(nsamples),
+         points.data_ptr(), out.data_ptr(), int(FPS_SMALL_THREADS), alg_bytes=ab)
     return out
+
+
+FPS_SMALL_THREADS = 0   # 0 = library heuristic (tests sweep 64..1024)
 
 
 def furthest_point_sampling_bruteforce(points, nsamples):

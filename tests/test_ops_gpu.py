@@ -66,6 +66,25 @@ def test_fps_bucketed_adversarial(ext, oracle):
         np.testing.assert_array_equal(brute, want, err_msg=name + " (brute)")
 
 
+@pytest.mark.parametrize("threads", [64, 128, 256, 512, 1024])
+def test_fps_small_any_geometry(ext, oracle, threads, monkeypatch):
+    """The tie-break emulation must not depend on the launch geometry."""
+    monkeypatch.setattr(ext, "FPS_SMALL_THREADS", threads)
+    for (B, N, m) in [(2, 500, 100), (2, 2048, 300), (1, 8192, 64), (3, 40, 10)]:
+        if (N + threads - 1) // threads > 8:
+            continue
+        xyz = scene_xyz(B, N, seed=N + threads, mode="surface")
+        np.testing.assert_array_equal(
+            ext.furthest_point_sampling(dev(xyz), m).cpu().numpy(),
+            oracle.furthest_point_sampling(xyz, m))
+    g = np.stack(np.meshgrid(np.arange(8), np.arange(8), np.arange(8),
+                             indexing="ij"), -1).reshape(1, -1, 3)
+    xyz = g.astype(np.float32) * 0.25 + 1.0          # lattice: ties everywhere
+    np.testing.assert_array_equal(
+        ext.furthest_point_sampling(dev(xyz), 120).cpu().numpy(),
+        oracle.furthest_point_sampling(xyz, 120))
+
+
 def test_fps_degenerate(ext, oracle):
     # every point skipped (|p|^2 <= 1e-3) -> all picks are 0 (sampling_gpu.cu:90)
     xyz = np.zeros((2, 128, 3), np.float32)
