@@ -61,6 +61,52 @@ class LossConfig(object):
         self.mean_size_arr = msa
 
 
+# entry point -> device kernels it launches (for the PMC traffic lookup)
+KERNELS_OF = {
+    "s2c_bn_relu_bwd": ("bn_bwd_stats_kernel", "bn_bwd_apply_kernel"),
+    "s2c_bn_relu_max_bwd": ("pool_bwd_stats_kernel", "pool_bwd_apply_kernel"),
+    "s2c_bn_relu": ("bn_relu_kernel",),
+    "s2c_bn_relu_max": ("bn_relu_max_kernel",),
+    "s2c_bn_train_stats": ("col_stats_kernel",),
+    "s2c_rows_gemm": ("rows_gemm_kernel",),
+    "s2c_sa_gather_gemm": ("rows_gemm_kernel<4, 1, 2>", "rows_gemm_kernel<2, 2, 2>"),
+    "s2c_sa_gather_rows": ("sa_gather_rows_kernel",),
+    "s2c_sa_scatter_rows": ("sa_scatter_rows_kernel",),
+    "s2c_small_linear": ("small_linear_kernel",),
+    "s2c_gru_fwd": ("gru_fwd_kernel",),
+    "s2c_ball_query": ("ball_query_kernel",),
+}
+
+
+def pmc_traffic(entry):
+    """Mean HBM bytes per launch of `entry` from the committed rocprofv3 PMC
+    summary (profiles/r01_pmc_bench.json: FETCH_SIZE and WRITE_SIZE collected in
+    separate passes over `bench.py --no-graph --steps 2 --warmup 1`).  gfx950
+    correction (MI355X_MICROARCH.md, re-calibrated in
+    profiles/r01_pmc_sa_kernels_calibration.json on bn_relu, whose byte count is
+    exact): FETCH_SIZE counts half of a 16-byte-per-lane streaming read, so
+    bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.  None when not available."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_bench.json")
+    keys = KERNELS_OF.get(entry)
+    if not keys or not os.path.exists(path):
+        return None
+    try:
+        table = json.load(open(path))
+    except Exception:
+        return None
+    total, hit = 0.0, False
+    for kname, c in table.items():
+        if any(k in kname for k in keys) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            n = c["FETCH_SIZE"]["dispatches"]
+            total += (2 * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * 1024 * n
+            hit = True
+    if not hit:
+        return None
+    calls = max(c["FETCH_SIZE"]["dispatches"] for kname, c in table.items()
+                if any(k in kname for k in keys) and "FETCH_SIZE" in c)
+    return total / max(calls, 1)
+
+
 def make_vocab(V, seed=0):
     rng = np.random.Generator(np.random.PCG64(seed))
     words = ["pad_", "unk", "sos", "eos"] + ["w%d" % i for i in range(V - 4)]
@@ -327,20 +373,29 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = B * world * args.steps / elapsed
-        # dominant hand-written kernel of the timed region
+        # dominant hand-written kernel of the timed region.  When the geometry stage
+        # runs ahead on side streams its kernels are off the critical path, so the
+        # roofline describes the dominant kernel of the main stream instead (the
+        # geometry kernels stay listed under "kernels").
+        off_path = ("s2c_furthest_point_sampling", "s2c_ball_query", "s2c_three_nn") \
+            if overlap else ()
         roof, table_k = None, []
         for name, r in sorted(kern.items(), key=lambda kv: -kv[1]["total_ms"]):
             avg_us = r["total_ms"] / max(r["calls"], 1) * 1e3
             gbs = r["alg_bytes"] / max(r["total_ms"], 1e-9) / 1e6
             table_k.append({"kernel": name, "calls_per_step": r["calls"] / kern_steps,
                             "ms_per_step": r["total_ms"] / kern_steps,
-                            "avg_us": avg_us, "alg_GBps": gbs})
+                            "avg_us": avg_us, "alg_GBps": gbs,
+                            "alg_bytes_per_launch": r["alg_bytes"] / max(r["calls"], 1)})
         if table_k:
-            top = table_k[0]
+            on_path = [k for k in table_k if not k["kernel"].startswith(off_path)] \
+                if off_path else table_k
+            top = (on_path or table_k)[0]
             roof = {"kernel": top["kernel"], "bound": "hbm",
                     "achieved": top["alg_GBps"], "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": top["alg_GBps"] / HBM_PEAK_GBS,
-                    "traffic": None,
+                    "traffic": pmc_traffic(top["kernel"]),
+                    "alg_bytes_per_launch": top["alg_bytes_per_launch"],
                     "avg_launch_us": top["avg_us"],
                     "share_of_step": top["ms_per_step"] / ms_per_step}
         out = {

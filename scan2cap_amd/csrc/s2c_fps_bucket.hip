@@ -56,9 +56,11 @@ __global__ __launch_bounds__(T) void fps_bucket_kernel(
   __shared__ int s_cnt[MAXC], s_start[MAXC], s_cursor[MAXC], s_cand[MAXC];
   __shared__ u32 s_bb[6][MAXC];
   __shared__ u64 s_cellkey[MAXC];
+  __shared__ float s_cellxyz[3][MAXC];   // coordinates of each cell's arg-max point
   __shared__ unsigned short s_list[MAXC];
   __shared__ int s_nactive[2];
   __shared__ u64 s_wkey[2][NW];
+  __shared__ float s_wxyz[2][NW][4];
   __shared__ u32 s_red[6][NW];
   __shared__ float s_grid[9];  // lo[3], inv cell[3]; dims as ints below
   __shared__ int s_dims[4];
@@ -183,12 +185,15 @@ __global__ __launch_bounds__(T) void fps_bucket_kernel(
 
   int old = 0;
   if (tid == 0) idx[0] = 0;
+  s_cellxyz[0][tid] = 0.f; s_cellxyz[1][tid] = 0.f; s_cellxyz[2][tid] = 0.f;
   __syncthreads();
 
   const int row = tid >> 4, rl = tid & 15;
+  // pivot coordinates travel with the arg-max through LDS (no dependent global
+  // load per round); x0.. is point 0 = first pivot and the "nothing selectable" case
+  const float x0 = xyz[0], y0 = xyz[1], z0 = xyz[2];
+  float px = x0, py = y0, pz = z0;
   for (int j = 1; j < m; ++j) {
-    const int so = __builtin_amdgcn_readfirstlane(old);
-    const float px = xyz[so * 3 + 0], py = xyz[so * 3 + 1], pz = xyz[so * 3 + 2];
     const int par = j & 1;
     // ---- A: which cells can change? ---------------------------------------
     bool active = false;
@@ -208,42 +213,86 @@ __global__ __launch_bounds__(T) void fps_bucket_kernel(
       if (active) s_list[base + mask_rank_below(amask)] = (unsigned short)tid;
     }
     __syncthreads();
-    // ---- B: re-evaluate the active cells, one 16-lane row per cell ----------
+    // ---- B: re-evaluate the active cells --------------------------------------
+    // few active cells (the common case: ~15 of 1024): one WAVE per cell, so a
+    // ~40-point cell is a single 64-lane pass; many: one 16-lane row per cell.
     const int na = s_nactive[par];
     if (tid == 0) s_nactive[par ^ 1] = 0;
-    for (int e = row; e < na; e += T / 16) {
-      const int c = s_list[e];
-      const int st = s_start[c], nc = s_cnt[c];
-      u64 best = 0ull;
-      for (int q = rl; q < nc; q += 16) {
-        const Pt p = spt[st + q];
-        const u32 rk = srank[st + q];
-        const float d = (p.x - px) * (p.x - px) + (p.y - py) * (p.y - py) +
-                        (p.z - pz) * (p.z - pz);
-        const float d2 = fminf(d, p.d2);
-        if (d2 != p.d2) spt[st + q].d2 = d2;
-        const u64 key = d2 < 0.0f ? 0ull
-                                  : ((u64)(__float_as_uint(d2) + 1u) << 32) |
-                                        (u64)(0xFFFFFFFFu - rk);
-        best = umax64(best, key);
+    if (na <= NW) {
+      if (wave < na) {
+        const int c = s_list[wave];
+        const int st = s_start[c], nc = s_cnt[c];
+        u64 best = 0ull;
+        float bx = 0.f, by = 0.f, bz = 0.f;
+        for (int q = lane; q < nc; q += 64) {
+          const Pt p = spt[st + q];
+          const u32 rk = srank[st + q];
+          const float d = (p.x - px) * (p.x - px) + (p.y - py) * (p.y - py) +
+                          (p.z - pz) * (p.z - pz);
+          const float d2 = fminf(d, p.d2);
+          if (d2 != p.d2) spt[st + q].d2 = d2;
+          const u64 key = d2 < 0.0f ? 0ull
+                                    : ((u64)(__float_as_uint(d2) + 1u) << 32) |
+                                          (u64)(0xFFFFFFFFu - rk);
+          if (key > best) { best = key; bx = p.x; by = p.y; bz = p.z; }
+        }
+        const u64 wbest = wave_max_u64(best);
+        if (best == wbest && wbest != 0ull) {   // unique lane (ranks are unique)
+          s_cellkey[c] = wbest;
+          s_cellxyz[0][c] = bx; s_cellxyz[1][c] = by; s_cellxyz[2][c] = bz;
+        }
       }
-      best = row16_max_u64(best);
-      if (rl == 0) s_cellkey[c] = best;
+    } else {
+      for (int e = row; e < na; e += T / 16) {
+        const int c = s_list[e];
+        const int st = s_start[c], nc = s_cnt[c];
+        u64 best = 0ull;
+        float bx = 0.f, by = 0.f, bz = 0.f;
+        for (int q = rl; q < nc; q += 16) {
+          const Pt p = spt[st + q];
+          const u32 rk = srank[st + q];
+          const float d = (p.x - px) * (p.x - px) + (p.y - py) * (p.y - py) +
+                          (p.z - pz) * (p.z - pz);
+          const float d2 = fminf(d, p.d2);
+          if (d2 != p.d2) spt[st + q].d2 = d2;
+          const u64 key = d2 < 0.0f ? 0ull
+                                    : ((u64)(__float_as_uint(d2) + 1u) << 32) |
+                                          (u64)(0xFFFFFFFFu - rk);
+          if (key > best) { best = key; bx = p.x; by = p.y; bz = p.z; }
+        }
+        const u64 rbest = row16_max_u64(best);
+        if (best == rbest && rbest != 0ull) {
+          s_cellkey[c] = rbest;
+          s_cellxyz[0][c] = bx; s_cellxyz[1][c] = by; s_cellxyz[2][c] = bz;
+        }
+      }
     }
     __syncthreads();
-    // ---- C: arg-max over the cell keys --------------------------------------
+    // ---- C: arg-max over the cell keys (coordinates ride along) ---------------
     mykey = s_cellkey[tid];
     u64 key = wave_max_u64(mykey);
-    if (lane == 0) s_wkey[par][wave] = key;
+    if (mykey == key && key != 0ull) {
+      s_wkey[par][wave] = key;
+      s_wxyz[par][wave][0] = s_cellxyz[0][tid];
+      s_wxyz[par][wave][1] = s_cellxyz[1][tid];
+      s_wxyz[par][wave][2] = s_cellxyz[2][tid];
+    } else if (key == 0ull && lane == 0) {
+      s_wkey[par][wave] = 0ull;
+    }
     __syncthreads();
     u64 v = lane < NW ? s_wkey[par][lane] : 0ull;
+    const u64 mine = v;
     v = row16_max_u64(v);
     key = readlane_u64(v, 0);
     if ((key >> 32) == 0ull) {
       old = 0;
+      px = x0; py = y0; pz = z0;
     } else {
       const u32 r = 0xFFFFFFFFu - (u32)key;
       old = (int)(((r & 0x3FFFFFu) << log2bs) | bitrev_n(r >> 22, log2bs));
+      const u64 wl = __ballot(lane < NW && mine == key);
+      const int w = (int)__builtin_ctzll(wl);
+      px = s_wxyz[par][w][0]; py = s_wxyz[par][w][1]; pz = s_wxyz[par][w][2];
     }
     if (tid == 0) idx[j] = old;
   }

@@ -31,14 +31,18 @@ def _p(t):
     return t.data_ptr() if t is not None else None
 
 
-def _call(name, *args):
+def _call(name, *args, alg_bytes=0):
+    if _C.TIMER.enabled:
+        _C.TIMER.alg_bytes = int(alg_bytes)
     _C.call(name, *args, _C.stream_ptr())
 
 
 def _lin(R, O, I, W, ldw, x, ldx, out, ldo, bias=None, add1=None, ld1=0, add2=None,
          ld2=0, gate=None, ldg=0, epi=0):
+    # algorithmic bytes: the weight block is streamed once, plus the small operands
     _call("s2c_small_linear", R, O, I, _p(W), ldw, _p(x), ldx, _p(bias), _p(add1), ld1,
-          _p(add2), ld2, _p(gate), ldg, epi, _p(out), ldo)
+          _p(add2), ld2, _p(gate), ldg, epi, _p(out), ldo,
+          alg_bytes=4 * (O * I + R * I + 2 * R * O))
 
 
 def supported(emb, hid, feat, K):
@@ -88,15 +92,18 @@ class TopDownDecode(Function):
                      ld1=T * E, add2=Ptf, ld2=E, epi=1)
                 _call("s2c_gru_fwd", R, H, E, _p(W_ih1), _p(W_hh1), _p(b_ih1),
                       _p(b_hh1), _p(X1[t]), E, _p(H1[t]), _p(H1[t + 1]),
-                      _p(S1[0][t]), _p(S1[1][t]), _p(S1[2][t]), _p(S1[3][t]))
+                      _p(S1[0][t]), _p(S1[1][t]), _p(S1[2][t]), _p(S1[3][t]),
+                      alg_bytes=4 * (3 * H * (E + H) + R * (E + 6 * H)))
                 _lin(R, H + E, H, Wqh, H, H1[t + 1], H, QL[t], H + E)
                 _call("s2c_attn_fwd", R, K, H, F, _p(M), _p(QL[t]), H + E, _p(wa),
-                      _p(mask), _p(O), _p(SC), _p(ALPHA[t]), _p(ATT[t]), F)
+                      _p(mask), _p(O), _p(SC), _p(ALPHA[t]), _p(ATT[t]), F,
+                      alg_bytes=4 * (R * K * (H + F) + R * (H + 2 * K + F)))
                 _lin(R, E, F, W_lang, ldlang, ATT[t], F, X2[t], E, bias=b_lang,
                      add1=QL[t][:, H:], ld1=H + E, epi=1)
                 _call("s2c_gru_fwd", R, H, E, _p(W_ih2), _p(W_hh2), _p(b_ih2),
                       _p(b_hh2), _p(X2[t]), E, _p(H2[t]), _p(H2[t + 1]),
-                      _p(S2[0][t]), _p(S2[1][t]), _p(S2[2][t]), _p(S2[3][t]))
+                      _p(S2[0][t]), _p(S2[1][t]), _p(S2[2][t]), _p(S2[3][t]),
+                      alg_bytes=4 * (3 * H * (E + H) + R * (E + 6 * H)))
             H2n = H2[1:].permute(1, 0, 2).contiguous()              # (R,T,H)
             logits = torch.addmm(b_cls, H2n.view(R * T, H), W_cls.t()).view(R, T, -1)
             attn = ALPHA.permute(1, 2, 0).contiguous()              # (R,K,T)
@@ -147,7 +154,8 @@ class TopDownDecode(Function):
                 _lin(R, F + H, E, WT_lang, E, DA2[t], E, dv, F + H)
                 _call("s2c_attn_bwd", R, K, H, F, _p(dv), F + H, _p(ALPHA[t]), _p(O),
                       _p(M), _p(QL[t]), H + E, _p(wa), _p(ds), _p(dO), _p(dM),
-                      _p(DQ[t]), _p(dwa))
+                      _p(DQ[t]), _p(dwa),
+                      alg_bytes=4 * (R * K * (3 * H + 3 * F) + R * (2 * H + 2 * K + F)))
                 _lin(R, H, H, WT_h, H, DQ[t], H, dh1_total, H, add1=dv[:, F:],
                      ld1=F + H, add2=dh1c, ld2=H)
                 _call("s2c_gru_gates_bwd", R, H, _p(dh1_total), None, _p(S1[0][t]),
