@@ -52,6 +52,10 @@ WORKLOADS = {
                  desc="B=8 N=40000 XYZ+normal+height, VoteNet 256 proposals, forward only"),
     "cfg1": dict(B=1, N=4096, C=1, K=32, V=3500, train=True,
                  desc="1 scene XYZ+height N=4096, 32 proposals"),
+    "cfg5": dict(B=16, N=80000, C=132, K=512, V=3500, train=False, caption=True,
+                 desc="B=16 N=80000 XYZ+multiview+normal+height, 512 proposals, "
+                      "relation graph + greedy top-down decode (len 30) of every "
+                      "proposal, forward only"),
 }
 
 
@@ -150,14 +154,15 @@ def make_batch(wl, B, seed, table, msa):
 
 
 def build_model(wl, vocabulary, embeddings, msa):
+    cap = wl["train"] or wl.get("caption", False)
     return CapNet(num_class=18, vocabulary=vocabulary, embeddings=embeddings,
                   num_heading_bin=1, num_size_cluster=18, mean_size_arr=msa,
                   input_feature_dim=wl["C"], num_proposal=wl["K"],
-                  num_locals=10 if wl["train"] else -1,
-                  no_caption=not wl["train"], use_topdown=True,
+                  num_locals=10 if cap else -1,
+                  no_caption=not cap, use_topdown=True,
                   query_mode="corner", graph_mode="edge_conv",
-                  num_graph_steps=2 if wl["train"] else 0,
-                  use_relation=wl["train"])
+                  num_graph_steps=2 if cap else 0,
+                  use_relation=cap)
 
 
 def to_device(batch, device):
@@ -400,7 +405,7 @@ def main():
                     "share_of_step": top["ms_per_step"] / ms_per_step}
         out = {
             "metric": "scenes/sec forward+backward, B=8 N=40000 pts" if wl["train"]
-                      else "scenes/sec forward, B=8 N=40000 pts",
+                      else "scenes/sec forward, B=%d N=%d pts" % (wl["B"], wl["N"]),
             "value": value, "unit": "scenes/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
