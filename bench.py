@@ -52,6 +52,9 @@ WORKLOADS = {
                  desc="B=8 N=40000 XYZ+normal+height, VoteNet 256 proposals, forward only"),
     "cfg1": dict(B=1, N=4096, C=1, K=32, V=3500, train=True,
                  desc="1 scene XYZ+height N=4096, 32 proposals"),
+    "cfg3e": dict(B=8, N=40000, C=132, K=256, V=3500, train=False, caption=True,
+                  desc="cfg3 shapes, forward only: detection + graph + greedy decode "
+                       "of every proposal"),
     "cfg5": dict(B=16, N=80000, C=132, K=512, V=3500, train=False, caption=True,
                  desc="B=16 N=80000 XYZ+multiview+normal+height, 512 proposals, "
                       "relation graph + greedy top-down decode (len 30) of every "
@@ -285,61 +288,69 @@ def main():
     dd = to_device(make_batch(wl, B, 42 + rank, table, msa), device)
 
     overlap = use_graph and not args.no_overlap
-    pipe = None
+    slots, depth = None, 0
     if overlap:
-        # software pipeline across batches: geometry of step i+1 on a side stream
-        # while step i runs; the captured step reads it from static buffers
-        from scan2cap_amd.pipeline import (GeometryPipeline, flatten_geometry,
-                                           unflatten_geometry)
+        # software pipeline across batches: geometry of step i+depth on a side
+        # stream while step i runs; each slot has its own captured step graph that
+        # reads the slot's static geometry tensors (scan2cap_amd/pipeline.py)
+        from scan2cap_amd.pipeline import GeometrySlots
         # a forward-only step is shorter than one FPS chain: keep 3 batches of
         # geometry in flight; a train step (~18 ms) hides one chain (~6.5 ms)
         depth = 1 if wl["train"] else 3
-        pipe = GeometryPipeline(model.backbone_net, depth=depth)
-        geo0 = model.backbone_net.compute_geometry(dd["point_clouds"])
-        static_geo = [torch.empty_like(t) for t in flatten_geometry(geo0)]
-        for d_, s_ in zip(static_geo, flatten_geometry(geo0)):
-            d_.copy_(s_)
-        dd["_geometry"] = unflatten_geometry(static_geo)
+        depth = int(os.environ.get("S2C_GEO_DEPTH", depth))
+        slots = GeometrySlots(model.backbone_net, dd["point_clouds"], depth)
 
     if use_graph:
         # whole step = one hipGraph replay (fwd + loss + bwd [+ Adam]); with N>1
         # the RCCL all-reduce stays an eager call between two graphs
         from scan2cap_amd.graphs import GraphedCallable
-        if wl["train"] and ddp is not None:
-            def fwd_bwd():
-                d = dict(dd)
-                ddp.drop_grads()
-                d = model(d, use_tf=True, is_eval=False)
-                d = get_scene_cap_loss(d, device, cfg_loss, None)
-                d["loss"].backward()
-                ddp.pack_grads()      # one multi-tensor copy into the flat bucket
-                return d["loss"]
-            g1 = GraphedCallable(fwd_bwd).capture()
-            g2 = GraphedCallable(lambda: optimizer.step()).capture()
 
-            def replay():
-                loss = g1()
-                ddp.reduce()
-                g2()
-                return loss
-        else:
-            g = GraphedCallable(lambda: eager_step(dd)).capture()
-            replay = g
+        def with_geometry(p):
+            d = dict(dd)
+            if slots is not None:
+                d["_geometry"] = slots.geometry(p)
+            return d
+
+        replays = []
+        g2 = None
+        for p in range(max(depth, 1)):
+            if wl["train"] and ddp is not None:
+                def fwd_bwd(p=p):
+                    d = with_geometry(p)
+                    ddp.drop_grads()
+                    d = model(d, use_tf=True, is_eval=False)
+                    d = get_scene_cap_loss(d, device, cfg_loss, None)
+                    d["loss"].backward()
+                    ddp.pack_grads()      # one multi-tensor copy into the flat bucket
+                    return d["loss"]
+                g1 = GraphedCallable(fwd_bwd).capture()
+                if g2 is None:
+                    g2 = GraphedCallable(lambda: optimizer.step()).capture()
+
+                def replay(g1=g1):
+                    loss = g1()
+                    ddp.reduce()
+                    g2()
+                    return loss
+            else:
+                replay = GraphedCallable(lambda p=p: eager_step(with_geometry(p))).capture()
+            replays.append(replay)
         if overlap:
-            from collections import deque
-            queue = deque(pipe.submit(dd["point_clouds"]) for _ in range(depth))
+            for p in range(depth):
+                slots.refill(p, dd["point_clouds"])
+            counter = {"i": 0}
 
             def step(_dd):
-                cur = queue.popleft()
-                queue.append(pipe.submit(dd["point_clouds"]))  # geometry of step i+depth
-                geo, done = cur
-                torch.cuda.current_stream().wait_event(done)
-                for d_, s_ in zip(static_geo, flatten_geometry(geo)):
-                    d_.copy_(s_, non_blocking=True)
-                return replay()
+                p = counter["i"] % depth
+                counter["i"] += 1
+                slots.acquire(p)                       # geometry of this step is published
+                out = replays[p]()
+                slots.release(p)
+                slots.refill(p, dd["point_clouds"])    # geometry of step i+depth
+                return out
         else:
             def step(_dd):
-                return replay()
+                return replays[0]()
     else:
         step = eager_step
 
@@ -348,16 +359,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    dbg = os.environ.get("S2C_DEBUG") == "1"
+
+    def trace(msg):
+        if dbg:
+            torch.cuda.synchronize()
+            print("[bench] ok:", msg, file=sys.stderr, flush=True)
+
+    trace("setup / capture done")
     for _ in range(args.warmup):
         step(dd)
+        trace("warmup step")
     barrier()
     if not use_graph:
         _C.TIMER.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(dd)
+        trace("timed step")
     barrier()
     elapsed = time.perf_counter() - t0
+    trace("timed region done")
     if use_graph:
         # per-kernel durations: HIP events cannot be read back from inside a graph
         # replay, so the same steps are run once more eagerly, un-timed for the
@@ -366,6 +388,7 @@ def main():
         dd.pop("_geometry", None)   # instrumented pass computes geometry in-line
         for _ in range(min(args.steps, 3)):
             eager_step(dd)
+            trace("instrumented eager step")
         kern_steps = min(args.steps, 3)
     else:
         kern_steps = args.steps

@@ -130,3 +130,61 @@ def unflatten_geometry(flat):
     for k in ("fp1", "fp2"):
         geo[k] = (next(it), next(it))
     return geo
+
+
+class GeometrySlots(object):
+    """Geometry-ahead pipeline for hipGraph-captured steps.
+
+    `depth` slots of STATIC geometry tensors.  A step graph is captured once per
+    slot with `data_dict["_geometry"] = slots.geometry(p)`, so the main stream never
+    runs an eager kernel between waiting for the geometry and launching the graph
+    (eager device-to-device copies directly in front of a hipGraph launch faulted
+    on ROCm 7.x at the cfg5 sizes).  The side stream computes the geometry of batch
+    i+depth into temporaries while batch i runs, and publishes it into the slot
+    with one multi-tensor copy AFTER the step that last read the slot has finished.
+
+        slots = GeometrySlots(backbone, point_clouds, depth)
+        graphs = [capture(step_fn reading slots.geometry(p)) for p in range(depth)]
+        for p in range(depth): slots.refill(p, point_clouds)          # prime
+        for i in ...:
+            p = i % depth
+            slots.acquire(p)          # main waits until slot p is published
+            graphs[p].replay()
+            slots.release(p)          # marks the slot consumed ...
+            slots.refill(p, next_point_clouds)   # ... and starts batch i+depth
+    """
+
+    def __init__(self, backbone, point_clouds, depth=1):
+        self.backbone = backbone
+        self.depth = max(1, depth)
+        self.streams = independent_streams(self.depth)
+        geo0 = backbone.compute_geometry(point_clouds)
+        self._slots = []
+        for _ in range(self.depth):
+            flat = [t.clone() for t in flatten_geometry(geo0)]
+            self._slots.append(flat)
+        self._published = [None] * self.depth
+        self._consumed = [None] * self.depth
+        torch.cuda.synchronize()
+
+    def geometry(self, p):
+        return unflatten_geometry(self._slots[p])
+
+    def refill(self, p, point_clouds):
+        side = self.streams[p]
+        with torch.cuda.stream(side):
+            geo = self.backbone.compute_geometry(point_clouds)
+            if self._consumed[p] is not None:
+                side.wait_event(self._consumed[p])   # the reader of slot p is done
+            torch._foreach_copy_(self._slots[p], flatten_geometry(geo))
+            ev = torch.cuda.Event()
+            ev.record(side)
+        self._published[p] = ev
+
+    def acquire(self, p):
+        torch.cuda.current_stream().wait_event(self._published[p])
+
+    def release(self, p):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self._consumed[p] = ev
