@@ -122,6 +122,26 @@ int s2c_small_linear(int R, int O, int I, const float *W, int ldw, const float *
                      const float *add2, int ld2, const float *gate, int ldg, int epi,
                      float *out, int ldo, void *stream);
 
+/* the same product as a descriptor */
+typedef struct s2c_lin_desc {
+  const float *W, *x, *bias, *add1, *add2, *gate;
+  float *out; /* may be NULL for problem 1 when a GRU epilogue consumes the value */
+  int O, I, ldw, ldx, ld1, ld2, ldg, ldo, epi;
+} s2c_lin_desc;
+
+/* gate part of a GRUCell backward (see s2c_gru_gates_bwd), H == O of the product */
+typedef struct s2c_gru_bwd_desc {
+  const float *sr, *sz, *sn, *sghn, *hprev;
+  float *dgi, *dgh, *dh_direct;
+} s2c_gru_bwd_desc;
+
+/* ONE launch for two independent products p1, p2 (p2 may be NULL); g1 (may be NULL)
+ * treats p1's values as dh' of a GRUCell and emits dgi, dgh, dh_direct for it.  The
+ * back-propagation-through-time chain of models/caption_module.py:250-292 is 6 such
+ * launches per step. */
+int s2c_small_linear_pair(int R, const s2c_lin_desc *p1, const s2c_lin_desc *p2,
+                          const s2c_gru_bwd_desc *g1, void *stream);
+
 /* torch.nn.GRUCell forward; saves r, z, n and gh_n (R x H each) for backward */
 int s2c_gru_fwd(int R, int H, int I, const float *Wih, const float *Whh,
                 const float *bih, const float *bhh, const float *x, int ldx,
@@ -140,12 +160,13 @@ int s2c_attn_fwd(int R, int K, int H, int F, const float *M, const float *q, int
                  const float *wa, const float *mask, const float *O, float *scores,
                  float *alpha, float *att, int lda, void *stream);
 
-/* its backward from datt (R x F): ds scratch (R x K); dq (R x H) overwritten;
- * dO (R x K x F), dM (R x K x H) and dwa (H) ACCUMULATE */
+/* its backward from datt (R x F) and the saved forward output att (R x F):
+ * dM (R x K x H), dq (R x H) and dwa (H) ACCUMULATE (caller zeroes them once).
+ * dO = sum_t alpha_t (x) datt_t has no recurrence: one batched GEMM in the caller. */
 int s2c_attn_bwd(int R, int K, int H, int F, const float *datt, int ldd,
-                 const float *alpha, const float *O, const float *M, const float *q,
-                 int ldq, const float *wa, float *ds, float *dO, float *dM, float *dq,
-                 float *dwa, void *stream);
+                 const float *att, int lda, const float *alpha, const float *O,
+                 const float *M, const float *q, int ldq, const float *wa, float *dM,
+                 float *dq, float *dwa, void *stream);
 
 #ifdef __cplusplus
 }

@@ -5,7 +5,7 @@
 // configuration) through T <= 31 strictly sequential steps.  Each step is ~10
 // MFLOP per row: far too little for library GEMMs -- the reference (and a naive
 // port) spends it in ~25 forward + ~50 backward micro-kernels per step whose cost
-// is launch latency, not work.  Here a step is 7 forward / 11 backward launches of
+// is launch latency, not work.  Here a step is 7 forward / 6 backward launches of
 // purpose-built kernels, the step-invariant pieces are hoisted into a few large
 // GEMMs outside the loop (word / target projections, classifier, every weight
 // gradient), and the whole sequence replays from a hipGraph.
@@ -39,24 +39,43 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 // Two independent accumulators / unroll 4 keep several 16-byte loads in flight
 // (these kernels are pure latency: ~1 wave per SIMD, a few KB per wave).
 constexpr int NCHUNK = 32;
+__device__ __forceinline__ float dot4(const float4 a, const float4 b) {
+  return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+}
+// U float4 pairs per lane, every load issued before the first use: one memory
+// round trip per call instead of one per loop iteration.
+template <int U>
+__device__ __forceinline__ void dot_row_u(const float4 *__restrict__ w,
+                                          const float4 *__restrict__ x, int n4, int j0,
+                                          float &acc0, float &acc1) {
+  float4 a[U], b[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int j = j0 + u * NCHUNK;
+    if (j < n4) {
+      a[u] = w[j];
+      b[u] = x[j];
+    } else {
+      a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      b[u] = a[u];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if (u & 1) acc1 += dot4(a[u], b[u]);
+    else acc0 += dot4(a[u], b[u]);
+  }
+}
 __device__ __forceinline__ float dot_row(const float *__restrict__ w,
                                          const float *__restrict__ x, int n4,
                                          int chunk) {
+  const float4 *w4 = reinterpret_cast<const float4 *>(w);
+  const float4 *x4 = reinterpret_cast<const float4 *>(x);
   float acc0 = 0.0f, acc1 = 0.0f;
-  int j = chunk;
-#pragma unroll 2
-  for (; j + NCHUNK < n4; j += 2 * NCHUNK) {
-    const float4 a0 = reinterpret_cast<const float4 *>(w)[j];
-    const float4 a1 = reinterpret_cast<const float4 *>(w)[j + NCHUNK];
-    const float4 b0 = reinterpret_cast<const float4 *>(x)[j];
-    const float4 b1 = reinterpret_cast<const float4 *>(x)[j + NCHUNK];
-    acc0 += a0.x * b0.x + a0.y * b0.y + a0.z * b0.z + a0.w * b0.w;
-    acc1 += a1.x * b1.x + a1.y * b1.y + a1.z * b1.z + a1.w * b1.w;
-  }
-  if (j < n4) {
-    const float4 a0 = reinterpret_cast<const float4 *>(w)[j];
-    const float4 b0 = reinterpret_cast<const float4 *>(x)[j];
-    acc0 += a0.x * b0.x + a0.y * b0.y + a0.z * b0.z + a0.w * b0.w;
+  if (n4 <= 4 * NCHUNK) {
+    dot_row_u<4>(w4, x4, n4, chunk, acc0, acc1);
+  } else {
+    for (int j = chunk; j < n4; j += 12 * NCHUNK) dot_row_u<12>(w4, x4, n4, j, acc0, acc1);
   }
   return acc0 + acc1;
 }
@@ -81,30 +100,49 @@ __device__ __forceinline__ void block_fold(float (&v)[NV], float (*s_part)[4][RB
 
 // ---------------------------------------------------------------------------
 // out[r, o] = epi( sum_i W[o, i] * x[r, i] + bias[o] + add1[r, o] + add2[r, o] )
-// epi: 0 none, 1 relu, 2 multiply by (gate[r, o] > 0)
+// epi: 0 none, 1 relu, 2 multiply by (gate[r, o] > 0).
+// One launch serves up to two independent problems (blockIdx.x < p1.O -> p1, else
+// p2) and can finish problem 1 with the gate part of a GRUCell backward
+// (value = dh' of unit o): the BPTT chain is 6 launches per step.
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ void gru_gates_bwd_one(const s2c_gru_bwd_desc &g, int H,
+                                                  int row, int u, float dh) {
+  const size_t e = (size_t)row * H + u;
+  const float r = g.sr[e], z = g.sz[e], n = g.sn[e];
+  const float dz = dh * (g.hprev[e] - n);
+  const float dn = dh * (1.0f - z);
+  const float dpn = dn * (1.0f - n * n);
+  const float dr = dpn * g.sghn[e];
+  const float dpr = dr * r * (1.0f - r);
+  const float dpz = dz * z * (1.0f - z);
+  float *gi = g.dgi + (size_t)row * 3 * H;
+  float *gh = g.dgh + (size_t)row * 3 * H;
+  gi[u] = dpr; gi[H + u] = dpz; gi[2 * H + u] = dpn;
+  gh[u] = dpr; gh[H + u] = dpz; gh[2 * H + u] = dpn * r;
+  g.dh_direct[e] = dh * z;
+}
+
 __global__ __launch_bounds__(256) void small_linear_kernel(
-    int R, int O, int I, const float *__restrict__ W, int ldw,
-    const float *__restrict__ x, int ldx, const float *__restrict__ bias,
-    const float *__restrict__ add1, int ld1, const float *__restrict__ add2,
-    int ld2, const float *__restrict__ gate, int ldg, int epi,
-    float *__restrict__ out, int ldo) {
+    int R, s2c_lin_desc p1, s2c_lin_desc p2, s2c_gru_bwd_desc g1, int has_g1) {
   __shared__ float s_part[1][4][RB];
   const int r = threadIdx.x & 7, chunk = threadIdx.x >> 3;   // 32 chunks
-  const int o = blockIdx.x;
+  const bool second = (int)blockIdx.x >= p1.O;
+  const s2c_lin_desc &p = second ? p2 : p1;
+  const int o = second ? (int)blockIdx.x - p1.O : (int)blockIdx.x;
   const int row = blockIdx.y * RB + r;
   const int rowc = row < R ? row : R - 1;
   float v[1];
-  v[0] = dot_row(W + (size_t)o * ldw, x + (size_t)rowc * ldx, I >> 2, chunk);
+  v[0] = dot_row(p.W + (size_t)o * p.ldw, p.x + (size_t)rowc * p.ldx, p.I >> 2, chunk);
   block_fold<1>(v, s_part);
   if (threadIdx.x < RB && row < R) {
     float acc = v[0];
-    if (bias) acc += bias[o];
-    if (add1) acc += add1[(size_t)row * ld1 + o];
-    if (add2) acc += add2[(size_t)row * ld2 + o];
-    if (epi == 1) acc = fmaxf(acc, 0.0f);
-    else if (epi == 2) acc = gate[(size_t)row * ldg + o] > 0.0f ? acc : 0.0f;
-    out[(size_t)row * ldo + o] = acc;
+    if (p.bias) acc += p.bias[o];
+    if (p.add1) acc += p.add1[(size_t)row * p.ld1 + o];
+    if (p.add2) acc += p.add2[(size_t)row * p.ld2 + o];
+    if (p.epi == 1) acc = fmaxf(acc, 0.0f);
+    else if (p.epi == 2) acc = p.gate[(size_t)row * p.ldg + o] > 0.0f ? acc : 0.0f;
+    if (p.out) p.out[(size_t)row * p.ldo + o] = acc;
+    if (has_g1 && !second) gru_gates_bwd_one(g1, p1.O, row, o, acc);
   }
 }
 
@@ -154,27 +192,13 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(
 //   dh_direct = dh' * z
 __global__ __launch_bounds__(256) void gru_gates_bwd_kernel(
     int R, int H, const float *__restrict__ dh1, const float *__restrict__ dh2,
-    const float *__restrict__ sr, const float *__restrict__ sz,
-    const float *__restrict__ sn, const float *__restrict__ sghn,
-    const float *__restrict__ hprev, float *__restrict__ dgi,
-    float *__restrict__ dgh, float *__restrict__ dh_direct) {
+    s2c_gru_bwd_desc g) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= R * H) return;
   const int row = e / H, u = e - row * H;
   float dh = dh1[e];
   if (dh2) dh += dh2[e];
-  const float r = sr[e], z = sz[e], n = sn[e];
-  const float dz = dh * (hprev[e] - n);
-  const float dn = dh * (1.0f - z);
-  const float dpn = dn * (1.0f - n * n);
-  const float dr = dpn * sghn[e];
-  const float dpr = dr * r * (1.0f - r);
-  const float dpz = dz * z * (1.0f - z);
-  float *gi = dgi + (size_t)row * 3 * H;
-  float *gh = dgh + (size_t)row * 3 * H;
-  gi[u] = dpr; gi[H + u] = dpz; gi[2 * H + u] = dpn;
-  gh[u] = dpr; gh[H + u] = dpz; gh[2 * H + u] = dpn * r;
-  dh_direct[e] = dh * z;
+  gru_gates_bwd_one(g, H, row, u, dh);
 }
 
 // ---------------------------------------------------------------------------
@@ -205,13 +229,17 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(
   if (lane == 0) scores[rk] = mask[rk] == 0.0f ? -1e30f : acc;
 }
 
-// softmax over K and att[r,:] = sum_k alpha[r,k] * O[r,k,:]; one block per row
+// softmax over K and att[r,:] = sum_k alpha[r,k] * O[r,k,:].
+// Block = (row, chunk of ATT_FC output features); every block of a row redoes the
+// (tiny) softmax, block 0 of the row stores alpha.  Thread = (feature, k group).
+constexpr int ATT_FC = 32;
 __global__ __launch_bounds__(256) void attn_softmax_kernel(
     int K, int F, const float *__restrict__ scores, const float *__restrict__ O,
     float *__restrict__ alpha, float *__restrict__ att, int lda) {
   __shared__ float s_red[4];
   __shared__ float s_alpha[1024];
-  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ float s_acc[256];
+  const int row = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float *s = scores + (size_t)row * K;
   float mx = -INFINITY;
   for (int k = tid; k < K; k += 256) mx = fmaxf(mx, s[k]);
@@ -236,72 +264,89 @@ __global__ __launch_bounds__(256) void attn_softmax_kernel(
   for (int k = tid; k < K; k += 256) {
     const float a = s_alpha[k] * inv;
     s_alpha[k] = a;
-    alpha[(size_t)row * K + k] = a;
+    if (blockIdx.x == 0) alpha[(size_t)row * K + k] = a;
   }
   __syncthreads();
+  const int fl = tid & (ATT_FC - 1), kg = tid / ATT_FC;      // 8 k groups
+  const int f = blockIdx.x * ATT_FC + fl;
   const float *o = O + (size_t)row * K * F;
-  for (int f = tid; f < F; f += 256) {
-    float acc = 0.0f;
-    for (int k = 0; k < K; ++k) acc += s_alpha[k] * o[(size_t)k * F + f];
-    att[(size_t)row * lda + f] = acc;
+  float acc = 0.0f;
+  if (f < F) {
+    float a0 = 0.0f, a1 = 0.0f;
+    int k = kg;
+    for (; k + 8 < K; k += 16) {
+      a0 += s_alpha[k] * o[(size_t)k * F + f];
+      a1 += s_alpha[k + 8] * o[(size_t)(k + 8) * F + f];
+    }
+    if (k < K) a0 += s_alpha[k] * o[(size_t)k * F + f];
+    acc = a0 + a1;
+  }
+  s_acc[tid] = acc;
+  __syncthreads();
+  if (tid < ATT_FC && f < F) {
+    float t = 0.0f;
+#pragma unroll
+    for (int g = 0; g < 256 / ATT_FC; ++g) t += s_acc[g * ATT_FC + tid];
+    att[(size_t)row * lda + f] = t;
   }
 }
 
-// attention backward, stage 1 (one block per row): ds[r,k] from datt, and the
-// dO accumulation  dO[r,k,:] += alpha[r,k] * datt[r,:]
-__global__ __launch_bounds__(256) void attn_bwd_ds_kernel(
-    int K, int F, const float *__restrict__ datt, int ldd,
-    const float *__restrict__ alpha, const float *__restrict__ O,
-    float *__restrict__ ds, float *__restrict__ dO) {
+// Attention backward for one step, block = (chunk of ATT_KC keys, row):
+//  (a) softmax backward without a row-wide pass:  sum_k alpha_k dalpha_k
+//      = <datt, sum_k alpha_k O_k> = <datt, att>  (att is the saved forward output);
+//      dalpha_k = <datt, O[r,k,:]> ; ds_k = alpha_k (dalpha_k - <datt, att>)
+//  (b) dpre = ds * wa * (1 - c^2), c = tanh(M + q);
+//      dM[r,k,:] += dpre ; dq[r,:] += sum_k dpre ; dwa[:] += sum_k ds * c
+//      (k loop keeps the dq / dwa partial sums in registers: one atomic per (block, h)).
+// dO = sum_t alpha_t (outer) datt_t has no recurrence and is one batched GEMM after
+// the time loop (decoder_fused.py).
+constexpr int ATT_KC = 16;
+__global__ __launch_bounds__(256) void attn_bwd_kernel(
+    int K, int H, int F, const float *__restrict__ datt, int ldd,
+    const float *__restrict__ att, int lda, const float *__restrict__ alpha,
+    const float *__restrict__ O, const float *__restrict__ M,
+    const float *__restrict__ q, int ldq, const float *__restrict__ wa,
+    float *__restrict__ dM, float *__restrict__ dq, float *__restrict__ dwa) {
   __shared__ float s_datt[512];
   __shared__ float s_red[4];
-  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int f = tid; f < F; f += 256) s_datt[f] = datt[(size_t)row * ldd + f];
-  __syncthreads();
-  const float *o = O + (size_t)row * K * F;
-  float *dor = dO + (size_t)row * K * F;
+  __shared__ float s_ds[ATT_KC];
+  const int row = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int k0 = blockIdx.x * ATT_KC;
+  const int k1 = min(K, k0 + ATT_KC);
   float part = 0.0f;
-  // thread per k (K <= 1024 handled in strides)
-  for (int k = tid; k < K; k += 256) {
-    float da = 0.0f;
-    for (int f = 0; f < F; ++f) da += s_datt[f] * o[(size_t)k * F + f];
-    const float a = alpha[(size_t)row * K + k];
-    ds[(size_t)row * K + k] = da;      // temporarily d(alpha)
-    part += a * da;
+  for (int f = tid; f < F; f += 256) {
+    const float d = datt[(size_t)row * ldd + f];
+    s_datt[f] = d;
+    part += d * att[(size_t)row * lda + f];
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
   if (lane == 0) s_red[wave] = part;
   __syncthreads();
   const float dot = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-  for (int k = tid; k < K; k += 256) {
-    const float a = alpha[(size_t)row * K + k];
-    ds[(size_t)row * K + k] = a * (ds[(size_t)row * K + k] - dot);
+  {
+    // 16 lanes per key
+    const int kk = k0 + (tid >> 4), sub = tid & 15;
+    float da = 0.0f;
+    if (kk < k1) {
+      const float *o = O + ((size_t)row * K + kk) * F;
+      for (int f = sub; f < F; f += 16) da += s_datt[f] * o[f];
+    }
+    da += __shfl_xor(da, 1, 64);
+    da += __shfl_xor(da, 2, 64);
+    da += __shfl_xor(da, 4, 64);
+    da += __shfl_xor(da, 8, 64);
+    if (sub == 0 && kk < k1) {
+      const float a = alpha[(size_t)row * K + kk];
+      s_ds[kk - k0] = a * (da - dot);
+    }
   }
-  // dO += alpha (outer) datt : coalesced over f
-  for (int e = tid; e < K * F; e += 256) {
-    const int k = e / F, f = e - k * F;
-    dor[e] += alpha[(size_t)row * K + k] * s_datt[f];
-  }
-}
-
-// stage 2: dpre = ds * wa * (1 - c^2), c = tanh(M + q);
-//   dM[r,k,:] += dpre ; dq[r,:] += sum_k dpre ; dwa[:] += sum_k ds * c
-// Block = (row, chunk of KC keys), thread = hidden unit(s): the k loop keeps the
-// dq / dwa partial sums in registers, so only one atomic per (block, h) is issued.
-constexpr int ATT_KC = 16;
-__global__ __launch_bounds__(256) void attn_bwd_pre_kernel(
-    int K, int H, const float *__restrict__ M, const float *__restrict__ q, int ldq,
-    const float *__restrict__ wa, const float *__restrict__ ds,
-    float *__restrict__ dM, float *__restrict__ dq, float *__restrict__ dwa) {
-  const int row = blockIdx.y;
-  const int k0 = blockIdx.x * ATT_KC;
-  const int k1 = min(K, k0 + ATT_KC);
-  for (int h = threadIdx.x; h < H; h += 256) {
+  __syncthreads();
+  for (int h = tid; h < H; h += 256) {
     const float qh = q[(size_t)row * ldq + h], wh = wa[h];
     float sq = 0.0f, sw = 0.0f;
     for (int k = k0; k < k1; ++k) {
-      const float d = ds[(size_t)row * K + k];   // block-uniform
+      const float d = s_ds[k - k0];              // block-uniform
       if (d == 0.0f) continue;                   // masked (alpha == 0)
       const size_t e = ((size_t)row * K + k) * H + h;
       const float c = tanhf(M[e] + qh);
@@ -326,16 +371,45 @@ static int chk(const char *k) {
   return 0;
 }
 
+static s2c_lin_desc one_desc(int O, int I, const float *W, int ldw, const float *x,
+                             int ldx, const float *bias, const float *add1, int ld1,
+                             const float *add2, int ld2, const float *gate, int ldg,
+                             int epi, float *out, int ldo) {
+  s2c_lin_desc d;
+  d.W = W; d.x = x; d.bias = bias; d.add1 = add1; d.add2 = add2; d.gate = gate;
+  d.out = out; d.O = O; d.I = I; d.ldw = ldw; d.ldx = ldx; d.ld1 = ld1; d.ld2 = ld2;
+  d.ldg = ldg; d.ldo = ldo; d.epi = epi;
+  return d;
+}
+static bool bad_desc(const s2c_lin_desc *p) {
+  return p->O <= 0 || p->I <= 0 || (p->I & 3) || (p->ldw & 3) || (p->ldx & 3) ||
+         !p->W || !p->x || (p->epi == 2 && !p->gate);
+}
+
+extern "C" int s2c_small_linear_pair(int R, const s2c_lin_desc *p1,
+                                     const s2c_lin_desc *p2,
+                                     const s2c_gru_bwd_desc *g1, void *stream) {
+  if (R <= 0 || !p1 || bad_desc(p1) || (p2 && bad_desc(p2))) return -1;
+  if (!p1->out && !g1) return -1;
+  if (p2 && !p2->out) return -1;
+  s2c_lin_desc q2 = p2 ? *p2 : *p1;
+  s2c_gru_bwd_desc g;
+  if (g1) g = *g1;
+  else g.sr = g.sz = g.sn = g.sghn = g.hprev = nullptr, g.dgi = g.dgh = g.dh_direct = nullptr;
+  const int O = p1->O + (p2 ? p2->O : 0);
+  hipLaunchKernelGGL(small_linear_kernel, dim3(O, (R + RB - 1) / RB), dim3(256), 0,
+                     (hipStream_t)stream, R, *p1, q2, g, g1 ? 1 : 0);
+  return chk("small_linear");
+}
+
 extern "C" int s2c_small_linear(int R, int O, int I, const float *W, int ldw,
                                 const float *x, int ldx, const float *bias,
                                 const float *add1, int ld1, const float *add2,
                                 int ld2, const float *gate, int ldg, int epi,
                                 float *out, int ldo, void *stream) {
-  if (R <= 0 || O <= 0 || I <= 0 || (I & 3) || (ldw & 3) || (ldx & 3)) return -1;
-  hipLaunchKernelGGL(small_linear_kernel, dim3(O, (R + RB - 1) / RB),
-                     dim3(256), 0, (hipStream_t)stream, R, O, I, W, ldw, x, ldx,
-                     bias, add1, ld1, add2, ld2, gate, ldg, epi, out, ldo);
-  return chk("small_linear");
+  const s2c_lin_desc d = one_desc(O, I, W, ldw, x, ldx, bias, add1, ld1, add2, ld2, gate,
+                                  ldg, epi, out, ldo);
+  return s2c_small_linear_pair(R, &d, nullptr, nullptr, stream);
 }
 
 extern "C" int s2c_gru_fwd(int R, int H, int I, const float *Wih, const float *Whh,
@@ -354,9 +428,11 @@ extern "C" int s2c_gru_gates_bwd(int R, int H, const float *dh1, const float *dh
                                  const float *sghn, const float *hprev, float *dgi,
                                  float *dgh, float *dh_direct, void *stream) {
   if (R <= 0 || H <= 0) return -1;
+  s2c_gru_bwd_desc g;
+  g.sr = sr; g.sz = sz; g.sn = sn; g.sghn = sghn; g.hprev = hprev;
+  g.dgi = dgi; g.dgh = dgh; g.dh_direct = dh_direct;
   hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3((R * H + 255) / 256), dim3(256), 0,
-                     (hipStream_t)stream, R, H, dh1, dh2, sr, sz, sn, sghn, hprev,
-                     dgi, dgh, dh_direct);
+                     (hipStream_t)stream, R, H, dh1, dh2, g);
   return chk("gru_gates_bwd");
 }
 
@@ -368,23 +444,20 @@ extern "C" int s2c_attn_fwd(int R, int K, int H, int F, const float *M,
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(attn_scores_kernel, dim3((unsigned)(((long long)R * K + 3) / 4)),
                      dim3(256), 0, st, R, K, H, M, q, ldq, wa, mask, scores);
-  hipLaunchKernelGGL(attn_softmax_kernel, dim3(R), dim3(256), 0, st, K, F, scores, O,
-                     alpha, att, lda);
+  hipLaunchKernelGGL(attn_softmax_kernel, dim3((F + ATT_FC - 1) / ATT_FC, R), dim3(256),
+                     0, st, K, F, scores, O, alpha, att, lda);
   return chk("attn_fwd");
 }
 
-// dq must be zeroed by the callee (done here); dM, dO, dwa accumulate.
+// dM (R x K x H), dq (R x H) and dwa (H) ACCUMULATE (the caller zeroes them once).
 extern "C" int s2c_attn_bwd(int R, int K, int H, int F, const float *datt, int ldd,
-                            const float *alpha, const float *O, const float *M,
-                            const float *q, int ldq, const float *wa, float *ds,
-                            float *dO, float *dM, float *dq, float *dwa,
+                            const float *att, int lda, const float *alpha,
+                            const float *O, const float *M, const float *q, int ldq,
+                            const float *wa, float *dM, float *dq, float *dwa,
                             void *stream) {
   if (R <= 0 || K <= 0 || K > 1024 || F > 512 || (H & 3)) return -1;
-  hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(dq, 0, sizeof(float) * (size_t)R * H, st) != hipSuccess) return -1;
-  hipLaunchKernelGGL(attn_bwd_ds_kernel, dim3(R), dim3(256), 0, st, K, F, datt, ldd,
-                     alpha, O, ds, dO);
-  hipLaunchKernelGGL(attn_bwd_pre_kernel, dim3((K + ATT_KC - 1) / ATT_KC, R),
-                     dim3(256), 0, st, K, H, M, q, ldq, wa, ds, dM, dq, dwa);
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3((K + ATT_KC - 1) / ATT_KC, R), dim3(256), 0,
+                     (hipStream_t)stream, K, H, F, datt, ldd, att, lda, alpha, O, M, q,
+                     ldq, wa, dM, dq, dwa);
   return chk("attn_bwd");
 }

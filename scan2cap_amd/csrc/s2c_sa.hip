@@ -176,7 +176,20 @@ __device__ __forceinline__ void col_reduce2(F f, long long M, int C,
   const long long r0 = (long long)blockIdx.x * rows_per_block;
   const long long r1 = min(M, r0 + rows_per_block);
   if (ty < ry) {
-    for (long long r = r0 + ty; r < r1; r += ry) {
+    long long r = r0 + ty;
+    // 4 rows in flight per thread (8 independent 16-byte loads); the sums are
+    // still accumulated in row order, so the result does not depend on the unroll
+    for (; r + 3LL * ry < r1; r += 4LL * ry) {
+      float4 p1[4], p2[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) f(r + (long long)u * ry, tx, p1[u], p2[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a.x += p1[u].x; a.y += p1[u].y; a.z += p1[u].z; a.w += p1[u].w;
+        b2.x += p2[u].x; b2.y += p2[u].y; b2.z += p2[u].z; b2.w += p2[u].w;
+      }
+    }
+    for (; r < r1; r += ry) {
       float4 q1, q2;
       f(r, tx, q1, q2);
       a.x += q1.x; a.y += q1.y; a.z += q1.z; a.w += q1.w;
@@ -220,7 +233,28 @@ __device__ __forceinline__ void wave_sum2(double &a, double &b) {
   }
 }
 
-__global__ __launch_bounds__(64) void bn_finalize_kernel(
+// 256 threads per channel: wave trees, then the 4 wave results in fixed order
+constexpr int FIN_BLOCK = 256;
+__device__ __forceinline__ void block_sum2(double &a, double &b) {
+  __shared__ double s_fin[2 * (FIN_BLOCK / 64)];
+  wave_sum2(a, b);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    s_fin[2 * w] = a;
+    s_fin[2 * w + 1] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a = s_fin[0];
+    b = s_fin[1];
+    for (int k = 1; k < FIN_BLOCK / 64; ++k) {
+      a += s_fin[2 * k];
+      b += s_fin[2 * k + 1];
+    }
+  }
+}
+
+__global__ __launch_bounds__(FIN_BLOCK) void bn_finalize_kernel(
     const float *__restrict__ partial, int nblk, int C, long long M, float eps,
     float momentum, const float *__restrict__ gamma,
     const float *__restrict__ beta, float *__restrict__ running_mean,
@@ -229,11 +263,11 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(
     float *__restrict__ save_invstd) {
   const int c = blockIdx.x;
   double s1 = 0.0, s2 = 0.0;
-  for (int k = threadIdx.x; k < nblk; k += 64) {
+  for (int k = threadIdx.x; k < nblk; k += FIN_BLOCK) {
     s1 += (double)partial[(long long)k * 2 * C + c];
     s2 += (double)partial[(long long)k * 2 * C + C + c];
   }
-  wave_sum2(s1, s2);
+  block_sum2(s1, s2);
   if (threadIdx.x != 0) return;
   const double mean = s1 / (double)M;
   double var = s2 / (double)M - mean * mean;
@@ -273,7 +307,7 @@ __global__ void bn_eval_coeffs_kernel(int C, float eps,
 }
 
 static int stat_blocks(long long M, long long *rows_per_block) {
-  long long nb = (M + 511) / 512;  // >= 512 rows per block
+  long long nb = (M + 63) / 64;  // >= 64 rows per block: small inputs still fill the chip
   if (nb > 1024) nb = 1024;
   if (nb < 1) nb = 1;
   *rows_per_block = (M + nb - 1) / nb;
@@ -301,7 +335,7 @@ extern "C" int s2c_bn_train_stats(long long M, int C, const float *Y,
   const int nb = stat_blocks(M, &rpb);
   hipLaunchKernelGGL(col_stats_kernel, dim3(nb), dim3(STAT_BLOCK), 0, st, Y, M, C,
                      partial, rpb);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, st,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(FIN_BLOCK), 0, st,
                      partial, nb, C, M, eps, momentum, gamma, beta, running_mean,
                      running_var, scale, shift, save_mean, save_invstd);
   return check2("bn_train_stats");
@@ -317,7 +351,7 @@ extern "C" int s2c_bn_finalize_partials(int nblk, long long M, int C,
                                         float *shift, float *save_mean,
                                         float *save_invstd, void *stream) {
   if (nblk <= 0 || M <= 0 || C <= 0) return fail2("bn_finalize_partials sizes");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(FIN_BLOCK), 0, (hipStream_t)stream,
                      partial, nblk, C, M, eps, momentum, gamma, beta, running_mean,
                      running_var, scale, shift, save_mean, save_invstd);
   return check2("bn_finalize_partials");
@@ -454,18 +488,18 @@ __global__ __launch_bounds__(STAT_BLOCK) void bn_bwd_stats_kernel(
 
 // sums -> dgamma (=s2), dbeta (=s1); also the per-channel coefficients used by
 // the apply pass: k0 = gamma*invstd, k1 = s1/M, k2 = s2/M (0 when frozen)
-__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(
+__global__ __launch_bounds__(FIN_BLOCK) void bn_bwd_finalize_kernel(
     const float *__restrict__ partial, int nblk, int C, long long M, int frozen,
     const float *__restrict__ gamma, const float *__restrict__ invstd,
     float *__restrict__ dgamma, float *__restrict__ dbeta,
     float *__restrict__ coef) {
   const int c = blockIdx.x;
   double s1 = 0.0, s2 = 0.0;
-  for (int k = threadIdx.x; k < nblk; k += 64) {
+  for (int k = threadIdx.x; k < nblk; k += FIN_BLOCK) {
     s1 += (double)partial[(long long)k * 2 * C + c];
     s2 += (double)partial[(long long)k * 2 * C + C + c];
   }
-  wave_sum2(s1, s2);
+  block_sum2(s1, s2);
   if (threadIdx.x != 0) return;
   if (dbeta) dbeta[c] = (float)s1;
   if (dgamma) dgamma[c] = (float)s2;
@@ -520,7 +554,7 @@ extern "C" int s2c_bn_relu_bwd(long long M, int C, const float *dA, const float 
   const int nb = stat_blocks(M, &rpb);
   hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(nb), dim3(STAT_BLOCK), 0, st, dA, Y,
                      scale, shift, mean, invstd, M, C, relu, partial, rpb);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(FIN_BLOCK), 0, st,
                      partial, nb, C, M, frozen, gamma, invstd, dgamma, dbeta, coef);
   const long long total4 = M * (C >> 2);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid1d(total4, 256)), dim3(256), 0,
@@ -609,7 +643,7 @@ extern "C" int s2c_bn_relu_max_bwd(long long J, int ns, int C, const float *dOut
   const long long M = J * ns;
   hipLaunchKernelGGL(pool_bwd_stats_kernel, dim3(nb), dim3(STAT_BLOCK), 0, st, dOut,
                      ymax, scale, shift, mean, invstd, J, C, partial, rpb);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(FIN_BLOCK), 0, st,
                      partial, nb, C, M, frozen, gamma, invstd, dgamma, dbeta, coef);
   hipLaunchKernelGGL(pool_bwd_apply_kernel, dim3(grid1d(J * (C >> 2), 256)), dim3(256),
                      0, st, dOut, arg, Y, scale, shift, mean, invstd, coef, dY, J, ns,

@@ -3,7 +3,7 @@ small-batch kernels of csrc/s2c_decoder.hip (C ABI: include/s2c_fused.h).
 
 Computes exactly TopDownSceneCaptionModule._step (models/caption_module.py:250-292)
 for `steps` sequential steps and its back-propagation through time, but:
-  * per step: 7 forward / 11 backward kernel launches instead of ~25 / ~50;
+  * per step: 7 forward / 6 backward kernel launches instead of ~25 / ~50;
   * everything that does not depend on the recurrence is hoisted into a handful of
     large GEMMs outside the loop: the word and target-feature columns of
     `map_topdown`, `map_feat(obj_feats)`, the classifier over all steps, and EVERY
@@ -24,7 +24,20 @@ _C.register("s2c_small_linear", [_I, _I, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I,
 _C.register("s2c_gru_fwd", [_I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_gru_gates_bwd", [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_attn_fwd", [_I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P])
-_C.register("s2c_attn_bwd", [_I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P])
+_C.register("s2c_attn_bwd", [_I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P])
+_C.register("s2c_small_linear_pair", [_I, _P, _P, _P, _P])
+
+
+class _LinDesc(ctypes.Structure):
+    """include/s2c_fused.h: s2c_lin_desc"""
+    _fields_ = ([(n, _P) for n in ("W", "x", "bias", "add1", "add2", "gate", "out")] +
+                [(n, _I) for n in ("O", "I", "ldw", "ldx", "ld1", "ld2", "ldg", "ldo", "epi")])
+
+
+class _GruBwdDesc(ctypes.Structure):
+    """include/s2c_fused.h: s2c_gru_bwd_desc"""
+    _fields_ = [(n, _P) for n in ("sr", "sz", "sn", "sghn", "hprev", "dgi", "dgh",
+                                  "dh_direct")]
 
 
 def _p(t):
@@ -43,6 +56,28 @@ def _lin(R, O, I, W, ldw, x, ldx, out, ldo, bias=None, add1=None, ld1=0, add2=No
     _call("s2c_small_linear", R, O, I, _p(W), ldw, _p(x), ldx, _p(bias), _p(add1), ld1,
           _p(add2), ld2, _p(gate), ldg, epi, _p(out), ldo,
           alg_bytes=4 * (O * I + R * I + 2 * R * O))
+
+
+def _desc(O, I, W, ldw, x, ldx, out, ldo, bias=None, add1=None, ld1=0, add2=None, ld2=0,
+          gate=None, ldg=0, epi=0):
+    return _LinDesc(_p(W), _p(x), _p(bias), _p(add1), _p(add2), _p(gate), _p(out),
+                    O, I, ldw, ldx, ld1, ld2, ldg, ldo, epi)
+
+
+def _gates(S, t, hprev, dgi, dgh, dh_direct):
+    return _GruBwdDesc(_p(S[0][t]), _p(S[1][t]), _p(S[2][t]), _p(S[3][t]), _p(hprev),
+                       _p(dgi), _p(dgh), _p(dh_direct))
+
+
+def _lin_pair(R, d1, d2=None, gates=None):
+    ab = 4 * (d1.O * d1.I + R * d1.I + 2 * R * d1.O)
+    if d2 is not None:
+        ab += 4 * (d2.O * d2.I + R * d2.I + 2 * R * d2.O)
+    if gates is not None:
+        ab += 4 * 12 * R * d1.O
+    _call("s2c_small_linear_pair", R, ctypes.addressof(d1),
+          ctypes.addressof(d2) if d2 is not None else None,
+          ctypes.addressof(gates) if gates is not None else None, alg_bytes=ab)
 
 
 def supported(emb, hid, feat, K):
@@ -132,48 +167,57 @@ class TopDownDecode(Function):
             WT_lang, WT_h = W_lang.t().contiguous(), W_h.t().contiguous()
             WT_ih1, WT_hh1 = W_ih1.t().contiguous(), W_hh1.t().contiguous()
             WT_td_h2 = W_td[:, E:E + H].t().contiguous()            # (H,E)
-            WT_td_tf = W_td[:, E + H:].t().contiguous()             # (F,E)
             z = lambda *s: torch.zeros(*s, device=dev)
             e = lambda *s: torch.empty(*s, device=dev)
-            dM, dO, dwa, dtf = z(R, K, H), z(R, K, F), z(H), z(R, F)
-            dh1c, dh2c = z(R, H), z(R, H)
+            dM, dwa = z(R, K, H), z(H)
+            dh1c, dh2_part = z(R, H), e(R, H)
             DA1, DA2 = e(T, R, E), e(T, R, E)
             DGI1, DGH1 = e(T, R, 3 * H), e(T, R, 3 * H)
             DGI2, DGH2 = e(T, R, 3 * H), e(T, R, 3 * H)
-            DQ = e(T, R, H)
+            DQ = z(T, R, H)                   # attention backward accumulates into it
+            DV = e(T, R, F + H)               # [datt | dh1 via map_lang]
             dh2_direct, dh1_direct = e(R, H), e(R, H)
-            dh2_part, dh1_total, dv, ds = e(R, H), e(R, H), e(R, F + H), e(R, K)
+            # 6 launches per step.  GRU-2's gate gradients of step t-1 come out of the
+            # epilogue of step t's last product (value = dh2 of step t-1); only the
+            # very first needs its own launch.
+            _call("s2c_gru_gates_bwd", R, H, _p(dH2[T - 1]), None, _p(S2[0][T - 1]),
+                  _p(S2[1][T - 1]), _p(S2[2][T - 1]), _p(S2[3][T - 1]), _p(H2[T - 1]),
+                  _p(DGI2[T - 1]), _p(DGH2[T - 1]), _p(dh2_direct))
             for t in range(T - 1, -1, -1):
-                _call("s2c_gru_gates_bwd", R, H, _p(dH2[t]), _p(dh2c), _p(S2[0][t]),
-                      _p(S2[1][t]), _p(S2[2][t]), _p(S2[3][t]), _p(H2[t]),
-                      _p(DGI2[t]), _p(DGH2[t]), _p(dh2_direct))
-                _lin(R, E, 3 * H, WT_ih2, 3 * H, DGI2[t], 3 * H, DA2[t], E,
-                     gate=X2[t], ldg=E, epi=2)
-                _lin(R, H, 3 * H, WT_hh2, 3 * H, DGH2[t], 3 * H, dh2_part, H,
-                     add1=dh2_direct, ld1=H)
-                _lin(R, F + H, E, WT_lang, E, DA2[t], E, dv, F + H)
-                _call("s2c_attn_bwd", R, K, H, F, _p(dv), F + H, _p(ALPHA[t]), _p(O),
-                      _p(M), _p(QL[t]), H + E, _p(wa), _p(ds), _p(dO), _p(dM),
+                _lin_pair(R,
+                          _desc(E, 3 * H, WT_ih2, 3 * H, DGI2[t], 3 * H, DA2[t], E,
+                                gate=X2[t], ldg=E, epi=2),
+                          _desc(H, 3 * H, WT_hh2, 3 * H, DGH2[t], 3 * H, dh2_part, H,
+                                add1=dh2_direct, ld1=H))
+                _lin_pair(R, _desc(F + H, E, WT_lang, E, DA2[t], E, DV[t], F + H))
+                _call("s2c_attn_bwd", R, K, H, F, _p(DV[t]), F + H, _p(ATT[t]), F,
+                      _p(ALPHA[t]), _p(O), _p(M), _p(QL[t]), H + E, _p(wa), _p(dM),
                       _p(DQ[t]), _p(dwa),
-                      alg_bytes=4 * (R * K * (3 * H + 3 * F) + R * (2 * H + 2 * K + F)))
-                _lin(R, H, H, WT_h, H, DQ[t], H, dh1_total, H, add1=dv[:, F:],
-                     ld1=F + H, add2=dh1c, ld2=H)
-                _call("s2c_gru_gates_bwd", R, H, _p(dh1_total), None, _p(S1[0][t]),
-                      _p(S1[1][t]), _p(S1[2][t]), _p(S1[3][t]), _p(H1[t]),
-                      _p(DGI1[t]), _p(DGH1[t]), _p(dh1_direct))
-                _lin(R, E, 3 * H, WT_ih1, 3 * H, DGI1[t], 3 * H, DA1[t], E,
-                     gate=X1[t], ldg=E, epi=2)
-                _lin(R, H, 3 * H, WT_hh1, 3 * H, DGH1[t], 3 * H, dh1c, H,
-                     add1=dh1_direct, ld1=H)
-                _lin(R, H, E, WT_td_h2, E, DA1[t], E, dh2c, H, add1=dh2_part, ld1=H)
-                _lin(R, F, E, WT_td_tf, E, DA1[t], E, dtf, F, add1=dtf, ld1=F)
+                      alg_bytes=4 * (R * K * (3 * H + F) + R * (2 * H + 2 * K + 2 * F)))
+                _lin_pair(R, _desc(H, H, WT_h, H, DQ[t], H, None, H, add1=DV[t][:, F:],
+                                   ld1=F + H, add2=dh1c, ld2=H),
+                          gates=_gates(S1, t, H1[t], DGI1[t], DGH1[t], dh1_direct))
+                _lin_pair(R,
+                          _desc(E, 3 * H, WT_ih1, 3 * H, DGI1[t], 3 * H, DA1[t], E,
+                                gate=X1[t], ldg=E, epi=2),
+                          _desc(H, 3 * H, WT_hh1, 3 * H, DGH1[t], 3 * H, dh1c, H,
+                                add1=dh1_direct, ld1=H))
+                if t > 0:
+                    _lin_pair(R, _desc(H, E, WT_td_h2, E, DA1[t], E, None, H,
+                                       add1=dh2_part, ld1=H, add2=dH2[t - 1], ld2=H),
+                              gates=_gates(S2, t - 1, H2[t - 1], DGI2[t - 1],
+                                           DGH2[t - 1], dh2_direct))
+            # no recurrence through these two: hoisted out of the time loop
+            DA1s = DA1.sum(0)
+            dtf = torch.mm(DA1s, W_td[:, E + H:])                             # (R,F)
+            dO = torch.bmm(ALPHA.permute(1, 2, 0), DV[:, :, :F].permute(1, 0, 2))
             # ---- every weight gradient: one stacked GEMM each ------------------
             TR = T * R
             da1 = DA1.view(TR, E)
             dW_td = torch.empty_like(W_td)
             dW_td[:, :E] = torch.mm(da1.t(), words.permute(1, 0, 2).reshape(TR, E))
             dW_td[:, E:E + H] = torch.mm(da1.t(), H2[:-1].reshape(TR, H))
-            dW_td[:, E + H:] = torch.mm(DA1.sum(0).t(), tf)
+            dW_td[:, E + H:] = torch.mm(DA1s.t(), tf)
             db_td = da1.sum(0)
             gi1, gh1 = DGI1.view(TR, 3 * H), DGH1.view(TR, 3 * H)
             dW_ih1 = torch.mm(gi1.t(), X1.view(TR, E))

@@ -17,6 +17,8 @@ opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5)
 dd0 = bench.to_device(bench.make_batch(wl, wl["B"], 42, table, msa), dev)
 cfg = bench.LossConfig(msa)
 
+HIST = {}
+
 def sections():
     dd = dict(dd0)
     out = {}
@@ -27,6 +29,11 @@ def sections():
             torch.cuda.synchronize()
         evs = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
         out[name] = (len(evs), sum(e.device_time for e in evs) / 1e3)
+        hist = {}
+        for e in evs:
+            k = e.name[:90]
+            c = hist.setdefault(k, [0, 0.0]); c[0] += 1; c[1] += e.device_time / 1e3
+        HIST[name] = hist
         return r
     opt.zero_grad(set_to_none=False)
     run("backbone", lambda: model.backbone_net(dd))
@@ -49,3 +56,8 @@ for _ in range(2):
     sections()
 for k, (n, ms) in sections().items():
     print("%-10s %5d launches %8.3f ms" % (k, n, ms))
+
+for sec in ("graph", "caption", "loss", "proposal", "backward"):
+    print("==", sec)
+    for k, (c, ms) in sorted(HIST[sec].items(), key=lambda kv: -kv[1][1])[:14]:
+        print("   %4d x %8.3f ms  %s" % (c, ms, k))
