@@ -161,12 +161,13 @@ int s2c_attn_fwd(int R, int K, int H, int F, const float *M, const float *q, int
                  float *alpha, float *att, int lda, void *stream);
 
 /* its backward from datt (R x F) and the saved forward output att (R x F):
- * dM (R x K x H), dq (R x H) and dwa (H) ACCUMULATE (caller zeroes them once).
+ * dM (R x K x H) and dwa_rows (R x H; dwa = its sum over rows) ACCUMULATE (caller
+ * zeroes them once); dq (R x H) is overwritten.  No atomics: deterministic.
  * dO = sum_t alpha_t (x) datt_t has no recurrence: one batched GEMM in the caller. */
 int s2c_attn_bwd(int R, int K, int H, int F, const float *datt, int ldd,
                  const float *att, int lda, const float *alpha, const float *O,
                  const float *M, const float *q, int ldq, const float *wa, float *dM,
-                 float *dq, float *dwa, void *stream);
+                 float *dq, float *dwa_rows, void *stream);
 
 #ifdef __cplusplus
 }

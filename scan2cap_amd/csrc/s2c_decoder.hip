@@ -32,7 +32,31 @@ __device__ __forceinline__ float fold_chunks(float v) {
   v += __shfl_xor(v, 32, 64);
   return v;
 }
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(
+      __float_as_int(v), __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+// sum over aligned groups of G lanes (G = 8..64, power of two); every lane of the
+// group receives the sum.  DPP inside a row of 16, bpermute above.
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+  v += dpp_f32<DPP_QUAD_1032>(v);
+  v += dpp_f32<DPP_QUAD_2301>(v);
+  v += dpp_f32<DPP_ROW_HALF_MIRROR>(v);
+  if (G > 8) v += dpp_f32<DPP_ROW_MIRROR>(v);
+  if (G > 16) v += __shfl_xor(v, 16, 64);
+  if (G > 32) v += __shfl_xor(v, 32, 64);
+  return v;
+}
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// tanh(x) = 1 - 2 / (e^{2x} + 1) on the hardware exp2 / rcp units (|abs error| < 1e-6;
+// saturates correctly for large |x|).  The attention kernels evaluate ~1M tanh per
+// launch on a few hundred waves: libm's tanhf made them ALU-bound.
+__device__ __forceinline__ float fast_tanh(float x) {
+  const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
 
 // partial dot product of one weight row with this lane's input row; the 32 chunk
 // lanes of a row (8 per wave x 4 waves of the block) stride over the float4s.
@@ -80,7 +104,41 @@ __device__ __forceinline__ float dot_row(const float *__restrict__ w,
   return acc0 + acc1;
 }
 
-// block-wide fold of per-lane partials: result valid in threads 0..7 (row = tid)
+// The input slice of a lane kept in registers and reused for several weight rows:
+// every block re-reads the (R x I) input from L2, so amortising it over OB outputs
+// cuts the dominant L2->CU traffic of these kernels by ~OB.
+template <int U>
+struct XSlice {
+  float4 v[U];
+  __device__ __forceinline__ void load(const float *__restrict__ x, int n4, int chunk) {
+    const float4 *x4 = reinterpret_cast<const float4 *>(x);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = chunk + u * NCHUNK;
+      v[u] = j < n4 ? x4[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __device__ __forceinline__ float dot(const float *__restrict__ w, int n4,
+                                       int chunk) const {
+    const float4 *w4 = reinterpret_cast<const float4 *>(w);
+    float4 a[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = chunk + u * NCHUNK;
+      a[u] = j < n4 ? w4[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float acc0 = 0.0f, acc1 = 0.0f;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (u & 1) acc1 += dot4(a[u], v[u]);
+      else acc0 += dot4(a[u], v[u]);
+    }
+    return acc0 + acc1;
+  }
+};
+
+// block-wide fold of per-lane partials into s_part[k][wave][row]; after the
+// barrier, fold_get(k, row) is the full sum (same association for every caller)
 template <int NV>
 __device__ __forceinline__ void block_fold(float (&v)[NV], float (*s_part)[4][RB]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -90,12 +148,9 @@ __device__ __forceinline__ void block_fold(float (&v)[NV], float (*s_part)[4][RB
     if (lane < RB) s_part[k][wave][lane] = v[k];
   }
   __syncthreads();
-  if (threadIdx.x < RB) {
-#pragma unroll
-    for (int k = 0; k < NV; ++k)
-      v[k] = (s_part[k][0][threadIdx.x] + s_part[k][1][threadIdx.x]) +
-             (s_part[k][2][threadIdx.x] + s_part[k][3][threadIdx.x]);
-  }
+}
+__device__ __forceinline__ float fold_get(float (*s_part)[4][RB], int k, int r) {
+  return (s_part[k][0][r] + s_part[k][1][r]) + (s_part[k][2][r] + s_part[k][3][r]);
 }
 
 // ---------------------------------------------------------------------------
@@ -122,28 +177,84 @@ __device__ __forceinline__ void gru_gates_bwd_one(const s2c_gru_bwd_desc &g, int
   g.dh_direct[e] = dh * z;
 }
 
-__global__ __launch_bounds__(256) void small_linear_kernel(
-    int R, s2c_lin_desc p1, s2c_lin_desc p2, s2c_gru_bwd_desc g1, int has_g1) {
-  __shared__ float s_part[1][4][RB];
+constexpr int LIN_OB = 4;   // outputs per block
+
+template <int U>
+__device__ __forceinline__ void small_linear_body(int R, const s2c_lin_desc &p, int og,
+                                                  const s2c_gru_bwd_desc &g1,
+                                                  bool gates,
+                                                  float (*s_part)[4][RB]) {
   const int r = threadIdx.x & 7, chunk = threadIdx.x >> 3;   // 32 chunks
-  const bool second = (int)blockIdx.x >= p1.O;
-  const s2c_lin_desc &p = second ? p2 : p1;
-  const int o = second ? (int)blockIdx.x - p1.O : (int)blockIdx.x;
   const int row = blockIdx.y * RB + r;
   const int rowc = row < R ? row : R - 1;
-  float v[1];
-  v[0] = dot_row(p.W + (size_t)o * p.ldw, p.x + (size_t)rowc * p.ldx, p.I >> 2, chunk);
-  block_fold<1>(v, s_part);
-  if (threadIdx.x < RB && row < R) {
-    float acc = v[0];
-    if (p.bias) acc += p.bias[o];
-    if (p.add1) acc += p.add1[(size_t)row * p.ld1 + o];
-    if (p.add2) acc += p.add2[(size_t)row * p.ld2 + o];
-    if (p.epi == 1) acc = fmaxf(acc, 0.0f);
-    else if (p.epi == 2) acc = p.gate[(size_t)row * p.ldg + o] > 0.0f ? acc : 0.0f;
-    if (p.out) p.out[(size_t)row * p.ldo + o] = acc;
-    if (has_g1 && !second) gru_gates_bwd_one(g1, p1.O, row, o, acc);
+  const int n4 = p.I >> 2;
+  const int o0 = og * LIN_OB;
+  // epilogue thread = (row, output of the group); its operands are requested up
+  // front so that they travel together with the weight rows (one round trip)
+  const int eo = o0 + chunk;
+  const bool eok = threadIdx.x < RB * LIN_OB && row < R && eo < p.O;
+  float e_bias = 0.f, e_a1 = 0.f, e_a2 = 0.f, e_gate = 1.f;
+  float e_r = 0.f, e_z = 0.f, e_n = 0.f, e_ghn = 0.f, e_hp = 0.f;
+  if (eok) {
+    if (p.bias) e_bias = p.bias[eo];
+    if (p.add1) e_a1 = p.add1[(size_t)row * p.ld1 + eo];
+    if (p.add2) e_a2 = p.add2[(size_t)row * p.ld2 + eo];
+    if (p.epi == 2) e_gate = p.gate[(size_t)row * p.ldg + eo];
+    if (gates) {
+      const size_t e = (size_t)row * p.O + eo;
+      e_r = g1.sr[e]; e_z = g1.sz[e]; e_n = g1.sn[e]; e_ghn = g1.sghn[e];
+      e_hp = g1.hprev[e];
+    }
   }
+  XSlice<U> xs;
+  xs.load(p.x + (size_t)rowc * p.ldx, n4, chunk);
+  float v[LIN_OB];
+#pragma unroll
+  for (int k = 0; k < LIN_OB; ++k) {
+    const int o = min(o0 + k, p.O - 1);
+    v[k] = xs.dot(p.W + (size_t)o * p.ldw, n4, chunk);
+    // long rows: keep two weight rows (not four) in flight -> no spills
+    if (U > 4 && (k & 1)) __builtin_amdgcn_sched_barrier(0);
+  }
+  block_fold<LIN_OB>(v, s_part);
+  if (eok) {
+    float acc = fold_get(s_part, chunk, r);
+    if (p.bias) acc += e_bias;
+    if (p.add1) acc += e_a1;
+    if (p.add2) acc += e_a2;
+    if (p.epi == 1) acc = fmaxf(acc, 0.0f);
+    else if (p.epi == 2) acc = e_gate > 0.0f ? acc : 0.0f;
+    if (p.out) p.out[(size_t)row * p.ldo + eo] = acc;
+    if (gates) {
+      const int H = p.O;
+      const size_t e = (size_t)row * H + eo;
+      const float dh = acc;
+      const float dz = dh * (e_hp - e_n);
+      const float dn = dh * (1.0f - e_z);
+      const float dpn = dn * (1.0f - e_n * e_n);
+      const float dr = dpn * e_ghn;
+      const float dpr = dr * e_r * (1.0f - e_r);
+      const float dpz = dz * e_z * (1.0f - e_z);
+      float *gi = g1.dgi + (size_t)row * 3 * H;
+      float *gh = g1.dgh + (size_t)row * 3 * H;
+      gi[eo] = dpr; gi[H + eo] = dpz; gi[2 * H + eo] = dpn;
+      gh[eo] = dpr; gh[H + eo] = dpz; gh[2 * H + eo] = dpn * e_r;
+      g1.dh_direct[e] = dh * e_z;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void small_linear_kernel(
+    int R, s2c_lin_desc p1, s2c_lin_desc p2, s2c_gru_bwd_desc g1, int has_g1,
+    int groups1) {
+  __shared__ float s_part[LIN_OB][4][RB];
+  const bool second = (int)blockIdx.x >= groups1;
+  const s2c_lin_desc &p = second ? p2 : p1;
+  const int og = second ? (int)blockIdx.x - groups1 : (int)blockIdx.x;
+  const bool gates = has_g1 && !second;
+  const int n4 = p.I >> 2;
+  if (n4 <= 4 * NCHUNK) small_linear_body<4>(R, p, og, g1, gates, s_part);
+  else small_linear_body<12>(R, p, og, g1, gates, s_part);   // I <= 1536
 }
 
 // ---------------------------------------------------------------------------
@@ -153,6 +264,65 @@ __global__ __launch_bounds__(256) void small_linear_kernel(
 //   h' = (1 - z) * n + z * h
 // One wave per hidden unit; saves r, z, n and gh_n (bias included) for BPTT.
 // ---------------------------------------------------------------------------
+constexpr int GRU_UB = 2;   // hidden units per block
+
+template <int UX, int UH>
+__device__ __forceinline__ void gru_fwd_body(
+    int R, int H, int I, const float *__restrict__ Wih,
+    const float *__restrict__ Whh, const float *__restrict__ bih,
+    const float *__restrict__ bhh, const float *__restrict__ x, int ldx,
+    const float *__restrict__ h, float *__restrict__ hnew,
+    float *__restrict__ sr, float *__restrict__ sz, float *__restrict__ sn,
+    float *__restrict__ sghn, float (*s_part)[4][RB]) {
+  const int r = threadIdx.x & 7, chunk = threadIdx.x >> 3;
+  const int u0 = blockIdx.x * GRU_UB;
+  const int row = blockIdx.y * RB + r;
+  const int rowc = row < R ? row : R - 1;
+  const float *hr = h + (size_t)rowc * H;
+  // epilogue thread = (row, unit of the block): operands requested up front
+  const int eu = u0 + chunk;
+  const bool eok = threadIdx.x < RB * GRU_UB && row < R && eu < H;
+  float b_i[3] = {0.f, 0.f, 0.f}, b_h[3] = {0.f, 0.f, 0.f}, hp = 0.f;
+  if (eok) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      b_i[k] = bih[k * H + eu];
+      b_h[k] = bhh[k * H + eu];
+    }
+    hp = hr[eu];
+  }
+  XSlice<UX> xs;
+  XSlice<UH> hs;
+  xs.load(x + (size_t)rowc * ldx, I >> 2, chunk);
+  hs.load(hr, H >> 2, chunk);
+  float g[6 * GRU_UB];
+#pragma unroll
+  for (int j = 0; j < GRU_UB; ++j) {
+    const int u = min(u0 + j, H - 1);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      g[6 * j + k] = xs.dot(Wih + (size_t)(k * H + u) * I, I >> 2, chunk);
+      g[6 * j + 3 + k] = hs.dot(Whh + (size_t)(k * H + u) * H, H >> 2, chunk);
+    }
+  }
+  block_fold<6 * GRU_UB>(g, s_part);
+  if (eok) {
+    const int j = chunk;
+    const float gir = fold_get(s_part, 6 * j, r) + b_i[0],
+                giz = fold_get(s_part, 6 * j + 1, r) + b_i[1],
+                gin = fold_get(s_part, 6 * j + 2, r) + b_i[2];
+    const float ghr = fold_get(s_part, 6 * j + 3, r) + b_h[0],
+                ghz = fold_get(s_part, 6 * j + 4, r) + b_h[1],
+                ghn = fold_get(s_part, 6 * j + 5, r) + b_h[2];
+    const float rr = sigmoidf_(gir + ghr);
+    const float zz = sigmoidf_(giz + ghz);
+    const float nn = tanhf(gin + rr * ghn);
+    const size_t e = (size_t)row * H + eu;
+    hnew[e] = (1.0f - zz) * nn + zz * hp;
+    sr[e] = rr; sz[e] = zz; sn[e] = nn; sghn[e] = ghn;
+  }
+}
+
 __global__ __launch_bounds__(256) void gru_fwd_kernel(
     int R, int H, int I, const float *__restrict__ Wih,
     const float *__restrict__ Whh, const float *__restrict__ bih,
@@ -160,31 +330,9 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(
     const float *__restrict__ h, float *__restrict__ hnew,
     float *__restrict__ sr, float *__restrict__ sz, float *__restrict__ sn,
     float *__restrict__ sghn) {
-  __shared__ float s_part[6][4][RB];
-  const int r = threadIdx.x & 7, chunk = threadIdx.x >> 3;
-  const int u = blockIdx.x;                      // one block per hidden unit
-  const int row = blockIdx.y * RB + r;
-  const int rowc = row < R ? row : R - 1;
-  const float *xr = x + (size_t)rowc * ldx;
-  const float *hr = h + (size_t)rowc * H;
-  float g[6];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    g[k] = dot_row(Wih + (size_t)(k * H + u) * I, xr, I >> 2, chunk);
-    g[3 + k] = dot_row(Whh + (size_t)(k * H + u) * H, hr, H >> 2, chunk);
-  }
-  block_fold<6>(g, s_part);
-  if (threadIdx.x < RB && row < R) {
-    const float gir = g[0] + bih[u], giz = g[1] + bih[H + u], gin = g[2] + bih[2 * H + u];
-    const float ghr = g[3] + bhh[u], ghz = g[4] + bhh[H + u], ghn = g[5] + bhh[2 * H + u];
-    const float rr = sigmoidf_(gir + ghr);
-    const float zz = sigmoidf_(giz + ghz);
-    const float nn = tanhf(gin + rr * ghn);
-    const float hp = hr[u];
-    const size_t e = (size_t)row * H + u;
-    hnew[e] = (1.0f - zz) * nn + zz * hp;
-    sr[e] = rr; sz[e] = zz; sn[e] = nn; sghn[e] = ghn;
-  }
+  __shared__ float s_part[6 * GRU_UB][4][RB];
+  gru_fwd_body<4, 4>(R, H, I, Wih, Whh, bih, bhh, x, ldx, h, hnew, sr, sz, sn, sghn, s_part);
+  // (host side rejects I, H > 512)
 }
 
 // GRUCell backward, gate part (elementwise over R x H):
@@ -221,8 +369,8 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(
     const float4 a = reinterpret_cast<const float4 *>(m)[h4];
     const float4 b = reinterpret_cast<const float4 *>(qq)[h4];
     const float4 w = reinterpret_cast<const float4 *>(wa)[h4];
-    acc += w.x * tanhf(a.x + b.x) + w.y * tanhf(a.y + b.y) +
-           w.z * tanhf(a.z + b.z) + w.w * tanhf(a.w + b.w);
+    acc += w.x * fast_tanh(a.x + b.x) + w.y * fast_tanh(a.y + b.y) +
+           w.z * fast_tanh(a.z + b.z) + w.w * fast_tanh(a.w + b.w);
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
@@ -291,28 +439,63 @@ __global__ __launch_bounds__(256) void attn_softmax_kernel(
   }
 }
 
-// Attention backward for one step, block = (chunk of ATT_KC keys, row):
+// Attention backward for one step.  Block = (chunk of ATT_HC hidden units, row);
+// it owns dq[row, chunk] and dwa_rows[row, chunk] outright: no atomics (device-scope
+// float atomics on a few hundred shared addresses serialise at the memory side and
+// made the first version of this kernel 5x slower), deterministic.
 //  (a) softmax backward without a row-wide pass:  sum_k alpha_k dalpha_k
 //      = <datt, sum_k alpha_k O_k> = <datt, att>  (att is the saved forward output);
 //      dalpha_k = <datt, O[r,k,:]> ; ds_k = alpha_k (dalpha_k - <datt, att>)
+//      (recomputed by every chunk block of the row: K*F MACs, L2-resident)
 //  (b) dpre = ds * wa * (1 - c^2), c = tanh(M + q);
-//      dM[r,k,:] += dpre ; dq[r,:] += sum_k dpre ; dwa[:] += sum_k ds * c
-//      (k loop keeps the dq / dwa partial sums in registers: one atomic per (block, h)).
+//      dM[r,k,:] += dpre ; dq[r,:] = sum_k dpre ; dwa_rows[r,:] += sum_k ds * c
 // dO = sum_t alpha_t (outer) datt_t has no recurrence and is one batched GEMM after
-// the time loop (decoder_fused.py).
-constexpr int ATT_KC = 16;
+// the time loop (decoder_fused.py); dwa = sum_r dwa_rows[r] likewise.
+constexpr int ATT_HC = 32;                 // hidden units per block (8 float4)
+constexpr int ATT_KG = 256 / (ATT_HC / 4); // key groups per block (32)
+constexpr int ATT_KB = 8;                  // keys in flight per thread
+constexpr int ATT_PB = 16;                 // stage (a) passes in flight
+template <int F4>
+__device__ __forceinline__ void attn_bwd_ds_stage(int K, int row, float dot,
+                                                  const float *s_datt,
+                                                  const float *__restrict__ O,
+                                                  const float *__restrict__ alpha,
+                                                  float *s_ds) {
+  const int tid = threadIdx.x;
+  const int sub = tid & (F4 - 1), kl = tid / F4;
+  constexpr int kpp = 256 / F4;
+  const float4 d4 = reinterpret_cast<const float4 *>(s_datt)[sub];
+  const float4 *O4 = reinterpret_cast<const float4 *>(O) + (size_t)row * K * F4;
+  for (int base = 0; base < K; base += kpp * ATT_PB) {
+    float4 o[ATT_PB];
+    float al[ATT_PB];
+#pragma unroll
+    for (int u = 0; u < ATT_PB; ++u) {
+      const int k = base + u * kpp + kl;
+      const bool in = k < K;
+      o[u] = in ? O4[(size_t)k * F4 + sub] : make_float4(0.f, 0.f, 0.f, 0.f);
+      al[u] = in ? alpha[(size_t)row * K + k] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < ATT_PB; ++u) {
+      const int k = base + u * kpp + kl;
+      const float da = group_sum<F4>(dot4(o[u], d4));
+      if (sub == 0 && k < K) s_ds[k] = al[u] * (da - dot);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void attn_bwd_kernel(
     int K, int H, int F, const float *__restrict__ datt, int ldd,
     const float *__restrict__ att, int lda, const float *__restrict__ alpha,
     const float *__restrict__ O, const float *__restrict__ M,
     const float *__restrict__ q, int ldq, const float *__restrict__ wa,
-    float *__restrict__ dM, float *__restrict__ dq, float *__restrict__ dwa) {
+    float *__restrict__ dM, float *__restrict__ dq, float *__restrict__ dwa_rows) {
   __shared__ float s_datt[512];
   __shared__ float s_red[4];
-  __shared__ float s_ds[ATT_KC];
+  __shared__ float s_ds[1024];
+  __shared__ float4 s_sq[ATT_KG][ATT_HC / 4], s_sw[ATT_KG][ATT_HC / 4];
   const int row = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int k0 = blockIdx.x * ATT_KC;
-  const int k1 = min(K, k0 + ATT_KC);
   float part = 0.0f;
   for (int f = tid; f < F; f += 256) {
     const float d = datt[(size_t)row * ldd + f];
@@ -324,39 +507,69 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(
   if (lane == 0) s_red[wave] = part;
   __syncthreads();
   const float dot = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-  {
-    // 16 lanes per key
-    const int kk = k0 + (tid >> 4), sub = tid & 15;
-    float da = 0.0f;
-    if (kk < k1) {
-      const float *o = O + ((size_t)row * K + kk) * F;
-      for (int f = sub; f < F; f += 16) da += s_datt[f] * o[f];
-    }
-    da += __shfl_xor(da, 1, 64);
-    da += __shfl_xor(da, 2, 64);
-    da += __shfl_xor(da, 4, 64);
-    da += __shfl_xor(da, 8, 64);
-    if (sub == 0 && kk < k1) {
-      const float a = alpha[(size_t)row * K + kk];
-      s_ds[kk - k0] = a * (da - dot);
+  // (a) O[row] is one contiguous (K x F) array: linear float4 streaming, F/4 lanes
+  // per key, ATT_PB passes in flight, DPP reduction inside the key's lane group
+  if (F == 128) attn_bwd_ds_stage<32>(K, row, dot, s_datt, O, alpha, s_ds);
+  else if (F == 64) attn_bwd_ds_stage<16>(K, row, dot, s_datt, O, alpha, s_ds);
+  else if (F == 32) attn_bwd_ds_stage<8>(K, row, dot, s_datt, O, alpha, s_ds);
+  else attn_bwd_ds_stage<64>(K, row, dot, s_datt, O, alpha, s_ds);
+  __syncthreads();
+  // (b) thread = (float4 of hidden units, key group); ATT_KB keys in flight
+  const int H4 = H >> 2;
+  const int hl = tid & (ATT_HC / 4 - 1), kg = tid / (ATT_HC / 4);
+  const int h4 = blockIdx.x * (ATT_HC / 4) + hl;
+  const bool ok = h4 < H4;
+  float4 sq = make_float4(0.f, 0.f, 0.f, 0.f), sw = sq;
+  if (ok) {
+    const float4 qh = reinterpret_cast<const float4 *>(q + (size_t)row * ldq)[h4];
+    const float4 wh = reinterpret_cast<const float4 *>(wa)[h4];
+    for (int kbase = kg; kbase < K; kbase += ATT_KG * ATT_KB) {
+      float4 m[ATT_KB], dm[ATT_KB];
+      float d[ATT_KB];
+#pragma unroll
+      for (int j = 0; j < ATT_KB; ++j) {
+        const int k = kbase + j * ATT_KG;
+        d[j] = k < K ? s_ds[k] : 0.0f;
+        if (d[j] != 0.0f) {
+          const size_t e4 = ((size_t)row * K + k) * H4 + h4;
+          m[j] = reinterpret_cast<const float4 *>(M)[e4];
+          dm[j] = reinterpret_cast<const float4 *>(dM)[e4];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < ATT_KB; ++j) {
+        if (d[j] == 0.0f) continue;
+        const int k = kbase + j * ATT_KG;
+        const size_t e4 = ((size_t)row * K + k) * H4 + h4;
+        const float cx = fast_tanh(m[j].x + qh.x), cy = fast_tanh(m[j].y + qh.y),
+                    cz = fast_tanh(m[j].z + qh.z), cw = fast_tanh(m[j].w + qh.w);
+        float4 dp;
+        dp.x = d[j] * wh.x * (1.0f - cx * cx);
+        dp.y = d[j] * wh.y * (1.0f - cy * cy);
+        dp.z = d[j] * wh.z * (1.0f - cz * cz);
+        dp.w = d[j] * wh.w * (1.0f - cw * cw);
+        dm[j].x += dp.x; dm[j].y += dp.y; dm[j].z += dp.z; dm[j].w += dp.w;
+        reinterpret_cast<float4 *>(dM)[e4] = dm[j];
+        sq.x += dp.x; sq.y += dp.y; sq.z += dp.z; sq.w += dp.w;
+        sw.x += d[j] * cx; sw.y += d[j] * cy; sw.z += d[j] * cz; sw.w += d[j] * cw;
+      }
     }
   }
+  s_sq[kg][hl] = sq;
+  s_sw[kg][hl] = sw;
   __syncthreads();
-  for (int h = tid; h < H; h += 256) {
-    const float qh = q[(size_t)row * ldq + h], wh = wa[h];
-    float sq = 0.0f, sw = 0.0f;
-    for (int k = k0; k < k1; ++k) {
-      const float d = s_ds[k - k0];              // block-uniform
-      if (d == 0.0f) continue;                   // masked (alpha == 0)
-      const size_t e = ((size_t)row * K + k) * H + h;
-      const float c = tanhf(M[e] + qh);
-      const float dp = d * wh * (1.0f - c * c);
-      dM[e] += dp;
-      sq += dp;
-      sw += d * c;
+  if (tid < ATT_HC / 4 && ok) {
+    float4 a = s_sq[0][tid], b = s_sw[0][tid];
+    for (int g = 1; g < ATT_KG; ++g) {             // fixed order: deterministic
+      const float4 u = s_sq[g][tid], v = s_sw[g][tid];
+      a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+      b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
     }
-    atomicAdd(dq + (size_t)row * H + h, sq);
-    atomicAdd(dwa + h, sw);
+    reinterpret_cast<float4 *>(dq + (size_t)row * H)[h4] = a;
+    float4 *dw = reinterpret_cast<float4 *>(dwa_rows + (size_t)row * H) + h4;
+    float4 w0 = *dw;
+    w0.x += b.x; w0.y += b.y; w0.z += b.z; w0.w += b.w;
+    *dw = w0;
   }
 }
 
@@ -382,7 +595,7 @@ static s2c_lin_desc one_desc(int O, int I, const float *W, int ldw, const float 
   return d;
 }
 static bool bad_desc(const s2c_lin_desc *p) {
-  return p->O <= 0 || p->I <= 0 || (p->I & 3) || (p->ldw & 3) || (p->ldx & 3) ||
+  return p->O <= 0 || p->I <= 0 || p->I > 1536 || (p->I & 3) || (p->ldw & 3) || (p->ldx & 3) ||
          !p->W || !p->x || (p->epi == 2 && !p->gate);
 }
 
@@ -396,9 +609,10 @@ extern "C" int s2c_small_linear_pair(int R, const s2c_lin_desc *p1,
   s2c_gru_bwd_desc g;
   if (g1) g = *g1;
   else g.sr = g.sz = g.sn = g.sghn = g.hprev = nullptr, g.dgi = g.dgh = g.dh_direct = nullptr;
-  const int O = p1->O + (p2 ? p2->O : 0);
-  hipLaunchKernelGGL(small_linear_kernel, dim3(O, (R + RB - 1) / RB), dim3(256), 0,
-                     (hipStream_t)stream, R, *p1, q2, g, g1 ? 1 : 0);
+  const int groups1 = (p1->O + LIN_OB - 1) / LIN_OB;
+  const int groups = groups1 + (p2 ? (p2->O + LIN_OB - 1) / LIN_OB : 0);
+  hipLaunchKernelGGL(small_linear_kernel, dim3(groups, (R + RB - 1) / RB), dim3(256), 0,
+                     (hipStream_t)stream, R, *p1, q2, g, g1 ? 1 : 0, groups1);
   return chk("small_linear");
 }
 
@@ -416,8 +630,8 @@ extern "C" int s2c_gru_fwd(int R, int H, int I, const float *Wih, const float *W
                            const float *bih, const float *bhh, const float *x,
                            int ldx, const float *h, float *hnew, float *sr,
                            float *sz, float *sn, float *sghn, void *stream) {
-  if (R <= 0 || (H & 3) || (I & 3) || (ldx & 3)) return -1;
-  hipLaunchKernelGGL(gru_fwd_kernel, dim3(H, (R + RB - 1) / RB), dim3(256),
+  if (R <= 0 || (H & 3) || (I & 3) || (ldx & 3) || H > 512 || I > 512) return -1;
+  hipLaunchKernelGGL(gru_fwd_kernel, dim3((H + GRU_UB - 1) / GRU_UB, (R + RB - 1) / RB), dim3(256),
                      0, (hipStream_t)stream, R, H, I, Wih, Whh, bih, bhh, x, ldx, h,
                      hnew, sr, sz, sn, sghn);
   return chk("gru_fwd");
@@ -449,15 +663,18 @@ extern "C" int s2c_attn_fwd(int R, int K, int H, int F, const float *M,
   return chk("attn_fwd");
 }
 
-// dM (R x K x H), dq (R x H) and dwa (H) ACCUMULATE (the caller zeroes them once).
+// dM (R x K x H) and dwa_rows (R x H) ACCUMULATE (the caller zeroes them once and
+// sums dwa_rows over the rows at the end); dq (R x H) is overwritten.
 extern "C" int s2c_attn_bwd(int R, int K, int H, int F, const float *datt, int ldd,
                             const float *att, int lda, const float *alpha,
                             const float *O, const float *M, const float *q, int ldq,
-                            const float *wa, float *dM, float *dq, float *dwa,
+                            const float *wa, float *dM, float *dq, float *dwa_rows,
                             void *stream) {
-  if (R <= 0 || K <= 0 || K > 1024 || F > 512 || (H & 3)) return -1;
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3((K + ATT_KC - 1) / ATT_KC, R), dim3(256), 0,
+  if (R <= 0 || K <= 0 || K > 1024 || F < 32 || F > 256 || (F & (F - 1)) || (H & 3) ||
+      (ldq & 3) || (ldd & 3))
+    return -1;
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3((H + ATT_HC - 1) / ATT_HC, R), dim3(256), 0,
                      (hipStream_t)stream, K, H, F, datt, ldd, att, lda, alpha, O, M, q,
-                     ldq, wa, dM, dq, dwa);
+                     ldq, wa, dM, dq, dwa_rows);
   return chk("attn_bwd");
 }

@@ -81,7 +81,8 @@ def _lin_pair(R, d1, d2=None, gates=None):
 
 
 def supported(emb, hid, feat, K):
-    return emb % 4 == 0 and hid % 4 == 0 and feat % 4 == 0 and K <= 1024 and feat <= 512
+    return (emb % 4 == 0 and hid % 4 == 0 and feat in (32, 64, 128, 256) and K <= 1024
+            and hid <= 512 and emb <= 512)     # register-resident input slices
 
 
 class TopDownDecode(Function):
@@ -169,12 +170,12 @@ class TopDownDecode(Function):
             WT_td_h2 = W_td[:, E:E + H].t().contiguous()            # (H,E)
             z = lambda *s: torch.zeros(*s, device=dev)
             e = lambda *s: torch.empty(*s, device=dev)
-            dM, dwa = z(R, K, H), z(H)
+            dM, dwa_rows = z(R, K, H), z(R, H)
             dh1c, dh2_part = z(R, H), e(R, H)
             DA1, DA2 = e(T, R, E), e(T, R, E)
             DGI1, DGH1 = e(T, R, 3 * H), e(T, R, 3 * H)
             DGI2, DGH2 = e(T, R, 3 * H), e(T, R, 3 * H)
-            DQ = z(T, R, H)                   # attention backward accumulates into it
+            DQ = e(T, R, H)
             DV = e(T, R, F + H)               # [datt | dh1 via map_lang]
             dh2_direct, dh1_direct = e(R, H), e(R, H)
             # 6 launches per step.  GRU-2's gate gradients of step t-1 come out of the
@@ -192,7 +193,7 @@ class TopDownDecode(Function):
                 _lin_pair(R, _desc(F + H, E, WT_lang, E, DA2[t], E, DV[t], F + H))
                 _call("s2c_attn_bwd", R, K, H, F, _p(DV[t]), F + H, _p(ATT[t]), F,
                       _p(ALPHA[t]), _p(O), _p(M), _p(QL[t]), H + E, _p(wa), _p(dM),
-                      _p(DQ[t]), _p(dwa),
+                      _p(DQ[t]), _p(dwa_rows),
                       alg_bytes=4 * (R * K * (3 * H + F) + R * (2 * H + 2 * K + 2 * F)))
                 _lin_pair(R, _desc(H, H, WT_h, H, DQ[t], H, None, H, add1=DV[t][:, F:],
                                    ld1=F + H, add2=dh1c, ld2=H),
@@ -242,7 +243,7 @@ class TopDownDecode(Function):
                 dwords = torch.matmul(DA1.permute(1, 0, 2), W_td[:, :E])
         ctx.stash = None
         return (dwords, dtf, dO, None, None, dW_td, db_td, dW_ih1, dW_hh1, db_ih1,
-                db_hh1, dW_f, dW_h, dwa.view_as(w_a), dW_lang, db_lang, dW_ih2, dW_hh2,
+                db_hh1, dW_f, dW_h, dwa_rows.sum(0).view_as(w_a), dW_lang, db_lang, dW_ih2, dW_hh2,
                 db_ih2, db_hh2, dW_cls, db_cls)
 
 
