@@ -169,6 +169,61 @@ int s2c_attn_bwd(int R, int K, int H, int F, const float *datt, int ldd,
                  const float *M, const float *q, int ldq, const float *wa, float *dM,
                  float *dq, float *dwa_rows, void *stream);
 
+/* ---------------------------------------------------------------------------
+ * Detection loss of get_scene_cap_loss (lib/loss_helper.py:24-187, :381-491;
+ * utils/nn_distance.py:13-59) as 2 forward + 1 backward launches.
+ * All arrays contiguous; labels int64 as lib/dataset.py produces them; seed_inds
+ * int32.  B scenes, S seeds x VF votes, N points, K proposals, G (<=256) padded GT
+ * boxes, NH heading bins, NS size clusters, NC classes (each <= 64), K <= 1024. */
+typedef struct s2c_detloss_args {
+  int B, S, VF, N, K, G, NH, NS, NC, ld_center_label;
+  float near_threshold, far_threshold, obj_w0, obj_w1;
+  const float *seed_xyz;              /* (B,S,3) */
+  const float *vote_xyz;              /* (B,S*VF,3) */
+  const int *seed_inds;               /* (B,S) */
+  const float *vote_label;            /* (B,N,9) */
+  const long long *vote_label_mask;   /* (B,N) */
+  const float *agg_xyz;               /* (B,K,3) aggregated_vote_xyz */
+  const float *center_label;          /* (B,G,ld_center_label), first 3 used */
+  const float *objectness_scores;     /* (B,K,2) */
+  const float *center;                /* (B,K,3) */
+  const float *box_label_mask;        /* (B,G) */
+  const long long *heading_class_label; /* (B,G) */
+  const float *heading_residual_label;  /* (B,G) */
+  const long long *size_class_label;    /* (B,G) */
+  const float *size_residual_label;     /* (B,G,3) */
+  const long long *sem_cls_label;       /* (B,G) */
+  const float *heading_scores;        /* (B,K,NH) */
+  const float *heading_res_norm;      /* (B,K,NH) */
+  const float *size_scores;           /* (B,K,NS) */
+  const float *size_res_norm;         /* (B,K,NS,3) */
+  const float *sem_cls_scores;        /* (B,K,NC) */
+  const float *mean_size_arr;         /* (NS,3) */
+  /* outputs of the forward (saved for the backward) */
+  long long *objectness_label;        /* (B,K) */
+  float *objectness_mask;             /* (B,K) */
+  long long *object_assignment;       /* (B,K) */
+  int *vote_arg;                      /* (B,S) */
+  int *center_g1;                     /* (B,K) */
+  int *center_k2;                     /* (B,G) */
+  float *partial;                     /* (B, s2c_detection_loss_partial_floats()) */
+  float *stats;                       /* 20 floats: [0..8] vote, objectness, center,
+    heading_cls, heading_reg, size_cls, size_reg, sem_cls, box; [9] = 10*(vote +
+    0.5 objectness + box + 0.1 sem_cls); [10] pos_ratio; [11] neg_ratio; [12] obj_acc;
+    [13..16] denominators */
+} s2c_detloss_args;
+
+typedef struct s2c_detloss_grads {    /* d stats[9] / d input, same shapes */
+  float *vote_xyz, *objectness_scores, *center, *heading_scores, *heading_res_norm,
+      *size_scores, *size_res_norm, *sem_cls_scores;
+} s2c_detloss_grads;
+
+int s2c_detection_loss_partial_floats(void);
+int s2c_detection_loss_fwd(const s2c_detloss_args *a, void *stream);
+/* gup: device pointer to the upstream gradient of stats[9] (one float) */
+int s2c_detection_loss_bwd(const s2c_detloss_args *a, const s2c_detloss_grads *d,
+                           const float *gup, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

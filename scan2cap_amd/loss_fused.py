@@ -1,0 +1,142 @@
+"""Detection part of `get_scene_cap_loss` (lib/loss_helper.py:24-187, :381-491) as
+ONE autograd Function over csrc/s2c_loss.hip: 2 forward + 1 backward launches
+instead of ~170 + ~250 micro-kernels.  Same terms, weights and
+reductions; tie rules = torch.min / torch.argmax (first extremum).
+
+Only the weighted detection total `10 * (vote + 0.5 objectness + box + 0.1 sem_cls)`
+carries a gradient; the individual terms are returned detached (the reference only
+ever logs them, lib/solver.py:314-330).
+"""
+import ctypes
+
+import numpy as np
+import torch
+from torch.autograd import Function
+
+from . import _C
+from .consts import array_const
+
+_I, _F, _P = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+
+_INTS = ("B", "S", "VF", "N", "K", "G", "NH", "NS", "NC", "ld_center_label")
+_FLOATS = ("near_threshold", "far_threshold", "obj_w0", "obj_w1")
+_PTRS = ("seed_xyz", "vote_xyz", "seed_inds", "vote_label", "vote_label_mask", "agg_xyz",
+         "center_label", "objectness_scores", "center", "box_label_mask",
+         "heading_class_label", "heading_residual_label", "size_class_label",
+         "size_residual_label", "sem_cls_label", "heading_scores", "heading_res_norm",
+         "size_scores", "size_res_norm", "sem_cls_scores", "mean_size_arr",
+         "objectness_label", "objectness_mask", "object_assignment", "vote_arg",
+         "center_g1", "center_k2", "partial", "stats")
+_GRADS = ("vote_xyz", "objectness_scores", "center", "heading_scores", "heading_res_norm",
+          "size_scores", "size_res_norm", "sem_cls_scores")
+
+
+class _Args(ctypes.Structure):
+    """include/s2c_fused.h: s2c_detloss_args"""
+    _fields_ = ([(n, _I) for n in _INTS] + [(n, _F) for n in _FLOATS] +
+                [(n, _P) for n in _PTRS])
+
+
+class _Grads(ctypes.Structure):
+    """include/s2c_fused.h: s2c_detloss_grads"""
+    _fields_ = [(n, _P) for n in _GRADS]
+
+
+_C.register("s2c_detection_loss_fwd", [_P, _P])
+_C.register("s2c_detection_loss_bwd", [_P, _P, _P, _P])
+
+STAT_NAMES = ("vote_loss", "objectness_loss", "center_loss", "heading_cls_loss",
+              "heading_reg_loss", "size_cls_loss", "size_reg_loss", "sem_cls_loss",
+              "box_loss")
+
+
+def _c(t, dtype):
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+class DetectionLoss(Function):
+    @staticmethod
+    def forward(ctx, vote_xyz, objectness_scores, center, heading_scores, heading_res_norm,
+                size_scores, size_res_norm, sem_cls_scores, labels, cfg):
+        dev = center.device
+        f32, i64 = torch.float32, torch.int64
+        t = {
+            "vote_xyz": _c(vote_xyz, f32), "objectness_scores": _c(objectness_scores, f32),
+            "center": _c(center, f32), "heading_scores": _c(heading_scores, f32),
+            "heading_res_norm": _c(heading_res_norm, f32),
+            "size_scores": _c(size_scores, f32), "size_res_norm": _c(size_res_norm, f32),
+            "sem_cls_scores": _c(sem_cls_scores, f32),
+            "seed_xyz": _c(labels["seed_xyz"], f32),
+            "seed_inds": _c(labels["seed_inds"], torch.int32),
+            "vote_label": _c(labels["vote_label"], f32),
+            "vote_label_mask": _c(labels["vote_label_mask"], i64),
+            "agg_xyz": _c(labels["aggregated_vote_xyz"], f32),
+            "center_label": _c(labels["center_label"], f32),
+            "box_label_mask": _c(labels["box_label_mask"], f32),
+            "heading_class_label": _c(labels["heading_class_label"], i64),
+            "heading_residual_label": _c(labels["heading_residual_label"], f32),
+            "size_class_label": _c(labels["size_class_label"], i64),
+            "size_residual_label": _c(labels["size_residual_label"], f32),
+            "sem_cls_label": _c(labels["sem_cls_label"], i64),
+            "mean_size_arr": array_const(np.asarray(cfg["mean_size_arr"], np.float32), dev),
+        }
+        B, K = t["center"].shape[:2]
+        S = t["seed_xyz"].shape[1]
+        G = t["center_label"].shape[1]
+        VF = t["vote_xyz"].shape[1] // S
+        t["objectness_label"] = torch.empty((B, K), dtype=i64, device=dev)
+        t["objectness_mask"] = torch.empty((B, K), dtype=f32, device=dev)
+        t["object_assignment"] = torch.empty((B, K), dtype=i64, device=dev)
+        t["vote_arg"] = torch.empty((B, S), dtype=torch.int32, device=dev)
+        t["center_g1"] = torch.empty((B, K), dtype=torch.int32, device=dev)
+        t["center_k2"] = torch.empty((B, G), dtype=torch.int32, device=dev)
+        lib = _C.load()
+        lib.s2c_detection_loss_partial_floats.restype = _I
+        t["partial"] = torch.empty((B, lib.s2c_detection_loss_partial_floats()), device=dev)
+        t["stats"] = torch.empty(20, device=dev)
+        w = cfg["objectness_cls_weights"]
+        args = _Args(B, S, VF, t["vote_label"].shape[1], K, G, t["heading_scores"].shape[2],
+                     t["size_scores"].shape[2], t["sem_cls_scores"].shape[2],
+                     t["center_label"].shape[2], float(cfg["near_threshold"]),
+                     float(cfg["far_threshold"]), float(w[0]), float(w[1]),
+                     *[t[n].data_ptr() for n in _PTRS])
+        with torch.cuda.device(dev):
+            _C.call("s2c_detection_loss_fwd", ctypes.addressof(args), _C.stream_ptr())
+        ctx.args, ctx.tensors = args, t
+        outs = (t["stats"], t["objectness_label"], t["objectness_mask"],
+                t["object_assignment"])
+        ctx.mark_non_differentiable(*outs)
+        return (t["stats"][9].clone(),) + outs
+
+    @staticmethod
+    def backward(ctx, gdet, *_unused):
+        t, args = ctx.tensors, ctx.args
+        dev = gdet.device
+        g = {n: torch.empty_like(t[n]) for n in _GRADS}
+        grads = _Grads(*[g[n].data_ptr() for n in _GRADS])
+        gup = gdet.to(torch.float32).contiguous()
+        with torch.cuda.device(dev):
+            _C.call("s2c_detection_loss_bwd", ctypes.addressof(args),
+                    ctypes.addressof(grads), gup.data_ptr(), _C.stream_ptr())
+        ctx.tensors = None
+        return tuple(g[n] for n in _GRADS) + (None, None)
+
+
+def available(data_dict):
+    c = data_dict["center"]
+    return (c.is_cuda and c.shape[1] <= 1024 and data_dict["center_label"].shape[1] <= 256
+            and max(data_dict["heading_scores"].shape[2], data_dict["size_scores"].shape[2],
+                    data_dict["sem_cls_scores"].shape[2]) <= 64)
+
+
+def detection_loss(data_dict, config, near, far, cls_weights):
+    """-> (det_total, stats, objectness_label, objectness_mask, object_assignment)."""
+    d = data_dict
+    cfg = {"mean_size_arr": config.mean_size_arr, "near_threshold": near,
+           "far_threshold": far, "objectness_cls_weights": cls_weights}
+    return DetectionLoss.apply(
+        d["vote_xyz"], d["objectness_scores"], d["center"], d["heading_scores"],
+        d["heading_residuals_normalized"], d["size_scores"],
+        d["size_residuals_normalized"], d["sem_cls_scores"], d, cfg)

@@ -12,7 +12,11 @@ import torch
 import torch.nn.functional as F
 
 from .config import CONF
+from . import loss_fused
 from .consts import array_const, const
+
+# CUDA tensors: detection terms from csrc/s2c_loss.hip (2 + 1 launches)
+FUSED_DETECTION_LOSS = True
 
 FAR_THRESHOLD = 0.6
 NEAR_THRESHOLD = 0.3
@@ -216,10 +220,53 @@ def compute_node_distance_loss(data_dict):
     return (err * w).sum() / w.sum()
 
 
+def _get_scene_cap_loss_fused(data_dict, device, config, weights, detection, caption,
+                              orientation, distance, num_bins):
+    """Same contract as below; detection terms from the fused HIP kernels."""
+    det, stats, objectness_label, objectness_mask, object_assignment = \
+        loss_fused.detection_loss(data_dict, config, NEAR_THRESHOLD, FAR_THRESHOLD,
+                                  OBJECTNESS_CLS_WEIGHTS)
+    data_dict["objectness_label"] = objectness_label
+    data_dict["objectness_mask"] = objectness_mask
+    data_dict["object_assignment"] = object_assignment
+    data_dict["pos_ratio"], data_dict["neg_ratio"] = stats[10], stats[11]
+    data_dict["obj_acc"] = stats[12]
+    zero = torch.zeros((), device=device)
+    for i, n in enumerate(loss_fused.STAT_NAMES):
+        data_dict[n] = stats[i] if detection else zero
+    if caption:
+        data_dict["cap_loss"], data_dict["cap_acc"] = compute_cap_loss(
+            data_dict, config, weights)
+    else:
+        data_dict["cap_loss"] = zero
+        data_dict["cap_acc"] = zero
+        data_dict["pred_ious"] = zero
+    if orientation:
+        data_dict["ori_loss"], data_dict["ori_acc"] = compute_node_orientation_loss(
+            data_dict, num_bins)
+    else:
+        data_dict["ori_loss"] = zero
+        data_dict["ori_acc"] = zero
+    data_dict["dist_loss"] = compute_node_distance_loss(data_dict) if distance else zero
+    if detection:
+        loss = det + data_dict["cap_loss"] if caption else det
+    else:
+        loss = data_dict["cap_loss"]
+    if orientation:
+        loss = loss + 0.1 * data_dict["ori_loss"]
+    if distance:
+        loss = loss + 0.1 * data_dict["dist_loss"]
+    data_dict["loss"] = loss
+    return data_dict
+
+
 def get_scene_cap_loss(data_dict, device, config, weights, detection=True,
                        caption=True, orientation=False, distance=False,
                        num_bins=CONF.TRAIN.NUM_BINS):
     """loss_helper.py:381-491: same keys written into data_dict, same weights."""
+    if FUSED_DETECTION_LOSS and loss_fused.available(data_dict):
+        return _get_scene_cap_loss_fused(data_dict, device, config, weights, detection,
+                                         caption, orientation, distance, num_bins)
     vote_loss = compute_vote_loss(data_dict)
     objectness_loss, objectness_label, objectness_mask, object_assignment = \
         compute_objectness_loss(data_dict)

@@ -149,3 +149,77 @@ def test_fused_decoder_matches_torch_loop():
     assert _rel(tgt.grad, tgt2.grad) < 1e-4
     for n, p in mod.named_parameters():
         assert _rel(p.grad, ref_grads[n]) < 2e-4, n
+
+
+@pytest.mark.parametrize("NH,VF", [(1, 1), (4, 2)])
+def test_fused_detection_loss_matches_op_by_op(NH, VF):
+    """csrc/s2c_loss.hip (2 + 1 launches) vs the op-by-op restatement of
+    lib/loss_helper.py:24-187 in scan2cap_amd/loss_helper.py: every loss term, the
+    labels, and the gradient of the total w.r.t. every network output.  Includes the
+    exact ties of real data: triplicated GT votes and zero-padded GT boxes."""
+    from types import SimpleNamespace
+    from scan2cap_amd import loss_helper as lh
+
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(7)
+    B, S, N, K, G, NS, NC = 3, 96, 700, 70, 128, 18, 18
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    nbox = 9
+    centers = torch.zeros(B, G, 3)
+    centers[:, :nbox] = torch.rand(B, nbox, 3, generator=g) * 4 - 2
+    blm = torch.zeros(B, G)
+    blm[:, :nbox] = 1
+    vote_label = torch.zeros(B, N, 9)
+    single = rnd(B, N, 3)
+    vote_label[:] = single.repeat(1, 1, 3)                 # one object: 3 identical votes
+    multi = torch.rand(B, N, generator=g) < 0.3
+    vote_label[multi] = rnd(int(multi.sum()), 9)
+    cls = torch.randint(0, NS, (B, G), generator=g)
+    msa = torch.rand(NS, 3, generator=g) + 0.3
+    labels = dict(
+        seed_xyz=rnd(B, S, 3), seed_inds=torch.randint(0, N, (B, S), generator=g).int(),
+        vote_label=vote_label, vote_label_mask=(torch.rand(B, N, generator=g) < 0.6).long(),
+        center_label=centers, box_label_mask=blm,
+        heading_class_label=torch.randint(0, NH, (B, G), generator=g),
+        heading_residual_label=rnd(B, G) * 0.3, size_class_label=cls,
+        size_residual_label=rnd(B, G, 3) * 0.2, sem_cls_label=cls.clone())
+    # proposals: some right on a GT centre (near), some far, some in between
+    agg = centers[:, torch.randint(0, nbox, (K,), generator=g)] + rnd(B, K, 3) * 0.25
+    agg[:, ::5] += 3.0
+    outs = dict(
+        vote_xyz=rnd(B, S * VF, 3), objectness_scores=rnd(B, K, 2),
+        center=agg + rnd(B, K, 3) * 0.1, heading_scores=rnd(B, K, NH),
+        heading_residuals_normalized=rnd(B, K, NH) * 2, size_scores=rnd(B, K, NS),
+        size_residuals_normalized=rnd(B, K, NS, 3) * 1.5, sem_cls_scores=rnd(B, K, NC))
+    cfg = SimpleNamespace(num_heading_bin=NH, num_size_cluster=NS, mean_size_arr=msa.numpy())
+
+    def run(fused):
+        dd = {k: v.to(dev) for k, v in labels.items()}
+        dd["aggregated_vote_xyz"] = agg.to(dev)
+        leaves = {k: v.to(dev).requires_grad_(True) for k, v in outs.items()}
+        dd.update(leaves)
+        old = lh.FUSED_DETECTION_LOSS
+        lh.FUSED_DETECTION_LOSS = fused
+        try:
+            dd = lh.get_scene_cap_loss(dd, dev, cfg, None, detection=True, caption=False)
+        finally:
+            lh.FUSED_DETECTION_LOSS = old
+        dd["loss"].backward()
+        return dd, leaves
+
+    ref, rl = run(False)
+    got, gl = run(True)
+    for k in ("vote_loss", "objectness_loss", "center_loss", "heading_cls_loss",
+              "heading_reg_loss", "size_cls_loss", "size_reg_loss", "sem_cls_loss",
+              "box_loss", "loss", "pos_ratio", "neg_ratio", "obj_acc"):
+        a, b = float(got[k].detach()), float(ref[k].detach())
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), (k, a, b)
+    for k in ("objectness_label", "object_assignment"):
+        assert torch.equal(got[k].long(), ref[k].long()), k
+    assert torch.equal(got["objectness_mask"], ref["objectness_mask"])
+    assert 0 < int(ref["objectness_label"].sum()) < B * K
+    for k in outs:
+        a, b = gl[k].grad, rl[k].grad
+        assert a is not None and b is not None, k
+        scale = float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= 1e-5 * scale + 1e-9, (k, float((a - b).abs().max()), scale)
