@@ -51,7 +51,8 @@ int s2c_bn_train_stats(long long M, int C, const float *Y, float *partial,
                        float eps, float momentum, const float *gamma,
                        const float *beta, float *running_mean, float *running_var,
                        float *scale, float *shift, float *save_mean,
-                       float *save_invstd, void *stream);
+                       float *save_invstd, long long *num_batches_tracked /* += 1, may be NULL */,
+                       void *stream);
 
 /* eval-mode coefficients from the running statistics */
 int s2c_bn_eval_coeffs(int C, float eps, const float *gamma, const float *beta,
@@ -107,7 +108,8 @@ int s2c_bn_finalize_partials(int nblk, long long M, int C, const float *partial,
                              float eps, float momentum, const float *gamma,
                              const float *beta, float *running_mean,
                              float *running_var, float *scale, float *shift,
-                             float *save_mean, float *save_invstd, void *stream);
+                             float *save_mean, float *save_invstd,
+                             long long *num_batches_tracked, void *stream);
 
 /* ---- teacher-forced top-down caption decoder (csrc/s2c_decoder.hip) -------
  * Small-batch (R <= a few dozen rows) building blocks of one recurrent step of

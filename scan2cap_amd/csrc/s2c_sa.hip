@@ -260,7 +260,7 @@ __global__ __launch_bounds__(FIN_BLOCK) void bn_finalize_kernel(
     const float *__restrict__ beta, float *__restrict__ running_mean,
     float *__restrict__ running_var, float *__restrict__ scale,
     float *__restrict__ shift, float *__restrict__ save_mean,
-    float *__restrict__ save_invstd) {
+    float *__restrict__ save_invstd, long long *__restrict__ num_batches_tracked) {
   const int c = blockIdx.x;
   double s1 = 0.0, s2 = 0.0;
   for (int k = threadIdx.x; k < nblk; k += FIN_BLOCK) {
@@ -269,6 +269,7 @@ __global__ __launch_bounds__(FIN_BLOCK) void bn_finalize_kernel(
   }
   block_sum2(s1, s2);
   if (threadIdx.x != 0) return;
+  if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;   // nn.BatchNorm bookkeeping
   const double mean = s1 / (double)M;
   double var = s2 / (double)M - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -326,7 +327,8 @@ extern "C" int s2c_bn_train_stats(long long M, int C, const float *Y,
                                   const float *gamma, const float *beta,
                                   float *running_mean, float *running_var,
                                   float *scale, float *shift, float *save_mean,
-                                  float *save_invstd, void *stream) {
+                                  float *save_invstd, long long *num_batches_tracked,
+                                  void *stream) {
   if (M <= 0 || C <= 0 || (C & 3) || C > 1024) return fail2("bn_train_stats: C%4==0, C<=1024, M>0");
   if (!Y || !partial || !scale || !shift || !save_mean || !save_invstd)
     return fail2("bn_train_stats: null pointer");
@@ -337,7 +339,7 @@ extern "C" int s2c_bn_train_stats(long long M, int C, const float *Y,
                      partial, rpb);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(FIN_BLOCK), 0, st,
                      partial, nb, C, M, eps, momentum, gamma, beta, running_mean,
-                     running_var, scale, shift, save_mean, save_invstd);
+                     running_var, scale, shift, save_mean, save_invstd, num_batches_tracked);
   return check2("bn_train_stats");
 }
 
@@ -349,11 +351,12 @@ extern "C" int s2c_bn_finalize_partials(int nblk, long long M, int C,
                                         const float *beta, float *running_mean,
                                         float *running_var, float *scale,
                                         float *shift, float *save_mean,
-                                        float *save_invstd, void *stream) {
+                                        float *save_invstd,
+                                        long long *num_batches_tracked, void *stream) {
   if (nblk <= 0 || M <= 0 || C <= 0) return fail2("bn_finalize_partials sizes");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(FIN_BLOCK), 0, (hipStream_t)stream,
                      partial, nblk, C, M, eps, momentum, gamma, beta, running_mean,
-                     running_var, scale, shift, save_mean, save_invstd);
+                     running_var, scale, shift, save_mean, save_invstd, num_batches_tracked);
   return check2("bn_finalize_partials");
 }
 

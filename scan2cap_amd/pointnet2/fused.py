@@ -24,14 +24,14 @@ _I, _L, _P, _F = ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_floa
 
 _C.register("s2c_sa_gather_rows", [_I, _I, _I, _I, _I, _L, _L, _F, _I, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_sa_scatter_rows", [_I, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P])
-_C.register("s2c_bn_train_stats", [_L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P])
+_C.register("s2c_bn_train_stats", [_L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_bn_eval_coeffs", [_I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_bn_relu", [_L, _I, _P, _P, _P, _P, _I, _P])
 _C.register("s2c_bn_relu_max", [_L, _I, _I, _P, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_bn_relu_bwd", [_L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_rows_gemm", [_L, _I, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _P])
 _C.register("s2c_sa_gather_gemm", [_I, _I, _I, _I, _I, _L, _L, _F, _I, _P, _P, _P, _P, _I, _P, _I, _P, _I, _P, _P])
-_C.register("s2c_bn_finalize_partials", [_I, _L, _I, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P])
+_C.register("s2c_bn_finalize_partials", [_I, _L, _I, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_bn_relu_max_bwd", [_L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P])
 
 
@@ -207,9 +207,7 @@ class _MLPRows(Function):
                           float(bn.eps), float(mom), _ptr(gamma), _ptr(beta),
                           _ptr(bn.running_mean), _ptr(bn.running_var),
                           scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
-                          invstd.data_ptr())
-                    if bn.num_batches_tracked is not None:
-                        bn.num_batches_tracked.add_(1)
+                          invstd.data_ptr(), _ptr(bn.num_batches_tracked))
                 elif train_stats:
                     nb = _stat_blocks(M)
                     if partial is None or partial.numel() < nb * 2 * Cout:
@@ -220,9 +218,7 @@ class _MLPRows(Function):
                           _ptr(gamma), _ptr(beta), _ptr(bn.running_mean),
                           _ptr(bn.running_var), scale.data_ptr(), shift.data_ptr(),
                           mean.data_ptr(), invstd.data_ptr(),
-                          alg_bytes=4 * M * Cout)
-                    if bn.num_batches_tracked is not None:
-                        bn.num_batches_tracked.add_(1)
+                          _ptr(bn.num_batches_tracked), alg_bytes=4 * M * Cout)
                 else:
                     _call("s2c_bn_eval_coeffs", Y, Cout, float(bn.eps), _ptr(gamma),
                           _ptr(beta), bn.running_mean.data_ptr(),

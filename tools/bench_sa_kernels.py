@@ -22,7 +22,7 @@ for (J, ns, C) in [(16384, 64, 128), (16384, 64, 64), (8192, 32, 256)]:
     part = torch.empty(nb * 2 * C, device="cuda"); coef = torch.empty(3 * C, device="cuda")
     dg = torch.empty(C, device="cuda"); db = torch.empty(C, device="cuda")
     rm = torch.zeros(C, device="cuda"); rv = torch.ones(C, device="cuda")
-    t = timeit(lambda: _call("s2c_bn_train_stats", Y, M, C, Y.data_ptr(), part.data_ptr(), 1e-5, 0.1, gamma.data_ptr(), sh.data_ptr(), rm.data_ptr(), rv.data_ptr(), sc.data_ptr(), sh.data_ptr(), mean.data_ptr(), inv.data_ptr()))
+    t = timeit(lambda: _call("s2c_bn_train_stats", Y, M, C, Y.data_ptr(), part.data_ptr(), 1e-5, 0.1, gamma.data_ptr(), sh.data_ptr(), rm.data_ptr(), rv.data_ptr(), sc.data_ptr(), sh.data_ptr(), mean.data_ptr(), inv.data_ptr(), None))
     report("bn_train_stats", t, 4 * M * C)
     t = timeit(lambda: _call("s2c_bn_relu", Y, M, C, Y.data_ptr(), sc.data_ptr(), sh.data_ptr(), A.data_ptr(), 1))
     report("bn_relu", t, 8 * M * C)
