@@ -447,9 +447,21 @@ def main():
             out["cpu_baseline"] = cpu_baseline(wl, vocabulary, embeddings, table, msa,
                                                args.cpu_sample_scenes)
             out["vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
+        line = json.dumps(out)
+    else:
+        line = None
     if dist.is_initialized():
         dist.destroy_process_group()
+    if line is not None:
+        # the JSON must be the LAST stdout line: push out whatever native libraries
+        # (e.g. the RCCL version banner) still hold in C stdio buffers first
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
+        print(line, flush=True)
 
 
 if __name__ == "__main__":

@@ -226,6 +226,27 @@ int s2c_detection_loss_fwd(const s2c_detloss_args *a, void *stream);
 int s2c_detection_loss_bwd(const s2c_detloss_args *a, const s2c_detloss_grads *d,
                            const float *gup, void *stream);
 
+/* ---------------------------------------------------------------------------
+ * parse_predictions post-processing (lib/ap_helper.py:40-178), float64 like numpy.
+ * counts[b,k] = number of points of scene b inside box k (cuboid rotated by `angle`
+ * about the Y axis, utils/box_util.py:340-358; closed intervals).  pts: float32,
+ * row stride pt_stride (>= 3) and batch stride in floats -- the (B,N,3+C) point
+ * cloud is read in place.  Replaces the per-box scipy Delaunay hull test
+ * (model_util_scannet.py:13-22). */
+int s2c_boxes_count_points(int b, int n, int K, const float *pts, long long pt_stride,
+                           long long pt_batch_stride, const double *center,
+                           const double *size, const double *angle, int *counts,
+                           void *stream);
+
+/* greedy NMS per scene (utils/nms.py:13-151): boxes (b,K,6) = [x1,y1,z1,x2,y2,z2],
+ * descending score, suppress IoU > thresh (old_type: inter / area_j); cls != NULL:
+ * only boxes of the same class suppress each other (nms_3d_faster_samecls, which
+ * also adds 1e-8 to the union: add_eps).  valid (b,K) 0/1 in, keep (b,K) 0/1 out.
+ * K <= 1024. */
+int s2c_nms(int b, int K, const double *boxes, const double *score, const long long *cls,
+            const unsigned char *valid, double thresh, int old_type, int add_eps,
+            unsigned char *keep, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
