@@ -88,6 +88,7 @@ class KernelTimer(object):
         self.enabled = False
         self.records = {}      # name -> list of (start_event, end_event, alg_bytes)
         self.alg_bytes = 0     # set by the op wrapper right before call()
+        self.alg_flops = 0     # ditto (GEMM entry points)
 
     def start(self):
         self.records = {}
@@ -101,15 +102,17 @@ class KernelTimer(object):
         torch.cuda.synchronize()
         out = {}
         for name, evs in self.records.items():
-            tot, nbytes, worst = 0.0, 0, (0.0, 0)
-            for s, e, ab in evs:
+            tot, nbytes, nflops, worst = 0.0, 0, 0, (0.0, 0)
+            for s, e, ab, af in evs:
                 ms = s.elapsed_time(e)
                 tot += ms
                 nbytes += ab
+                nflops += af
                 if ms > worst[0]:
                     worst = (ms, ab)
             out[name] = {"calls": len(evs), "total_ms": tot, "alg_bytes": nbytes,
-                         "max_ms": worst[0], "max_call_bytes": worst[1]}
+                         "alg_flops": nflops, "max_ms": worst[0],
+                         "max_call_bytes": worst[1]}
         self.records = {}
         return out
 
@@ -126,8 +129,9 @@ def call(name, *args):
         s.record()
         rc = getattr(lib, name)(*args)
         e.record()
-        TIMER.records.setdefault(name, []).append((s, e, TIMER.alg_bytes))
+        TIMER.records.setdefault(name, []).append((s, e, TIMER.alg_bytes, TIMER.alg_flops))
         TIMER.alg_bytes = 0
+        TIMER.alg_flops = 0
     else:
         rc = getattr(lib, name)(*args)
     if rc != 0:

@@ -206,12 +206,22 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(
     store_slice();
     __syncthreads();
     if (k0 + BK < K) load_slice(k0 + BK);   // prefetch under the MFMAs
+    // operand reads of group q+1 are issued BEFORE the 16 MFMAs of group q (the
+    // scheduling barriers pin that order): LDS latency hides under the matrix pipe
+    float4 a0 = *reinterpret_cast<const float4 *>(a_base0);
+    float4 a1 = *reinterpret_cast<const float4 *>(a_base1);
+    float4 b0 = *reinterpret_cast<const float4 *>(w_base0);
+    float4 b1 = *reinterpret_cast<const float4 *>(w_base1);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const float4 a0 = *reinterpret_cast<const float4 *>(a_base0 + 4 * q);
-      const float4 a1 = *reinterpret_cast<const float4 *>(a_base1 + 4 * q);
-      const float4 b0 = *reinterpret_cast<const float4 *>(w_base0 + 4 * q);
-      const float4 b1 = *reinterpret_cast<const float4 *>(w_base1 + 4 * q);
+      float4 na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
+      if (q < 3) {
+        na0 = *reinterpret_cast<const float4 *>(a_base0 + 4 * (q + 1));
+        na1 = *reinterpret_cast<const float4 *>(a_base1 + 4 * (q + 1));
+        nb0 = *reinterpret_cast<const float4 *>(w_base0 + 4 * (q + 1));
+        nb1 = *reinterpret_cast<const float4 *>(w_base1 + 4 * (q + 1));
+      }
+      __builtin_amdgcn_sched_barrier(0);
       const float a0v[4] = {a0.x, a0.y, a0.z, a0.w}, a1v[4] = {a1.x, a1.y, a1.z, a1.w};
       const float b0v[4] = {b0.x, b0.y, b0.z, b0.w}, b1v[4] = {b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
@@ -221,6 +231,8 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v[s], b0v[s], acc[1][0], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v[s], b1v[s], acc[1][1], 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
     }
   }
 

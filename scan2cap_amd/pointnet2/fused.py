@@ -39,9 +39,10 @@ def _ptr(t):
     return t.data_ptr() if t is not None else None
 
 
-def _call(name, ref, *args, alg_bytes=0):
+def _call(name, ref, *args, alg_bytes=0, alg_flops=0):
     if _C.TIMER.enabled:
         _C.TIMER.alg_bytes = int(alg_bytes)
+        _C.TIMER.alg_flops = int(alg_flops)
     with torch.cuda.device(ref.device):
         _C.call(name, *args, _C.stream_ptr())
 
@@ -180,7 +181,8 @@ class _MLPRows(Function):
                       g.radius, g.normalize, g.xyz.data_ptr(), g.new_xyz.data_ptr(),
                       _ptr(g.feats), g.idx.data_ptr(), Cout, W.data_ptr(), W.stride(0),
                       Y.data_ptr(), Cout, _ptr(gpart),
-                      alg_bytes=4 * (min(g.B * g.N, M) * (3 + g.C) + M + M * Cout))
+                      alg_bytes=4 * (min(g.B * g.N, M) * (3 + g.C) + M + M * Cout),
+                      alg_flops=2 * M * (3 + g.C) * Cout)
             elif gemm_stats:
                 # hand-written f32 MFMA GEMM; BN batch statistics come out of its
                 # epilogue as per-row-block partials (no extra pass over Y)
@@ -190,7 +192,8 @@ class _MLPRows(Function):
                 K_in = A.shape[1]
                 _call("s2c_rows_gemm", Y, M, Cout, K_in, A.data_ptr(), A.stride(0),
                       W.data_ptr(), W.stride(0), None, None, Y.data_ptr(), Cout,
-                      gpart.data_ptr(), alg_bytes=4 * (M * K_in + M * Cout))
+                      gpart.data_ptr(), alg_bytes=4 * (M * K_in + M * Cout),
+                      alg_flops=2 * M * K_in * Cout)
             else:
                 Y = torch.addmm(bias, A, W.t()) if bias is not None else torch.mm(A, W.t())
             rec = {"A_in": None if from_gather else A, "W": W,
