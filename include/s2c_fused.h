@@ -247,6 +247,15 @@ int s2c_nms(int b, int K, const double *boxes, const double *score, const long l
             const unsigned char *valid, double thresh, int old_type, int add_eps,
             unsigned char *keep, void *stream);
 
+/* `_query_locals` (models/graph_module.py:182-222, models/caption_module.py:322-381)
+ * for T targets per scene at once: corners (B,K,8,3) float64, object_masks (B,K) and
+ * target_ids (B,T) int64 -> local_masks (B,T,K) float 0/1 and ids (B,T,L) int64,
+ * ascending.  corner_mode 1: min over the target's 8 corners, 0: centre distance. */
+int s2c_query_locals(int B, int K, int T, int L, const double *corners,
+                     const long long *object_masks, const long long *target_ids,
+                     int corner_mode, int include_self, double overlay_threshold,
+                     float *local_masks, long long *ids_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

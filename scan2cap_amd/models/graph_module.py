@@ -26,9 +26,18 @@ are summed at `col` (graph_module.py:102-109 + MessagePassing defaults).
 import torch
 import torch.nn as nn
 
+import ctypes
+
+from .. import _C
 from ..box_util import aabb_iou, box_min_max
 from ..pointnet2 import fused
 from ..config import CONF
+
+
+_I, _D, _P = ctypes.c_int, ctypes.c_double, ctypes.c_void_p
+_C.register("s2c_query_locals", [_I, _I, _I, _I, _P, _P, _P, _I, _I, _D, _P, _P, _P])
+# one launch instead of ~35 (csrc/s2c_graph.hip); False: batched torch restatement
+USE_QUERY_KERNEL = True
 
 
 def query_locals(corners, object_masks, target_ids, num_locals, query_mode,
@@ -43,6 +52,20 @@ def query_locals(corners, object_masks, target_ids, num_locals, query_mode,
     """
     B, K = object_masks.shape
     T = target_ids.shape[1]
+    if (USE_QUERY_KERNEL and corners.is_cuda and corners.dtype == torch.float64
+            and K <= 1024 and num_locals <= min(64, K)
+            and query_mode in ("center", "corner")):
+        c = corners.contiguous()
+        om = object_masks.to(torch.int64).contiguous()
+        tg = target_ids.to(torch.int64).contiguous()
+        local_masks = torch.empty(B, T, K, device=c.device)
+        ids = torch.empty(B, T, num_locals, dtype=torch.int64, device=c.device)
+        with torch.cuda.device(c.device):
+            _C.call("s2c_query_locals", B, K, T, num_locals, c.data_ptr(), om.data_ptr(),
+                    tg.data_ptr(), int(query_mode == "corner"), int(bool(include_self)),
+                    float(overlay_threshold), local_masks.data_ptr(), ids.data_ptr(),
+                    _C.stream_ptr())
+        return local_masks, ids
     bmin, bmax = box_min_max(corners)               # (B,K,3)
     centers = (bmin + bmax) / 2
     gi = target_ids.view(B, T, 1)

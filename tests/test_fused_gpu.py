@@ -223,3 +223,39 @@ def test_fused_detection_loss_matches_op_by_op(NH, VF):
         assert a is not None and b is not None, k
         scale = float(b.abs().max()) + 1e-12
         assert float((a - b).abs().max()) <= 1e-5 * scale + 1e-9, (k, float((a - b).abs().max()), scale)
+
+
+@pytest.mark.parametrize("K,T,mode,include_self", [(256, 256, "corner", False),
+                                                   (256, 1, "corner", True),
+                                                   (70, 70, "center", False),
+                                                   (512, 33, "corner", False)])
+def test_query_locals_kernel_matches_torch(K, T, mode, include_self):
+    """csrc/s2c_graph.hip (one launch) vs the batched torch restatement of
+    graph_module.py:182-222: same 0/1 masks and the same sorted neighbour ids."""
+    from scan2cap_amd.models import graph_module as gm
+    from scan2cap_amd.box_util import get_3d_box_batch
+
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(K + T)
+    B, L = 3, 10
+    center = torch.rand(B, K, 3, generator=g, dtype=torch.float64) * 6 - 3
+    size = torch.rand(B, K, 3, generator=g, dtype=torch.float64) * 1.2 + 0.2
+    corners = get_3d_box_batch(size, torch.zeros(B, K, dtype=torch.float64), center).to(dev)
+    masks = (torch.rand(B, K, generator=g) < 0.7).long().to(dev)
+    if T == K:
+        targets = torch.arange(K).view(1, K).expand(B, K).contiguous().to(dev)
+    else:
+        targets = torch.stack([torch.randperm(K, generator=g)[:T] for _ in range(B)]).to(dev)
+    old = gm.USE_QUERY_KERNEL
+    try:
+        gm.USE_QUERY_KERNEL = False
+        ref_m, ref_ids = gm.query_locals(corners, masks, targets, L, mode, include_self)
+        gm.USE_QUERY_KERNEL = True
+        got_m, got_ids = gm.query_locals(corners, masks, targets, L, mode, include_self)
+    finally:
+        gm.USE_QUERY_KERNEL = old
+    # the comparison is meaningful only where the top-L has no 1e30 ties
+    assert int(masks.sum(1).min()) > 3 * L
+    assert torch.equal(got_ids, ref_ids)
+    assert torch.equal(got_m, ref_m)
+    assert got_m.sum(-1).eq(L).all()
