@@ -40,6 +40,13 @@ int s2c_sa_scatter_rows(int b, int n, int m, int ns, int C, float radius,
                         float *d_feats, float *d_xyz, float *d_new_xyz,
                         void *stream);
 
+/* For the weight gradient of a gather-fused layer whose inputs need no gradient:
+ * Z (b,n,C) = sum of the dY rows (b*m*ns x C) that gathered each point (zeroed by the
+ * callee), S (b,m,C) = sum over the ns rows of each centre.  Then
+ * dW = [ (Z^T xyz - S^T new_xyz)(/r) | Z^T feats ]  -- no (rows x (3+C)) operand. */
+int s2c_sa_scatter_sum(int b, int n, int m, int ns, int C, const float *dY, const int *idx,
+                       float *Z, float *S, void *stream);
+
 /* number of row slabs (partial-sum blocks) the statistics kernels use for M rows;
  * `partial` buffers must hold s2c_bn_stat_blocks(M) * 2 * C floats. */
 int s2c_bn_stat_blocks(long long M);

@@ -150,6 +150,53 @@ extern "C" int s2c_sa_scatter_rows(int b, int n, int m, int ns, int C,
   return check2("sa_scatter_rows");
 }
 
+// Weight gradient of a gather-fused first layer WITHOUT re-materialising the gathered
+// operand (used when xyz / features need no gradient, e.g. SA1 on the input cloud):
+//   dW = dY^T G,  G[(b,j,s),:] = [ (xyz[b,p]-new_xyz[b,j])(/r) | feats[b,p,:] ], p = idx[row]
+//      = [ (Z^T xyz - S^T new_xyz)(/r) | Z^T feats ]
+// with Z[b,p,:] = sum of the dY rows that gathered point p (row-coalesced hardware
+// atomics) and S[b,j,:] = sum over the ns rows of centre j (in-block, deterministic).
+// The two products run over B*N point rows instead of B*m*ns gathered rows, and the
+// (rows x (3+C)) operand (566 MB at SA1) is neither written nor re-read.
+// Block = one centre; wave = every 4th sample row; lane = channel (strided).
+__global__ __launch_bounds__(256) void sa_scatter_sum_kernel(
+    int n, int m, int ns, int C, const float *__restrict__ dY,
+    const int *__restrict__ idx, float *__restrict__ Z, float *__restrict__ S) {
+  __shared__ float s_sum[4][1024];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long bj = blockIdx.x;
+  const long long b = bj / m;
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    const int c = c0 + lane;
+    float acc = 0.f;
+    for (int s = wave; s < ns; s += 4) {
+      const long long r = bj * ns + s;
+      const int p = idx[r];
+      if (c < C) {
+        const float v = dY[r * C + c];
+        acc += v;
+        atomicAdd(Z + (b * n + p) * (long long)C + c, v);
+      }
+    }
+    if (c < C) s_sum[wave][c] = acc;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256)
+    S[bj * C + c] = (s_sum[0][c] + s_sum[1][c]) + (s_sum[2][c] + s_sum[3][c]);
+}
+
+extern "C" int s2c_sa_scatter_sum(int b, int n, int m, int ns, int C, const float *dY,
+                                  const int *idx, float *Z, float *S, void *stream) {
+  if (b <= 0 || n <= 0 || m <= 0 || ns <= 0 || C <= 0 || C > 1024 || !dY || !idx || !Z || !S)
+    return fail2("sa_scatter_sum: sizes / null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(Z, 0, sizeof(float) * (size_t)b * n * C, st) != hipSuccess)
+    return fail2("memset");
+  hipLaunchKernelGGL(sa_scatter_sum_kernel, dim3((unsigned)(b * m)), dim3(256), 0, st, n, m,
+                     ns, C, dY, idx, Z, S);
+  return check2("sa_scatter_sum");
+}
+
 // ---------------------------------------------------------------------------
 // 2. column statistics of a row-major (M x C) matrix, C % 4 == 0.
 // Stage 1: each block reduces a slab of rows to partial [sum | sumsq] (float).

@@ -24,6 +24,7 @@ _I, _L, _P, _F = ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_floa
 
 _C.register("s2c_sa_gather_rows", [_I, _I, _I, _I, _I, _L, _L, _F, _I, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_sa_scatter_rows", [_I, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P])
+_C.register("s2c_sa_scatter_sum", [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P])
 _C.register("s2c_bn_train_stats", [_L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_bn_eval_coeffs", [_I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_bn_relu", [_L, _I, _P, _P, _P, _P, _I, _P])
@@ -63,6 +64,9 @@ def _gemm_blocks(M, N):
 
 # use the hand-written MFMA GEMM (statistics in its epilogue) for BN layers
 USE_MFMA_GEMM = True
+# weight gradient of a gather-fused first layer from point-indexed sums when its
+# inputs need no gradient (no re-materialised operand)
+SCATTER_DW = True
 
 
 def fused_available(t):
@@ -277,11 +281,15 @@ class _MLPRows(Function):
         for li in range(nl - 1, -1, -1):
             rec, sp = saved[li], specs[li]
             W, A_in = rec["W"], rec["A_in"]
+            lazy_dw = False
             if A_in is None:
-                # first layer of a gather-fused stack: rebuild its operand now
-                A_in = gather.materialise()
+                if gather.needs_grad or not SCATTER_DW:
+                    # first layer of a gather-fused stack: rebuild its operand now
+                    A_in = gather.materialise()
+                else:
+                    lazy_dw = True      # dW from point-indexed sums (GatherSpec.weight_grad)
             Cout = W.shape[0]
-            M = A_in.shape[0]
+            M = A_in.shape[0] if A_in is not None else gather.rows
             dgamma = dbeta = None
             if sp.bn is not None:
                 Y = rec["Y"]
@@ -314,7 +322,7 @@ class _MLPRows(Function):
                 dY = dA * (rec["Y"] > 0)
             else:
                 dY = dA
-            dW = _weight_grad(dY, A_in)
+            dW = gather.weight_grad(dY) if lazy_dw else _weight_grad(dY, A_in)
             dbias = dY.sum(0) if rec["has_bias"] else None
             need_dA = li > 0 or ctx.x_needs_grad
             dA = torch.mm(dY, W) if need_dA else None
@@ -379,6 +387,31 @@ class GatherSpec(object):
               alg_bytes=4 * (min(self.B * self.N, self.rows) * (3 + self.C)
                              + self.rows + self.rows * (3 + self.C)))
         return X
+
+    def weight_grad(self, dY):
+        """dW (Cout, 3+C) = dY^T G without building G (csrc/s2c_sa.hip:
+        sa_scatter_sum): the products run over the B*N points."""
+        dev = dY.device
+        Cout = dY.shape[1]
+        dY = dY.contiguous()
+        Z = torch.empty((self.B, self.N, Cout), device=dev)
+        S = torch.empty((self.B, self.m, Cout), device=dev)
+        _call("s2c_sa_scatter_sum", dY, self.B, self.N, self.m, self.ns, Cout,
+              dY.data_ptr(), self.idx.data_ptr(), Z.data_ptr(), S.data_ptr(),
+              alg_bytes=4 * (self.rows * (Cout + 1) + (self.B * self.N + self.B * self.m) * Cout))
+        Z2 = Z.view(self.B * self.N, Cout)
+        dWx = _weight_grad(Z2, self.xyz.view(-1, 3)) - \
+            _weight_grad(S.view(-1, Cout), self.new_xyz.view(-1, 3))
+        if self.normalize:
+            dWx = dWx / self.radius
+        if self.C == 0:
+            return dWx
+        f = self.feats
+        if f.stride(0) == f.shape[1] * f.stride(1):
+            f2 = f.as_strided((self.B * self.N, self.C), (f.stride(1), 1), f.storage_offset())
+        else:
+            f2 = f.reshape(self.B * self.N, self.C)
+        return torch.cat([dWx, _weight_grad(Z2, f2)], 1)
 
     def scatter(self, dX):
         """Row gradients (rows, 3+C) -> d_xyz (B,N,3), d_new_xyz (B,m,3),
