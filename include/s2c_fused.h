@@ -47,6 +47,20 @@ int s2c_sa_scatter_rows(int b, int n, int m, int ns, int C, float radius,
 int s2c_sa_scatter_sum(int b, int n, int m, int ns, int C, const float *dY, const int *idx,
                        float *Z, float *S, void *stream);
 
+/* Feature propagation on point-major rows (pointnet2_modules.py:398-410):
+ * out (b*n, C2+C1) = [ three_interpolate(known (b,m,C2), idx (b,n,3), weight (b,n,3)) |
+ * skip (b,n,C1) with the given row / batch strides in floats ].  skip may be NULL with
+ * C1 == 0. */
+int s2c_fp_interp_rows(int b, int n, int m, int C2, int C1, const float *known,
+                       const int *idx, const float *weight, const float *skip,
+                       long long skip_row_stride, long long skip_batch_stride, float *out,
+                       void *stream);
+/* d_known (b,m,C2) = scatter of w * dOut[:, :C2] (dOut row stride ld); zeroed by the
+ * callee.  The skip gradient is dOut[:, C2:] itself. */
+int s2c_fp_interp_rows_grad(int b, int n, int m, int C2, int ld, const float *dOut,
+                            const int *idx, const float *weight, float *d_known,
+                            void *stream);
+
 /* number of row slabs (partial-sum blocks) the statistics kernels use for M rows;
  * `partial` buffers must hold s2c_bn_stat_blocks(M) * 2 * C floats. */
 int s2c_bn_stat_blocks(long long M);

@@ -197,6 +197,84 @@ extern "C" int s2c_sa_scatter_sum(int b, int n, int m, int ns, int C, const floa
   return check2("sa_scatter_sum");
 }
 
+// Feature propagation on point-major rows (PointnetFPModule.forward,
+// pointnet2_modules.py:398-410): out[b,i,:] = [ sum_j w[b,i,j] * known[b,idx[b,i,j],:]
+// | skip[b,i,:] ] written straight into the (B*n, C2+C1) operand of the FP MLP: no
+// channel-major copy, no torch.cat, no transpose.  Same left-to-right arithmetic as
+// three_interpolate (interpolate_gpu.cu:87-99).  Wave per output row, lane = channel.
+__global__ __launch_bounds__(256) void fp_interp_rows_kernel(
+    int n, int m, int C2, int C1, const float *__restrict__ known,
+    const int *__restrict__ idx, const float *__restrict__ weight,
+    const float *__restrict__ skip, long long skip_rs, long long skip_bs,
+    float *__restrict__ out, long long rows) {
+  const int lane = threadIdx.x & 63;
+  const int ld = C2 + C1;
+  for (long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows;
+       r += (long long)gridDim.x * 4) {
+    const long long b = r / n, i = r - b * n;
+    const int i0 = idx[r * 3], i1 = idx[r * 3 + 1], i2 = idx[r * 3 + 2];
+    const float w0 = weight[r * 3], w1 = weight[r * 3 + 1], w2 = weight[r * 3 + 2];
+    const float *k0 = known + (b * m + i0) * (long long)C2;
+    const float *k1 = known + (b * m + i1) * (long long)C2;
+    const float *k2 = known + (b * m + i2) * (long long)C2;
+    float *o = out + r * ld;
+    for (int c = lane; c < C2; c += 64) o[c] = k0[c] * w0 + k1[c] * w1 + k2[c] * w2;
+    if (C1 > 0) {
+      const float *sk = skip + b * skip_bs + i * skip_rs;
+      for (int c = lane; c < C1; c += 64) o[C2 + c] = sk[c];
+    }
+  }
+}
+
+// backward: d_known[b, idx, :] += w * dOut[b,i,:C2]  (row-coalesced float atomics);
+// the skip part of dOut is returned as a view by the caller.
+__global__ __launch_bounds__(256) void fp_interp_rows_grad_kernel(
+    int n, int m, int C2, int ld, const float *__restrict__ dOut,
+    const int *__restrict__ idx, const float *__restrict__ weight,
+    float *__restrict__ d_known, long long rows) {
+  const int lane = threadIdx.x & 63;
+  for (long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows;
+       r += (long long)gridDim.x * 4) {
+    const long long b = r / n;
+    const float *g = dOut + r * ld;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int ij = idx[r * 3 + j];
+      const float w = weight[r * 3 + j];
+      float *dst = d_known + (b * m + ij) * (long long)C2;
+      for (int c = lane; c < C2; c += 64) atomicAdd(dst + c, g[c] * w);
+    }
+  }
+}
+
+extern "C" int s2c_fp_interp_rows(int b, int n, int m, int C2, int C1, const float *known,
+                                  const int *idx, const float *weight, const float *skip,
+                                  long long skip_row_stride, long long skip_batch_stride,
+                                  float *out, void *stream) {
+  if (b <= 0 || n <= 0 || m <= 0 || C2 <= 0 || C1 < 0 || !known || !idx || !weight || !out ||
+      (C1 > 0 && !skip))
+    return fail2("fp_interp_rows: sizes / null pointer");
+  const long long rows = (long long)b * n;
+  hipLaunchKernelGGL(fp_interp_rows_kernel, dim3(grid1d(rows, 4, 256 * 32)), dim3(256), 0,
+                     (hipStream_t)stream, n, m, C2, C1, known, idx, weight, skip,
+                     skip_row_stride, skip_batch_stride, out, rows);
+  return check2("fp_interp_rows");
+}
+
+extern "C" int s2c_fp_interp_rows_grad(int b, int n, int m, int C2, int ld,
+                                       const float *dOut, const int *idx,
+                                       const float *weight, float *d_known, void *stream) {
+  if (b <= 0 || n <= 0 || m <= 0 || C2 <= 0 || ld < C2 || !dOut || !idx || !weight || !d_known)
+    return fail2("fp_interp_rows_grad: sizes / null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(d_known, 0, sizeof(float) * (size_t)b * m * C2, st) != hipSuccess)
+    return fail2("memset");
+  const long long rows = (long long)b * n;
+  hipLaunchKernelGGL(fp_interp_rows_grad_kernel, dim3(grid1d(rows, 4, 256 * 32)), dim3(256),
+                     0, st, n, m, C2, ld, dOut, idx, weight, d_known, rows);
+  return check2("fp_interp_rows_grad");
+}
+
 // ---------------------------------------------------------------------------
 // 2. column statistics of a row-major (M x C) matrix, C % 4 == 0.
 // Stage 1: each block reduces a slab of rows to partial [sum | sumsq] (float).

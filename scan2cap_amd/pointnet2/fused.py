@@ -25,6 +25,8 @@ _I, _L, _P, _F = ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_floa
 _C.register("s2c_sa_gather_rows", [_I, _I, _I, _I, _I, _L, _L, _F, _I, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_sa_scatter_rows", [_I, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_sa_scatter_sum", [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P])
+_C.register("s2c_fp_interp_rows", [_I, _I, _I, _I, _I, _P, _P, _P, _P, _L, _L, _P, _P])
+_C.register("s2c_fp_interp_rows_grad", [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P])
 _C.register("s2c_bn_train_stats", [_L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_bn_eval_coeffs", [_I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_bn_relu", [_L, _I, _P, _P, _P, _P, _I, _P])
@@ -127,6 +129,49 @@ class _GatherRows(Function):
 # ---------------------------------------------------------------------------
 # MLP over rows
 # ---------------------------------------------------------------------------
+class _FPRows(Function):
+    """known (B,m,C2) point-major, skip (B,n,C1) point-major view or None, idx / weight
+    (B,n,3) -> rows (B*n, C2+C1) = [three_interpolate | skip] (pointnet2_modules.py:398-410)."""
+
+    @staticmethod
+    def forward(ctx, known, skip, idx, weight):
+        B, m, C2 = known.shape
+        n = idx.shape[1]
+        known = known.contiguous()
+        if skip is not None and skip.stride(2) != 1:
+            skip = skip.contiguous()
+        C1 = skip.shape[2] if skip is not None else 0
+        idx, weight = idx.contiguous(), weight.contiguous()
+        out = torch.empty((B * n, C2 + C1), device=known.device)
+        _call("s2c_fp_interp_rows", out, B, n, m, C2, C1, known.data_ptr(), idx.data_ptr(),
+              weight.data_ptr(), _ptr(skip), skip.stride(1) if skip is not None else 0,
+              skip.stride(0) if skip is not None else 0, out.data_ptr(),
+              alg_bytes=4 * (B * n * (3 * C2 + C1 + 6) + B * n * (C2 + C1)))
+        ctx.save_for_backward(idx, weight)
+        ctx.dims = (B, n, m, C2, C1)
+        return out
+
+    @staticmethod
+    def backward(ctx, dOut):
+        idx, weight = ctx.saved_tensors
+        B, n, m, C2, C1 = ctx.dims
+        dOut = dOut.contiguous()
+        d_known = None
+        if ctx.needs_input_grad[0]:
+            d_known = torch.empty((B, m, C2), device=dOut.device)
+            _call("s2c_fp_interp_rows_grad", dOut, B, n, m, C2, C2 + C1, dOut.data_ptr(),
+                  idx.data_ptr(), weight.data_ptr(), d_known.data_ptr(),
+                  alg_bytes=4 * (B * n * (C2 + 6) + 3 * B * n * C2))
+        d_skip = None
+        if C1 > 0 and ctx.needs_input_grad[1]:
+            d_skip = dOut.view(B, n, C2 + C1)[:, :, C2:]
+        return d_known, d_skip, None, None
+
+
+def fp_rows(known_pm, skip_pm, idx, weight):
+    return _FPRows.apply(known_pm, skip_pm, idx, weight)
+
+
 class LayerSpec(object):
     """One shared-MLP layer: Y = X W^T (+ bias) -> [BatchNorm] -> [ReLU]."""
     __slots__ = ("has_bias", "bn", "relu")

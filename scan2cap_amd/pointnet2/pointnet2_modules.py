@@ -112,6 +112,10 @@ class PointnetSAModuleVotes(nn.Module):
         return new_xyz, new_features, inds
 
 
+# feature propagation on point-major rows (csrc/s2c_sa.hip: fp_interp_rows)
+FUSE_FP = True
+
+
 class PointnetFPModule(nn.Module):
     """three_nn -> inverse-distance weights -> three_interpolate -> concat skip
     -> SharedMLP (pointnet2_modules.py:371-416)."""
@@ -130,6 +134,19 @@ class PointnetFPModule(nn.Module):
         return idx, dist_recip / norm
 
     def forward(self, unknown, known, unknow_feats, known_feats, geom=None):
+        if known is not None and known_feats.is_cuda and FUSE_FP:
+            specs, params = fused.shared_mlp_specs(self.mlp)
+            if fused.mlp_supported(specs, params):
+                # point-major: interpolation + skip concat written straight into the
+                # MLP's row operand (features arrive as transposed views of row data)
+                idx, weight = geom if geom is not None else self.geometry(unknown, known)
+                B, n = idx.shape[:2]
+                rows = fused.fp_rows(
+                    known_feats.transpose(1, 2),
+                    unknow_feats.transpose(1, 2) if unknow_feats is not None else None,
+                    idx, weight)
+                out = fused.mlp_rows(rows, specs, params)
+                return out.view(B, n, -1).transpose(1, 2)
         if known is not None:
             idx, weight = geom if geom is not None else self.geometry(unknown, known)
             interpolated = pointnet2_utils.three_interpolate(

@@ -263,3 +263,37 @@ def test_query_locals_kernel_matches_torch(K, T, mode, include_self):
     assert torch.equal(got_ids, ref_ids)
     assert torch.equal(got_m, ref_m)
     assert got_m.sum(-1).eq(L).all()
+
+
+def test_fp_module_point_major_matches_channel_major():
+    """PointnetFPModule on point-major rows (fp_interp_rows: interpolation + skip concat in
+    one kernel) vs the channel-major three_interpolate / cat path
+    (pointnet2_modules.py:371-416): outputs and every gradient."""
+    from scan2cap_amd.pointnet2 import pointnet2_modules as pm
+    torch.manual_seed(1)
+    B, n, m, C1, C2 = 3, 384, 100, 96, 160
+    fp = pm.PointnetFPModule(mlp=[C1 + C2, 128, 64]).cuda().train()
+    ref = copy.deepcopy(fp)
+    unknown = torch.from_numpy(scene_xyz(B, n, seed=3)).cuda()
+    known = unknown[:, torch.randperm(n)[:m]].contiguous()
+    # features as the SA stages hand them over: (B,C,N) views of point-major data
+    uf = torch.randn(B, n, C1, device="cuda").requires_grad_(True)
+    kf = torch.randn(B, m, C2, device="cuda").requires_grad_(True)
+    uf2, kf2 = uf.detach().clone().requires_grad_(True), kf.detach().clone().requires_grad_(True)
+    old = pm.FUSE_FP
+    try:
+        pm.FUSE_FP = True
+        out = fp(unknown, known, uf.transpose(1, 2), kf.transpose(1, 2))
+        pm.FUSE_FP = False
+        exp = ref(unknown, known, uf2.transpose(1, 2), kf2.transpose(1, 2))
+    finally:
+        pm.FUSE_FP = old
+    assert out.shape == exp.shape == (B, 64, n)
+    assert _rel(out, exp) < 1e-5
+    g = torch.randn_like(exp)
+    (out * g).sum().backward()
+    (exp * g).sum().backward()
+    assert _rel(uf.grad, uf2.grad) < 1e-5
+    assert _rel(kf.grad, kf2.grad) < 1e-4          # float atomics: summation order
+    for (n1, p1), (_, p2) in zip(fp.named_parameters(), ref.named_parameters()):
+        assert _rel(p1.grad, p2.grad) < 2e-4, n1
