@@ -192,6 +192,15 @@ int s2c_attn_bwd(int R, int K, int H, int F, const float *datt, int ldd,
                  const float *M, const float *q, int ldq, const float *wa, float *dM,
                  float *dq, float *dwa_rows, void *stream);
 
+/* local attention of the greedy decode (caption_module.py:502-592 with num_locals):
+ * mapped (R,L,H) = map_feat of the L gathered objects of each row, q (R,H) = map_hidd(h1),
+ * wa (H) / ba = the `attend` layer, valid (R,L) 0/1 or NULL, feats (R,L,F):
+ * alpha (R,L) = softmax_l(wa . tanh(mapped + q) + ba), att (R,F) = sum_l alpha feats.
+ * L <= 32.  Forward only (evaluation). */
+int s2c_attn_local_fwd(int R, int L, int H, int F, const float *mapped, const float *q,
+                       int ldq, const float *wa, float ba, const float *valid,
+                       const float *feats, float *alpha, float *att, int lda, void *stream);
+
 /* ---------------------------------------------------------------------------
  * Detection loss of get_scene_cap_loss (lib/loss_helper.py:24-187, :381-491;
  * utils/nn_distance.py:13-59) as 2 forward + 1 backward launches.

@@ -573,6 +573,73 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------
+// Greedy decoding of every proposal (caption_module.py:502-592) attends over the
+// L = num_locals gathered objects of each row: R = B*K rows (2048..8192) per step.
+// One wave per row, ONE pass over mapped (R,L,H) and feats (R,L,F) instead of the
+// add / tanh / attend-GEMV / masked_fill / softmax / mul / sum chain (~8 passes over
+// the 168 MB `mapped` tensor at cfg5):
+//   s[l] = sum_h wa[h] * tanh(mapped[r,l,h] + q[r,h]) + ba ; invalid -> -1e30
+//   alpha = softmax_l(s) ; att[r,:] = sum_l alpha[l] * feats[r,l,:]
+// ---------------------------------------------------------------------------
+constexpr int AL_MAXL = 32;
+__global__ __launch_bounds__(256) void attn_local_kernel(
+    int R, int L, int H, int F, const float *__restrict__ mapped,
+    const float *__restrict__ q, int ldq, const float *__restrict__ wa, float ba,
+    const float *__restrict__ valid, const float *__restrict__ feats,
+    float *__restrict__ alpha, float *__restrict__ att, int lda) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const int H4 = H >> 2;
+  float sc[AL_MAXL];
+#pragma unroll
+  for (int l = 0; l < AL_MAXL; ++l) sc[l] = 0.0f;
+  for (int h4 = lane; h4 < H4; h4 += 64) {
+    const float4 qq = reinterpret_cast<const float4 *>(q + (size_t)r * ldq)[h4];
+    const float4 w = reinterpret_cast<const float4 *>(wa)[h4];
+#pragma unroll
+    for (int l = 0; l < AL_MAXL; ++l) {
+      if (l < L) {
+        const float4 m = reinterpret_cast<const float4 *>(mapped + ((size_t)r * L + l) * H)[h4];
+        sc[l] += w.x * fast_tanh(m.x + qq.x) + w.y * fast_tanh(m.y + qq.y) +
+                 w.z * fast_tanh(m.z + qq.z) + w.w * fast_tanh(m.w + qq.w);
+      }
+    }
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int l = 0; l < AL_MAXL; ++l) {
+    if (l < L) {
+      float v = sc[l];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+      v += ba;
+      if (valid != nullptr && valid[(size_t)r * L + l] == 0.0f) v = -1e30f;
+      sc[l] = v;
+      mx = fmaxf(mx, v);
+    }
+  }
+  float sum = 0.0f;
+#pragma unroll
+  for (int l = 0; l < AL_MAXL; ++l)
+    if (l < L) { sc[l] = expf(sc[l] - mx); sum += sc[l]; }
+  const float inv = 1.0f / sum;
+#pragma unroll
+  for (int l = 0; l < AL_MAXL; ++l)
+    if (l < L) {
+      sc[l] *= inv;
+      if (lane == 0) alpha[(size_t)r * L + l] = sc[l];
+    }
+  for (int f = lane; f < F; f += 64) {
+    float a = 0.0f;
+#pragma unroll
+    for (int l = 0; l < AL_MAXL; ++l)
+      if (l < L) a += sc[l] * feats[((size_t)r * L + l) * F + f];
+    att[(size_t)r * lda + f] = a;
+  }
+}
+
 }  // namespace
 
 static int chk(const char *k) {
@@ -677,4 +744,17 @@ extern "C" int s2c_attn_bwd(int R, int K, int H, int F, const float *datt, int l
                      (hipStream_t)stream, K, H, F, datt, ldd, att, lda, alpha, O, M, q,
                      ldq, wa, dM, dq, dwa_rows);
   return chk("attn_bwd");
+}
+
+extern "C" int s2c_attn_local_fwd(int R, int L, int H, int F, const float *mapped,
+                                  const float *q, int ldq, const float *wa, float ba,
+                                  const float *valid, const float *feats, float *alpha,
+                                  float *att, int lda, void *stream) {
+  if (R <= 0 || L <= 0 || L > AL_MAXL || (H & 3) || (ldq & 3) || F <= 0 || !mapped || !q ||
+      !wa || !feats || !alpha || !att)
+    return -1;
+  hipLaunchKernelGGL(attn_local_kernel, dim3((R + 3) / 4), dim3(256), 0,
+                     (hipStream_t)stream, R, L, H, F, mapped, q, ldq, wa, ba, valid, feats,
+                     alpha, att, lda);
+  return chk("attn_local_fwd");
 }

@@ -18,10 +18,18 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+import ctypes
+
+from .. import _C
 from ..box_util import box3d_iou_batch_tensor
 from ..config import CONF
 from . import decoder_fused
 from .graph_module import query_locals
+
+_I, _F32, _P = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+_C.register("s2c_attn_local_fwd", [_I, _I, _I, _I, _P, _P, _I, _P, _F32, _P, _P, _P, _P, _I, _P])
+# greedy decode: split-weight step + one-pass local attention kernel
+FUSE_EVAL_STEP = True
 
 
 def select_target(data_dict):
@@ -325,12 +333,44 @@ class TopDownSceneCaptionModule(nn.Module):
         T = max_len - 1
         lang_cap = torch.empty(B, K, T, self.num_vocabs, device=dev)
         attn = torch.zeros(R, K, T, device=dev)
+        fused_step = (FUSE_EVAL_STEP and dev.type == "cuda" and L <= 32
+                      and self.hidden_size % 4 == 0 and self.attend.bias is None)
+        if fused_step:
+            # Same step as `_step`, re-associated so that nothing step-invariant and no
+            # concatenation is recomputed: map_topdown / map_lang are split by column
+            # blocks (the target-feature block is hoisted), and the whole attention
+            # (add, tanh, attend, mask, softmax, weighted sum) is ONE pass over
+            # `mapped` (csrc/s2c_decoder.hip: attn_local_kernel).
+            E, H = self.emb_size, self.hidden_size
+            W_td, b_td = self.map_topdown[0].weight, self.map_topdown[0].bias
+            Wx_t, Wh_t = W_td[:, :E].t(), W_td[:, E:E + H].t()
+            P_tf = torch.addmm(b_td, target_feats, W_td[:, E + H:].t())      # (R,E)
+            W_lang, b_lang = self.map_lang[0].weight, self.map_lang[0].bias
+            Wa_t, Wl_t = W_lang[:, :F_].t(), W_lang[:, F_:].t()
+            wa = self.attend.weight.reshape(-1).contiguous()
+            mapped_c, local_c = mapped.contiguous(), local.contiguous()
+            alpha = torch.empty(R, L, device=dev)
+            att = torch.empty(R, F_, device=dev)
         for t in range(T):
-            hidden_1, hidden_2, m = self._step(
-                step_input, target_feats, local, hidden_1, hidden_2, ones, mapped)
+            if fused_step:
+                x1 = torch.addmm(P_tf, step_input, Wx_t)
+                x1.addmm_(hidden_2, Wh_t).relu_()
+                hidden_1 = self.recurrent_cell_1(x1, hidden_1)
+                qh = self.map_hidd(hidden_1)
+                _C.call("s2c_attn_local_fwd", R, L, H, F_, mapped_c.data_ptr(),
+                        qh.data_ptr(), H, wa.data_ptr(), 0.0, None, local_c.data_ptr(),
+                        alpha.data_ptr(), att.data_ptr(), F_, _C.stream_ptr())
+                x2 = torch.addmm(b_lang, att, Wa_t)
+                x2.addmm_(hidden_1, Wl_t).relu_()
+                hidden_2 = self.recurrent_cell_2(x2, hidden_2)
+                m = alpha
+            else:
+                hidden_1, hidden_2, m = self._step(
+                    step_input, target_feats, local, hidden_1, hidden_2, ones, mapped)
+                m = m.squeeze(-1)
             logits = self.classifier(hidden_2)                           # (R,V)
             lang_cap[:, :, t] = logits.view(B, K, -1)
-            attn[:, :, t].scatter_(1, ids, m.squeeze(-1))
+            attn[:, :, t].scatter_(1, ids, m)
             step_input = self._emb_table[logits.argmax(dim=-1)]          # greedy
         data_dict["lang_cap"] = lang_cap                         # (B,K,T,V)
         data_dict["topdown_attn"] = attn.view(B, K, K, T)        # (B,K,K,T)

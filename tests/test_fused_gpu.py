@@ -297,3 +297,43 @@ def test_fp_module_point_major_matches_channel_major():
     assert _rel(kf.grad, kf2.grad) < 1e-4          # float atomics: summation order
     for (n1, p1), (_, p2) in zip(fp.named_parameters(), ref.named_parameters()):
         assert _rel(p1.grad, p2.grad) < 2e-4, n1
+
+
+def test_eval_greedy_decode_fused_step_matches_step_loop():
+    """Greedy decode of every proposal (caption_module.py:502-592): the split-weight step
+    with the one-pass local-attention kernel vs the module's plain `_step` loop.  Before
+    the first word where two logits tie to < 1e-5 the argmax sequences must agree, so the
+    whole (B,K,T,V) output must match."""
+    from scan2cap_amd.models import caption_module as cm
+    from scan2cap_amd.box_util import get_3d_box_batch
+    torch.manual_seed(5)
+    V, B, K, L = 60, 2, 48, 10
+    words = ["w%d" % i for i in range(V)]
+    vocab = {"word2idx": {w: i for i, w in enumerate(words)},
+             "idx2word": {str(i): w for i, w in enumerate(words)}}
+    emb = {w: np.random.randn(300).astype(np.float32) for w in words}
+    mod = cm.TopDownSceneCaptionModule(vocab, emb, 300, 128, 512, K, num_locals=L).cuda().eval()
+    g = torch.Generator().manual_seed(2)
+    center = torch.rand(B, K, 3, generator=g, dtype=torch.float64) * 6 - 3
+    size = torch.rand(B, K, 3, generator=g, dtype=torch.float64) * 0.8 + 0.2
+    dd = {
+        "bbox_corner": get_3d_box_batch(size, torch.zeros(B, K, dtype=torch.float64), center).cuda(),
+        "bbox_mask": (torch.rand(B, K, generator=g) < 0.8).long().cuda(),
+        "bbox_feature": (torch.randn(B, K, 128, generator=g) * 0.5).cuda(),
+        "lang_feat": (torch.randn(B, 32, 300, generator=g) * 0.3).cuda(),
+    }
+    outs = {}
+    old = cm.FUSE_EVAL_STEP
+    try:
+        for flag in (False, True):
+            cm.FUSE_EVAL_STEP = flag
+            with torch.no_grad():
+                outs[flag] = mod(dict(dd), use_tf=False, is_eval=True, max_len=8)
+    finally:
+        cm.FUSE_EVAL_STEP = old
+    a, b = outs[True], outs[False]
+    assert a["lang_cap"].shape == b["lang_cap"].shape == (B, K, 7, V)
+    assert torch.equal(a["lang_cap"].argmax(-1), b["lang_cap"].argmax(-1))
+    assert _rel(a["lang_cap"], b["lang_cap"]) < 1e-4
+    assert _rel(a["topdown_attn"], b["topdown_attn"]) < 1e-4
+    assert torch.equal(a["valid_masks"], b["valid_masks"])
