@@ -331,7 +331,10 @@ class TopDownSceneCaptionModule(nn.Module):
         hidden_2 = torch.zeros(R, self.hidden_size, device=dev)
         step_input = word_embs[:, 0].repeat_interleave(K, dim=0)         # sos
         T = max_len - 1
-        lang_cap = torch.empty(B, K, T, self.num_vocabs, device=dev)
+        # logits are produced step-major (T,R,V) so that the classifier GEMM writes each
+        # step in place; the (B,K,T,V) result is a permuted view of that buffer (no
+        # 115 MB copy per step at cfg5)
+        cap_buf = torch.empty(T, R, self.num_vocabs, device=dev)
         attn = torch.zeros(R, K, T, device=dev)
         fused_step = (FUSE_EVAL_STEP and dev.type == "cuda" and L <= 32
                       and self.hidden_size % 4 == 0 and self.attend.bias is None)
@@ -368,11 +371,11 @@ class TopDownSceneCaptionModule(nn.Module):
                 hidden_1, hidden_2, m = self._step(
                     step_input, target_feats, local, hidden_1, hidden_2, ones, mapped)
                 m = m.squeeze(-1)
-            logits = self.classifier(hidden_2)                           # (R,V)
-            lang_cap[:, :, t] = logits.view(B, K, -1)
+            logits = torch.addmm(self.classifier.bias, hidden_2, self.classifier.weight.t(),
+                                 out=cap_buf[t])                         # (R,V)
             attn[:, :, t].scatter_(1, ids, m)
             step_input = self._emb_table[logits.argmax(dim=-1)]          # greedy
-        data_dict["lang_cap"] = lang_cap                         # (B,K,T,V)
+        data_dict["lang_cap"] = cap_buf.view(T, B, K, -1).permute(1, 2, 0, 3)  # (B,K,T,V)
         data_dict["topdown_attn"] = attn.view(B, K, K, T)        # (B,K,K,T)
         data_dict["valid_masks"] = valid                          # (B,K,K)
         return data_dict
