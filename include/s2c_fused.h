@@ -114,6 +114,10 @@ int s2c_bn_relu_max_bwd(long long J, int ns, int C, const float *dOut,
  * [sum | sumsq] of Y, s2c_rows_gemm_blocks(M,N) * 2N floats, to be reduced by
  * s2c_bn_finalize_partials (BN batch statistics without another pass over Y). */
 int s2c_rows_gemm_blocks(long long M, int N);
+/* products of s2c_rows_gemm / s2c_sa_gather_gemm: 1 = bf16x3 split on the bf16 matrix
+ * pipe (fp32-accurate, ~1e-7 relative; default), 0 = exact fp32 MFMA chain.  Returns
+ * the previous setting. */
+int s2c_gemm_set_split(int on);
 int s2c_rows_gemm(long long M, int N, int K, const float *A, int lda, const float *W,
                   int ldw, const float *pscale, const float *pshift, float *Y,
                   int ldy, float *partial, void *stream);

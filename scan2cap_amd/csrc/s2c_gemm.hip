@@ -34,6 +34,7 @@
 #include "../../include/s2c_fused.h"
 
 #include <stdio.h>
+#include <stdlib.h>
 
 using namespace s2c;
 
@@ -279,6 +280,260 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------
+// bf16x3 variant: fp32-accurate products on the bf16 matrix pipe.
+// x = hi + mid + lo with hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid)
+// (the two residuals are exact in fp32; 3 x 8 mantissa bits cover the 24 of fp32), and
+// x*y ~= the 6 plane products with i + j <= 2 (dropped: mid*lo, lo*mid, lo*lo <= 2^-24
+// relative), each exact in the fp32 accumulator: the result differs from an fp32 FMA
+// chain by ~1e-7 relative -- the size of fp32's own rounding -- while the bf16
+// `v_mfma_f32_32x32x16_bf16` runs at 16x the fp32 MFMA rate (6 MFMAs = 2.7x faster).
+// The split happens once per staged element on the VALU (v_cvt_pk_bf16_f32).
+// ---------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int X3_LD = 40;   // bf16 per LDS row: 32 + 8 pad (80 bytes, conflict-free b128)
+
+__device__ __forceinline__ void x3_split2(f32x2 v, unsigned &hi, unsigned &mid, unsigned &lo) {
+  const bf16x2 h = __builtin_convertvector(v, bf16x2);
+  const f32x2 r1 = v - __builtin_convertvector(h, f32x2);
+  const bf16x2 m = __builtin_convertvector(r1, bf16x2);
+  const f32x2 r2 = r1 - __builtin_convertvector(m, f32x2);
+  const bf16x2 l = __builtin_convertvector(r2, bf16x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  mid = __builtin_bit_cast(unsigned, m);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+
+// quad sq of a row: k = 4 sq .. 4 sq + 3 -> 8 bytes at bf16 offset 4 sq of each plane
+__device__ __forceinline__ void x3_store_quad(unsigned short *base, int rows, int row, int sq,
+                                              float4 v) {
+  unsigned h0, m0, l0, h1, m1, l1;
+  f32x2 p0 = {v.x, v.y}, p1 = {v.z, v.w};
+  x3_split2(p0, h0, m0, l0);
+  x3_split2(p1, h1, m1, l1);
+  unsigned short *d = base + row * X3_LD + 4 * sq;
+  *reinterpret_cast<uint2 *>(d) = make_uint2(h0, h1);
+  *reinterpret_cast<uint2 *>(d + rows * X3_LD) = make_uint2(m0, m1);
+  *reinterpret_cast<uint2 *>(d + 2 * rows * X3_LD) = make_uint2(l0, l1);
+}
+
+template <int WM, int WN, int PRO>
+__global__ __launch_bounds__(256) void rows_gemm_x3_kernel(
+    long long M, int N, int K, const float *__restrict__ A, int lda,
+    const float *__restrict__ W, int ldw, const float *__restrict__ pscale,
+    const float *__restrict__ pshift, GatherArgs ga, float *__restrict__ Y, int ldy,
+    float *__restrict__ partial, int avec, int wvec) {
+  constexpr int BM = 64 * WM, BN = 64 * WN;
+  // three bf16 planes (hi, mid, lo) per operand tile, rows of X3_LD bf16 (32 + 8 pad)
+  extern __shared__ __attribute__((aligned(16))) unsigned char x3_smem[];
+  unsigned short *As = reinterpret_cast<unsigned short *>(x3_smem);
+  unsigned short *Ws = As + 3 * BM * X3_LD;
+  float (*s_stat)[WM][BN] = reinterpret_cast<float (*)[WM][BN]>(Ws + 3 * BN * X3_LD);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const long long m0 = (long long)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+
+  // staging map: thread -> (row = tid / 8 + 32*i, k-quad = tid % 8)
+  const int sq = tid & 7, sr = tid >> 3;
+  constexpr int AI = BM / 32, WI = BN / 32;
+  float4 ra[AI], rw[WI];
+
+  // PRO_GATHER: per staged row, the source-row offsets (computed once)
+  long long g_src[PRO == PRO_GATHER ? AI : 1];
+  int g_pt[PRO == PRO_GATHER ? AI : 1], g_ctr[PRO == PRO_GATHER ? AI : 1];
+  if (PRO == PRO_GATHER) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const long long row = m0 + sr + 32 * i;
+      const long long rc = row < M ? row : M - 1;
+      const long long bj = rc / ga.ns;
+      const long long b = bj / ga.m;
+      const int p = ga.idx[rc];
+      g_src[i] = b * ga.fbs + (long long)p * ga.frs;
+      g_pt[i] = (int)((b * ga.n + p) * 3);
+      g_ctr[i] = (int)(bj * 3);
+    }
+  }
+
+  auto load_slice = [&](int k0) {
+    const int k = k0 + sq * 4;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (PRO == PRO_BNRELU) {
+      if (k + 3 < K) {
+        sc = *reinterpret_cast<const float4 *>(pscale + k);
+        sh = *reinterpret_cast<const float4 *>(pshift + k);
+      } else {
+        if (k < K) { sc.x = pscale[k]; sh.x = pshift[k]; }
+        if (k + 1 < K) { sc.y = pscale[k + 1]; sh.y = pshift[k + 1]; }
+        if (k + 2 < K) { sc.z = pscale[k + 2]; sh.z = pshift[k + 2]; }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const long long row = m0 + sr + 32 * i;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < M) {
+        if (PRO == PRO_GATHER) {
+          float e[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int kc = k + c;
+            float x = 0.f;
+            if (kc < K) {
+              if (kc < 3) {
+                x = ga.xyz[g_pt[i] + kc] - ga.new_xyz[g_ctr[i] + kc];
+                if (ga.normalize) x = x / ga.radius;
+              } else {
+                x = ga.feats[g_src[i] + (kc - 3)];
+              }
+            }
+            e[c] = x;
+          }
+          v = make_float4(e[0], e[1], e[2], e[3]);
+        } else {
+          const float *p = A + row * lda + k;
+          if (k + 3 < K) {
+            if (avec) v = *reinterpret_cast<const float4 *>(p);
+            else { v.x = p[0]; v.y = p[1]; v.z = p[2]; v.w = p[3]; }
+          } else {
+            if (k < K) v.x = p[0];
+            if (k + 1 < K) v.y = p[1];
+            if (k + 2 < K) v.z = p[2];
+          }
+          if (PRO == PRO_BNRELU) {
+            // columns >= K keep scale 1 / shift 0 on a zero operand
+            v.x = fmaxf(v.x * sc.x + sh.x, 0.f); v.y = fmaxf(v.y * sc.y + sh.y, 0.f);
+            v.z = fmaxf(v.z * sc.z + sh.z, 0.f); v.w = fmaxf(v.w * sc.w + sh.w, 0.f);
+            if (k + 3 >= K) {
+              if (k >= K) v.x = 0.f;
+              if (k + 1 >= K) v.y = 0.f;
+              if (k + 2 >= K) v.z = 0.f;
+              v.w = 0.f;
+            }
+          }
+        }
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+      const int n = n0 + sr + 32 * i;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n < N) {
+        const float *p = W + (long long)n * ldw + k;
+        if (k + 3 < K) {
+          if (wvec) v = *reinterpret_cast<const float4 *>(p);
+          else { v.x = p[0]; v.y = p[1]; v.z = p[2]; v.w = p[3]; }
+        } else {
+          if (k < K) v.x = p[0];
+          if (k + 1 < K) v.y = p[1];
+          if (k + 2 < K) v.z = p[2];
+        }
+      }
+      rw[i] = v;
+    }
+  };
+  auto store_slice = [&]() {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) x3_store_quad(As, BM, sr + 32 * i, sq, ra[i]);
+#pragma unroll
+    for (int i = 0; i < WI; ++i) x3_store_quad(Ws, BN, sr + 32 * i, sq, rw[i]);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int li = lane & 31, lk = lane >> 5;
+  // operand address of (plane, row, k-half s, lane group lk): 8 bf16 = 16 bytes
+  const unsigned short *a_row0 = As + (wm * 64 + li) * X3_LD + lk * 8;
+  const unsigned short *w_row0 = Ws + (wn * 64 + li) * X3_LD + lk * 8;
+
+  load_slice(0);
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    __syncthreads();           // previous slice fully consumed
+    store_slice();
+    __syncthreads();
+    if (k0 + BK < K) load_slice(k0 + BK);   // prefetch under the MFMAs
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 a[2][3], b[2][3];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          a[t][p] = *reinterpret_cast<const bf16x8 *>(a_row0 + (p * BM + t * 32) * X3_LD + s * 16);
+          b[t][p] = *reinterpret_cast<const bf16x8 *>(w_row0 + (p * BN + t * 32) * X3_LD + s * 16);
+        }
+      // x*y ~= sum of the 6 plane products with i + j <= 2 (hi=0, mid=1, lo=2):
+      // small terms first
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          f32x16 c = acc[i][j];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
+          acc[i][j] = c;
+        }
+    }
+  }
+
+  // ---- epilogue: store Y, column statistics -------------------------------
+  // C/D layout of 32x32: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wn * 64 + j * 32 + li;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const long long row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+        const float v = acc[i][j][e];
+        if (row < M && col < N) {
+          Y[row * ldy + col] = v;
+          s1 += v;
+          s2 += v * v;
+        }
+      }
+    }
+    if (partial != nullptr) {
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (lk == 0) {
+        s_stat[0][wm][wn * 64 + j * 32 + li] = s1;
+        s_stat[1][wm][wn * 64 + j * 32 + li] = s2;
+      }
+    }
+  }
+  if (partial != nullptr) {
+    __syncthreads();
+    for (int c = tid; c < BN; c += 256) {
+      if (n0 + c < N) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) { s1 += s_stat[0][w][c]; s2 += s_stat[1][w][c]; }
+        float *p = partial + (long long)blockIdx.x * 2 * N;
+        p[n0 + c] = s1;
+        p[N + n0 + c] = s2;
+      }
+    }
+  }
+}
+
 template <int PRO>
 int launch(long long M, int N, int K, const float *A, int lda, const float *W, int ldw,
            const float *pscale, const float *pshift, const GatherArgs &ga, float *Y,
@@ -302,6 +557,60 @@ int launch(long long M, int N, int K, const float *A, int lda, const float *W, i
   return 0;
 }
 
+
+template <int WM, int WN>
+constexpr size_t x3_lds_bytes() {
+  return (size_t)3 * (64 * WM + 64 * WN) * X3_LD * sizeof(unsigned short) +
+         sizeof(float) * 2 * WM * 64 * WN;
+}
+
+template <int PRO>
+int launch_x3(long long M, int N, int K, const float *A, int lda, const float *W, int ldw,
+              const float *pscale, const float *pshift, const GatherArgs &ga, float *Y,
+              int ldy, float *partial, hipStream_t st) {
+  const int avec = A && ((lda & 3) == 0) && (((uintptr_t)A & 15) == 0);
+  const int wvec = ((ldw & 3) == 0) && (((uintptr_t)W & 15) == 0);
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void *)rows_gemm_x3_kernel<4, 1, PRO>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)x3_lds_bytes<4, 1>()) != hipSuccess ||
+        hipFuncSetAttribute((const void *)rows_gemm_x3_kernel<2, 2, PRO>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)x3_lds_bytes<2, 2>()) != hipSuccess)
+      return -1;
+    attr_done = true;
+  }
+  const size_t lds41 = x3_lds_bytes<4, 1>(), lds22 = x3_lds_bytes<2, 2>();
+  if (N <= 64) {
+    dim3 grid((unsigned)((M + 255) / 256), 1);
+    hipLaunchKernelGGL((rows_gemm_x3_kernel<4, 1, PRO>), grid, dim3(256), lds41,
+                       st, M, N, K, A, lda, W, ldw, pscale, pshift, ga, Y, ldy, partial, avec,
+                       wvec);
+  } else {
+    dim3 grid((unsigned)((M + 127) / 128), (unsigned)((N + 127) / 128));
+    hipLaunchKernelGGL((rows_gemm_x3_kernel<2, 2, PRO>), grid, dim3(256), lds22,
+                       st, M, N, K, A, lda, W, ldw, pscale, pshift, ga, Y, ldy, partial, avec,
+                       wvec);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    fprintf(stderr, "s2c_rows_gemm(bf16x3) launch failed: %s\n", hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
+// 0: exact fp32 MFMA chain, 1: bf16x3 split (default; S2C_GEMM_SPLIT=0 turns it off)
+static int g_gemm_split = -1;
+static bool use_split() {
+  if (g_gemm_split < 0) {
+    const char *e = getenv("S2C_GEMM_SPLIT");
+    g_gemm_split = e ? atoi(e) : 1;
+  }
+  return g_gemm_split != 0;
+}
+
 }  // namespace
 
 extern "C" int s2c_rows_gemm_blocks(long long M, int N) {
@@ -323,9 +632,15 @@ extern "C" int s2c_rows_gemm(long long M, int N, int K, const float *A, int lda,
   GatherArgs ga = {};
   if (pscale != nullptr) {
     if (((uintptr_t)pscale & 15) || ((uintptr_t)pshift & 15)) return -1;
+    if (use_split())
+      return launch_x3<PRO_BNRELU>(M, N, K, A, lda, W, ldw, pscale, pshift, ga, Y, ldy,
+                                   partial, (hipStream_t)stream);
     return launch<PRO_BNRELU>(M, N, K, A, lda, W, ldw, pscale, pshift, ga, Y, ldy,
                               partial, (hipStream_t)stream);
   }
+  if (use_split())
+    return launch_x3<PRO_NONE>(M, N, K, A, lda, W, ldw, nullptr, nullptr, ga, Y, ldy, partial,
+                               (hipStream_t)stream);
   return launch<PRO_NONE>(M, N, K, A, lda, W, ldw, nullptr, nullptr, ga, Y, ldy, partial,
                           (hipStream_t)stream);
 }
@@ -351,6 +666,17 @@ extern "C" int s2c_sa_gather_gemm(int b, int n, int m, int ns, int C,
   ga.xyz = xyz; ga.new_xyz = new_xyz; ga.feats = feats; ga.idx = idx;
   ga.frs = feat_row_stride; ga.fbs = feat_batch_stride;
   ga.n = n; ga.m = m; ga.ns = ns; ga.radius = radius; ga.normalize = normalize;
+  if (use_split())
+    return launch_x3<PRO_GATHER>(M, N, K, nullptr, K, W, ldw, nullptr, nullptr, ga, Y, ldy,
+                                 partial, (hipStream_t)stream);
   return launch<PRO_GATHER>(M, N, K, nullptr, K, W, ldw, nullptr, nullptr, ga, Y, ldy,
                             partial, (hipStream_t)stream);
+}
+
+/* 1: bf16x3 split products (default), 0: exact fp32 MFMA chain.  Returns the previous
+ * setting.  (Also: environment S2C_GEMM_SPLIT read at first use.) */
+extern "C" int s2c_gemm_set_split(int on) {
+  const int old = use_split() ? 1 : 0;
+  g_gemm_split = on ? 1 : 0;
+  return old;
 }
