@@ -58,31 +58,36 @@ class CapNet(nn.Module):
                 self.caption = SceneCaptionModule(
                     vocabulary, embeddings, emb_size, 128, hidden_size, num_proposal)
 
-    def forward(self, data_dict, use_tf=True, is_eval=False):
-        # The teacher-forced decoder needs max(lang_len) as a host integer.  Read
-        # it before anything is enqueued (callers that already know it may pass
-        # data_dict["_num_words"] and avoid the device read altogether).
-        if (not self.no_caption and not is_eval and "_num_words" not in data_dict
-                and "lang_len" in data_dict):
+    # Stage outputs are published under the reference's key names (SURVEY Appendix A:
+    # backbone -> seeds -> votes -> proposals -> graph -> captions); the stages
+    # themselves are the re-assignable sub-modules.
+    _SEED_KEYS = (("seed_inds", "fp2_inds"), ("seed_xyz", "fp2_xyz"),
+                  ("seed_features", "fp2_features"))
+
+    def _host_prologue(self, data_dict, is_eval):
+        """The teacher-forced decoder needs max(lang_len) as a host integer: read it
+        before anything is enqueued (callers that know it pass `_num_words` and avoid
+        the device read altogether)."""
+        wants = not (self.no_caption or is_eval)
+        if wants and "_num_words" not in data_dict and "lang_len" in data_dict:
             data_dict["_num_words"] = int(data_dict["lang_len"].max())
 
-        # ---- detection branch ----
+    def detect(self, data_dict):
+        """capnet.py:86-109: backbone, vote generation (L2-normalised vote features),
+        proposal aggregation + box heads."""
         data_dict = self.backbone_net(data_dict)
-        xyz = data_dict["fp2_xyz"]
-        features = data_dict["fp2_features"]
-        data_dict["seed_inds"] = data_dict["fp2_inds"]
-        data_dict["seed_xyz"] = xyz
-        data_dict["seed_features"] = features
-        xyz, features = self.vgen(xyz, features)
-        features_norm = torch.norm(features, p=2, dim=1)
-        features = features.div(features_norm.unsqueeze(1))
-        data_dict["vote_xyz"] = xyz
-        data_dict["vote_features"] = features
-        data_dict = self.proposal(xyz, features, data_dict)
-        # ---- graph enhancement ----
-        if self.num_graph_steps > 0:
+        for dst, src in self._SEED_KEYS:
+            data_dict[dst] = data_dict[src]
+        vote_xyz, vote_feat = self.vgen(data_dict["seed_xyz"], data_dict["seed_features"])
+        vote_feat = vote_feat.div(torch.norm(vote_feat, p=2, dim=1).unsqueeze(1))
+        data_dict.update(vote_xyz=vote_xyz, vote_features=vote_feat)
+        return self.proposal(vote_xyz, vote_feat, data_dict)
+
+    def forward(self, data_dict, use_tf=True, is_eval=False):
+        self._host_prologue(data_dict, is_eval)
+        data_dict = self.detect(data_dict)
+        if self.num_graph_steps > 0:                     # relational graph (:111-116)
             data_dict = self.graph(data_dict)
-        # ---- caption branch ----
-        if not self.no_caption:
+        if not self.no_caption:                          # captioner (:118-121)
             data_dict = self.caption(data_dict, use_tf, is_eval)
         return data_dict
