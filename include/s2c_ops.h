@@ -4,7 +4,7 @@
  *
  * Drop-in boundary: these entry points replace, one for one, the
  * `*_kernel_wrapper` functions that the reference's C++ op layer forward-declares
- * and calls with raw device pointers (lib/pointnet2/_ext_src/src/*.cpp), i.e.
+ * and calls with raw device pointers (the .cpp files of lib/pointnet2/_ext_src/src), i.e.
  * exactly what a binding for the `pointnet2._ext` module
  * (lib/pointnet2/_ext_src/src/bindings.cpp:6-19) links against.  Same argument
  * order and meaning as the reference wrappers, plus a trailing stream.

@@ -20,7 +20,7 @@ HIPCC_FLAGS = [
     # hardware float atomics (global_atomic_add_f32) instead of CAS loops in the
     # scatter-add (grad) kernels
     "-munsafe-fp-atomics",
-    "-shared", "-fPIC", "-Wno-comment",
+    "-shared", "-fPIC",
 ]
 
 

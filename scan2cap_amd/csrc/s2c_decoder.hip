@@ -66,44 +66,6 @@ constexpr int NCHUNK = 32;
 __device__ __forceinline__ float dot4(const float4 a, const float4 b) {
   return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
 }
-// U float4 pairs per lane, every load issued before the first use: one memory
-// round trip per call instead of one per loop iteration.
-template <int U>
-__device__ __forceinline__ void dot_row_u(const float4 *__restrict__ w,
-                                          const float4 *__restrict__ x, int n4, int j0,
-                                          float &acc0, float &acc1) {
-  float4 a[U], b[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int j = j0 + u * NCHUNK;
-    if (j < n4) {
-      a[u] = w[j];
-      b[u] = x[j];
-    } else {
-      a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      b[u] = a[u];
-    }
-  }
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    if (u & 1) acc1 += dot4(a[u], b[u]);
-    else acc0 += dot4(a[u], b[u]);
-  }
-}
-__device__ __forceinline__ float dot_row(const float *__restrict__ w,
-                                         const float *__restrict__ x, int n4,
-                                         int chunk) {
-  const float4 *w4 = reinterpret_cast<const float4 *>(w);
-  const float4 *x4 = reinterpret_cast<const float4 *>(x);
-  float acc0 = 0.0f, acc1 = 0.0f;
-  if (n4 <= 4 * NCHUNK) {
-    dot_row_u<4>(w4, x4, n4, chunk, acc0, acc1);
-  } else {
-    for (int j = chunk; j < n4; j += 12 * NCHUNK) dot_row_u<12>(w4, x4, n4, j, acc0, acc1);
-  }
-  return acc0 + acc1;
-}
-
 // The input slice of a lane kept in registers and reused for several weight rows:
 // every block re-reads the (R x I) input from L2, so amortising it over OB outputs
 // cuts the dominant L2->CU traffic of these kernels by ~OB.
