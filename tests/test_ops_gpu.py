@@ -219,3 +219,31 @@ def test_errors_raise(ext):
     with pytest.raises(RuntimeError):
         ext.gather_points(torch.zeros(1, 3, 8).cuda(),
                           torch.zeros(1, 2, dtype=torch.int64).cuda())  # wrong dtype
+
+
+def test_extreme_shapes(ext, oracle):
+    """Smallest / largest legal arguments of every index op: one sample, every point
+    sampled, one known point for three_nn (two of the three slots keep their sentinels,
+    interpolate_gpu.cu:27-49), nsample 1 and nsample > N for ball_query."""
+    xyz = scene_xyz(2, 257, seed=77)
+    for m in (1, 257):
+        np.testing.assert_array_equal(
+            ext.furthest_point_sampling(dev(xyz), m).cpu().numpy(),
+            oracle.furthest_point_sampling(xyz, m))
+    d_want, i_want = oracle.three_nn(xyz[:, :50], xyz[:, 60:61])
+    d_got, i_got = ext.three_nn(dev(xyz[:, :50]), dev(xyz[:, 60:61]))
+    np.testing.assert_array_equal(i_got.cpu().numpy(), i_want)
+    np.testing.assert_array_equal(d_got.cpu().numpy(), d_want)
+    new_xyz = xyz[:, :9].copy()
+    for ns in (1, 300):
+        np.testing.assert_array_equal(
+            ext.ball_query(dev(new_xyz), dev(xyz), 0.5, ns).cpu().numpy(),
+            oracle.ball_query(new_xyz, xyz, 0.5, ns))
+    # single-point cloud
+    one = xyz[:, :1].copy()
+    np.testing.assert_array_equal(
+        ext.furthest_point_sampling(dev(one), 1).cpu().numpy(),
+        oracle.furthest_point_sampling(one, 1))
+    np.testing.assert_array_equal(
+        ext.ball_query(dev(one), dev(one), 0.1, 4).cpu().numpy(),
+        oracle.ball_query(one, one, 0.1, 4))
