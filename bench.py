@@ -69,18 +69,27 @@ class LossConfig(object):
 
 
 # entry point -> device kernels it launches (for the PMC traffic lookup)
+_GEMM_PLAIN = tuple("rows_gemm%s_kernel<%s, %d>" % (v, g, p)
+                    for v in ("", "_x3") for g in ("2, 2", "4, 1") for p in (0, 1))
+_GEMM_GATHER = tuple("rows_gemm%s_kernel<%s, 2>" % (v, g)
+                     for v in ("", "_x3") for g in ("2, 2", "4, 1"))
 KERNELS_OF = {
     "s2c_bn_relu_bwd": ("bn_bwd_stats_kernel", "bn_bwd_apply_kernel"),
     "s2c_bn_relu_max_bwd": ("pool_bwd_stats_kernel", "pool_bwd_apply_kernel"),
     "s2c_bn_relu": ("bn_relu_kernel",),
     "s2c_bn_relu_max": ("bn_relu_max_kernel",),
     "s2c_bn_train_stats": ("col_stats_kernel",),
-    "s2c_rows_gemm": ("rows_gemm_kernel",),
-    "s2c_sa_gather_gemm": ("rows_gemm_kernel<4, 1, 2>", "rows_gemm_kernel<2, 2, 2>"),
+    "s2c_rows_gemm": _GEMM_PLAIN,
+    "s2c_sa_gather_gemm": _GEMM_GATHER,
     "s2c_sa_gather_rows": ("sa_gather_rows_kernel",),
     "s2c_sa_scatter_rows": ("sa_scatter_rows_kernel",),
+    "s2c_sa_scatter_sum": ("sa_scatter_sum_kernel",),
+    "s2c_fp_interp_rows": ("fp_interp_rows_kernel",),
+    "s2c_fp_interp_rows_grad": ("fp_interp_rows_grad_kernel",),
     "s2c_small_linear": ("small_linear_kernel",),
+    "s2c_small_linear_pair": ("small_linear_kernel",),
     "s2c_gru_fwd": ("gru_fwd_kernel",),
+    "s2c_attn_bwd": ("attn_bwd_kernel",),
     "s2c_ball_query": ("ball_query_kernel",),
 }
 
