@@ -337,3 +337,22 @@ def test_eval_greedy_decode_fused_step_matches_step_loop():
     assert _rel(a["lang_cap"], b["lang_cap"]) < 1e-4
     assert _rel(a["topdown_attn"], b["topdown_attn"]) < 1e-4
     assert torch.equal(a["valid_masks"], b["valid_masks"])
+
+
+def test_device_prefetcher_delivers_identical_batches():
+    """scan2cap_amd/data_pipeline.py: pinned staging + copy stream; values, order and the
+    pass-through of non-tensor entries (solver.py:280-287 moves the same keys)."""
+    from scan2cap_amd.data_pipeline import DevicePrefetcher
+    g = torch.Generator().manual_seed(0)
+    host = [{"point_clouds": torch.randn(2, 1000, 7, generator=g),
+             "lang_len": torch.randint(3, 9, (2,), generator=g),
+             "scan_idx": i, "names": ["a", "b"]} for i in range(5)]
+    seen = 0
+    for i, dd in enumerate(DevicePrefetcher(host, "cuda", depth=2)):
+        assert dd["scan_idx"] == i and dd["names"] == ["a", "b"]
+        assert dd["point_clouds"].is_cuda and dd["lang_len"].is_cuda
+        # consume on the current stream right away: the event wait must order the copy
+        assert torch.equal((dd["point_clouds"] * 1.0).cpu(), host[i]["point_clouds"])
+        assert torch.equal(dd["lang_len"].cpu(), host[i]["lang_len"])
+        seen += 1
+    assert seen == 5
