@@ -307,7 +307,7 @@ def main():
         # reads the slot's static geometry tensors (scan2cap_amd/pipeline.py)
         from scan2cap_amd.pipeline import GeometrySlots
         # a forward-only step is shorter than one FPS chain: keep 3 batches of
-        # geometry in flight; a train step (~18 ms) hides one chain (~6.5 ms)
+        # geometry in flight; a train step (~12.6 ms) hides one chain (~5.8 ms)
         depth = 1 if wl["train"] else 3
         depth = int(os.environ.get("S2C_GEO_DEPTH", depth))
         slots = GeometrySlots(model.backbone_net, dd["point_clouds"], depth)
