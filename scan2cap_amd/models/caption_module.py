@@ -360,6 +360,8 @@ class TopDownSceneCaptionModule(nn.Module):
                 x1.addmm_(hidden_2, Wh_t).relu_()
                 hidden_1 = self.recurrent_cell_1(x1, hidden_1)
                 qh = self.map_hidd(hidden_1)
+                if _C.TIMER.enabled:      # one pass over mapped + local features
+                    _C.TIMER.alg_bytes = 4 * (R * L * (H + F_ + 1) + R * (H + F_))
                 _C.call("s2c_attn_local_fwd", R, L, H, F_, mapped_c.data_ptr(),
                         qh.data_ptr(), H, wa.data_ptr(), 0.0, None, local_c.data_ptr(),
                         alpha.data_ptr(), att.data_ptr(), F_, _C.stream_ptr())

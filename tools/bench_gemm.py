@@ -38,6 +38,12 @@ def run(M, N, K, stats=True, pro=False):
     byt = 4.0 * (M * K + M * N) / 1e9
     print(f"M={M:8d} N={N:4d} K={K:4d} pro={int(pro)}: mine {t1:8.1f} us ({gf/t1*1e3:6.1f} TF, {byt/t1*1e3:5.2f} TB/s)  torch.mm {t2:8.1f} us  relerr {err:.1e} stats {e1:.1e} {e2:.1e}")
 
+DECODE = [(8192, 1536, 512), (8192, 1536, 300), (8192, 3500, 512), (8192, 300, 940),
+          (2048, 1536, 512), (2048, 3500, 512)]
+if os.environ.get("S2C_BENCH_DECODE"):
+    for (M, N, K) in DECODE:
+        run(M, N, K, stats=False)
+    sys.exit(0)
 for (M, N, K) in [(1048576, 64, 135), (1048576, 64, 64), (1048576, 128, 64), (262144, 128, 131),
                   (262144, 128, 128), (262144, 256, 128), (65536, 128, 259), (65536, 256, 128),
                   (32768, 128, 259), (8192, 256, 512), (1000, 64, 135)]:
