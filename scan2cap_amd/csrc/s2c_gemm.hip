@@ -47,6 +47,9 @@ constexpr int LDS_LD = 36;  // floats per LDS row (32 + 4 pad, 16-byte aligned)
 
 enum { PRO_NONE = 0, PRO_BNRELU = 1, PRO_GATHER = 2 };
 
+// 16 bytes, 4-byte aligned (rows of the (B,N,3+C) cloud are not 16-byte aligned)
+struct __attribute__((packed, aligned(4))) F4U { float x, y, z, w; };
+
 struct GatherArgs {
   const float *xyz;       // (b, n, 3)
   const float *new_xyz;   // (b, m, 3)
@@ -121,22 +124,30 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (row < M) {
         if (PRO == PRO_GATHER) {
-          float e[4];
+          if (k >= 3 && k + 3 < K) {
+            // whole quad inside the feature part: ONE 16-byte load.  A gathered row
+            // starts at a multiple of (3+C)*4 bytes, so the address is only 4-byte
+            // aligned (global memory takes dword-aligned dwordx4 loads).
+            const F4U q = *reinterpret_cast<const F4U *>(ga.feats + g_src[i] + (k - 3));
+            v = make_float4(q.x, q.y, q.z, q.w);
+          } else {
+            float e[4];
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const int kc = k + c;
-            float x = 0.f;
-            if (kc < K) {
-              if (kc < 3) {
-                x = ga.xyz[g_pt[i] + kc] - ga.new_xyz[g_ctr[i] + kc];
-                if (ga.normalize) x = x / ga.radius;
-              } else {
-                x = ga.feats[g_src[i] + (kc - 3)];
+            for (int c = 0; c < 4; ++c) {
+              const int kc = k + c;
+              float x = 0.f;
+              if (kc < K) {
+                if (kc < 3) {
+                  x = ga.xyz[g_pt[i] + kc] - ga.new_xyz[g_ctr[i] + kc];
+                  if (ga.normalize) x = x / ga.radius;
+                } else {
+                  x = ga.feats[g_src[i] + (kc - 3)];
+                }
               }
+              e[c] = x;
             }
-            e[c] = x;
+            v = make_float4(e[0], e[1], e[2], e[3]);
           }
-          v = make_float4(e[0], e[1], e[2], e[3]);
         } else {
           const float *p = A + row * lda + k;
           if (k + 3 < K) {
@@ -378,22 +389,30 @@ __global__ __launch_bounds__(256) void rows_gemm_x3_kernel(
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (row < M) {
         if (PRO == PRO_GATHER) {
-          float e[4];
+          if (k >= 3 && k + 3 < K) {
+            // whole quad inside the feature part: ONE 16-byte load.  A gathered row
+            // starts at a multiple of (3+C)*4 bytes, so the address is only 4-byte
+            // aligned (global memory takes dword-aligned dwordx4 loads).
+            const F4U q = *reinterpret_cast<const F4U *>(ga.feats + g_src[i] + (k - 3));
+            v = make_float4(q.x, q.y, q.z, q.w);
+          } else {
+            float e[4];
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const int kc = k + c;
-            float x = 0.f;
-            if (kc < K) {
-              if (kc < 3) {
-                x = ga.xyz[g_pt[i] + kc] - ga.new_xyz[g_ctr[i] + kc];
-                if (ga.normalize) x = x / ga.radius;
-              } else {
-                x = ga.feats[g_src[i] + (kc - 3)];
+            for (int c = 0; c < 4; ++c) {
+              const int kc = k + c;
+              float x = 0.f;
+              if (kc < K) {
+                if (kc < 3) {
+                  x = ga.xyz[g_pt[i] + kc] - ga.new_xyz[g_ctr[i] + kc];
+                  if (ga.normalize) x = x / ga.radius;
+                } else {
+                  x = ga.feats[g_src[i] + (kc - 3)];
+                }
               }
+              e[c] = x;
             }
-            e[c] = x;
+            v = make_float4(e[0], e[1], e[2], e[3]);
           }
-          v = make_float4(e[0], e[1], e[2], e[3]);
         } else {
           const float *p = A + row * lda + k;
           if (k + 3 < K) {
