@@ -114,6 +114,23 @@ int s2c_bn_relu_max_bwd(long long J, int ns, int C, const float *dOut,
  * [sum | sumsq] of Y, s2c_rows_gemm_blocks(M,N) * 2N floats, to be reduced by
  * s2c_bn_finalize_partials (BN batch statistics without another pass over Y). */
 int s2c_rows_gemm_blocks(long long M, int N);
+/* Inference layers (frozen BatchNorm): out = [max over groups of pool_ns rows of]
+ * relu?(Y * scale + shift), Y = A W^T, scale = gamma / sqrt(var + eps), shift = beta -
+ * mean * scale -- BN, ReLU and the set-abstraction max-pool (pointnet2_modules.py:
+ * 251-257) in the GEMM epilogue.  pool_ns in {0, 16, 32, 64}; out is (M x N) or
+ * (M/pool_ns x N) with row stride ldo.  gamma / beta may be NULL. */
+int s2c_rows_gemm_bn_eval(long long M, int N, int K, const float *A, int lda, const float *W,
+                          int ldw, const float *gamma, const float *beta, const float *mean,
+                          const float *var, float eps, int relu, int pool_ns, float *out,
+                          int ldo, void *stream);
+int s2c_sa_gather_gemm_bn_eval(int b, int n, int m, int ns, int C, long long feat_row_stride,
+                               long long feat_batch_stride, float radius, int normalize,
+                               const float *xyz, const float *new_xyz, const float *feats,
+                               const int *idx, int N, const float *W, int ldw,
+                               const float *gamma, const float *beta, const float *mean,
+                               const float *var, float eps, int relu, int pool_ns, float *out,
+                               int ldo, void *stream);
+
 /* products of s2c_rows_gemm / s2c_sa_gather_gemm: 1 = bf16x3 split on the bf16 matrix
  * pipe (fp32-accurate, ~1e-7 relative; default), 0 = exact fp32 MFMA chain.  Returns
  * the previous setting. */

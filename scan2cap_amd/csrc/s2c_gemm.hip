@@ -40,8 +40,6 @@ using namespace s2c;
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
 constexpr int BK = 32;
 constexpr int LDS_LD = 36;  // floats per LDS row (32 + 4 pad, 16-byte aligned)
 
@@ -61,6 +59,75 @@ struct GatherArgs {
   int normalize;
 };
 
+// Inference epilogue (frozen BatchNorm): out = relu(acc * scale[c] + shift[c]) with
+// scale = gamma / sqrt(var + eps), shift = beta - mean * scale (the arithmetic of
+// bn_eval_coeffs + bn_relu in s2c_sa.hip), optionally max-pooled over groups of
+// pool_ns consecutive rows (the nsample rows of a centre) -- the layer's BN, ReLU and
+// the set-abstraction max-pool leave with the GEMM: no Y tensor, no extra pass.
+struct EpiArgs {
+  const float *gamma, *beta, *mean, *var;   // mean == nullptr: epilogue off
+  float eps;
+  int relu, pool_ns;                         // pool_ns in {0, 16, 32, 64}
+  float *out;
+  int ldo;
+};
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void affine_epilogue(const f32x16 (&acc)[2][2], const EpiArgs &ep,
+                                                long long M, int N, long long m0w, int n0w,
+                                                int li, int lk) {
+  // m0w / n0w: first row / column of this wave's 64 x 64 tile
+  // C/D layout of 32x32: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0w + j * 32 + li;
+    const bool ok = col < N;
+    float sc = 0.f, sh = 0.f;
+    if (ok) {
+      const float invstd = 1.0f / sqrtf(ep.var[col] + ep.eps);
+      sc = (ep.gamma ? ep.gamma[col] : 1.0f) * invstd;
+      sh = (ep.beta ? ep.beta[col] : 0.0f) - ep.mean[col] * sc;
+    }
+    if (ep.pool_ns == 0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const long long row = m0w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+          float v = acc[i][j][e] * sc + sh;
+          if (ep.relu) v = fmaxf(v, 0.f);
+          if (ok && row < M) ep.out[row * ep.ldo + col] = v;
+        }
+    } else {
+      const int ns = ep.pool_ns;
+      float g[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          float v = acc[i][j][e] * sc + sh;
+          if (ep.relu) v = fmaxf(v, 0.f);
+          // 16-row quarter of the wave tile this element belongs to: 2 i + (e >> 3)
+          const int q = 2 * i + (e >> 3);
+          const int grp = ns == 64 ? 0 : (ns == 32 ? (q >> 1) : q);
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            if (t == grp) g[t] = fmaxf(g[t], v);
+        }
+      const int groups = 64 / ns;
+      const long long centre0 = m0w / ns, centres = M / ns;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (t < groups) {
+          const float m = fmaxf(g[t], __shfl_xor(g[t], 32, 64));
+          if (lk == 0 && ok && centre0 + t < centres) ep.out[(centre0 + t) * ep.ldo + col] = m;
+        }
+      }
+    }
+  }
+}
+
 __device__ __forceinline__ void lds_store_quad(float *row, int sq, float4 v) {
   // k = 4sq .. 4sq+3 -> even ks at [2sq, 2sq+1], odd ks at 16 + [2sq, 2sq+1]
   *reinterpret_cast<float2 *>(row + 2 * sq) = make_float2(v.x, v.z);
@@ -72,7 +139,7 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(
     long long M, int N, int K, const float *__restrict__ A, int lda,
     const float *__restrict__ W, int ldw, const float *__restrict__ pscale,
     const float *__restrict__ pshift, GatherArgs ga, float *__restrict__ Y, int ldy,
-    float *__restrict__ partial, int avec, int wvec) {
+    float *__restrict__ partial, int avec, int wvec, EpiArgs ep) {
   constexpr int BM = 64 * WM, BN = 64 * WN;
   __shared__ __attribute__((aligned(16))) float As[BM * LDS_LD];
   __shared__ __attribute__((aligned(16))) float Ws[BN * LDS_LD];
@@ -248,6 +315,10 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(
     }
   }
 
+  if (ep.mean != nullptr) {    // inference: BN + ReLU (+ max-pool) leave with the GEMM
+    affine_epilogue(acc, ep, M, N, m0 + wm * 64, n0 + wn * 64, li, lk);
+    return;
+  }
   // ---- epilogue: store Y, column statistics -------------------------------
   // C/D layout of 32x32: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
 #pragma unroll
@@ -335,7 +406,7 @@ __global__ __launch_bounds__(256) void rows_gemm_x3_kernel(
     long long M, int N, int K, const float *__restrict__ A, int lda,
     const float *__restrict__ W, int ldw, const float *__restrict__ pscale,
     const float *__restrict__ pshift, GatherArgs ga, float *__restrict__ Y, int ldy,
-    float *__restrict__ partial, int avec, int wvec) {
+    float *__restrict__ partial, int avec, int wvec, EpiArgs ep) {
   constexpr int BM = 64 * WM, BN = 64 * WN;
   // three bf16 planes (hi, mid, lo) per operand tile, rows of X3_LD bf16 (32 + 8 pad)
   extern __shared__ __attribute__((aligned(16))) unsigned char x3_smem[];
@@ -510,6 +581,10 @@ __global__ __launch_bounds__(256) void rows_gemm_x3_kernel(
     }
   }
 
+  if (ep.mean != nullptr) {    // inference: BN + ReLU (+ max-pool) leave with the GEMM
+    affine_epilogue(acc, ep, M, N, m0 + wm * 64, n0 + wn * 64, li, lk);
+    return;
+  }
   // ---- epilogue: store Y, column statistics -------------------------------
   // C/D layout of 32x32: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
 #pragma unroll
@@ -556,17 +631,17 @@ __global__ __launch_bounds__(256) void rows_gemm_x3_kernel(
 template <int PRO>
 int launch(long long M, int N, int K, const float *A, int lda, const float *W, int ldw,
            const float *pscale, const float *pshift, const GatherArgs &ga, float *Y,
-           int ldy, float *partial, hipStream_t st) {
+           int ldy, float *partial, hipStream_t st, const EpiArgs &ep = EpiArgs()) {
   const int avec = A && ((lda & 3) == 0) && (((uintptr_t)A & 15) == 0);
   const int wvec = ((ldw & 3) == 0) && (((uintptr_t)W & 15) == 0);
   if (N <= 64) {
     dim3 grid((unsigned)((M + 255) / 256), 1);
     hipLaunchKernelGGL((rows_gemm_kernel<4, 1, PRO>), grid, dim3(256), 0, st, M, N, K, A,
-                       lda, W, ldw, pscale, pshift, ga, Y, ldy, partial, avec, wvec);
+                       lda, W, ldw, pscale, pshift, ga, Y, ldy, partial, avec, wvec, ep);
   } else {
     dim3 grid((unsigned)((M + 127) / 128), (unsigned)((N + 127) / 128));
     hipLaunchKernelGGL((rows_gemm_kernel<2, 2, PRO>), grid, dim3(256), 0, st, M, N, K, A,
-                       lda, W, ldw, pscale, pshift, ga, Y, ldy, partial, avec, wvec);
+                       lda, W, ldw, pscale, pshift, ga, Y, ldy, partial, avec, wvec, ep);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -586,7 +661,7 @@ constexpr size_t x3_lds_bytes() {
 template <int PRO>
 int launch_x3(long long M, int N, int K, const float *A, int lda, const float *W, int ldw,
               const float *pscale, const float *pshift, const GatherArgs &ga, float *Y,
-              int ldy, float *partial, hipStream_t st) {
+              int ldy, float *partial, hipStream_t st, const EpiArgs &ep = EpiArgs()) {
   const int avec = A && ((lda & 3) == 0) && (((uintptr_t)A & 15) == 0);
   const int wvec = ((ldw & 3) == 0) && (((uintptr_t)W & 15) == 0);
   static bool attr_done = false;
@@ -605,12 +680,12 @@ int launch_x3(long long M, int N, int K, const float *A, int lda, const float *W
     dim3 grid((unsigned)((M + 255) / 256), 1);
     hipLaunchKernelGGL((rows_gemm_x3_kernel<4, 1, PRO>), grid, dim3(256), lds41,
                        st, M, N, K, A, lda, W, ldw, pscale, pshift, ga, Y, ldy, partial, avec,
-                       wvec);
+                       wvec, ep);
   } else {
     dim3 grid((unsigned)((M + 127) / 128), (unsigned)((N + 127) / 128));
     hipLaunchKernelGGL((rows_gemm_x3_kernel<2, 2, PRO>), grid, dim3(256), lds22,
                        st, M, N, K, A, lda, W, ldw, pscale, pshift, ga, Y, ldy, partial, avec,
-                       wvec);
+                       wvec, ep);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -698,4 +773,61 @@ extern "C" int s2c_gemm_set_split(int on) {
   const int old = use_split() ? 1 : 0;
   g_gemm_split = on ? 1 : 0;
   return old;
+}
+
+static bool bad_epi(long long M, int pool_ns, const float *mean, const float *var, float *out) {
+  return !mean || !var || !out ||
+         !(pool_ns == 0 || ((pool_ns == 16 || pool_ns == 32 || pool_ns == 64) && M % pool_ns == 0));
+}
+
+// Inference layer in one launch: out = [max over groups of pool_ns rows of]
+// relu?( (A W^T) * gamma/sqrt(var+eps) + beta - mean*gamma/sqrt(var+eps) ).
+// out is (M x N) or (M/pool_ns x N), row stride ldo.
+extern "C" int s2c_rows_gemm_bn_eval(long long M, int N, int K, const float *A, int lda,
+                                     const float *W, int ldw, const float *gamma,
+                                     const float *beta, const float *mean, const float *var,
+                                     float eps, int relu, int pool_ns, float *out, int ldo,
+                                     void *stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || !A || !W || lda < K || ldw < K ||
+      bad_epi(M, pool_ns, mean, var, out)) {
+    fprintf(stderr, "s2c_rows_gemm_bn_eval: bad arguments\n");
+    return -1;
+  }
+  GatherArgs ga = {};
+  EpiArgs ep = {gamma, beta, mean, var, eps, relu, pool_ns, out, ldo};
+  if (use_split())
+    return launch_x3<PRO_NONE>(M, N, K, A, lda, W, ldw, nullptr, nullptr, ga, out, ldo, nullptr,
+                               (hipStream_t)stream, ep);
+  return launch<PRO_NONE>(M, N, K, A, lda, W, ldw, nullptr, nullptr, ga, out, ldo, nullptr,
+                          (hipStream_t)stream, ep);
+}
+
+// the same with the ball-query grouping fused into the operand load
+extern "C" int s2c_sa_gather_gemm_bn_eval(int b, int n, int m, int ns, int C,
+                                          long long feat_row_stride,
+                                          long long feat_batch_stride, float radius,
+                                          int normalize, const float *xyz,
+                                          const float *new_xyz, const float *feats,
+                                          const int *idx, int N, const float *W, int ldw,
+                                          const float *gamma, const float *beta,
+                                          const float *mean, const float *var, float eps,
+                                          int relu, int pool_ns, float *out, int ldo,
+                                          void *stream) {
+  const long long M = (long long)b * m * ns;
+  const int K = 3 + C;
+  if (M <= 0 || N <= 0 || !xyz || !new_xyz || !idx || !W || ldw < K || (C > 0 && !feats) ||
+      bad_epi(M, pool_ns, mean, var, out)) {
+    fprintf(stderr, "s2c_sa_gather_gemm_bn_eval: bad arguments\n");
+    return -1;
+  }
+  GatherArgs ga;
+  ga.xyz = xyz; ga.new_xyz = new_xyz; ga.feats = feats; ga.idx = idx;
+  ga.frs = feat_row_stride; ga.fbs = feat_batch_stride;
+  ga.n = n; ga.m = m; ga.ns = ns; ga.radius = radius; ga.normalize = normalize;
+  EpiArgs ep = {gamma, beta, mean, var, eps, relu, pool_ns, out, ldo};
+  if (use_split())
+    return launch_x3<PRO_GATHER>(M, N, K, nullptr, K, W, ldw, nullptr, nullptr, ga, out, ldo,
+                                 nullptr, (hipStream_t)stream, ep);
+  return launch<PRO_GATHER>(M, N, K, nullptr, K, W, ldw, nullptr, nullptr, ga, out, ldo,
+                            nullptr, (hipStream_t)stream, ep);
 }

@@ -27,6 +27,9 @@ _C.register("s2c_sa_scatter_rows", [_I, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, 
 _C.register("s2c_sa_scatter_sum", [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P])
 _C.register("s2c_fp_interp_rows", [_I, _I, _I, _I, _I, _P, _P, _P, _P, _L, _L, _P, _P])
 _C.register("s2c_fp_interp_rows_grad", [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P])
+_C.register("s2c_rows_gemm_bn_eval", [_L, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _F, _I, _I, _P, _I, _P])
+_C.register("s2c_sa_gather_gemm_bn_eval", [_I, _I, _I, _I, _I, _L, _L, _F, _I, _P, _P, _P, _P, _I, _P, _I,
+                                           _P, _P, _P, _P, _F, _I, _I, _P, _I, _P])
 _C.register("s2c_bn_train_stats", [_L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_bn_eval_coeffs", [_I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_bn_relu", [_L, _I, _P, _P, _P, _P, _I, _P])
@@ -389,6 +392,57 @@ class _MLPRows(Function):
         return (dA, d_xyz, d_new, d_feats, None, None, None) + tuple(flat)
 
 
+# inference: BN + ReLU (+ max-pool) in the GEMM epilogue (s2c_rows_gemm_bn_eval)
+FUSE_EVAL_EPILOGUE = True
+
+
+def _eval_fusable(specs, params, pool_ns):
+    if not (FUSE_EVAL_EPILOGUE and USE_MFMA_GEMM) or pool_ns not in (0, 16, 32, 64):
+        return False
+    pi = 0
+    for sp in specs:
+        W = params[pi]
+        pi += 1 + (1 if sp.has_bias else 0) + (2 if sp.bn is not None else 0)
+        bn = sp.bn
+        if (sp.has_bias or bn is None or bn.training or bn.running_mean is None
+                or W.stride(1) != 1):
+            return False
+    return True
+
+
+def _eval_stack(X, gather, M, dev, specs, pool_ns, params):
+    """Frozen-BN layer stack: one launch per layer, no pre-activation tensor, the last
+    layer leaves max-pooled."""
+    A, pi, nl = X, 0, len(specs)
+    for li, sp in enumerate(specs):
+        W, gamma, beta = params[pi], params[pi + 1], params[pi + 2]
+        pi += 3
+        bn, Cout = sp.bn, W.shape[0]
+        pn = pool_ns if li == nl - 1 else 0
+        out = torch.empty((M // pn if pn else M, Cout), device=dev)
+        if gather is not None and li == 0:
+            g = gather
+            _call("s2c_sa_gather_gemm_bn_eval", out, g.B, g.N, g.m, g.ns, g.C, g.frs, g.fbs,
+                  g.radius, g.normalize, g.xyz.data_ptr(), g.new_xyz.data_ptr(),
+                  _ptr(g.feats), g.idx.data_ptr(), Cout, W.data_ptr(), W.stride(0),
+                  _ptr(gamma), _ptr(beta), bn.running_mean.data_ptr(),
+                  bn.running_var.data_ptr(), float(bn.eps), int(sp.relu), pn,
+                  out.data_ptr(), Cout,
+                  alg_bytes=4 * (min(g.B * g.N, M) * (3 + g.C) + M + out.numel()),
+                  alg_flops=2 * M * (3 + g.C) * Cout)
+        else:
+            if A.stride(1) != 1:
+                A = A.contiguous()
+            K_in = A.shape[1]
+            _call("s2c_rows_gemm_bn_eval", out, M, Cout, K_in, A.data_ptr(), A.stride(0),
+                  W.data_ptr(), W.stride(0), _ptr(gamma), _ptr(beta),
+                  bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.eps),
+                  int(sp.relu), pn, out.data_ptr(), Cout,
+                  alg_bytes=4 * (M * K_in + out.numel()), alg_flops=2 * M * K_in * Cout)
+        A = out
+    return A
+
+
 def _weight_grad(dY, A):
     """dW (Cout,Cin) = dY^T (Cout,M) @ A (M,Cin) with M up to ~1e6 and a tiny
     output: a plain GEMM call gives the library ONE output tile and a million-deep
@@ -508,8 +562,19 @@ def mlp_supported(specs, params):
     return True
 
 
+def _no_backward(*tensors):
+    """True when nothing downstream can ask for a gradient (torch.no_grad(), or no
+    input / parameter requires one).  ctx.needs_input_grad inside a Function ignores the
+    grad mode, so this is decided before Function.apply."""
+    if not torch.is_grad_enabled():
+        return True
+    return not any(t is not None and torch.is_tensor(t) and t.requires_grad for t in tensors)
+
+
 def mlp_rows(X, specs, params, pool_ns=0):
     """Apply the layer stack to row-major X (M, Cin) -> (M or M/pool_ns, Cout)."""
+    if _no_backward(X, *params) and _eval_fusable(specs, params, pool_ns):
+        return _eval_stack(X, None, X.shape[0], X.device, specs, pool_ns, params)
     return _MLPRows.apply(X, None, None, None, None, specs, pool_ns, *params)
 
 
@@ -528,6 +593,9 @@ def sa_group_mlp_pool(xyz, new_xyz, feats_pm, idx, radius, normalize, mlp):
     first_bn = specs[0].bn
     if (FUSE_GATHER and USE_MFMA_GEMM and not specs[0].has_bias
             and params[0].stride(1) == 1):
+        if _no_backward(xyz, new_xyz, feats_pm, *params) and _eval_fusable(specs, params, ns):
+            g = GatherSpec(xyz, new_xyz, feats_pm, idx, radius, normalize)
+            return _eval_stack(None, g, g.rows, xyz.device, specs, ns, params).view(B, m, -1)
         out = _MLPRows.apply(None, xyz, new_xyz, feats_pm, (idx, radius, normalize),
                              specs, ns, *params)
     else:

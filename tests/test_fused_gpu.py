@@ -356,3 +356,42 @@ def test_device_prefetcher_delivers_identical_batches():
         assert torch.equal(dd["lang_len"].cpu(), host[i]["lang_len"])
         seen += 1
     assert seen == 5
+
+
+@pytest.mark.parametrize("B,N,C,npoint,radius,ns,mlp", [
+    (2, 4096, 5, 512, 0.3, 64, [64, 64, 128]),
+    (2, 1024, 128, 256, 0.5, 32, [128, 128, 256]),
+    (3, 700, 61, 90, 0.6, 16, [128, 128, 100]),
+])
+def test_sa_inference_epilogue_matches_unfused(B, N, C, npoint, radius, ns, mlp):
+    """eval() + no_grad: BN, ReLU and the max-pool leave with the GEMM
+    (s2c_*_gemm_bn_eval) -- same values as the op-by-op torch path."""
+    from scan2cap_amd.pointnet2.pointnet2_modules import PointnetSAModuleVotes
+    from scan2cap_amd.pointnet2 import fused
+    torch.manual_seed(2)
+    sa = PointnetSAModuleVotes(npoint=npoint, radius=radius, nsample=ns,
+                               mlp=[C] + mlp, use_xyz=True, normalize_xyz=True).cuda()
+    for m in sa.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.uniform_(-0.3, 0.3)
+            m.running_mean.uniform_(-0.2, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+    sa.eval()
+    ref = copy.deepcopy(sa)
+    ref._fused_ok = lambda xyz: False
+    xyz = torch.from_numpy(scene_xyz(B, N, seed=4)).cuda()
+    feats = torch.randn(B, N, C, device="cuda")
+    with torch.no_grad():
+        assert fused.FUSE_EVAL_EPILOGUE
+        nx, nf, ni = sa(xyz, feats.transpose(1, 2))
+        rx, rf, ri = ref(xyz, feats.transpose(1, 2).contiguous())
+        fused.FUSE_EVAL_EPILOGUE = False
+        try:
+            _, nf2, _ = sa(xyz, feats.transpose(1, 2))
+        finally:
+            fused.FUSE_EVAL_EPILOGUE = True
+    assert torch.equal(ni, ri) and torch.equal(nx, rx)
+    assert nf.shape == rf.shape
+    assert _rel(nf, rf) < 1e-4
+    assert _rel(nf, nf2) < 1e-6          # same GEMM, same affine arithmetic
