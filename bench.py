@@ -314,7 +314,13 @@ def main():
         # geometry in flight; a train step (~12.6 ms) hides one chain (~5.8 ms)
         depth = 1 if wl["train"] else 3
         depth = int(os.environ.get("S2C_GEO_DEPTH", depth))
-        slots = GeometrySlots(model.backbone_net, dd["point_clouds"], depth)
+        # forward-only steps are shorter than one FPS chain even with 3 chains in
+        # flight: compute the geometry of `group` batches per pass (stacked clouds),
+        # two groups alternating
+        group = int(os.environ.get("S2C_GEO_GROUP", 1 if wl["train"] else 3))
+        if group > 1:
+            depth = 2 * group
+        slots = GeometrySlots(model.backbone_net, dd["point_clouds"], depth, group)
 
     if use_graph:
         # whole step = one hipGraph replay (fwd + loss + bwd [+ Adam]); with N>1
@@ -352,8 +358,13 @@ def main():
                 replay = GraphedCallable(lambda p=p: eager_step(with_geometry(p))).capture()
             replays.append(replay)
         if overlap:
-            for p in range(depth):
-                slots.refill(p, dd["point_clouds"])
+            G = slots.group
+            if G > 1:
+                for g in range(depth // G):
+                    slots.refill_group(g, [dd["point_clouds"]] * G)
+            else:
+                for p in range(depth):
+                    slots.refill(p, dd["point_clouds"])
             counter = {"i": 0}
 
             def step(_dd):
@@ -362,7 +373,10 @@ def main():
                 slots.acquire(p)                       # geometry of this step is published
                 out = replays[p]()
                 slots.release(p)
-                slots.refill(p, dd["point_clouds"])    # geometry of step i+depth
+                if G == 1:
+                    slots.refill(p, dd["point_clouds"])    # geometry of step i+depth
+                elif (p + 1) % G == 0:                 # group fully consumed: next G batches
+                    slots.refill_group(p // G, [dd["point_clouds"]] * G)
                 return out
         else:
             def step(_dd):
@@ -466,7 +480,9 @@ def main():
                        "scenes_per_gpu": B, "global_batch": B * world,
                        "parallelism": "dp%d" % world,
                        "launch": "hipGraph replay" if use_graph else "eager",
-                       "geometry": ("%d batch(es) ahead on side stream(s)" % depth)
+                       "geometry": ("%d batch(es) ahead on side stream(s)%s" % (
+                           depth, ", %d batches per geometry pass" % slots.group
+                           if slots is not None and slots.group > 1 else ""))
                                    if overlap else "in-line",
                        "grad_allreduce_bytes": ddp.nbytes if ddp else 0},
             "roofline": roof,
