@@ -545,34 +545,40 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(
 //   alpha = softmax_l(s) ; att[r,:] = sum_l alpha[l] * feats[r,l,:]
 // ---------------------------------------------------------------------------
 constexpr int AL_MAXL = 32;
+// LT > 0: L == LT known at compile time (straight-line code, every load of a row in
+// flight at once); LT == 0: runtime L <= AL_MAXL.
+template <int LT>
 __global__ __launch_bounds__(256) void attn_local_kernel(
-    int R, int L, int H, int F, const float *__restrict__ mapped,
+    int R, int Lrt, int H, int F, const float *__restrict__ mapped,
     const float *__restrict__ q, int ldq, const float *__restrict__ wa, float ba,
     const float *__restrict__ valid, const float *__restrict__ feats,
     float *__restrict__ alpha, float *__restrict__ att, int lda) {
+  constexpr int LM = LT > 0 ? LT : AL_MAXL;
+  const int L = LT > 0 ? LT : Lrt;
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= R) return;
   const int H4 = H >> 2;
-  float sc[AL_MAXL];
+  float sc[LM];
 #pragma unroll
-  for (int l = 0; l < AL_MAXL; ++l) sc[l] = 0.0f;
+  for (int l = 0; l < LM; ++l) sc[l] = 0.0f;
+  const float4 *m4 = reinterpret_cast<const float4 *>(mapped + (size_t)r * L * H);
   for (int h4 = lane; h4 < H4; h4 += 64) {
     const float4 qq = reinterpret_cast<const float4 *>(q + (size_t)r * ldq)[h4];
     const float4 w = reinterpret_cast<const float4 *>(wa)[h4];
+    float4 m[LM];
 #pragma unroll
-    for (int l = 0; l < AL_MAXL; ++l) {
-      if (l < L) {
-        const float4 m = reinterpret_cast<const float4 *>(mapped + ((size_t)r * L + l) * H)[h4];
-        sc[l] += w.x * fast_tanh(m.x + qq.x) + w.y * fast_tanh(m.y + qq.y) +
-                 w.z * fast_tanh(m.z + qq.z) + w.w * fast_tanh(m.w + qq.w);
-      }
-    }
+    for (int l = 0; l < LM; ++l)
+      m[l] = (LT > 0 || l < L) ? m4[(size_t)l * H4 + h4] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int l = 0; l < LM; ++l)
+      sc[l] += w.x * fast_tanh(m[l].x + qq.x) + w.y * fast_tanh(m[l].y + qq.y) +
+               w.z * fast_tanh(m[l].z + qq.z) + w.w * fast_tanh(m[l].w + qq.w);
   }
   float mx = -INFINITY;
 #pragma unroll
-  for (int l = 0; l < AL_MAXL; ++l) {
-    if (l < L) {
+  for (int l = 0; l < LM; ++l) {
+    if (LT > 0 || l < L) {
       float v = sc[l];
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -584,20 +590,24 @@ __global__ __launch_bounds__(256) void attn_local_kernel(
   }
   float sum = 0.0f;
 #pragma unroll
-  for (int l = 0; l < AL_MAXL; ++l)
-    if (l < L) { sc[l] = expf(sc[l] - mx); sum += sc[l]; }
+  for (int l = 0; l < LM; ++l)
+    if (LT > 0 || l < L) { sc[l] = expf(sc[l] - mx); sum += sc[l]; }
   const float inv = 1.0f / sum;
 #pragma unroll
-  for (int l = 0; l < AL_MAXL; ++l)
-    if (l < L) {
+  for (int l = 0; l < LM; ++l)
+    if (LT > 0 || l < L) {
       sc[l] *= inv;
       if (lane == 0) alpha[(size_t)r * L + l] = sc[l];
     }
   for (int f = lane; f < F; f += 64) {
+    float v[LM];
+#pragma unroll
+    for (int l = 0; l < LM; ++l)
+      v[l] = (LT > 0 || l < L) ? feats[((size_t)r * L + l) * F + f] : 0.0f;
     float a = 0.0f;
 #pragma unroll
-    for (int l = 0; l < AL_MAXL; ++l)
-      if (l < L) a += sc[l] * feats[((size_t)r * L + l) * F + f];
+    for (int l = 0; l < LM; ++l)
+      if (LT > 0 || l < L) a += sc[l] * v[l];
     att[(size_t)r * lda + f] = a;
   }
 }
@@ -715,8 +725,13 @@ extern "C" int s2c_attn_local_fwd(int R, int L, int H, int F, const float *mappe
   if (R <= 0 || L <= 0 || L > AL_MAXL || (H & 3) || (ldq & 3) || F <= 0 || !mapped || !q ||
       !wa || !feats || !alpha || !att)
     return -1;
-  hipLaunchKernelGGL(attn_local_kernel, dim3((R + 3) / 4), dim3(256), 0,
-                     (hipStream_t)stream, R, L, H, F, mapped, q, ldq, wa, ba, valid, feats,
-                     alpha, att, lda);
+  if (L == 10)       // CONF default num_locals (scripts/train.py:332)
+    hipLaunchKernelGGL(attn_local_kernel<10>, dim3((R + 3) / 4), dim3(256), 0,
+                       (hipStream_t)stream, R, L, H, F, mapped, q, ldq, wa, ba, valid, feats,
+                       alpha, att, lda);
+  else
+    hipLaunchKernelGGL(attn_local_kernel<0>, dim3((R + 3) / 4), dim3(256), 0,
+                       (hipStream_t)stream, R, L, H, F, mapped, q, ldq, wa, ba, valid, feats,
+                       alpha, att, lda);
   return chk("attn_local_fwd");
 }
