@@ -213,6 +213,14 @@ int s2c_attn_bwd(int R, int K, int H, int F, const float *datt, int ldd,
                  const float *M, const float *q, int ldq, const float *wa, float *dM,
                  float *dq, float *dwa_rows, void *stream);
 
+/* bf16x3 planes of a row-major fp32 matrix A (M x K, row stride lda) for a library
+ * bf16 GEMM: out (M x 6*Kp) bf16, Kp = K rounded up to 8, K-block b of every row holds
+ * plane order6[b] (0 hi = bf16(x), 1 mid = bf16(x - hi), 2 lo = bf16(x - hi - mid)),
+ * zero padded.  With order (0,0,1,1,0,2) for the activations and (0,1,0,1,2,0) for the
+ * weights, A6 W6^T is the fp32-accurate product from ONE bf16 GEMM of depth 6*Kp. */
+int s2c_split_bf16x3(long long M, int K, const float *A, long long lda, void *out,
+                     const int *order6, void *stream);
+
 /* local attention of the greedy decode (caption_module.py:502-592 with num_locals):
  * mapped (R,L,H) = map_feat of the L gathered objects of each row, q (R,H) = map_hidd(h1),
  * wa (H) / ba = the `attend` layer, valid (R,L) 0/1 or NULL, feats (R,L,F):

@@ -30,6 +30,44 @@ _I, _F32, _P = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 _C.register("s2c_attn_local_fwd", [_I, _I, _I, _I, _P, _P, _I, _P, _F32, _P, _P, _P, _P, _I, _P])
 # greedy decode: split-weight step + one-pass local attention kernel
 FUSE_EVAL_STEP = True
+# greedy decode GEMMs (thousands of rows: on the fp32 MFMA roof) as ONE library bf16 GEMM
+# over the bf16x3 planes of both operands (csrc/s2c_decoder.hip: split_bf16x3)
+SPLIT_EVAL_GEMMS = True
+SPLIT_EVAL_MIN_ROWS = 4096     # measured: +5 % at 8192 rows (cfg5), -9 % at 2048 (cfg3e)
+_split_ok = None
+
+
+def _split_gemm_available():
+    """torch.mm(bf16, bf16, out_dtype=float32) and the fused GRU pointwise op exist?"""
+    global _split_ok
+    if _split_ok is None:
+        try:
+            a = torch.zeros(8, 16, dtype=torch.bfloat16, device="cuda")
+            torch.mm(a, a.t(), out_dtype=torch.float32)
+            _split_ok = hasattr(torch.ops.aten, "_thnn_fused_gru_cell")
+        except Exception:
+            _split_ok = False
+    return _split_ok
+_C.register("s2c_split_bf16x3", [ctypes.c_longlong, _I, _P, ctypes.c_longlong, _P, _P, _P])
+_ORDER_A = (ctypes.c_int * 6)(0, 0, 1, 1, 0, 2)      # activations: hi hi mid mid hi lo
+_ORDER_W = (ctypes.c_int * 6)(0, 1, 0, 1, 2, 0)      # weights:     hi mid hi mid lo hi
+
+
+def _split6(x, order):
+    """fp32 (M,K) (row stride >= K, unit column stride) -> bf16 (M, 6*Kp) planes."""
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    M, K = x.shape
+    Kp = (K + 7) // 8 * 8
+    out = torch.empty((M, 6 * Kp), dtype=torch.bfloat16, device=x.device)
+    _C.call("s2c_split_bf16x3", M, K, x.data_ptr(), x.stride(0), out.data_ptr(),
+            ctypes.addressof(order), _C.stream_ptr())
+    return out
+
+
+def _mm6(a6, w6):
+    """fp32-accurate a @ w^T from the planes of both (one bf16 GEMM, fp32 accumulate)."""
+    return torch.mm(a6, w6.t(), out_dtype=torch.float32)
 
 
 def select_target(data_dict):
@@ -354,8 +392,39 @@ class TopDownSceneCaptionModule(nn.Module):
             mapped_c, local_c = mapped.contiguous(), local.contiguous()
             alpha = torch.empty(R, L, device=dev)
             att = torch.empty(R, F_, device=dev)
+            split = (SPLIT_EVAL_GEMMS and R >= SPLIT_EVAL_MIN_ROWS
+                     and _split_gemm_available())
+            if split:
+                c1, c2 = self.recurrent_cell_1, self.recurrent_cell_2
+                w6 = {"x": _split6(W_td[:, :E], _ORDER_W), "h": _split6(W_td[:, E:E + H], _ORDER_W),
+                      "ih1": _split6(c1.weight_ih, _ORDER_W), "hh1": _split6(c1.weight_hh, _ORDER_W),
+                      "q": _split6(self.map_hidd.weight, _ORDER_W),
+                      "l": _split6(W_lang[:, F_:], _ORDER_W),
+                      "ih2": _split6(c2.weight_ih, _ORDER_W), "hh2": _split6(c2.weight_hh, _ORDER_W)}
+                gru = torch.ops.aten._thnn_fused_gru_cell
+                h1_6 = _split6(hidden_1, _ORDER_A)
+                h2_6 = _split6(hidden_2, _ORDER_A)
         for t in range(T):
-            if fused_step:
+            if fused_step and split:
+                # every GEMM of the step with K >= 300 on the bf16 pipe; each activation
+                # is split once and shared by the products that read it
+                x1 = (_mm6(_split6(step_input, _ORDER_A), w6["x"]) + P_tf).add_(
+                    _mm6(h2_6, w6["h"])).relu_()
+                hidden_1 = gru(_mm6(_split6(x1, _ORDER_A), w6["ih1"]), _mm6(h1_6, w6["hh1"]),
+                               hidden_1, c1.bias_ih, c1.bias_hh)[0]
+                h1_6 = _split6(hidden_1, _ORDER_A)
+                qh = _mm6(h1_6, w6["q"])
+                if _C.TIMER.enabled:
+                    _C.TIMER.alg_bytes = 4 * (R * L * (H + F_ + 1) + R * (H + F_))
+                _C.call("s2c_attn_local_fwd", R, L, H, F_, mapped_c.data_ptr(),
+                        qh.data_ptr(), H, wa.data_ptr(), 0.0, None, local_c.data_ptr(),
+                        alpha.data_ptr(), att.data_ptr(), F_, _C.stream_ptr())
+                x2 = torch.addmm(b_lang, att, Wa_t).add_(_mm6(h1_6, w6["l"])).relu_()
+                hidden_2 = gru(_mm6(_split6(x2, _ORDER_A), w6["ih2"]), _mm6(h2_6, w6["hh2"]),
+                               hidden_2, c2.bias_ih, c2.bias_hh)[0]
+                h2_6 = _split6(hidden_2, _ORDER_A)
+                m = alpha
+            elif fused_step:
                 x1 = torch.addmm(P_tf, step_input, Wx_t)
                 x1.addmm_(hidden_2, Wh_t).relu_()
                 hidden_1 = self.recurrent_cell_1(x1, hidden_1)

@@ -344,14 +344,22 @@ def test_eval_greedy_decode_fused_step_matches_step_loop():
         "lang_feat": (torch.randn(B, 32, 300, generator=g) * 0.3).cuda(),
     }
     outs = {}
-    old = cm.FUSE_EVAL_STEP
+    old = (cm.FUSE_EVAL_STEP, cm.SPLIT_EVAL_MIN_ROWS)
     try:
-        for flag in (False, True):
-            cm.FUSE_EVAL_STEP = flag
+        for flag in (False, True, "split"):
+            cm.FUSE_EVAL_STEP = bool(flag)
+            # "split": the GEMMs of the step as bf16x3-plane library GEMMs (normally only
+            # from 4096 rows up)
+            cm.SPLIT_EVAL_MIN_ROWS = 1 if flag == "split" else 1 << 30
             with torch.no_grad():
                 outs[flag] = mod(dict(dd), use_tf=False, is_eval=True, max_len=8)
     finally:
-        cm.FUSE_EVAL_STEP = old
+        cm.FUSE_EVAL_STEP, cm.SPLIT_EVAL_MIN_ROWS = old
+    assert cm._split_gemm_available()
+    s_, b = outs["split"], outs[False]
+    assert torch.equal(s_["lang_cap"].argmax(-1), b["lang_cap"].argmax(-1))
+    assert _rel(s_["lang_cap"], b["lang_cap"]) < 1e-4
+    assert _rel(s_["topdown_attn"], b["topdown_attn"]) < 1e-4
     a, b = outs[True], outs[False]
     assert a["lang_cap"].shape == b["lang_cap"].shape == (B, K, 7, V)
     assert torch.equal(a["lang_cap"].argmax(-1), b["lang_cap"].argmax(-1))
