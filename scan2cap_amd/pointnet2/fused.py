@@ -74,6 +74,15 @@ USE_MFMA_GEMM = True
 SCATTER_DW = True
 
 
+def set_gemm_split(on):
+    """Products of the rows GEMMs: True = bf16x3 split on the bf16 matrix pipe (default,
+    fp32-accurate), False = exact fp32 MFMA chain.  Returns the previous setting."""
+    lib = _C.load()
+    lib.s2c_gemm_set_split.argtypes = [_I]
+    lib.s2c_gemm_set_split.restype = _I
+    return bool(lib.s2c_gemm_set_split(int(bool(on))))
+
+
 def fused_available(t):
     return t.is_cuda
 

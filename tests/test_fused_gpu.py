@@ -424,3 +424,28 @@ def test_sa_inference_epilogue_matches_unfused(B, N, C, npoint, radius, ns, mlp)
     assert nf.shape == rf.shape
     assert _rel(nf, rf) < 1e-4
     assert _rel(nf, nf2) < 1e-6          # same GEMM, same affine arithmetic
+
+
+def test_gemm_split_products_match_exact_fp32_chain():
+    """bf16x3 split products (6 bf16 MFMAs per product) vs the exact fp32 MFMA chain on a
+    whole set-abstraction stack, train mode: both within 2e-6 of scale of each other,
+    i.e. two orders of magnitude inside the 1e-4 feature tolerance."""
+    from scan2cap_amd.pointnet2.pointnet2_modules import PointnetSAModuleVotes
+    from scan2cap_amd.pointnet2 import fused
+    torch.manual_seed(0)
+    sa = PointnetSAModuleVotes(npoint=512, radius=0.3, nsample=32, mlp=[131, 128, 128, 256],
+                               use_xyz=True, normalize_xyz=True).cuda().train()
+    xyz = torch.from_numpy(scene_xyz(2, 4096, seed=9)).cuda()
+    feats = torch.randn(2, 4096, 131, device="cuda")
+    state = copy.deepcopy(sa.state_dict())
+    outs = {}
+    prev = fused.set_gemm_split(True)
+    try:
+        for mode in (True, False):
+            fused.set_gemm_split(mode)
+            sa.load_state_dict(state)
+            with torch.no_grad():
+                outs[mode] = sa(xyz, feats.transpose(1, 2))[1].clone()
+    finally:
+        fused.set_gemm_split(prev)
+    assert _rel(outs[True], outs[False]) < 2e-6
