@@ -402,7 +402,7 @@ __device__ __forceinline__ void x3_store_quad(unsigned short *base, int rows, in
 }
 
 template <int WM, int WN, int PRO>
-__global__ __launch_bounds__(256) void rows_gemm_x3_kernel(
+__global__ __launch_bounds__(256, 2) void rows_gemm_x3_kernel(
     long long M, int N, int K, const float *__restrict__ A, int lda,
     const float *__restrict__ W, int ldw, const float *__restrict__ pscale,
     const float *__restrict__ pshift, GatherArgs ga, float *__restrict__ Y, int ldy,
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void rows_gemm_x3_kernel(
   // staging map: thread -> (row = tid / 8 + 32*i, k-quad = tid % 8)
   const int sq = tid & 7, sr = tid >> 3;
   constexpr int AI = BM / 32, WI = BN / 32;
-  float4 ra[AI], rw[WI];
+  float4 ra[AI], rw[WI], rb[AI], rwb[WI];   // two slices of register prefetch
 
   // PRO_GATHER: per staged row, the source-row offsets (computed once)
   long long g_src[PRO == PRO_GATHER ? AI : 1];
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256) void rows_gemm_x3_kernel(
     }
   }
 
-  auto load_slice = [&](int k0) {
+  auto load_slice = [&](float4 (&ra)[AI], float4 (&rw)[WI], int k0) {
     const int k = k0 + sq * 4;
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
     if (PRO == PRO_BNRELU) {
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256) void rows_gemm_x3_kernel(
       rw[i] = v;
     }
   };
-  auto store_slice = [&]() {
+  auto store_slice = [&](float4 (&ra)[AI], float4 (&rw)[WI]) {
 #pragma unroll
     for (int i = 0; i < AI; ++i) x3_store_quad(As, BM, sr + 32 * i, sq, ra[i]);
 #pragma unroll
@@ -547,12 +547,7 @@ __global__ __launch_bounds__(256) void rows_gemm_x3_kernel(
   const unsigned short *a_row0 = As + (wm * 64 + li) * X3_LD + lk * 8;
   const unsigned short *w_row0 = Ws + (wn * 64 + li) * X3_LD + lk * 8;
 
-  load_slice(0);
-  for (int k0 = 0; k0 < K; k0 += BK) {
-    __syncthreads();           // previous slice fully consumed
-    store_slice();
-    __syncthreads();
-    if (k0 + BK < K) load_slice(k0 + BK);   // prefetch under the MFMAs
+  auto mfma_slice = [&]() {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       bf16x8 a[2][3], b[2][3];
@@ -579,6 +574,25 @@ __global__ __launch_bounds__(256) void rows_gemm_x3_kernel(
           acc[i][j] = c;
         }
     }
+  };
+
+  // Two slices of loads are in flight at any time (the MFMA phase of a slice is now
+  // shorter than one memory round trip): slice s+2 is requested as soon as the
+  // registers of slice s have been drained into LDS.
+  load_slice(ra, rw, 0);
+  if (K > BK) load_slice(rb, rwb, BK);
+  for (int k0 = 0; k0 < K; k0 += 2 * BK) {
+    __syncthreads();           // previous slice fully consumed
+    store_slice(ra, rw);
+    __syncthreads();
+    if (k0 + 2 * BK < K) load_slice(ra, rw, k0 + 2 * BK);
+    mfma_slice();
+    if (k0 + BK >= K) break;
+    __syncthreads();
+    store_slice(rb, rwb);
+    __syncthreads();
+    if (k0 + 3 * BK < K) load_slice(rb, rwb, k0 + 3 * BK);
+    mfma_slice();
   }
 
   if (ep.mean != nullptr) {    // inference: BN + ReLU (+ max-pool) leave with the GEMM
