@@ -315,6 +315,22 @@ int s2c_query_locals(int B, int K, int T, int L, const double *corners,
                      int corner_mode, int include_self, double overlay_threshold,
                      float *local_masks, long long *ids_out, void *stream);
 
+/* EdgeConv message passing (models/graph_module.py:74-115): edge e = (b,i,l) from row i
+ * to column j = nbr[b,i,l] (int64, (B,K,L)); x (B,K,F).
+ *   s2c_edge_rows:    rows (B*K*L, 2F) = [ x[b,j] | x[b,i] - x[b,j] ]
+ *   s2c_edge_scatter: out (B,K,F) = sum over edges into j of msg[e]*slot[e] (zeroed by the
+ *                     callee), msgm (B*K*L,F) = msg*slot;  slot (B,K,L) uint8
+ * and their gradients (dx zeroed by the callee; d_msgm may be NULL). */
+int s2c_edge_rows(int B, int K, int L, int F, const float *x, const long long *nbr,
+                  float *rows, void *stream);
+int s2c_edge_rows_grad(int B, int K, int L, int F, const float *d_rows, const long long *nbr,
+                       float *dx, void *stream);
+int s2c_edge_scatter(int B, int K, int L, int F, const float *msg, const long long *nbr,
+                     const unsigned char *slot, float *out, float *msgm, void *stream);
+int s2c_edge_scatter_grad(int B, int K, int L, int F, const float *d_out, const float *d_msgm,
+                          const long long *nbr, const unsigned char *slot, float *d_msg,
+                          void *stream);
+
 #ifdef __cplusplus
 }
 #endif

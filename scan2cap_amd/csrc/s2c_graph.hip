@@ -139,6 +139,93 @@ __global__ __launch_bounds__(64 * QL_WAVES) void query_locals_kernel(
   if (lane < L) ids_out[((size_t)b * T + t) * L + rank] = my_pick;
 }
 
+// ---------------------------------------------------------------------------
+// EdgeConv message passing (models/graph_module.py:74-115 on torch_geometric's
+// source_to_target flow): edge e = (b, i, l) runs from row i to column j = nbr[b,i,l];
+//   rows[e] = [ x[b,j,:] | x[b,i,:] - x[b,j,:] ]              (message input)
+//   out[b,j,:] += msg[e,:] * slot[e] ; msgm[e,:] = msg[e,:] * slot[e]   (aggregation "add")
+// One wave per edge, lanes over the feature dimension; row-coalesced float atomics.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void edge_rows_kernel(
+    int K, int L, int F, const float *__restrict__ x, const long long *__restrict__ nbr,
+    float *__restrict__ rows, long long E) {
+  const int lane = threadIdx.x & 63;
+  for (long long e = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); e < E;
+       e += (long long)gridDim.x * 4) {
+    const long long bi = e / L, b = bi / K;
+    const long long j = nbr[e];
+    const float *xi = x + bi * F, *xj = x + (b * K + j) * F;
+    float *r = rows + e * 2 * F;
+    for (int f = lane; f < F; f += 64) {
+      const float vj = xj[f];
+      r[f] = vj;
+      r[F + f] = xi[f] - vj;
+    }
+  }
+}
+
+// dx[b,j,:] += dR[e,:F] - dR[e,F:] ; dx[b,i,:] += dR[e,F:]      (dx zeroed by the caller)
+__global__ __launch_bounds__(256) void edge_rows_grad_kernel(
+    int K, int L, int F, const float *__restrict__ dR, const long long *__restrict__ nbr,
+    float *__restrict__ dx, long long E) {
+  const int lane = threadIdx.x & 63;
+  for (long long e = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); e < E;
+       e += (long long)gridDim.x * 4) {
+    const long long bi = e / L, b = bi / K;
+    const long long j = nbr[e];
+    const float *g = dR + e * 2 * F;
+    float *di = dx + bi * F, *dj = dx + (b * K + j) * F;
+    for (int f = lane; f < F; f += 64) {
+      const float a = g[f], d = g[F + f];
+      atomicAdd(dj + f, a - d);
+      atomicAdd(di + f, d);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void edge_scatter_kernel(
+    int K, int L, int F, const float *__restrict__ msg, const long long *__restrict__ nbr,
+    const unsigned char *__restrict__ slot, float *__restrict__ out,
+    float *__restrict__ msgm, long long E) {
+  const int lane = threadIdx.x & 63;
+  for (long long e = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); e < E;
+       e += (long long)gridDim.x * 4) {
+    const long long b = e / ((long long)K * L);
+    const bool on = slot[e] != 0;
+    const float *m = msg + e * F;
+    float *o = out + (b * K + nbr[e]) * F;
+    for (int f = lane; f < F; f += 64) {
+      const float v = on ? m[f] : 0.0f;
+      msgm[e * F + f] = v;
+      if (on) atomicAdd(o + f, v);
+    }
+  }
+}
+
+// d_msg[e,:] = (d_out[b,j,:] + d_msgm[e,:]) * slot[e]        (d_msgm may be NULL)
+__global__ __launch_bounds__(256) void edge_scatter_grad_kernel(
+    int K, int L, int F, const float *__restrict__ d_out, const float *__restrict__ d_msgm,
+    const long long *__restrict__ nbr, const unsigned char *__restrict__ slot,
+    float *__restrict__ d_msg, long long E) {
+  const int lane = threadIdx.x & 63;
+  for (long long e = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); e < E;
+       e += (long long)gridDim.x * 4) {
+    const long long b = e / ((long long)K * L);
+    const bool on = slot[e] != 0;
+    const float *g = d_out + (b * K + nbr[e]) * F;
+    for (int f = lane; f < F; f += 64) {
+      float v = 0.0f;
+      if (on) v = g[f] + (d_msgm ? d_msgm[e * F + f] : 0.0f);
+      d_msg[e * F + f] = v;
+    }
+  }
+}
+
+static unsigned edge_grid(long long E) {
+  long long b = (E + 3) / 4;
+  return (unsigned)(b > 256 * 16 ? 256 * 16 : (b < 1 ? 1 : b));
+}
+
 }  // namespace
 
 extern "C" int s2c_query_locals(int B, int K, int T, int L, const double *corners,
@@ -159,4 +246,55 @@ extern "C" int s2c_query_locals(int B, int K, int T, int L, const double *corner
     return (int)e;
   }
   return 0;
+}
+
+static int chk_graph(const char *k) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    fprintf(stderr, "s2c: %s launch failed: %s\n", k, hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
+extern "C" int s2c_edge_rows(int B, int K, int L, int F, const float *x, const long long *nbr,
+                             float *rows, void *stream) {
+  if (B <= 0 || K <= 0 || L <= 0 || F <= 0 || !x || !nbr || !rows) return -1;
+  const long long E = (long long)B * K * L;
+  hipLaunchKernelGGL(edge_rows_kernel, dim3(edge_grid(E)), dim3(256), 0, (hipStream_t)stream,
+                     K, L, F, x, nbr, rows, E);
+  return chk_graph("edge_rows");
+}
+
+extern "C" int s2c_edge_rows_grad(int B, int K, int L, int F, const float *d_rows,
+                                  const long long *nbr, float *dx, void *stream) {
+  if (B <= 0 || K <= 0 || L <= 0 || F <= 0 || !d_rows || !nbr || !dx) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(dx, 0, sizeof(float) * (size_t)B * K * F, st) != hipSuccess) return -1;
+  const long long E = (long long)B * K * L;
+  hipLaunchKernelGGL(edge_rows_grad_kernel, dim3(edge_grid(E)), dim3(256), 0, st, K, L, F,
+                     d_rows, nbr, dx, E);
+  return chk_graph("edge_rows_grad");
+}
+
+extern "C" int s2c_edge_scatter(int B, int K, int L, int F, const float *msg,
+                                const long long *nbr, const unsigned char *slot, float *out,
+                                float *msgm, void *stream) {
+  if (B <= 0 || K <= 0 || L <= 0 || F <= 0 || !msg || !nbr || !slot || !out || !msgm) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * K * F, st) != hipSuccess) return -1;
+  const long long E = (long long)B * K * L;
+  hipLaunchKernelGGL(edge_scatter_kernel, dim3(edge_grid(E)), dim3(256), 0, st, K, L, F, msg,
+                     nbr, slot, out, msgm, E);
+  return chk_graph("edge_scatter");
+}
+
+extern "C" int s2c_edge_scatter_grad(int B, int K, int L, int F, const float *d_out,
+                                     const float *d_msgm, const long long *nbr,
+                                     const unsigned char *slot, float *d_msg, void *stream) {
+  if (B <= 0 || K <= 0 || L <= 0 || F <= 0 || !d_out || !nbr || !slot || !d_msg) return -1;
+  const long long E = (long long)B * K * L;
+  hipLaunchKernelGGL(edge_scatter_grad_kernel, dim3(edge_grid(E)), dim3(256), 0,
+                     (hipStream_t)stream, K, L, F, d_out, d_msgm, nbr, slot, d_msg, E);
+  return chk_graph("edge_scatter_grad");
 }

@@ -38,6 +38,75 @@ _I, _D, _P = ctypes.c_int, ctypes.c_double, ctypes.c_void_p
 _C.register("s2c_query_locals", [_I, _I, _I, _I, _P, _P, _P, _I, _I, _D, _P, _P, _P])
 # one launch instead of ~35 (csrc/s2c_graph.hip); False: batched torch restatement
 USE_QUERY_KERNEL = True
+# EdgeConv gather / scatter as HIP kernels (csrc/s2c_graph.hip); False: torch ops
+USE_EDGE_KERNELS = True
+_C.register("s2c_edge_rows", [_I, _I, _I, _I, _P, _P, _P, _P])
+_C.register("s2c_edge_rows_grad", [_I, _I, _I, _I, _P, _P, _P, _P])
+_C.register("s2c_edge_scatter", [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P])
+_C.register("s2c_edge_scatter_grad", [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P])
+
+
+class _EdgeRows(torch.autograd.Function):
+    """x (B,K,F), nbr (B,K,L) int64 -> rows (B*K*L, 2F) = [x_j | x_i - x_j] of every edge
+    i -> j = nbr[b,i,l] (graph_module.py:102-109)."""
+
+    @staticmethod
+    def forward(ctx, x, nbr):
+        x, nbr = x.contiguous(), nbr.contiguous()
+        B, K, F = x.shape
+        L = nbr.shape[2]
+        rows = torch.empty((B * K * L, 2 * F), device=x.device)
+        with torch.cuda.device(x.device):
+            _C.call("s2c_edge_rows", B, K, L, F, x.data_ptr(), nbr.data_ptr(), rows.data_ptr(),
+                    _C.stream_ptr())
+        ctx.save_for_backward(nbr)
+        ctx.dims = (B, K, L, F)
+        return rows
+
+    @staticmethod
+    def backward(ctx, d_rows):
+        (nbr,) = ctx.saved_tensors
+        B, K, L, F = ctx.dims
+        d_rows = d_rows.contiguous()
+        dx = torch.empty((B, K, F), device=d_rows.device)
+        with torch.cuda.device(d_rows.device):
+            _C.call("s2c_edge_rows_grad", B, K, L, F, d_rows.data_ptr(), nbr.data_ptr(),
+                    dx.data_ptr(), _C.stream_ptr())
+        return dx, None
+
+
+class _EdgeScatter(torch.autograd.Function):
+    """msg (B*K*L, F), nbr, slot (B,K,L) bool -> (out (B,K,F) = messages summed at their
+    target column, msg * slot) (aggregation "add", :74-100)."""
+
+    @staticmethod
+    def forward(ctx, msg, nbr, slot):
+        msg, nbr = msg.contiguous(), nbr.contiguous()
+        slot8 = slot.to(torch.uint8).contiguous()
+        B, K, L = nbr.shape
+        F = msg.shape[1]
+        out = torch.empty((B, K, F), device=msg.device)
+        msgm = torch.empty_like(msg)
+        with torch.cuda.device(msg.device):
+            _C.call("s2c_edge_scatter", B, K, L, F, msg.data_ptr(), nbr.data_ptr(),
+                    slot8.data_ptr(), out.data_ptr(), msgm.data_ptr(), _C.stream_ptr())
+        ctx.save_for_backward(nbr, slot8)
+        ctx.dims = (B, K, L, F)
+        return out, msgm
+
+    @staticmethod
+    def backward(ctx, d_out, d_msgm):
+        nbr, slot8 = ctx.saved_tensors
+        B, K, L, F = ctx.dims
+        d_out = d_out.contiguous()
+        if d_msgm is not None:
+            d_msgm = d_msgm.contiguous()
+        d_msg = torch.empty((B * K * L, F), device=d_out.device)
+        with torch.cuda.device(d_out.device):
+            _C.call("s2c_edge_scatter_grad", B, K, L, F, d_out.data_ptr(),
+                    d_msgm.data_ptr() if d_msgm is not None else None, nbr.data_ptr(),
+                    slot8.data_ptr(), d_msg.data_ptr(), _C.stream_ptr())
+        return d_msg, None, None
 
 
 def query_locals(corners, object_masks, target_ids, num_locals, query_mode,
@@ -129,6 +198,12 @@ class EdgeConv(nn.Module):
         messages (B,K,L,F'))."""
         B, K, L = nbr.shape
         F = x.shape[-1]
+        if USE_EDGE_KERNELS and x.is_cuda and x.dtype == torch.float32:
+            l1, l2 = self.map_edge[0], self.map_edge[2]
+            rows = _EdgeRows.apply(x, nbr)
+            m = fused.mlp_rows(rows, _EDGE_SPECS, (l1.weight, l1.bias, l2.weight, l2.bias))
+            out, msgm = _EdgeScatter.apply(m, nbr, slot)
+            return out, msgm.view(B, K, L, -1)
         x_j = x.unsqueeze(2).expand(B, K, L, F)                        # source=row
         x_i = torch.gather(x, 1, nbr.view(B, K * L, 1).expand(B, K * L, F)
                            ).view(B, K, L, F)                          # target=col
