@@ -10,11 +10,14 @@
 // GEMMs outside the loop (word / target projections, classifier, every weight
 // gradient), and the whole sequence replays from a hipGraph.
 //
-// Lane layout of the small-batch matrix-vector kernels: a wave owns one output
-// feature; lane = (row r = lane & 7, chunk c = lane >> 3).  The 8 chunk lanes of a
-// row read consecutive float4s of the weight row (128 B per load instruction, the
-// 8 row lanes of a chunk share the address), each lane accumulates its row's
-// partial dot product, and 3 xor-shuffles fold the chunks.  R <= 8 rows per pass.
+// Lane layout of the small-batch matrix-vector kernels: a block of 256 threads owns a
+// few outputs (4 for the plain products, 2 hidden units for the GRU); thread = (row r =
+// tid & 7, chunk c = tid >> 3 of 32).  The chunk lanes stride over the float4s of the
+// input row, which each lane keeps in registers for all outputs of the block; partial
+// dot products are folded with 3 xor-shuffles per wave and one LDS exchange.  R <= 8
+// rows per pass (blockIdx.y walks larger batches).  The greedy-decode kernels at the
+// bottom (local attention, bf16x3 operand split) serve the evaluation path, where the
+// batch is B*K rows and the GEMMs go to the library.
 #include "s2c_common.h"
 #include "../../include/s2c_fused.h"
 
