@@ -560,19 +560,18 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_x3_kernel(
         }
       // x*y ~= sum of the 6 plane products with i + j <= 2 (hi=0, mid=1, lo=2):
       // small terms first
+      // term-major order: the four accumulators take turns, so consecutive MFMAs are
+      // independent (a chain of six on one accumulator stalls on every RAW: the SQ
+      // counters showed 49 % issue-stall cycles)
+      constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int t = 0; t < 6; ++t)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          f32x16 c = acc[i][j];
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
-          acc[i][j] = c;
-        }
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[t]], b[j][TB[t]],
+                                                                acc[i][j], 0, 0, 0);
     }
   };
 
