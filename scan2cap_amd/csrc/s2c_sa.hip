@@ -434,7 +434,7 @@ __global__ void bn_eval_coeffs_kernel(int C, float eps,
 
 static int stat_blocks(long long M, long long *rows_per_block) {
   long long nb = (M + 63) / 64;  // >= 64 rows per block: small inputs still fill the chip
-  if (nb > 1024) nb = 1024;
+  if (nb > 4096) nb = 4096;
   if (nb < 1) nb = 1;
   *rows_per_block = (M + nb - 1) / nb;
   return (int)((M + *rows_per_block - 1) / *rows_per_block);
