@@ -1,0 +1,334 @@
+"""Training items assembled ON THE DEVICE from HBM-resident scenes.
+
+Reference: `ScannetReferenceDataset.__getitem__` (lib/dataset.py:320-540) builds every item
+in numpy on a DataLoader worker -- vertex sampling, channel concatenation, flips and
+rotations, votes, box labels -- and the trainer copies the batch to the GPU
+(lib/solver.py:280-287: 173 MB per cfg3 step, plus h5py reads of the multiview features).
+
+Here the scenes live in device memory (`SceneStore`; the whole ScanNet train split with its
+128 multiview channels is ~100 GB, a third of one MI355X) and a batch is one gather pass +
+three small kernels (csrc/s2c_scene.hip).  The host keeps exactly one job: drawing the
+random numbers with numpy in the reference's order (`SceneBatchBuilder.draw`), so that
+an item is bit-for-bit the reference's item for the same `np.random` state.  Per step the
+host sends B*N vertex indices and 32 doubles per item (2.6 MB at cfg3) in ONE pinned copy.
+
+    store = SceneStore(device, multiview_width=128)
+    store.add_scene("scene0000_00", mesh_vertices, instance_labels, semantic_labels,
+                    instance_bboxes, multiview=..., rotations={object_id: 3x3})
+    store.finalize()
+    builder = SceneBatchBuilder(store, mean_size_arr, num_points=40000, use_normal=True,
+                                use_multiview=True, augment=True)
+    draws = builder.draw(scene_ids)                       # host, numpy
+    data_dict = builder.build(scene_ids, object_ids, draws)   # device tensors
+
+There is no CPU path: `build` raises `_C.S2CError` if libs2c_hip.so is missing.
+Not produced: `pcl_color`, `load_time` (visualisation / logging only) and the language
+entries, which `AnnotationTable` serves from resident tensors.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _C
+
+MAX_NUM_OBJ = 128        # lib/dataset.py:27
+MAX_INSTANCE = 2048      # include/s2c_scene.h
+
+# nyu40 ids with votes / boxes (model_util_scannet.py:88) and their ScanRefer class
+# (model_util_scannet.py:100-115 over scannetv2-labels.combined.tsv; "others" = 17)
+NYU40IDS = (3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 23, 24, 25,
+            26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40)
+_NAMED = {3: 0, 4: 1, 5: 2, 6: 3, 7: 4, 8: 5, 9: 6, 10: 7, 11: 8, 12: 9, 14: 10, 16: 11,
+          24: 12, 28: 13, 33: 14, 34: 15, 36: 16}
+CLASS_OF_NYU40 = np.full(41, -1, np.int32)
+for _i in NYU40IDS:
+    CLASS_OF_NYU40[_i] = _NAMED.get(_i, 17)
+VOTE_ID_MASK = sum(1 << i for i in NYU40IDS)
+
+_I, _L, _P = ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p
+
+
+class _Labels(ctypes.Structure):
+    """s2c_scene_labels (include/s2c_scene.h)."""
+    _names = ("center_label", "size_class_label", "size_residual_label", "sem_cls_label",
+              "scene_object_ids", "scene_object_rotations", "scene_object_rotation_masks",
+              "box_label_mask", "ref_box_label", "gt_box_corner_label", "gt_box_masks",
+              "gt_box_object_ids", "num_bbox", "ref_center_label", "ref_size_class_label",
+              "ref_size_residual_label", "ref_box_corner_label")
+    _fields_ = [(n, _P) for n in _names]
+
+
+_C.register("s2c_scene_floor_height", [_L, _P, _I, _P, _P])
+_C.register("s2c_scene_gather", [_I] * 9 + [_P] * 9)
+_C.register("s2c_scene_votes", [_I, _I, _I, _P, _P, _P, _P, _P, _P, ctypes.c_ulonglong,
+                                _P, _P, _P])
+_C.register("s2c_scene_box_labels", [_I, _I] + [_P] * 9 + [_Labels, _P])
+
+# (shape after (B,), dtype) of the per-box / per-item outputs
+_LABEL_SPECS = {
+    "center_label": ((MAX_NUM_OBJ, 3), torch.float32),
+    "size_class_label": ((MAX_NUM_OBJ,), torch.int64),
+    "size_residual_label": ((MAX_NUM_OBJ, 3), torch.float32),
+    "sem_cls_label": ((MAX_NUM_OBJ,), torch.int64),
+    "scene_object_ids": ((MAX_NUM_OBJ,), torch.int64),
+    "scene_object_rotations": ((MAX_NUM_OBJ, 3, 3), torch.float32),
+    "scene_object_rotation_masks": ((MAX_NUM_OBJ,), torch.int64),
+    "box_label_mask": ((MAX_NUM_OBJ,), torch.float32),
+    "ref_box_label": ((MAX_NUM_OBJ,), torch.int64),
+    "gt_box_corner_label": ((MAX_NUM_OBJ, 8, 3), torch.float64),
+    "gt_box_masks": ((MAX_NUM_OBJ,), torch.int64),
+    "gt_box_object_ids": ((MAX_NUM_OBJ,), torch.int64),
+    "num_bbox": ((), torch.int64),
+    "ref_center_label": ((3,), torch.float32),
+    "ref_size_class_label": ((), torch.int64),
+    "ref_size_residual_label": ((3,), torch.float32),
+    "ref_box_corner_label": ((8, 3), torch.float64),
+}
+
+
+def _rot(axis, t):
+    """utils/pc_utils.py:282-320 (rotx / roty / rotz)."""
+    c, s = np.cos(t), np.sin(t)
+    if axis == "x":
+        return np.array([[1, 0, 0], [0, c, -s], [0, s, c]])
+    if axis == "y":
+        return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+    return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])
+
+
+class SceneStore(object):
+    """Scenes concatenated in device memory.  `add_scene` takes the arrays of the
+    reference's preprocessed files (data/scannet/load_scannet_data.py:147-152):
+    mesh_vertices (Nv, 6|9) f32, instance / semantic labels (Nv), instance_bboxes (nb, 8)."""
+
+    def __init__(self, device, multiview_width=0, vert_cols=9):
+        self.device = torch.device(device)
+        self.Cm, self.cols = int(multiview_width), int(vert_cols)
+        self._host = []
+        self.index = {}
+        self.final = False
+
+    def add_scene(self, scene_id, mesh_vertices, instance_labels, semantic_labels,
+                  instance_bboxes, multiview=None, rotations=None):
+        if self.final:
+            raise RuntimeError("SceneStore is finalized")
+        v = np.ascontiguousarray(mesh_vertices, np.float32)
+        nv = v.shape[0]
+        if v.ndim != 2 or v.shape[1] != self.cols or nv == 0:
+            raise ValueError("mesh_vertices must be (Nv>0, %d)" % self.cols)
+        ins = np.asarray(instance_labels).astype(np.int64)
+        sem = np.asarray(semantic_labels).astype(np.int64)
+        if ins.shape != (nv,) or sem.shape != (nv,):
+            raise ValueError("labels must be (Nv,)")
+        if ins.min() < 0 or ins.max() >= MAX_INSTANCE:
+            raise ValueError("instance ids must be in [0, %d)" % MAX_INSTANCE)
+        boxes = np.ascontiguousarray(instance_bboxes, np.float64)
+        if boxes.ndim != 2 or boxes.shape[1] != 8 or not 1 <= boxes.shape[0] <= MAX_NUM_OBJ:
+            # the reference leaves gt_box_corner_label unbound / mis-shaped on such a
+            # scene (lib/dataset.py:463-477)
+            raise ValueError("a scene needs 1..%d boxes of 8 numbers" % MAX_NUM_OBJ)
+        ids = boxes[:, 6].astype(np.int64)
+        if ((ids < 0) | (ids > 40)).any() or (CLASS_OF_NYU40[np.clip(ids, 0, 40)] < 0).any():
+            raise KeyError("box with a nyu40 id outside the 37 box classes "
+                           "(DC.nyu40id2class, lib/dataset.py:445)")
+        mv = None
+        if self.Cm:
+            mv = np.ascontiguousarray(multiview, np.float32)
+            if mv.shape != (nv, self.Cm):
+                raise ValueError("multiview must be (Nv, %d)" % self.Cm)
+        rot = np.zeros((boxes.shape[0], 9), np.float32)
+        rot_mask = np.zeros(boxes.shape[0], np.uint8)
+        if rotations:
+            for i, oid in enumerate(boxes[:, 7].astype(int)):   # lib/dataset.py:495-503
+                r = rotations.get(int(oid), rotations.get(str(int(oid))))
+                if r is not None:
+                    rot[i] = np.asarray(r, np.float64).reshape(9)
+                    rot_mask[i] = 1
+        self.index[scene_id] = len(self._host)
+        self._host.append((v, ins.astype(np.int32), sem.astype(np.int32), boxes, mv, rot,
+                           rot_mask))
+
+    def finalize(self):
+        """Upload, then compute every scene's floor height on the device."""
+        if not self._host:
+            raise RuntimeError("SceneStore is empty")
+        dev = self.device
+        nvs = [h[0].shape[0] for h in self._host]
+        nbs = [h[3].shape[0] for h in self._host]
+        self.vert_off_host = np.concatenate([[0], np.cumsum(nvs)]).astype(np.int64)
+        self.box_off_host = np.concatenate([[0], np.cumsum(nbs)]).astype(np.int32)
+        self.num_vertices = np.asarray(nvs, np.int64)
+        cat = lambda k: torch.from_numpy(np.concatenate([h[k] for h in self._host], 0)).to(dev)
+        self.verts, self.ins, self.sem, self.boxes = cat(0), cat(1), cat(2), cat(3)
+        self.mv = cat(4) if self.Cm else None
+        self.box_rot, self.box_rot_mask = cat(5), cat(6)
+        self.vert_off = torch.from_numpy(self.vert_off_host).to(dev)
+        self.box_off = torch.from_numpy(self.box_off_host).to(dev)
+        self.floor = torch.empty(len(nvs), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            st = _C.stream_ptr()
+            for s, nv in enumerate(nvs):
+                _C.call("s2c_scene_floor_height", int(nv),
+                        self.verts.data_ptr() + int(self.vert_off_host[s]) * self.cols * 4,
+                        self.cols, self.floor.data_ptr() + 4 * s, st)
+        self._host = None
+        self.final = True
+        return self
+
+    def __len__(self):
+        return len(self.index)
+
+    def resident_bytes(self):
+        ts = [self.verts, self.ins, self.sem, self.boxes, self.box_rot, self.box_rot_mask]
+        if self.mv is not None:
+            ts.append(self.mv)
+        return sum(t.numel() * t.element_size() for t in ts)
+
+
+class SceneBatchBuilder(object):
+    """Mirror of the reference dataset's options (lib/dataset.py:288-299)."""
+
+    def __init__(self, store, mean_size_arr, num_points=40000, use_color=False,
+                 use_height=True, use_normal=False, use_multiview=False, augment=False):
+        if not store.final:
+            raise RuntimeError("finalize the SceneStore first")
+        if use_multiview and not store.Cm:
+            raise ValueError("the store holds no multiview features")
+        if (use_color and store.cols < 6) or (use_normal and store.cols < 9):
+            raise ValueError("the store's vertices lack the requested channels")
+        self.store, self.N = store, int(num_points)
+        self.use_color, self.use_height = bool(use_color), bool(use_height)
+        self.use_normal, self.use_multiview = bool(use_normal), bool(use_multiview)
+        self.augment = bool(augment)
+        self.Cout = (3 + 3 * self.use_color + 3 * self.use_normal
+                     + store.Cm * self.use_multiview + 1 * self.use_height)
+        dev = store.device
+        self.mean_size = torch.as_tensor(np.asarray(mean_size_arr, np.float64), device=dev)
+        self.class_of = torch.from_numpy(CLASS_OF_NYU40).to(dev)
+        self._staging = {}
+
+    # ---- host: the random numbers, in the reference's order ------------------------
+    def draw(self, scene_ids, rng=np.random):
+        """One dict per item: `choices` (utils/pc_utils.py:36-37) and, when augmenting,
+        flips, the three rotation matrices and the translation (lib/dataset.py:398-424,
+        :273-275).  `rng`: `np.random` (the reference's global state) or a RandomState."""
+        out = []
+        for sid in scene_ids:
+            nv = int(self.store.num_vertices[self.store.index[sid]])
+            d = {"choices": rng.choice(nv, self.N, replace=nv < self.N)}
+            if self.augment:
+                d["flip_x"] = bool(rng.random() > 0.5)
+                d["flip_y"] = bool(rng.random() > 0.5)
+                for ax in "xyz":
+                    d["rot_" + ax] = _rot(ax, (rng.random() * np.pi / 18) - np.pi / 36)
+                grid = np.arange(-0.5, 0.501, 0.001)
+                d["shift"] = np.array([rng.choice(grid, size=1)[0] for _ in range(3)])
+            out.append(d)
+        return out
+
+    def _pack(self, scene_ids, object_ids, draws):
+        """All per-step host data in one pinned buffer: choices (B,N) i64 | aug (B,32) f64
+        | object ids (B) i64 | scene slots (B) i32."""
+        B, N = len(scene_ids), self.N
+        nbytes = B * N * 8 + B * 32 * 8 + B * 8 + B * 4
+        ring = self._staging.setdefault(B, {"next": 0, "slots": []})
+        if len(ring["slots"]) < 3:
+            ring["slots"].append([torch.empty(nbytes, dtype=torch.uint8,
+                                              pin_memory=self.store.device.type == "cuda"),
+                                  None])
+            slot_rec = ring["slots"][-1]
+        else:
+            slot_rec = ring["slots"][ring["next"] % 3]
+            ring["next"] += 1
+            if slot_rec[1] is not None:
+                slot_rec[1].synchronize()     # the H2D copy that last read this buffer
+        buf = slot_rec[0]
+        raw = buf.numpy()
+        o1, o2, o3 = B * N * 8, B * N * 8 + B * 256, B * N * 8 + B * 256 + B * 8
+        ch = raw[:o1].view(np.int64).reshape(B, N)
+        aug = raw[o1:o2].view(np.float64).reshape(B, 32)
+        oid = raw[o2:o3].view(np.int64)
+        slot = raw[o3:].view(np.int32)
+        aug[:] = 0
+        for b, (sid, d) in enumerate(zip(scene_ids, draws)):
+            ch[b] = d["choices"]
+            slot[b] = self.store.index[sid]
+            oid[b] = int(object_ids[b])
+            if self.augment:
+                aug[b, 0], aug[b, 1] = d["flip_x"], d["flip_y"]
+                aug[b, 2:11] = np.asarray(d["rot_x"], np.float64).reshape(9)
+                aug[b, 11:20] = np.asarray(d["rot_y"], np.float64).reshape(9)
+                aug[b, 20:29] = np.asarray(d["rot_z"], np.float64).reshape(9)
+                aug[b, 29:32] = d["shift"]
+        return slot_rec, (o1, o2, o3)
+
+    # ---- device ----------------------------------------------------------------------
+    def build(self, scene_ids, object_ids, draws):
+        """-> data_dict of device tensors with the reference's keys and dtypes."""
+        st = self.store
+        dev = st.device
+        B, N = len(scene_ids), self.N
+        if not (len(object_ids) == len(draws) == B) or B == 0:
+            raise ValueError("scene_ids, object_ids and draws must have one entry per item")
+        rec, (o1, o2, o3) = self._pack(scene_ids, object_ids, draws)
+        with torch.cuda.device(dev):
+            d = rec[0].to(dev, non_blocking=True)
+            rec[1] = torch.cuda.Event()
+            rec[1].record()
+            choices = d[:o1].view(torch.int64)
+            aug = d[o1:o2].view(torch.float64)
+            oid = d[o2:o3].view(torch.int64)
+            slot = d[o3:].view(torch.int32)
+            s = _C.stream_ptr()
+            cloud = torch.empty((B, N, self.Cout), dtype=torch.float32, device=dev)
+            _C.TIMER.alg_bytes = 8 * B * N * self.Cout + 8 * B * N
+            _C.call("s2c_scene_gather", B, N, st.cols, st.Cm, int(self.use_color),
+                    int(self.use_normal), int(self.use_multiview), int(self.use_height),
+                    int(self.augment), st.verts.data_ptr(),
+                    st.mv.data_ptr() if st.mv is not None else None, st.vert_off.data_ptr(),
+                    st.floor.data_ptr(), slot.data_ptr(), choices.data_ptr(),
+                    aug.data_ptr(), cloud.data_ptr(), s)
+            votes = torch.empty((B, N, 9), dtype=torch.float32, device=dev)
+            vmask = torch.empty((B, N), dtype=torch.int64, device=dev)
+            _C.call("s2c_scene_votes", B, N, self.Cout, cloud.data_ptr(), st.ins.data_ptr(),
+                    st.sem.data_ptr(), st.vert_off.data_ptr(), slot.data_ptr(),
+                    choices.data_ptr(), VOTE_ID_MASK, votes.data_ptr(), vmask.data_ptr(), s)
+            out = {k: torch.empty((B,) + shp, dtype=dt, device=dev)
+                   for k, (shp, dt) in _LABEL_SPECS.items()}
+            lab = _Labels(**{k: out[k].data_ptr() for k in _Labels._names})
+            _C.call("s2c_scene_box_labels", B, int(self.augment), st.boxes.data_ptr(),
+                    st.box_off.data_ptr(), st.box_rot.data_ptr(), st.box_rot_mask.data_ptr(),
+                    slot.data_ptr(), oid.data_ptr(), aug.data_ptr(), self.class_of.data_ptr(),
+                    self.mean_size.data_ptr(), lab, s)
+            zeros = torch.zeros((B, MAX_NUM_OBJ), dtype=torch.int64, device=dev)
+        out.update(point_clouds=cloud, vote_label=votes, vote_label_mask=vmask,
+                   heading_class_label=zeros,
+                   heading_residual_label=zeros.to(torch.float32),
+                   ref_heading_class_label=zeros[:, 0].clone(),
+                   ref_heading_residual_label=zeros[:, 0].clone(),
+                   object_id=oid.clone())
+        return out
+
+
+class AnnotationTable(object):
+    """The language side of an item (lib/dataset.py:326-329, :505-508, :531-534) served
+    from resident tensors: `lang_feat` (A,32,300) f32, `lang_ids` (A,32) i64, `lang_len`
+    (A) i64 (already clipped to MAX_DES_LEN + 2), plus per-annotation integers."""
+
+    def __init__(self, device, lang_feat, lang_ids, lang_len, object_id, ann_id,
+                 object_cat, unique_multiple):
+        dev = torch.device(device)
+        t = lambda a, dt: torch.as_tensor(np.asarray(a), dtype=dt).to(dev)
+        self.t = {"lang_feat": t(lang_feat, torch.float32), "lang_ids": t(lang_ids, torch.int64),
+                  "lang_len": t(lang_len, torch.int64), "object_id": t(object_id, torch.int64),
+                  "ann_id": t(ann_id, torch.int64), "object_cat": t(object_cat, torch.int64),
+                  "unique_multiple": t(unique_multiple, torch.int64)}
+        self.object_id_host = np.asarray(object_id, np.int64)
+        self.device = dev
+
+    def gather(self, indices):
+        idx = torch.as_tensor(np.asarray(indices, np.int64)).to(self.device, non_blocking=True)
+        out = {k: v.index_select(0, idx) for k, v in self.t.items()}
+        out["dataset_idx"] = idx
+        return out

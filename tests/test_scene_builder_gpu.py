@@ -1,0 +1,192 @@
+"""SURVEY §8 f3 on the GPU: items assembled by csrc/s2c_scene.hip (through the C ABI of
+include/s2c_scene.h) against (1) the outputs of the reference's own `__getitem__`
+(tests/golden/scene_items.npz), (2) the numpy oracle on batches over a multi-scene store,
+(3) np.percentile for the floor height, and (4) size-independent properties at the cfg3
+size (B=8, N=40000, 135 channels).
+
+Tolerances: everything is compared bit-exactly (float32 and float64): the kernels perform
+numpy's operations in numpy's order (float64 dgemm = fused multiply-add chain over k)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import scene_builder as osb
+from tests import scene_common as sc
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "scene_items.npz")
+
+
+def _sb():
+    from scan2cap_amd import scene_builder
+    return scene_builder
+
+
+def _store(scenes, mvw, rotations=None):
+    sb = _sb()
+    store = sb.SceneStore("cuda:0", multiview_width=mvw)
+    for i, s in enumerate(scenes):
+        store.add_scene("s%d" % i, s["mesh_vertices"], s["instance_labels"],
+                        s["semantic_labels"], s["instance_bboxes"], s.get("multiview"),
+                        rotations[i] if rotations else None)
+    return store.finalize()
+
+
+def _assert_item(got, b, want, tag):
+    for k in sc.ITEM_KEYS:
+        g = got[k][b].cpu().numpy()
+        w = np.asarray(want[k])
+        assert g.dtype == w.dtype, (tag, k, g.dtype, w.dtype)
+        assert g.shape == w.shape, (tag, k, g.shape, w.shape)
+        if not np.array_equal(g, w):
+            d = np.abs(g.astype(np.float64) - w.astype(np.float64))
+            raise AssertionError("%s %s: %d of %d differ, max %g" %
+                                 (tag, k, int((g != w).sum()), g.size, d.max()))
+
+
+@pytest.mark.parametrize("name", list(sc.CASES))
+def test_items_match_reference_golden(name):
+    golden = np.load(GOLDEN)
+    sseed, nv, npts, mvw, opts, rseed, oid = sc.CASES[name]
+    scene = sc.make_scene(sseed, nv, mvw)
+    rot = sc.make_rotations(sseed, scene) if name.endswith("_rot") else None
+    store = _store([scene], mvw, [rot])
+    builder = _sb().SceneBatchBuilder(store, golden["mean_size_arr"], num_points=npts, **opts)
+    np.random.seed(rseed)
+    draws = builder.draw(["s0"])
+    out = builder.build(["s0"], [oid], draws)
+    torch.cuda.synchronize()
+    want = {k: golden[name + "/" + k] for k in sc.ITEM_KEYS}
+    _assert_item(out, 0, want, name)
+
+
+@pytest.mark.parametrize("mvw,opts", [
+    (16, dict(use_color=False, use_height=True, use_normal=True, use_multiview=True,
+              augment=True)),
+    (0, dict(use_color=True, use_height=True, use_normal=True, use_multiview=False,
+             augment=True)),
+    (0, dict(use_color=False, use_height=False, use_normal=False, use_multiview=False,
+             augment=False)),
+])
+def test_batches_match_oracle(mvw, opts):
+    golden = np.load(GOLDEN)
+    msa = golden["mean_size_arr"]
+    scenes = [sc.make_scene(20, 5000, mvw), sc.make_scene(21, 900, mvw),
+              sc.make_scene(22, 12000, mvw, num_instances=40)]
+    rots = [sc.make_rotations(20 + i, s) for i, s in enumerate(scenes)]
+    store = _store(scenes, mvw, rots)
+    N = 2048
+    builder = _sb().SceneBatchBuilder(store, msa, num_points=N, **opts)
+    ids = ["s2", "s0", "s1", "s2", "s0"]
+    oids = [int(scenes[int(s[1])]["instance_bboxes"][k % 5, 7]) for k, s in enumerate(ids)]
+    oids[2] = 12345            # no such object: reference labels stay zero
+    rs = np.random.RandomState(77)
+    draws = builder.draw(ids, rng=rs)
+    out = builder.build(ids, oids, draws)
+    # a second batch right behind the first (staging ring, no host sync in between)
+    draws2 = builder.draw(ids[::-1], rng=rs)
+    out2 = builder.build(ids[::-1], oids[::-1], draws2)
+    torch.cuda.synchronize()
+    for o, idl, oidl, dr in ((out, ids, oids, draws), (out2, ids[::-1], oids[::-1], draws2)):
+        for b, sid in enumerate(idl):
+            i = int(sid[1])
+            want = osb.build_item(scenes[i], dr[b], oidl[b], N, msa, rotations=rots[i], **opts)
+            _assert_item(o, b, want, "item %d (%s)" % (b, sid))
+        assert o["heading_class_label"].dtype == torch.int64
+        assert int(o["heading_class_label"].abs().sum()) == 0
+
+
+def test_draw_consumes_numpy_state_like_the_oracle():
+    scene = sc.make_scene(3, 3000)
+    store = _store([scene], 0)
+    builder = _sb().SceneBatchBuilder(store, np.ones((18, 3)), num_points=512, augment=True)
+    np.random.seed(5)
+    a = builder.draw(["s0", "s0"])
+    tail_a = np.random.random()
+    np.random.seed(5)
+    b = [osb.draw(3000, 512, True), osb.draw(3000, 512, True)]
+    tail_b = np.random.random()
+    assert tail_a == tail_b
+    for x, y in zip(a, b):
+        assert sorted(x) == sorted(y)
+        for k in x:
+            assert np.array_equal(np.asarray(x[k]), np.asarray(y[k])), k
+
+
+@pytest.mark.parametrize("nv,quant", [(1, 0), (2, 0), (3, 0), (101, 0), (1000, 8), (150001, 0),
+                                      (262144, 64)])
+def test_floor_height_matches_numpy_percentile(nv, quant):
+    from scan2cap_amd import _C
+    g = np.random.Generator(np.random.PCG64(nv))
+    z = g.normal(0.3, 1.0, size=nv).astype(np.float32)
+    if quant:
+        z = (np.round(z * quant) / quant).astype(np.float32)      # many repeated values
+    verts = np.zeros((nv, 9), np.float32)
+    verts[:, 2] = z
+    verts[:, 0] = g.normal(size=nv)
+    d = torch.from_numpy(verts).cuda()
+    out = torch.zeros(1, device="cuda")
+    _C.call("s2c_scene_floor_height", nv, d.data_ptr(), 9, out.data_ptr(), _C.stream_ptr())
+    want = np.percentile(verts[:, 2], 0.99)
+    assert out.item() == float(want), (out.item(), float(want))
+
+
+def test_cfg3_size_properties():
+    """B=8 items of N=40000 points x 135 channels from ~150k-vertex scenes."""
+    sb = _sb()
+    mvw, N, B = 128, 40000, 8
+    scenes = [sc.make_scene(40 + i, 150000 + 1111 * i, mvw, num_instances=60) for i in range(3)]
+    store = _store(scenes, mvw)
+    opts = dict(use_color=False, use_height=True, use_normal=True, use_multiview=True,
+                augment=True)
+    builder = sb.SceneBatchBuilder(store, np.full((18, 3), 0.5), num_points=N, **opts)
+    ids = ["s%d" % (b % 3) for b in range(B)]
+    oids = [int(scenes[b % 3]["instance_bboxes"][b, 7]) for b in range(B)]
+    rs = np.random.RandomState(3)
+    draws = builder.draw(ids, rng=rs)
+    out = builder.build(ids, oids, draws)
+    torch.cuda.synchronize()
+    cloud = out["point_clouds"]
+    assert cloud.shape == (B, N, 135)
+    for b in range(B):
+        s = b % 3
+        rows = torch.from_numpy(draws[b]["choices"]).cuda() + int(store.vert_off_host[s])
+        # copied channels are bit-identical to the resident scene
+        assert torch.equal(cloud[b, :, 3:6], store.verts[rows, 6:9])
+        assert torch.equal(cloud[b, :, 6:134], store.mv[rows])
+        assert torch.equal(cloud[b, :, 134], store.verts[rows, 2] - store.floor[s])
+        # augmentation is rigid: distances to the (transformed) origin are preserved
+        raw = store.verts[rows, :3].double()
+        shift = torch.from_numpy(draws[b]["shift"]).cuda()
+        aug = cloud[b, :, :3].double() - shift
+        assert torch.allclose(aug.norm(dim=1), raw.norm(dim=1), atol=2e-6, rtol=0)
+        # votes: every voting point + its vote = the centre of its instance's sampled box
+        ins = store.ins[rows].long()
+        sem = store.sem[rows].long()
+        vm = out["vote_label_mask"][b].bool()
+        xyz = cloud[b, :, :3]
+        lo = torch.full((sb.MAX_INSTANCE, 3), float("inf"), device="cuda")
+        hi = -lo
+        lo = lo.scatter_reduce(0, ins[:, None].expand(-1, 3), xyz, "amin")
+        hi = hi.scatter_reduce(0, ins[:, None].expand(-1, 3), xyz, "amax")
+        first = torch.full((sb.MAX_INSTANCE,), N, device="cuda").scatter_reduce(
+            0, ins, torch.arange(N, device="cuda"), "amin")
+        valid_id = torch.zeros(64, dtype=torch.bool, device="cuda")
+        valid_id[list(sb.NYU40IDS)] = True
+        want_mask = valid_id[sem[first.clamp(max=N - 1)]][ins]
+        assert torch.equal(vm, want_mask)
+        centre = (0.5 * (lo + hi))[ins]
+        v = out["vote_label"][b]
+        assert torch.equal(v[:, 0:3], v[:, 3:6]) and torch.equal(v[:, 0:3], v[:, 6:9])
+        assert torch.equal(v[vm, 0:3], (centre - xyz)[vm])
+        assert int(v[~vm].abs().sum()) == 0
+    # boxes: labels of the described object agree with the per-box tables
+    for b in range(B):
+        r = int(out["ref_box_label"][b].argmax())
+        assert int(out["scene_object_ids"][b, r]) == oids[b]
+        assert torch.equal(out["ref_center_label"][b], out["center_label"][b, r])
+        assert torch.equal(out["ref_box_corner_label"][b], out["gt_box_corner_label"][b, r])
+        nb = int(out["num_bbox"][b])
+        assert int(out["box_label_mask"][b].sum()) == nb == len(scenes[b % 3]["instance_bboxes"])
