@@ -55,11 +55,14 @@ int s2c_scene_gather(int B, int N, int vert_cols, int Cm, int use_color, int use
  * FIRST sampled point has a nyu40 id in `vote_id_mask` (bit i = id i votes), the vote
  * of each of its points is 0.5*(min+max) of the instance's sampled (augmented) xyz minus
  * the point.  vote_label (B,N,9) f32 = the vote three times, vote_label_mask (B,N) i64.
- * cloud row stride = Cout floats. */
+ * cloud row stride = Cout floats.  workspace: s2c_scene_votes_workspace_bytes(B) bytes of
+ * device memory (per-instance tables; initialised by the callee). */
+long long s2c_scene_votes_workspace_bytes(int B);
 int s2c_scene_votes(int B, int N, int Cout, const float *cloud, const int *ins,
                     const int *sem, const long long *vert_off, const int *scene_ids,
                     const long long *choices, unsigned long long vote_id_mask,
-                    float *vote_label, long long *vote_label_mask, void *stream);
+                    void *workspace, float *vote_label, long long *vote_label_mask,
+                    void *stream);
 
 /* per-box labels; every pointer is (B, 128, ...) unless noted */
 typedef struct {
@@ -87,7 +90,8 @@ typedef struct {
  * accumulation order.  box_rot (NB,9) f32 / box_rot_mask (NB) u8 = Scan2CAD rotations per
  * stored box (may be NULL), class_of_nyu40 (41) i32 (-1 = not a box class), mean_size
  * (num_class,3) f64, object_ids (B) i64 = the described object of each item.
- * A scene with 0 or more than 128 boxes is an error (the reference fails on it too). */
+ * Scenes hold 1..128 boxes with nyu40 ids of the table (the host mirror rejects anything
+ * else when a scene is registered; the reference fails on such scenes too). */
 int s2c_scene_box_labels(int B, int augment, const double *boxes, const int *box_off,
                          const float *box_rot, const unsigned char *box_rot_mask,
                          const int *scene_ids, const long long *object_ids,

@@ -111,26 +111,39 @@ __device__ __forceinline__ void rot_f32(float &x, float &y, float &z, const doub
 
 constexpr int GROWS = 32;   // cloud rows per workgroup
 
+// The workgroup's GROWS output rows are one contiguous span of the cloud: they are put
+// together in LDS (row thread: xyz chain + the small channels; all threads: the multiview
+// row as 16-byte loads) and leave as 16-byte coalesced stores.
 __global__ __launch_bounds__(256) void scene_gather_kernel(
     int N, int cols, int Cm, int use_color, int use_normal, int use_height, int augment,
     int Cout, const float *__restrict__ verts, const float *__restrict__ mv,
     const long long *__restrict__ vert_off, const float *__restrict__ floor_h,
     const int *__restrict__ scene_ids, const long long *__restrict__ choices,
     const double *__restrict__ aug, float *__restrict__ cloud) {
+  extern __shared__ __align__(16) float s_tile[];   // GROWS x Cout
   __shared__ long long s_src[GROWS];
-  __shared__ float s_xyz[GROWS][3];
-  __shared__ float s_h[GROWS];
   const int b = blockIdx.y, t = threadIdx.x;
   const int row0 = blockIdx.x * GROWS;
   const int nrows = min(GROWS, N - row0);
   const int scene = scene_ids[b];
   const long long voff = vert_off[scene];
+  const int c_nrm = 3 + (use_color ? 3 : 0), c_mv = c_nrm + (use_normal ? 3 : 0);
+  const int c_h = c_mv + Cm;
   if (t < nrows) {
     const long long v = voff + choices[(size_t)b * N + row0 + t];
     const float *p = verts + v * cols;
     float x = p[0], y = p[1], z = p[2];
+    float *row = s_tile + t * Cout;
     s_src[t] = v;
-    s_h[t] = use_height ? z - floor_h[scene] : 0.0f;
+    if (use_color) {
+      row[3] = (float)(((double)p[3] - 109.8) / 256.0);   // MEAN_COLOR_RGB, lib/dataset.py:28
+      row[4] = (float)(((double)p[4] - 97.2) / 256.0);
+      row[5] = (float)(((double)p[5] - 83.8) / 256.0);
+    }
+    if (use_normal) {
+      row[c_nrm] = p[6]; row[c_nrm + 1] = p[7]; row[c_nrm + 2] = p[8];
+    }
+    if (use_height) row[c_h] = z - floor_h[scene];
     if (augment) {
       const double *A = aug + (size_t)b * 32;
       if (A[0] != 0.0) x = -1.0f * x;
@@ -142,85 +155,122 @@ __global__ __launch_bounds__(256) void scene_gather_kernel(
       y = (float)((double)y + A[30]);
       z = (float)((double)z + A[31]);
     }
-    s_xyz[t][0] = x; s_xyz[t][1] = y; s_xyz[t][2] = z;
+    row[0] = x; row[1] = y; row[2] = z;
   }
   __syncthreads();
-  const int c_rgb = 3, c_nrm = c_rgb + (use_color ? 3 : 0), c_mv = c_nrm + (use_normal ? 3 : 0);
-  const int c_h = c_mv + Cm;
+  if (Cm > 0) {
+    if ((Cm & 3) == 0) {
+      const int q4 = Cm >> 2, nf4 = nrows * q4;
+#pragma unroll 4
+      for (int f = t; f < nf4; f += 256) {
+        const int r = f / q4, q = f - r * q4;
+        const float4 v = *reinterpret_cast<const float4 *>(mv + s_src[r] * Cm + 4 * q);
+        float *o = s_tile + r * Cout + c_mv + 4 * q;
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+      }
+    } else {
+      const int tot = nrows * Cm;
+      for (int f = t; f < tot; f += 256) {
+        const int r = f / Cm, q = f - r * Cm;
+        s_tile[r * Cout + c_mv + q] = mv[s_src[r] * Cm + q];
+      }
+    }
+  }
+  __syncthreads();
   float *dst = cloud + ((size_t)b * N + row0) * Cout;
   const int total = nrows * Cout;
-  for (int e = t; e < total; e += 256) {
-    const int r = e / Cout, c = e - r * Cout;
-    float v;
-    if (c >= c_mv && c < c_h) {
-      v = mv[s_src[r] * Cm + (c - c_mv)];
-    } else if (c < 3) {
-      v = s_xyz[r][c];
-    } else if (c < c_nrm) {
-      const double mean = (c == 3) ? 109.8 : (c == 4) ? 97.2 : 83.8;   // lib/dataset.py:28
-      v = (float)(((double)verts[s_src[r] * cols + c] - mean) / 256.0);
-    } else if (c < c_mv) {
-      v = verts[s_src[r] * cols + 6 + (c - c_nrm)];
-    } else {
-      v = s_h[r];
-    }
-    dst[e] = v;
+  if ((((size_t)dst & 15) == 0) && (total & 3) == 0) {
+    const float4 *s4 = reinterpret_cast<const float4 *>(s_tile);
+    float4 *d4 = reinterpret_cast<float4 *>(dst);
+    for (int e = t; e < (total >> 2); e += 256) d4[e] = s4[e];
+  } else {
+    for (int e = t; e < total; e += 256) dst[e] = s_tile[e];
   }
 }
 
 // ---------------------------------------------------------------------------------
-// votes: workgroup per item; per-instance min / max / first sampled point in LDS
-__global__ __launch_bounds__(1024) void scene_votes_kernel(
+// votes, pass 1: per-instance min / max / first sampled point.  Grid (VCHUNKS, B): every
+// workgroup reduces its slice of the item in LDS and merges the instances it met into the
+// item's table in global memory (tab_lo (B,MAXINST,4) = min x,y,z keys + first index,
+// memset to 0xFF; tab_hi (B,MAXINST,3) = max keys, memset to 0).
+constexpr int VCHUNKS = 32;
+
+__global__ __launch_bounds__(512) void scene_votes_minmax_kernel(
     int N, int Cout, const float *__restrict__ cloud, const int *__restrict__ ins,
-    const int *__restrict__ sem, const long long *__restrict__ vert_off,
-    const int *__restrict__ scene_ids, const long long *__restrict__ choices,
-    unsigned long long vote_mask, float *__restrict__ vote_label,
-    long long *__restrict__ vote_label_mask) {
-  __shared__ unsigned s_min[3][MAXINST];
-  __shared__ unsigned s_max[3][MAXINST];
-  __shared__ int s_first[MAXINST];
-  const int b = blockIdx.x, t = threadIdx.x;
+    const long long *__restrict__ vert_off, const int *__restrict__ scene_ids,
+    const long long *__restrict__ choices, unsigned *__restrict__ tab_lo,
+    unsigned *__restrict__ tab_hi) {
+  __shared__ unsigned s_lo[MAXINST][4];
+  __shared__ unsigned s_hi[MAXINST][3];
+  const int b = blockIdx.y, t = threadIdx.x;
   const long long voff = vert_off[scene_ids[b]];
   const long long *ch = choices + (size_t)b * N;
   const float *pc = cloud + (size_t)b * N * Cout;
-  for (int i = t; i < MAXINST; i += 1024) {
-    s_min[0][i] = s_min[1][i] = s_min[2][i] = 0xFFFFFFFFu;
-    s_max[0][i] = s_max[1][i] = s_max[2][i] = 0u;
-    s_first[i] = 0x7FFFFFFF;
+  for (int i = t; i < MAXINST; i += 512) {
+    s_lo[i][0] = s_lo[i][1] = s_lo[i][2] = s_lo[i][3] = 0xFFFFFFFFu;
+    s_hi[i][0] = s_hi[i][1] = s_hi[i][2] = 0u;
   }
   __syncthreads();
-  for (int i = t; i < N; i += 1024) {
+  const int per = (N + VCHUNKS - 1) / VCHUNKS;
+  const int i0 = blockIdx.x * per, i1 = min(N, i0 + per);
+  for (int i = i0 + t; i < i1; i += 512) {
     const int inst = ins[voff + ch[i]] & (MAXINST - 1);
     const float *p = pc + (size_t)i * Cout;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const unsigned key = f2key(p[c]);
-      atomicMin(&s_min[c][inst], key);
-      atomicMax(&s_max[c][inst], key);
+      atomicMin(&s_lo[inst][c], key);
+      atomicMax(&s_hi[inst][c], key);
     }
-    atomicMin(&s_first[inst], i);
+    atomicMin(&s_lo[inst][3], (unsigned)i);
   }
   __syncthreads();
-  for (int i = t; i < N; i += 1024) {
-    const int inst = ins[voff + ch[i]] & (MAXINST - 1);
-    const unsigned s = (unsigned)sem[voff + ch[s_first[inst]]];
-    const bool votes = s < 64u && ((vote_mask >> s) & 1ull);
-    const float *p = pc + (size_t)i * Cout;
-    float v[3] = {0.0f, 0.0f, 0.0f};
-    if (votes) {
+  unsigned *glo = tab_lo + (size_t)b * MAXINST * 4;
+  unsigned *ghi = tab_hi + (size_t)b * MAXINST * 3;
+  for (int i = t; i < MAXINST; i += 512) {
+    if (s_lo[i][3] == 0xFFFFFFFFu) continue;      // instance not in this slice
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float centre = 0.5f * (key2f(s_min[c][inst]) + key2f(s_max[c][inst]));
-        v[c] = centre - p[c];
-      }
+    for (int c = 0; c < 3; ++c) {
+      atomicMin(&glo[i * 4 + c], s_lo[i][c]);
+      atomicMax(&ghi[i * 3 + c], s_hi[i][c]);
     }
-    float *o = vote_label + ((size_t)b * N + i) * 9;
-#pragma unroll
-    for (int rep = 0; rep < 3; ++rep) {
-      o[rep * 3 + 0] = v[0]; o[rep * 3 + 1] = v[1]; o[rep * 3 + 2] = v[2];
-    }
-    vote_label_mask[(size_t)b * N + i] = votes ? 1 : 0;
+    atomicMin(&glo[i * 4 + 3], s_lo[i][3]);
   }
+}
+
+// votes, pass 2: thread per point
+__global__ __launch_bounds__(256) void scene_votes_apply_kernel(
+    int N, int Cout, const float *__restrict__ cloud, const int *__restrict__ ins,
+    const int *__restrict__ sem, const long long *__restrict__ vert_off,
+    const int *__restrict__ scene_ids, const long long *__restrict__ choices,
+    unsigned long long vote_mask, const unsigned *__restrict__ tab_lo,
+    const unsigned *__restrict__ tab_hi, float *__restrict__ vote_label,
+    long long *__restrict__ vote_label_mask) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const long long voff = vert_off[scene_ids[b]];
+  const long long *ch = choices + (size_t)b * N;
+  const int inst = ins[voff + ch[i]] & (MAXINST - 1);
+  const unsigned *lo = tab_lo + ((size_t)b * MAXINST + inst) * 4;
+  const unsigned *hi = tab_hi + ((size_t)b * MAXINST + inst) * 3;
+  const unsigned s = (unsigned)sem[voff + ch[lo[3]]];
+  const bool votes = s < 64u && ((vote_mask >> s) & 1ull);
+  const float *p = cloud + ((size_t)b * N + i) * Cout;
+  float v[3] = {0.0f, 0.0f, 0.0f};
+  if (votes) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float centre = 0.5f * (key2f(lo[c]) + key2f(hi[c]));
+      v[c] = centre - p[c];
+    }
+  }
+  float *o = vote_label + ((size_t)b * N + i) * 9;
+#pragma unroll
+  for (int rep = 0; rep < 3; ++rep) {
+    o[rep * 3 + 0] = v[0]; o[rep * 3 + 1] = v[1]; o[rep * 3 + 2] = v[2];
+  }
+  vote_label_mask[(size_t)b * N + i] = votes ? 1 : 0;
 }
 
 // ---------------------------------------------------------------------------------
@@ -380,23 +430,37 @@ extern "C" int s2c_scene_gather(int B, int N, int vert_cols, int Cm, int use_col
   if (augment && !aug) return -1;
   const int cm = use_multiview ? Cm : 0;
   const int Cout = 3 + (use_color ? 3 : 0) + (use_normal ? 3 : 0) + cm + (use_height ? 1 : 0);
-  hipLaunchKernelGGL(scene_gather_kernel, dim3((N + GROWS - 1) / GROWS, B), dim3(256), 0,
+  const size_t lds = sizeof(float) * (size_t)GROWS * Cout;
+  if (lds > 60 * 1024) return -1;
+  hipLaunchKernelGGL(scene_gather_kernel, dim3((N + GROWS - 1) / GROWS, B), dim3(256), lds,
                      (hipStream_t)stream, N, vert_cols, cm, use_color, use_normal, use_height,
                      augment, Cout, verts, mv, vert_off, floor, scene_ids, choices, aug, cloud);
   return chk5("scene_gather");
 }
 
+extern "C" long long s2c_scene_votes_workspace_bytes(int B) {
+  return B > 0 ? (long long)B * MAXINST * 7 * 4 : 0;
+}
+
 extern "C" int s2c_scene_votes(int B, int N, int Cout, const float *cloud, const int *ins,
                                const int *sem, const long long *vert_off,
                                const int *scene_ids, const long long *choices,
-                               unsigned long long vote_id_mask, float *vote_label,
-                               long long *vote_label_mask, void *stream) {
+                               unsigned long long vote_id_mask, void *workspace,
+                               float *vote_label, long long *vote_label_mask, void *stream) {
   if (B <= 0 || N <= 0 || Cout < 3 || !cloud || !ins || !sem || !vert_off || !scene_ids ||
-      !choices || !vote_label || !vote_label_mask)
+      !choices || !workspace || !vote_label || !vote_label_mask)
     return -1;
-  hipLaunchKernelGGL(scene_votes_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, N, Cout,
-                     cloud, ins, sem, vert_off, scene_ids, choices, vote_id_mask, vote_label,
-                     vote_label_mask);
+  hipStream_t st = (hipStream_t)stream;
+  unsigned *tab_lo = (unsigned *)workspace;
+  unsigned *tab_hi = tab_lo + (size_t)B * MAXINST * 4;
+  if (hipMemsetAsync(tab_lo, 0xFF, sizeof(unsigned) * (size_t)B * MAXINST * 4, st) != hipSuccess ||
+      hipMemsetAsync(tab_hi, 0, sizeof(unsigned) * (size_t)B * MAXINST * 3, st) != hipSuccess)
+    return -1;
+  hipLaunchKernelGGL(scene_votes_minmax_kernel, dim3(VCHUNKS, B), dim3(512), 0, st, N, Cout,
+                     cloud, ins, vert_off, scene_ids, choices, tab_lo, tab_hi);
+  hipLaunchKernelGGL(scene_votes_apply_kernel, dim3((N + 255) / 256, B), dim3(256), 0, st, N,
+                     Cout, cloud, ins, sem, vert_off, scene_ids, choices, vote_id_mask, tab_lo,
+                     tab_hi, vote_label, vote_label_mask);
   return chk5("scene_votes");
 }
 

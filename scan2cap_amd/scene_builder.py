@@ -62,7 +62,7 @@ class _Labels(ctypes.Structure):
 _C.register("s2c_scene_floor_height", [_L, _P, _I, _P, _P])
 _C.register("s2c_scene_gather", [_I] * 9 + [_P] * 9)
 _C.register("s2c_scene_votes", [_I, _I, _I, _P, _P, _P, _P, _P, _P, ctypes.c_ulonglong,
-                                _P, _P, _P])
+                                _P, _P, _P, _P])
 _C.register("s2c_scene_box_labels", [_I, _I] + [_P] * 9 + [_Labels, _P])
 
 # (shape after (B,), dtype) of the per-box / per-item outputs
@@ -209,14 +209,25 @@ class SceneBatchBuilder(object):
         self._staging = {}
 
     # ---- host: the random numbers, in the reference's order ------------------------
-    def draw(self, scene_ids, rng=np.random):
+    def draw(self, scene_ids, rng=np.random, device_choices=False):
         """One dict per item: `choices` (utils/pc_utils.py:36-37) and, when augmenting,
         flips, the three rotation matrices and the translation (lib/dataset.py:398-424,
-        :273-275).  `rng`: `np.random` (the reference's global state) or a RandomState."""
+        :273-275).  `rng`: `np.random` (the reference's global state) or a RandomState.
+
+        device_choices=True draws the vertex sample on the GPU instead (torch.randperm:
+        the same distribution -- N distinct vertices uniformly, with replacement only when
+        the scene has fewer than N -- but not numpy's stream).  numpy's legacy `choice`
+        permutes all Nv vertices per item (~2.5 ms for 150k on one core; the reference
+        spreads it over DataLoader workers), which a 12 ms training step cannot hide."""
         out = []
+        dev = self.store.device
         for sid in scene_ids:
             nv = int(self.store.num_vertices[self.store.index[sid]])
-            d = {"choices": rng.choice(nv, self.N, replace=nv < self.N)}
+            if device_choices:
+                d = {"choices": torch.randperm(nv, device=dev)[:self.N] if nv >= self.N
+                     else torch.randint(nv, (self.N,), device=dev)}
+            else:
+                d = {"choices": rng.choice(nv, self.N, replace=nv < self.N)}
             if self.augment:
                 d["flip_x"] = bool(rng.random() > 0.5)
                 d["flip_y"] = bool(rng.random() > 0.5)
@@ -228,13 +239,17 @@ class SceneBatchBuilder(object):
         return out
 
     def _pack(self, scene_ids, object_ids, draws):
-        """All per-step host data in one pinned buffer: choices (B,N) i64 | aug (B,32) f64
-        | object ids (B) i64 | scene slots (B) i32."""
+        """All per-step host data in one pinned buffer: aug (B,32) f64 | object ids (B) i64
+        | scene slots (B) i32 (padded to 8 bytes) | choices (B,N) i64 -- the last part only
+        when the choices were drawn on the host."""
         B, N = len(scene_ids), self.N
-        nbytes = B * N * 8 + B * 32 * 8 + B * 8 + B * 4
+        o1, o2 = B * 256, B * 256 + B * 8
+        o3 = o2 + ((B * 4 + 7) // 8) * 8
+        host_choices = not torch.is_tensor(draws[0]["choices"])
+        used = o3 + (B * N * 8 if host_choices else 0)
         ring = self._staging.setdefault(B, {"next": 0, "slots": []})
         if len(ring["slots"]) < 3:
-            ring["slots"].append([torch.empty(nbytes, dtype=torch.uint8,
+            ring["slots"].append([torch.empty(o3 + B * N * 8, dtype=torch.uint8,
                                               pin_memory=self.store.device.type == "cuda"),
                                   None])
             slot_rec = ring["slots"][-1]
@@ -243,16 +258,16 @@ class SceneBatchBuilder(object):
             ring["next"] += 1
             if slot_rec[1] is not None:
                 slot_rec[1].synchronize()     # the H2D copy that last read this buffer
-        buf = slot_rec[0]
-        raw = buf.numpy()
-        o1, o2, o3 = B * N * 8, B * N * 8 + B * 256, B * N * 8 + B * 256 + B * 8
-        ch = raw[:o1].view(np.int64).reshape(B, N)
-        aug = raw[o1:o2].view(np.float64).reshape(B, 32)
-        oid = raw[o2:o3].view(np.int64)
-        slot = raw[o3:].view(np.int32)
+        raw = slot_rec[0].numpy()
+        aug = raw[:o1].view(np.float64).reshape(B, 32)
+        oid = raw[o1:o2].view(np.int64)
+        slot = raw[o2:o2 + B * 4].view(np.int32)
         aug[:] = 0
+        if host_choices:
+            ch = raw[o3:used].view(np.int64).reshape(B, N)
         for b, (sid, d) in enumerate(zip(scene_ids, draws)):
-            ch[b] = d["choices"]
+            if host_choices:
+                ch[b] = d["choices"]
             slot[b] = self.store.index[sid]
             oid[b] = int(object_ids[b])
             if self.augment:
@@ -261,7 +276,7 @@ class SceneBatchBuilder(object):
                 aug[b, 11:20] = np.asarray(d["rot_y"], np.float64).reshape(9)
                 aug[b, 20:29] = np.asarray(d["rot_z"], np.float64).reshape(9)
                 aug[b, 29:32] = d["shift"]
-        return slot_rec, (o1, o2, o3)
+        return slot_rec, (o1, o2, o3, used)
 
     # ---- device ----------------------------------------------------------------------
     def build(self, scene_ids, object_ids, draws):
@@ -271,15 +286,18 @@ class SceneBatchBuilder(object):
         B, N = len(scene_ids), self.N
         if not (len(object_ids) == len(draws) == B) or B == 0:
             raise ValueError("scene_ids, object_ids and draws must have one entry per item")
-        rec, (o1, o2, o3) = self._pack(scene_ids, object_ids, draws)
+        rec, (o1, o2, o3, used) = self._pack(scene_ids, object_ids, draws)
         with torch.cuda.device(dev):
-            d = rec[0].to(dev, non_blocking=True)
+            d = rec[0][:used].to(dev, non_blocking=True)
             rec[1] = torch.cuda.Event()
             rec[1].record()
-            choices = d[:o1].view(torch.int64)
-            aug = d[o1:o2].view(torch.float64)
-            oid = d[o2:o3].view(torch.int64)
-            slot = d[o3:].view(torch.int32)
+            aug = d[:o1].view(torch.float64)
+            oid = d[o1:o2].view(torch.int64)
+            slot = d[o2:o2 + B * 4].view(torch.int32)
+            if used > o3:
+                choices = d[o3:used].view(torch.int64)
+            else:
+                choices = torch.stack([x["choices"] for x in draws]).contiguous()
             s = _C.stream_ptr()
             cloud = torch.empty((B, N, self.Cout), dtype=torch.float32, device=dev)
             _C.TIMER.alg_bytes = 8 * B * N * self.Cout + 8 * B * N
@@ -291,9 +309,11 @@ class SceneBatchBuilder(object):
                     aug.data_ptr(), cloud.data_ptr(), s)
             votes = torch.empty((B, N, 9), dtype=torch.float32, device=dev)
             vmask = torch.empty((B, N), dtype=torch.int64, device=dev)
+            work = torch.empty(B * MAX_INSTANCE * 7, dtype=torch.int32, device=dev)
             _C.call("s2c_scene_votes", B, N, self.Cout, cloud.data_ptr(), st.ins.data_ptr(),
                     st.sem.data_ptr(), st.vert_off.data_ptr(), slot.data_ptr(),
-                    choices.data_ptr(), VOTE_ID_MASK, votes.data_ptr(), vmask.data_ptr(), s)
+                    choices.data_ptr(), VOTE_ID_MASK, work.data_ptr(), votes.data_ptr(),
+                    vmask.data_ptr(), s)
             out = {k: torch.empty((B,) + shp, dtype=dt, device=dev)
                    for k, (shp, dt) in _LABEL_SPECS.items()}
             lab = _Labels(**{k: out[k].data_ptr() for k in _Labels._names})
