@@ -214,18 +214,18 @@ class SceneBatchBuilder(object):
         flips, the three rotation matrices and the translation (lib/dataset.py:398-424,
         :273-275).  `rng`: `np.random` (the reference's global state) or a RandomState.
 
-        device_choices=True draws the vertex sample on the GPU instead (torch.randperm:
-        the same distribution -- N distinct vertices uniformly, with replacement only when
+        device_choices=True draws the vertex sample on the GPU instead (one batched sort of
+        uniform keys: the same distribution -- N distinct vertices uniformly, with replacement only when
         the scene has fewer than N -- but not numpy's stream).  numpy's legacy `choice`
         permutes all Nv vertices per item (~2.5 ms for 150k on one core; the reference
         spreads it over DataLoader workers), which a 12 ms training step cannot hide."""
         out = []
         dev = self.store.device
-        for sid in scene_ids:
-            nv = int(self.store.num_vertices[self.store.index[sid]])
+        nvs = [int(self.store.num_vertices[self.store.index[sid]]) for sid in scene_ids]
+        dev_rows = self._device_choices(nvs) if device_choices else None
+        for b, nv in enumerate(nvs):
             if device_choices:
-                d = {"choices": torch.randperm(nv, device=dev)[:self.N] if nv >= self.N
-                     else torch.randint(nv, (self.N,), device=dev)}
+                d = {"choices": dev_rows[b]}
             else:
                 d = {"choices": rng.choice(nv, self.N, replace=nv < self.N)}
             if self.augment:
@@ -237,6 +237,26 @@ class SceneBatchBuilder(object):
                 d["shift"] = np.array([rng.choice(grid, size=1)[0] for _ in range(3)])
             out.append(d)
         return out
+
+    def _device_choices(self, nvs):
+        """(B,N) vertex samples drawn on the device: one batched sort of uniform keys (the
+        first N of a random permutation of each scene's vertices); scenes with fewer than N
+        vertices are sampled with replacement, like the reference."""
+        dev, N = self.store.device, self.N
+        B, top = len(nvs), max(nvs)
+        nv = torch.as_tensor(nvs, device=dev)
+        if top >= N:
+            keys = torch.rand((B, top), device=dev)
+            keys.masked_fill_(torch.arange(top, device=dev)[None, :] >= nv[:, None], 2.0)
+            rows = keys.argsort(dim=1)[:, :N]
+        else:
+            rows = torch.zeros((B, N), dtype=torch.int64, device=dev)
+        if min(nvs) < N:
+            small = torch.as_tensor([n < N for n in nvs], device=dev)
+            repl = (torch.rand((B, N), device=dev) * nv[:, None]).long().clamp_(max=top - 1)
+            repl = torch.minimum(repl, nv[:, None] - 1)
+            rows = torch.where(small[:, None], repl, rows)
+        return rows
 
     def _pack(self, scene_ids, object_ids, draws):
         """All per-step host data in one pinned buffer: aug (B,32) f64 | object ids (B) i64

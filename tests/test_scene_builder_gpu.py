@@ -115,6 +115,39 @@ def test_draw_consumes_numpy_state_like_the_oracle():
             assert np.array_equal(np.asarray(x[k]), np.asarray(y[k])), k
 
 
+def test_device_side_vertex_sampling():
+    """device_choices=True: N distinct in-range vertices per item (with replacement only for
+    a scene smaller than N), every vertex equally likely, and `build` consumes them."""
+    scenes = [sc.make_scene(30, 6000), sc.make_scene(31, 700), sc.make_scene(32, 4100)]
+    store = _store(scenes, 0)
+    N = 2048
+    builder = _sb().SceneBatchBuilder(store, np.ones((18, 3)), num_points=N, augment=True)
+    ids = ["s0", "s1", "s2", "s0"]
+    rs = np.random.RandomState(1)
+    hits = torch.zeros(6000, device="cuda")
+    for rep in range(40):
+        draws = builder.draw(ids, rng=rs, device_choices=True)
+        for b, sid in enumerate(ids):
+            ch = draws[b]["choices"]
+            nv = len(scenes[int(sid[1])]["mesh_vertices"])
+            assert ch.shape == (N,) and ch.dtype == torch.int64 and ch.is_cuda
+            assert int(ch.min()) >= 0 and int(ch.max()) < nv
+            if nv >= N:
+                assert ch.unique().numel() == N
+        hits += torch.bincount(draws[0]["choices"], minlength=6000)
+        hits += torch.bincount(draws[3]["choices"], minlength=6000)
+    # 80 samples of 2048/6000: every vertex expected 27.3 times, sd 4.2
+    assert float(hits.min()) > 5 and float(hits.max()) < 55
+    assert abs(float(hits.mean()) - 80 * N / 6000.0) < 1e-3
+    out = builder.build(ids, [0, 0, 0, 1], draws)
+    torch.cuda.synchronize()
+    for b, sid in enumerate(ids):
+        i = int(sid[1])
+        d = dict(draws[b], choices=draws[b]["choices"].cpu().numpy())
+        want = osb.build_item(scenes[i], d, [0, 0, 0, 1][b], N, np.ones((18, 3)), augment=True)
+        _assert_item(out, b, want, "device-sampled item %d" % b)
+
+
 @pytest.mark.parametrize("nv,quant", [(1, 0), (2, 0), (3, 0), (101, 0), (1000, 8), (150001, 0),
                                       (262144, 64)])
 def test_floor_height_matches_numpy_percentile(nv, quant):
@@ -190,3 +223,66 @@ def test_cfg3_size_properties():
         assert torch.equal(out["ref_box_corner_label"][b], out["gt_box_corner_label"][b, r])
         nb = int(out["num_bbox"][b])
         assert int(out["box_label_mask"][b].sum()) == nb == len(scenes[b % 3]["instance_bboxes"])
+
+
+def test_builder_batch_trains_a_step_like_a_host_built_batch():
+    """The device-built data_dict (+ AnnotationTable) drives the solver's step
+    (lib/solver.py:293-302) exactly like the same items assembled on the host by the
+    oracle and copied over (the reference's DataLoader route)."""
+    import bench
+    sb = _sb()
+    B, N, K, V = 2, 4096, 64, 200
+    wl = dict(B=B, N=N, C=4, K=K, V=V, train=True, desc="test")
+    dev = torch.device("cuda")
+    vocabulary, embeddings, table = bench.make_vocab(V)
+    msa = np.random.Generator(np.random.PCG64(5)).uniform(0.3, 1.5, size=(18, 3))
+    scenes = [sc.make_scene(60, 9000, num_instances=20), sc.make_scene(61, 7000,
+                                                                       num_instances=20)]
+    store = _store(scenes, 0)
+    opts = dict(use_color=False, use_height=True, use_normal=True, use_multiview=False,
+                augment=True)
+    builder = sb.SceneBatchBuilder(store, msa, num_points=N, **opts)
+    # annotations: 3 per scene
+    g = np.random.Generator(np.random.PCG64(9))
+    A, T = 6, 32
+    lang_len = g.integers(8, T + 1, A).astype(np.int64)
+    lang_ids = np.zeros((A, T), np.int64)
+    for a in range(A):
+        toks = [2] + list(g.integers(4, V, lang_len[a] - 2)) + [3]
+        lang_ids[a, :len(toks)] = toks
+    lang_feat = (table[lang_ids] * (lang_ids != 0)[..., None]).astype(np.float32)
+    ann_scene = [0, 0, 0, 1, 1, 1]
+    ann_obj = [int(scenes[s]["instance_bboxes"][a % 3, 7]) for a, s in enumerate(ann_scene)]
+    anns = sb.AnnotationTable(dev, lang_feat, lang_ids, lang_len, ann_obj, np.arange(A) % 3,
+                              np.full(A, 2), np.zeros(A))
+    picks = [4, 1]
+    ids = ["s%d" % ann_scene[a] for a in picks]
+    oids = [ann_obj[a] for a in picks]
+    rs = np.random.RandomState(11)
+    draws = builder.draw(ids, rng=rs)
+    dd = builder.build(ids, oids, draws)
+    dd.update(anns.gather(picks))
+    dd["_num_words"] = int(lang_len[picks].max())
+    assert torch.equal(dd["object_id"], torch.as_tensor(oids, device=dev))
+    # host route
+    items = [osb.build_item(scenes[ann_scene[a]], draws[b], ann_obj[a], N, msa, **opts)
+             for b, a in enumerate(picks)]
+    host = {k: torch.from_numpy(np.stack([it[k] for it in items])).to(dev) for k in items[0]}
+    host.update(lang_feat=torch.from_numpy(lang_feat[picks]).to(dev),
+                lang_ids=torch.from_numpy(lang_ids[picks]).to(dev),
+                lang_len=torch.from_numpy(lang_len[picks]).to(dev),
+                _num_words=dd["_num_words"])
+    torch.manual_seed(0)
+    model = bench.build_model(wl, vocabulary, embeddings, msa).to(dev).train()
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5, capturable=True,
+                           fused=True)
+    step = bench.make_step(model, wl, bench.LossConfig(msa), opt, None, dev)
+    got = float(step(dd).detach())
+    model.load_state_dict(state)
+    opt2 = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5, capturable=True,
+                            fused=True)
+    step2 = bench.make_step(model, wl, bench.LossConfig(msa), opt2, None, dev)
+    want = float(step2(host).detach())
+    assert np.isfinite(got)
+    np.testing.assert_allclose(got, want, rtol=1e-5)
