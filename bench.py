@@ -181,6 +181,47 @@ def build_model(wl, vocabulary, embeddings, msa):
                   use_relation=cap)
 
 
+def make_feeder(wl, dd, depth, msa, device, num_scenes, rank, stream=None):
+    """--feed builder: synthetic ScanNet-like scenes resident in HBM (150k vertices, the
+    workload's channels), `depth` static copies of the batch tensors the builder writes, and
+    the item picker (round-robin over scenes; the language entries of `dd` are reused so
+    that the decoder length of every step equals the resident run's)."""
+    from scan2cap_amd import scene_builder as sb
+    from tests.scene_common import make_scene
+    B, N, C = wl["B"], wl["N"], wl["C"]
+    mvw = 128 if C >= 132 else 0
+    scenes = [make_scene(900 + 31 * rank + i, 140000 + 1777 * i, mvw, num_instances=48)
+              for i in range(num_scenes)]
+    store = sb.SceneStore(device, multiview_width=mvw)
+    for i, sc in enumerate(scenes):
+        store.add_scene(i, sc["mesh_vertices"], sc["instance_labels"], sc["semantic_labels"],
+                        sc["instance_bboxes"], sc.get("multiview"))
+    store.finalize()
+    builder = sb.SceneBatchBuilder(store, msa, num_points=N, use_color=False, use_height=True,
+                                   use_normal=C >= 4, use_multiview=C >= 132, augment=True)
+    assert builder.Cout == 3 + C
+    probe = builder.build([0] * B, [0] * B, builder.draw([0] * B,
+                                                         rng=np.random.RandomState(1)))
+    produced = [k for k in probe if k in dd and torch.is_tensor(dd[k])
+                and dd[k].shape == probe[k].shape and dd[k].dtype == probe[k].dtype]
+    assert "point_clouds" in produced and "vote_label" in produced, produced
+    sets = []
+    for p in range(depth):
+        d = dict(dd)
+        for k in produced:
+            d[k] = dd[k].clone()
+        sets.append(d)
+    feeder = sb.BatchFeeder(builder, None, sets, device_choices=True,
+                            rng=np.random.RandomState(7 + rank), stream=stream)
+    box_ids = [sc["instance_bboxes"][:, 7].astype(int) for sc in scenes]
+
+    def pick(k):
+        ids = [(k * B + b) % num_scenes for b in range(B)]
+        return ids, [int(box_ids[s][(k + b) % len(box_ids[s])]) for b, s in enumerate(ids)]
+
+    return feeder, sets, pick
+
+
 def to_device(batch, device):
     dd = {k: torch.from_numpy(v).to(device) for k, v in batch.items()}
     dd["_num_words"] = int(batch["lang_len"].max())   # host-known: no device read
@@ -264,6 +305,12 @@ def main():
                     help="launch every kernel eagerly instead of replaying the "
                          "captured hipGraph of the step")
     ap.add_argument("--cpu-sample-scenes", type=int, default=8)
+    ap.add_argument("--feed", choices=["resident", "builder"], default="resident",
+                    help="resident: one batch resident in HBM is replayed (the contract's "
+                         "headline); builder: every step trains on a NEW batch assembled on "
+                         "the device from HBM-resident synthetic scenes "
+                         "(scan2cap_amd/scene_builder.py, SURVEY 8 f3), one batch ahead")
+    ap.add_argument("--feed-scenes", type=int, default=12)
     args = ap.parse_args()
 
     rank, world, local_rank = init_from_env()
@@ -313,6 +360,8 @@ def main():
         # a forward-only step is shorter than one FPS chain: keep 3 batches of
         # geometry in flight; a train step (~12.6 ms) hides one chain (~5.8 ms)
         depth = 1 if wl["train"] else 3
+        if args.feed == "builder":
+            depth = 3          # three static batch sets / graphs: host-paced hand-over
         depth = int(os.environ.get("S2C_GEO_DEPTH", depth))
         # forward-only steps are shorter than one FPS chain even with 3 chains in
         # flight: compute the geometry of `group` batches per pass (stacked clouds),
@@ -322,13 +371,22 @@ def main():
             depth = 2 * group
         slots = GeometrySlots(model.backbone_net, dd["point_clouds"], depth, group)
 
+    feeder = None
+    dd_sets = [dd] * max(depth, 1)
+    if args.feed == "builder":
+        if not (overlap and wl["train"] and slots.group == 1 and wl["C"] in (1, 4, 132)):
+            raise SystemExit("--feed builder needs the default graphed train step")
+        from scan2cap_amd.pipeline import independent_streams
+        feeder, dd_sets, feed_pick = make_feeder(
+            wl, dd, depth, msa, device, args.feed_scenes, rank,
+            independent_streams(1, avoid=slots.streams)[0])
     if use_graph:
         # whole step = one hipGraph replay (fwd + loss + bwd [+ Adam]); with N>1
         # the RCCL all-reduce stays an eager call between two graphs
         from scan2cap_amd.graphs import GraphedCallable
 
         def with_geometry(p):
-            d = dict(dd)
+            d = dict(dd_sets[p])
             if slots is not None:
                 d["_geometry"] = slots.geometry(p)
             return d
@@ -366,8 +424,45 @@ def main():
                 for p in range(depth):
                     slots.refill(p, dd["point_clouds"])
             counter = {"i": 0}
+            if feeder is not None:
+                for p in range(depth - 1 if depth >= 3 else depth):
+                    feeder.produce(p, *feed_pick(p))
+                    slots.streams[p].wait_event(feeder.ready[p])
+                    slots.refill(p, dd_sets[p]["point_clouds"])
+
+            host_ms = {"replay": 0.0, "produce": 0.0, "refill": 0.0, "n": 0}
+            host_paced = feeder is not None and depth >= 3
+
+            def fed_step(_dd):
+                """Step i trains on buffer set i % depth; batch i + depth - 1 (host-paced,
+                depth 3: the host waits for step i-1 itself, so that no stream parks on an
+                event) or i + depth (stream-paced) is assembled and its geometry computed
+                while the following steps run."""
+                i = counter["i"]
+                p = i % depth
+                counter["i"] += 1
+                t_a = time.perf_counter()
+                feeder.acquire(p)                      # batch i is assembled
+                slots.acquire(p)                       # ... and its geometry published
+                out = replays[p]()
+                slots.release(p)
+                feeder.release(p)
+                t_b = time.perf_counter()
+                q, nxt = ((i + depth - 1) % depth, i + depth - 1) if host_paced else (p, i + depth)
+                feeder.produce(q, *feed_pick(nxt), host_wait=host_paced)
+                t_c = time.perf_counter()
+                slots.streams[q].wait_event(feeder.ready[q])
+                slots.refill(q, dd_sets[q]["point_clouds"])
+                t_d = time.perf_counter()
+                host_ms["replay"] += 1e3 * (t_b - t_a)
+                host_ms["produce"] += 1e3 * (t_c - t_b)
+                host_ms["refill"] += 1e3 * (t_d - t_c)
+                host_ms["n"] += 1
+                return out
 
             def step(_dd):
+                if feeder is not None:
+                    return fed_step(_dd)
                 p = counter["i"] % depth
                 counter["i"] += 1
                 slots.acquire(p)                       # geometry of this step is published
@@ -410,6 +505,9 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     trace("timed region done")
+    if feeder is not None and os.environ.get("S2C_DEBUG_HOST") == "1":
+        print("[bench] host ms per step:", {k: round(v / host_ms["n"], 3) for k, v in
+                                            host_ms.items() if k != "n"}, file=sys.stderr)
     if use_graph:
         # per-kernel durations: HIP events cannot be read back from inside a graph
         # replay, so the same steps are run once more eagerly, un-timed for the
@@ -484,6 +582,9 @@ def main():
                            depth, ", %d batches per geometry pass" % slots.group
                            if slots is not None and slots.group > 1 else ""))
                                    if overlap else "in-line",
+                       "feed": ("a new batch per step assembled on the device from %d "
+                                "HBM-resident scenes, one batch ahead" % args.feed_scenes)
+                               if feeder is not None else "one batch resident in HBM",
                        "grad_allreduce_bytes": ddp.nbytes if ddp else 0},
             "roofline": roof,
             "kernels": table_k[:8],

@@ -38,6 +38,13 @@ extern "C" {
 int s2c_scene_floor_height(long long nv, const float *verts, int vert_cols, float *floor,
                            void *stream);
 
+/* choices (B, N) i64: N vertex indices of scene scene_ids[b] drawn on the device with the
+ * distribution of utils/pc_utils.py:32-40 (distinct, random order; with replacement only
+ * when the scene has fewer than N vertices) from seeds (B) u64 -- a keyed Feistel
+ * permutation of [0, Nv) evaluated at 0..N-1, not numpy's stream.  Scenes < 2^31 vertices. */
+int s2c_scene_sample(int B, int N, const long long *vert_off, const int *scene_ids,
+                     const unsigned long long *seeds, long long *choices, void *stream);
+
 /* cloud (B, N, Cout) f32, Cout = 3 + 3*use_color + 3*use_normal + Cm*use_multiview +
  * use_height: row (b, i) = vertex choices[b, i] of scene scene_ids[b] with
  *   xyz      flipped / rotated about x, y, z / translated (each rotation in f64, rounded

@@ -100,6 +100,53 @@ __global__ __launch_bounds__(1024) void floor_height_kernel(long long nv,
 }
 
 // ---------------------------------------------------------------------------------
+// Vertex sampling on the device (utils/pc_utils.py:32-40: N distinct vertices of Nv in random
+// order; with replacement only when Nv < N).  choices[i] = pi(i), i < N, where pi is a keyed
+// pseudo-random PERMUTATION of [0, Nv): a 6-round balanced Feistel network over 2h >= log2(Nv)
+// bits, restricted to [0, Nv) by cycle walking (<= 4 applications on average).  O(N) work,
+// no sort, distinct by construction.
+__device__ __forceinline__ unsigned mix32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+
+__global__ __launch_bounds__(256) void scene_sample_kernel(
+    int N, const long long *__restrict__ vert_off, const int *__restrict__ scene_ids,
+    const unsigned long long *__restrict__ seeds, long long *__restrict__ choices) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const int scene = scene_ids[b];
+  const unsigned long long nv = (unsigned long long)(vert_off[scene + 1] - vert_off[scene]);
+  const unsigned long long seed = seeds[b];
+  const unsigned k0 = mix32((unsigned)seed), k1 = mix32((unsigned)(seed >> 32) ^ 0x9e3779b9u);
+  long long out;
+  if (nv < (unsigned long long)N) {
+    // with replacement: independent uniform draws
+    const unsigned r = mix32(mix32((unsigned)i ^ k0) + k1);
+    out = (long long)(((unsigned long long)r * nv) >> 32);
+  } else {
+    int h = 1;
+    while ((1ull << (2 * h)) < nv) ++h;        // nv < 2^31 => h <= 16
+    const unsigned mask = (1u << h) - 1u;
+    unsigned x = (unsigned)i;
+    do {
+      unsigned L = x >> h, R = x & mask;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        const unsigned key = (r & 1 ? k1 : k0) + 0x9e3779b9u * (unsigned)(r + 1);
+        const unsigned t = L ^ (mix32(R ^ key) & mask);
+        L = R;
+        R = t;
+      }
+      x = (L << h) | R;
+    } while ((unsigned long long)x >= nv);
+    out = (long long)x;
+  }
+  choices[(size_t)b * N + i] = out;
+}
+
+// ---------------------------------------------------------------------------------
 // one rotation of numpy's `np.dot(xyz_f32, R.T)` assigned back into a float32 array
 __device__ __forceinline__ void rot_f32(float &x, float &y, float &z, const double *R) {
   const double dx = x, dy = y, dz = z;
@@ -415,6 +462,15 @@ extern "C" int s2c_scene_floor_height(long long nv, const float *verts, int vert
   hipLaunchKernelGGL(floor_height_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, nv,
                      verts, vert_cols, floor);
   return chk5("scene_floor_height");
+}
+
+extern "C" int s2c_scene_sample(int B, int N, const long long *vert_off, const int *scene_ids,
+                                const unsigned long long *seeds, long long *choices,
+                                void *stream) {
+  if (B <= 0 || N <= 0 || !vert_off || !scene_ids || !seeds || !choices) return -1;
+  hipLaunchKernelGGL(scene_sample_kernel, dim3((N + 255) / 256, B), dim3(256), 0,
+                     (hipStream_t)stream, N, vert_off, scene_ids, seeds, choices);
+  return chk5("scene_sample");
 }
 
 extern "C" int s2c_scene_gather(int B, int N, int vert_cols, int Cm, int use_color,

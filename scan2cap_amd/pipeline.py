@@ -40,9 +40,10 @@ def _shares_queue(a, b, probe):
     return busy0.elapsed_time(t1) > 0.8 * busy0.elapsed_time(busy1)
 
 
-def independent_streams(n, candidates=12):
+def independent_streams(n, candidates=12, avoid=()):
     """`n` side streams that share a hardware queue neither with the current
-    stream nor with each other (best effort: falls back to plain new streams)."""
+    stream, nor with each other, nor with the streams in `avoid` (best effort: falls
+    back to plain new streams)."""
     if not torch.cuda.is_available():
         return [torch.cuda.Stream() for _ in range(n)]
     main = torch.cuda.current_stream()
@@ -66,7 +67,7 @@ def independent_streams(n, candidates=12):
             break
         if _shares_queue(c, main, probe) or _shares_queue(main, c, probe):
             continue
-        if any(_shares_queue(c, p, probe) for p in picked):
+        if any(_shares_queue(c, p, probe) for p in list(picked) + list(avoid)):
             continue
         picked.append(c)
     while len(picked) < n:

@@ -60,6 +60,7 @@ class _Labels(ctypes.Structure):
 
 
 _C.register("s2c_scene_floor_height", [_L, _P, _I, _P, _P])
+_C.register("s2c_scene_sample", [_I, _I, _P, _P, _P, _P, _P])
 _C.register("s2c_scene_gather", [_I] * 9 + [_P] * 9)
 _C.register("s2c_scene_votes", [_I, _I, _I, _P, _P, _P, _P, _P, _P, ctypes.c_ulonglong,
                                 _P, _P, _P, _P])
@@ -95,6 +96,43 @@ def _rot(axis, t):
     if axis == "y":
         return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
     return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])
+
+
+def _wait(event):
+    """Host wait for an event by polling (the caller keeps the GIL only in slices and never
+    sits inside the HIP runtime)."""
+    import time
+    while not event.query():
+        time.sleep(0.0002)
+
+
+class _SmallUploads(object):
+    """Tiny host arrays -> device without a host synchronisation: a ring of pinned
+    buffers (a pageable `tensor.to(device)` blocks the host until the stream gets there,
+    which stalls a producer that queues work behind a running training step)."""
+
+    def __init__(self, device, slots=8, nbytes=4096):
+        self.device = torch.device(device)
+        pin = self.device.type == "cuda"
+        self.ring = [[torch.empty(nbytes, dtype=torch.uint8, pin_memory=pin), None]
+                     for _ in range(slots)]
+        self.next = 0
+
+    def __call__(self, array):
+        a = np.ascontiguousarray(array)
+        rec = self.ring[self.next % len(self.ring)]
+        self.next += 1
+        if rec[1] is not None:
+            _wait(rec[1])
+        if a.nbytes > rec[0].numel():
+            rec[0] = torch.empty(a.nbytes, dtype=torch.uint8,
+                                 pin_memory=self.device.type == "cuda")
+        rec[0].numpy()[:a.nbytes] = a.view(np.uint8).reshape(-1)
+        out = rec[0][:a.nbytes].to(self.device, non_blocking=True)
+        if self.device.type == "cuda":
+            rec[1] = torch.cuda.Event()
+            rec[1].record()
+        return out.view(torch.from_numpy(a[:0]).dtype).reshape(a.shape)
 
 
 class SceneStore(object):
@@ -207,6 +245,8 @@ class SceneBatchBuilder(object):
         self.mean_size = torch.as_tensor(np.asarray(mean_size_arr, np.float64), device=dev)
         self.class_of = torch.from_numpy(CLASS_OF_NYU40).to(dev)
         self._staging = {}
+        import os
+        self.ring_slots = int(os.environ.get("S2C_FEED_RING", "3"))
 
     # ---- host: the random numbers, in the reference's order ------------------------
     def draw(self, scene_ids, rng=np.random, device_choices=False):
@@ -214,18 +254,18 @@ class SceneBatchBuilder(object):
         flips, the three rotation matrices and the translation (lib/dataset.py:398-424,
         :273-275).  `rng`: `np.random` (the reference's global state) or a RandomState.
 
-        device_choices=True draws the vertex sample on the GPU instead (one batched sort of
-        uniform keys: the same distribution -- N distinct vertices uniformly, with replacement only when
-        the scene has fewer than N -- but not numpy's stream).  numpy's legacy `choice`
-        permutes all Nv vertices per item (~2.5 ms for 150k on one core; the reference
-        spreads it over DataLoader workers), which a 12 ms training step cannot hide."""
+        device_choices=True leaves the vertex sample to the GPU (`s2c_scene_sample`: a keyed
+        Feistel permutation of the scene's vertices evaluated at 0..N-1 -- the same
+        distribution: N distinct vertices in random order, with replacement only when the
+        scene has fewer than N -- but not numpy's stream); the host only draws a 62-bit
+        seed per item.  numpy's legacy `choice` permutes all Nv vertices per item (~2.5 ms
+        for 150k on one core; the reference spreads it over DataLoader workers), which a
+        12 ms training step cannot hide."""
         out = []
-        dev = self.store.device
-        nvs = [int(self.store.num_vertices[self.store.index[sid]]) for sid in scene_ids]
-        dev_rows = self._device_choices(nvs) if device_choices else None
-        for b, nv in enumerate(nvs):
+        for sid in scene_ids:
+            nv = int(self.store.num_vertices[self.store.index[sid]])
             if device_choices:
-                d = {"choices": dev_rows[b]}
+                d = {"seed": int(rng.randint(0, 2 ** 62, dtype=np.int64))}
             else:
                 d = {"choices": rng.choice(nv, self.N, replace=nv < self.N)}
             if self.augment:
@@ -238,49 +278,30 @@ class SceneBatchBuilder(object):
             out.append(d)
         return out
 
-    def _device_choices(self, nvs):
-        """(B,N) vertex samples drawn on the device: one batched sort of uniform keys (the
-        first N of a random permutation of each scene's vertices); scenes with fewer than N
-        vertices are sampled with replacement, like the reference."""
-        dev, N = self.store.device, self.N
-        B, top = len(nvs), max(nvs)
-        nv = torch.as_tensor(nvs, device=dev)
-        if top >= N:
-            keys = torch.rand((B, top), device=dev)
-            keys.masked_fill_(torch.arange(top, device=dev)[None, :] >= nv[:, None], 2.0)
-            rows = keys.argsort(dim=1)[:, :N]
-        else:
-            rows = torch.zeros((B, N), dtype=torch.int64, device=dev)
-        if min(nvs) < N:
-            small = torch.as_tensor([n < N for n in nvs], device=dev)
-            repl = (torch.rand((B, N), device=dev) * nv[:, None]).long().clamp_(max=top - 1)
-            repl = torch.minimum(repl, nv[:, None] - 1)
-            rows = torch.where(small[:, None], repl, rows)
-        return rows
-
     def _pack(self, scene_ids, object_ids, draws):
         """All per-step host data in one pinned buffer: aug (B,32) f64 | object ids (B) i64
-        | scene slots (B) i32 (padded to 8 bytes) | choices (B,N) i64 -- the last part only
-        when the choices were drawn on the host."""
+        | sampling seeds (B) u64 | scene slots (B) i32 (padded to 8 bytes) | choices (B,N)
+        i64 -- the last part only when the choices were drawn on the host."""
         B, N = len(scene_ids), self.N
-        o1, o2 = B * 256, B * 256 + B * 8
+        o1, o2 = B * 256, B * 256 + B * 16
         o3 = o2 + ((B * 4 + 7) // 8) * 8
-        host_choices = not torch.is_tensor(draws[0]["choices"])
+        host_choices = "choices" in draws[0]
         used = o3 + (B * N * 8 if host_choices else 0)
         ring = self._staging.setdefault(B, {"next": 0, "slots": []})
-        if len(ring["slots"]) < 3:
+        if len(ring["slots"]) < self.ring_slots:
             ring["slots"].append([torch.empty(o3 + B * N * 8, dtype=torch.uint8,
                                               pin_memory=self.store.device.type == "cuda"),
                                   None])
             slot_rec = ring["slots"][-1]
         else:
-            slot_rec = ring["slots"][ring["next"] % 3]
+            slot_rec = ring["slots"][ring["next"] % self.ring_slots]
             ring["next"] += 1
             if slot_rec[1] is not None:
-                slot_rec[1].synchronize()     # the H2D copy that last read this buffer
+                _wait(slot_rec[1])            # the H2D copy that last read this buffer
         raw = slot_rec[0].numpy()
         aug = raw[:o1].view(np.float64).reshape(B, 32)
-        oid = raw[o1:o2].view(np.int64)
+        oid = raw[o1:o1 + B * 8].view(np.int64)
+        seeds = raw[o1 + B * 8:o2].view(np.int64)
         slot = raw[o2:o2 + B * 4].view(np.int32)
         aug[:] = 0
         if host_choices:
@@ -288,6 +309,8 @@ class SceneBatchBuilder(object):
         for b, (sid, d) in enumerate(zip(scene_ids, draws)):
             if host_choices:
                 ch[b] = d["choices"]
+            else:
+                seeds[b] = d["seed"]
             slot[b] = self.store.index[sid]
             oid[b] = int(object_ids[b])
             if self.augment:
@@ -299,27 +322,54 @@ class SceneBatchBuilder(object):
         return slot_rec, (o1, o2, o3, used)
 
     # ---- device ----------------------------------------------------------------------
-    def build(self, scene_ids, object_ids, draws):
-        """-> data_dict of device tensors with the reference's keys and dtypes."""
-        st = self.store
-        dev = st.device
-        B, N = len(scene_ids), self.N
+    def stage(self, scene_ids, object_ids, draws):
+        """Host half of `build`: packs the draws and starts their (pinned, asynchronous)
+        copy to the device on the current stream.  Touches no output buffer, so a producer
+        can issue it before it waits for its output buffers to become free."""
+        B = len(scene_ids)
         if not (len(object_ids) == len(draws) == B) or B == 0:
             raise ValueError("scene_ids, object_ids and draws must have one entry per item")
-        rec, (o1, o2, o3, used) = self._pack(scene_ids, object_ids, draws)
-        with torch.cuda.device(dev):
-            d = rec[0][:used].to(dev, non_blocking=True)
+        rec, offs = self._pack(scene_ids, object_ids, draws)
+        with torch.cuda.device(self.store.device):
+            d = rec[0][:offs[3]].to(self.store.device, non_blocking=True)
             rec[1] = torch.cuda.Event()
             rec[1].record()
+        return B, d, offs
+
+    def build(self, scene_ids, object_ids, draws, out=None, staged=None):
+        """-> data_dict of device tensors with the reference's keys and dtypes.
+        `out`: a data_dict whose tensors are written in place where the key exists (static
+        buffers of a captured hipGraph); a shape / dtype mismatch raises.
+        `staged`: the result of `stage(...)` for the same arguments."""
+        st = self.store
+        dev = st.device
+        if staged is None:
+            staged = self.stage(scene_ids, object_ids, draws)
+        B, d, (o1, o2, o3, used) = staged
+        N = self.N
+        given = out if out is not None else {}
+
+        def buf(key, shape, dtype, zero=False):
+            t = given.get(key)
+            if t is None:
+                return (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=dev)
+            if tuple(t.shape) != tuple(shape) or t.dtype != dtype or not t.is_contiguous():
+                raise ValueError("out[%r] must be a contiguous %s tensor of shape %s"
+                                 % (key, dtype, tuple(shape)))
+            return t.zero_() if zero else t
+        with torch.cuda.device(dev):
             aug = d[:o1].view(torch.float64)
-            oid = d[o1:o2].view(torch.int64)
+            oid = d[o1:o1 + B * 8].view(torch.int64)
+            seeds = d[o1 + B * 8:o2].view(torch.int64)
             slot = d[o2:o2 + B * 4].view(torch.int32)
-            if used > o3:
-                choices = d[o3:used].view(torch.int64)
-            else:
-                choices = torch.stack([x["choices"] for x in draws]).contiguous()
             s = _C.stream_ptr()
-            cloud = torch.empty((B, N, self.Cout), dtype=torch.float32, device=dev)
+            if used > o3:
+                choices = d[o3:used].view(torch.int64).view(B, N)
+            else:
+                choices = torch.empty((B, N), dtype=torch.int64, device=dev)
+                _C.call("s2c_scene_sample", B, N, st.vert_off.data_ptr(), slot.data_ptr(),
+                        seeds.data_ptr(), choices.data_ptr(), s)
+            cloud = buf("point_clouds", (B, N, self.Cout), torch.float32)
             _C.TIMER.alg_bytes = 8 * B * N * self.Cout + 8 * B * N
             _C.call("s2c_scene_gather", B, N, st.cols, st.Cm, int(self.use_color),
                     int(self.use_normal), int(self.use_multiview), int(self.use_height),
@@ -327,28 +377,30 @@ class SceneBatchBuilder(object):
                     st.mv.data_ptr() if st.mv is not None else None, st.vert_off.data_ptr(),
                     st.floor.data_ptr(), slot.data_ptr(), choices.data_ptr(),
                     aug.data_ptr(), cloud.data_ptr(), s)
-            votes = torch.empty((B, N, 9), dtype=torch.float32, device=dev)
-            vmask = torch.empty((B, N), dtype=torch.int64, device=dev)
+            votes = buf("vote_label", (B, N, 9), torch.float32)
+            vmask = buf("vote_label_mask", (B, N), torch.int64)
             work = torch.empty(B * MAX_INSTANCE * 7, dtype=torch.int32, device=dev)
             _C.call("s2c_scene_votes", B, N, self.Cout, cloud.data_ptr(), st.ins.data_ptr(),
                     st.sem.data_ptr(), st.vert_off.data_ptr(), slot.data_ptr(),
                     choices.data_ptr(), VOTE_ID_MASK, work.data_ptr(), votes.data_ptr(),
                     vmask.data_ptr(), s)
-            out = {k: torch.empty((B,) + shp, dtype=dt, device=dev)
-                   for k, (shp, dt) in _LABEL_SPECS.items()}
-            lab = _Labels(**{k: out[k].data_ptr() for k in _Labels._names})
+            res = {k: buf(k, (B,) + shp, dt) for k, (shp, dt) in _LABEL_SPECS.items()}
+            lab = _Labels(**{k: res[k].data_ptr() for k in _Labels._names})
             _C.call("s2c_scene_box_labels", B, int(self.augment), st.boxes.data_ptr(),
                     st.box_off.data_ptr(), st.box_rot.data_ptr(), st.box_rot_mask.data_ptr(),
                     slot.data_ptr(), oid.data_ptr(), aug.data_ptr(), self.class_of.data_ptr(),
                     self.mean_size.data_ptr(), lab, s)
-            zeros = torch.zeros((B, MAX_NUM_OBJ), dtype=torch.int64, device=dev)
-        out.update(point_clouds=cloud, vote_label=votes, vote_label_mask=vmask,
-                   heading_class_label=zeros,
-                   heading_residual_label=zeros.to(torch.float32),
-                   ref_heading_class_label=zeros[:, 0].clone(),
-                   ref_heading_residual_label=zeros[:, 0].clone(),
-                   object_id=oid.clone())
-        return out
+            res.update(
+                point_clouds=cloud, vote_label=votes, vote_label_mask=vmask,
+                heading_class_label=buf("heading_class_label", (B, MAX_NUM_OBJ), torch.int64, True),
+                heading_residual_label=buf("heading_residual_label", (B, MAX_NUM_OBJ),
+                                           torch.float32, True),
+                ref_heading_class_label=buf("ref_heading_class_label", (B,), torch.int64, True),
+                ref_heading_residual_label=buf("ref_heading_residual_label", (B,), torch.int64,
+                                               True))
+            res["object_id"] = buf("object_id", (B,), torch.int64).copy_(oid)
+            res["_choices"] = choices          # the sampled vertex of every cloud row
+        return res
 
 
 class AnnotationTable(object):
@@ -366,9 +418,72 @@ class AnnotationTable(object):
                   "unique_multiple": t(unique_multiple, torch.int64)}
         self.object_id_host = np.asarray(object_id, np.int64)
         self.device = dev
+        self._upload = _SmallUploads(dev)
 
     def gather(self, indices):
-        idx = torch.as_tensor(np.asarray(indices, np.int64)).to(self.device, non_blocking=True)
+        idx = self._upload(np.asarray(indices, np.int64))
         out = {k: v.index_select(0, idx) for k, v in self.t.items()}
         out["dataset_idx"] = idx
         return out
+
+
+class BatchFeeder(object):
+    """Producer for a captured training step: batches are assembled into static buffer sets
+    (`buffers[p]` = the data_dict the p-th graph was captured on; only keys present in it
+    are written) on the feeder's own stream while other steps run.
+
+        feeder.acquire(p); graphs[p].replay(); feeder.release(p)
+        feeder.produce(q, scene_ids, object_ids, ann_indices, host_wait=True)
+
+    Measured in `bench.py --feed builder` (cfg3 train step, 12.5 ms with one resident
+    batch): with TWO sets and the producer's stream parked on the event that frees its set
+    (plus the geometry stream parked on the producer) the step takes 14.2 ms although
+    neither is on the critical path -- every stream parked on a cross-stream event cost the
+    training stream 0.3-0.7 ms per step on this stack.  With THREE sets and host_wait=True
+    (the host itself waits for step i-1 before enqueuing batch i+2, so nothing ever
+    parks) the same work costs 12.9 ms."""
+
+    def __init__(self, builder, annotations, buffers, device_choices=True, rng=None,
+                 stream=None):
+        """stream: the producer's stream; pass one that shares no hardware queue with the
+        training stream (pipeline.independent_streams) -- the producer parks on an event
+        until the previous reader of a buffer set is done, and a parked stream holds up
+        every other stream mapped to the same queue."""
+        self.builder, self.annotations, self.buffers = builder, annotations, buffers
+        self.device_choices = device_choices
+        self.rng = rng if rng is not None else np.random.RandomState(0)
+        self.stream = stream if stream is not None else torch.cuda.Stream(builder.store.device)
+        self.ready = [None] * len(buffers)
+        self.consumed = [None] * len(buffers)
+
+    def produce(self, p, scene_ids, object_ids, ann_indices=None, host_wait=False):
+        """host_wait=True: the HOST waits (polling) until the last reader of set p is done and
+        only then enqueues the work, so no stream ever parks on an event (with three buffer
+        sets the host then runs one step ahead of the GPU)."""
+        with torch.cuda.stream(self.stream):
+            draws = self.builder.draw(scene_ids, rng=self.rng,
+                                      device_choices=self.device_choices)
+            staged = self.builder.stage(scene_ids, object_ids, draws)
+            if self.consumed[p] is not None:
+                if host_wait:
+                    _wait(self.consumed[p])
+                self.stream.wait_event(self.consumed[p])      # the reader of set p is done
+            self.builder.build(scene_ids, object_ids, draws, out=self.buffers[p],
+                               staged=staged)
+            if ann_indices is not None and self.annotations is not None:
+                for k, v in self.annotations.gather(ann_indices).items():
+                    t = self.buffers[p].get(k)
+                    if torch.is_tensor(t):
+                        t.copy_(v)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self.ready[p] = ev
+        return ev
+
+    def acquire(self, p):
+        torch.cuda.current_stream().wait_event(self.ready[p])
+
+    def release(self, p):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.consumed[p] = ev

@@ -116,35 +116,50 @@ def test_draw_consumes_numpy_state_like_the_oracle():
 
 
 def test_device_side_vertex_sampling():
-    """device_choices=True: N distinct in-range vertices per item (with replacement only for
-    a scene smaller than N), every vertex equally likely, and `build` consumes them."""
+    """device_choices=True (s2c_scene_sample): N distinct in-range vertices per item (with
+    replacement only for a scene smaller than N), every vertex about equally likely, no
+    order bias, and the item built from them equals the oracle's for the same choices."""
     scenes = [sc.make_scene(30, 6000), sc.make_scene(31, 700), sc.make_scene(32, 4100)]
     store = _store(scenes, 0)
     N = 2048
-    builder = _sb().SceneBatchBuilder(store, np.ones((18, 3)), num_points=N, augment=True)
+    msa = np.ones((18, 3))
+    builder = _sb().SceneBatchBuilder(store, msa, num_points=N, augment=True)
     ids = ["s0", "s1", "s2", "s0"]
+    oids = [0, 0, 0, 1]
     rs = np.random.RandomState(1)
     hits = torch.zeros(6000, device="cuda")
-    for rep in range(40):
+    first = torch.zeros(6000, device="cuda")
+    small_hits = torch.zeros(700, device="cuda")
+    reps = 60
+    for rep in range(reps):
         draws = builder.draw(ids, rng=rs, device_choices=True)
+        out = builder.build(ids, oids, draws)
+        ch = out["_choices"]
+        assert ch.shape == (4, N) and ch.dtype == torch.int64
         for b, sid in enumerate(ids):
-            ch = draws[b]["choices"]
             nv = len(scenes[int(sid[1])]["mesh_vertices"])
-            assert ch.shape == (N,) and ch.dtype == torch.int64 and ch.is_cuda
-            assert int(ch.min()) >= 0 and int(ch.max()) < nv
+            assert int(ch[b].min()) >= 0 and int(ch[b].max()) < nv
             if nv >= N:
-                assert ch.unique().numel() == N
-        hits += torch.bincount(draws[0]["choices"], minlength=6000)
-        hits += torch.bincount(draws[3]["choices"], minlength=6000)
-    # 80 samples of 2048/6000: every vertex expected 27.3 times, sd 4.2
-    assert float(hits.min()) > 5 and float(hits.max()) < 55
-    assert abs(float(hits.mean()) - 80 * N / 6000.0) < 1e-3
-    out = builder.build(ids, [0, 0, 0, 1], draws)
+                assert ch[b].unique().numel() == N
+        assert not torch.equal(ch[0], ch[3])          # different seeds, same scene
+        for b in (0, 3):
+            hits += torch.bincount(ch[b], minlength=6000)
+            first += torch.bincount(ch[b, :256], minlength=6000)
+        small_hits += torch.bincount(ch[1], minlength=700)
+    n = 2 * reps
+    mean, sd = n * N / 6000.0, (n * (N / 6000.0) * (1 - N / 6000.0)) ** 0.5
+    assert abs(float(hits.mean()) - mean) < 1e-3
+    assert float(hits.min()) > mean - 6 * sd and float(hits.max()) < mean + 6 * sd
+    assert 0.8 * sd < float(hits.std()) < 1.2 * sd            # binomial spread, not clumped
+    m1 = n * 256 / 6000.0
+    assert float(first.max()) < m1 + 6 * m1 ** 0.5 + 1        # no vertex favoured up front
+    ms = reps * N / 700.0
+    assert ms - 6 * ms ** 0.5 < float(small_hits.min()) and float(small_hits.max()) < ms + 6 * ms ** 0.5
     torch.cuda.synchronize()
+    chn = out["_choices"].cpu().numpy()
     for b, sid in enumerate(ids):
-        i = int(sid[1])
-        d = dict(draws[b], choices=draws[b]["choices"].cpu().numpy())
-        want = osb.build_item(scenes[i], d, [0, 0, 0, 1][b], N, np.ones((18, 3)), augment=True)
+        d = dict(draws[b], choices=chn[b])
+        want = osb.build_item(scenes[int(sid[1])], d, oids[b], N, msa, augment=True)
         _assert_item(out, b, want, "device-sampled item %d" % b)
 
 
