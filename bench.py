@@ -463,7 +463,8 @@ def main():
             def step(_dd):
                 if feeder is not None:
                     return fed_step(_dd)
-                p = counter["i"] % depth
+                i = counter["i"]
+                p = i % depth
                 counter["i"] += 1
                 slots.acquire(p)                       # geometry of this step is published
                 out = replays[p]()
