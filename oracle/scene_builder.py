@@ -94,15 +94,10 @@ def _corners(size, center):
     return _CORNER_SIGNS * (np.asarray(size)[..., None, :] / 2) + np.asarray(center)[..., None, :]
 
 
-def build_item(scene, draws, object_id, num_points, mean_size_arr, use_color=False,
-               use_height=True, use_normal=False, use_multiview=False, augment=False,
-               rotations=None):
-    """scene: dict(mesh_vertices (Nv,>=6[9]) f32, instance_labels (Nv), semantic_labels
-    (Nv), instance_bboxes (nb,8) f64 [cx cy cz dx dy dz nyu40id object_id], multiview
-    (Nv,Cm) f32 when use_multiview).  rotations: {object_id: 3x3} (Scan2CAD) or None.
-    Returns the tensor-valued entries of the reference's item dict."""
+def _channels(scene, use_color, use_height, use_normal, use_multiview):
+    """lib/dataset.py:338-363 (= :575-598 of the test dataset): xyz [rgb] [normal]
+    [multiview] [height] for every vertex."""
     verts = scene["mesh_vertices"]
-    boxes_in = scene["instance_bboxes"]
     cols = [verts[:, 0:3]]
     if use_color:
         # one application of the normalisation (the reference writes it back into its
@@ -117,6 +112,26 @@ def build_item(scene, draws, object_id, num_points, mean_size_arr, use_color=Fal
     if use_height:
         floor = np.percentile(cloud[:, 2], 0.99)
         cloud = np.concatenate([cloud, (cloud[:, 2] - floor)[:, None]], 1)
+    return cloud
+
+
+def build_test_item(scene, draws, use_color=False, use_height=True, use_normal=False,
+                    use_multiview=False):
+    """`ScannetReferenceTestDataset.__getitem__` (lib/dataset.py:567-609): the sampled,
+    un-augmented cloud."""
+    cloud = _channels(scene, use_color, use_height, use_normal, use_multiview)
+    return {"point_clouds": cloud[draws["choices"]].astype(np.float32)}
+
+
+def build_item(scene, draws, object_id, num_points, mean_size_arr, use_color=False,
+               use_height=True, use_normal=False, use_multiview=False, augment=False,
+               rotations=None):
+    """scene: dict(mesh_vertices (Nv,>=6[9]) f32, instance_labels (Nv), semantic_labels
+    (Nv), instance_bboxes (nb,8) f64 [cx cy cz dx dy dz nyu40id object_id], multiview
+    (Nv,Cm) f32 when use_multiview).  rotations: {object_id: 3x3} (Scan2CAD) or None.
+    Returns the tensor-valued entries of the reference's item dict."""
+    boxes_in = scene["instance_bboxes"]
+    cloud = _channels(scene, use_color, use_height, use_normal, use_multiview)
     choices = draws["choices"]
     cloud = cloud[choices]
     ins = scene["instance_labels"][choices]

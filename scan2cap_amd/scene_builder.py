@@ -146,11 +146,24 @@ class SceneStore(object):
         self._host = []
         self.index = {}
         self.final = False
+        self.bare = False
 
-    def add_scene(self, scene_id, mesh_vertices, instance_labels, semantic_labels,
-                  instance_bboxes, multiview=None, rotations=None):
+    def add_scene(self, scene_id, mesh_vertices, instance_labels=None, semantic_labels=None,
+                  instance_bboxes=None, multiview=None, rotations=None):
+        """Labels and boxes may be omitted for ALL scenes of a store (the test split,
+        lib/dataset.py:611-617, loads vertices only): such a store serves
+        `SceneBatchBuilder.build_clouds` but not `build`."""
         if self.final:
             raise RuntimeError("SceneStore is finalized")
+        bare = instance_labels is None and semantic_labels is None and instance_bboxes is None
+        if self._host and bare != self.bare:
+            raise ValueError("a store holds either labelled or vertices-only scenes")
+        self.bare = bare
+        if bare:
+            nv0 = np.asarray(mesh_vertices).shape[0]
+            instance_labels = np.zeros(nv0, np.int32)
+            semantic_labels = np.zeros(nv0, np.int32)
+            instance_bboxes = np.array([[0, 0, 0, 1, 1, 1, 3, 0]], np.float64)   # placeholder
         v = np.ascontiguousarray(mesh_vertices, np.float32)
         nv = v.shape[0]
         if v.ndim != 2 or v.shape[1] != self.cols or nv == 0:
@@ -343,6 +356,8 @@ class SceneBatchBuilder(object):
         `staged`: the result of `stage(...)` for the same arguments."""
         st = self.store
         dev = st.device
+        if st.bare:
+            raise ValueError("the store holds vertices only: use build_clouds")
         if staged is None:
             staged = self.stage(scene_ids, object_ids, draws)
         B, d, (o1, o2, o3, used) = staged
@@ -401,6 +416,38 @@ class SceneBatchBuilder(object):
             res["object_id"] = buf("object_id", (B,), torch.int64).copy_(oid)
             res["_choices"] = choices          # the sampled vertex of every cloud row
         return res
+
+    def build_clouds(self, scene_ids, draws, out=None):
+        """`point_clouds` only -- the item of the reference's TEST dataset
+        (`ScannetReferenceTestDataset.__getitem__`, lib/dataset.py:567-609: sampling and the
+        feature channels, no augmentation, no labels).  -> {"point_clouds": (B,N,3+C)}"""
+        st = self.store
+        dev = st.device
+        B, d, (o1, o2, o3, used) = self.stage(scene_ids, [0] * len(scene_ids), draws)
+        N = self.N
+        with torch.cuda.device(dev):
+            slot = d[o2:o2 + B * 4].view(torch.int32)
+            seeds = d[o1 + B * 8:o2].view(torch.int64)
+            s = _C.stream_ptr()
+            if used > o3:
+                choices = d[o3:used].view(torch.int64).view(B, N)
+            else:
+                choices = torch.empty((B, N), dtype=torch.int64, device=dev)
+                _C.call("s2c_scene_sample", B, N, st.vert_off.data_ptr(), slot.data_ptr(),
+                        seeds.data_ptr(), choices.data_ptr(), s)
+            cloud = out["point_clouds"] if out is not None and "point_clouds" in out else \
+                torch.empty((B, N, self.Cout), dtype=torch.float32, device=dev)
+            if tuple(cloud.shape) != (B, N, self.Cout) or cloud.dtype != torch.float32 \
+                    or not cloud.is_contiguous():
+                raise ValueError("out['point_clouds'] must be a contiguous float32 (B,N,%d) tensor"
+                                 % self.Cout)
+            _C.TIMER.alg_bytes = 8 * B * N * self.Cout + 8 * B * N
+            _C.call("s2c_scene_gather", B, N, st.cols, st.Cm, int(self.use_color),
+                    int(self.use_normal), int(self.use_multiview), int(self.use_height), 0,
+                    st.verts.data_ptr(), st.mv.data_ptr() if st.mv is not None else None,
+                    st.vert_off.data_ptr(), st.floor.data_ptr(), slot.data_ptr(),
+                    choices.data_ptr(), d[:o1].view(torch.float64).data_ptr(), cloud.data_ptr(), s)
+        return {"point_clouds": cloud, "_choices": choices}
 
 
 class AnnotationTable(object):

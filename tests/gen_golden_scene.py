@@ -55,6 +55,22 @@ def main():
         print(name, "boxes", int(res["num_bbox"]), "voting points",
               int(res["vote_label_mask"].sum()), "ref", int(res["ref_box_label"].sum()),
               "cloud", res["point_clouds"].shape)
+    # the test split's dataset (lib/dataset.py:542-617): vertices only
+    sseed, nv, npts, mvw, opts, rseed = sc.TEST_CASE
+    scene = sc.make_scene(sseed, nv, mvw)
+    tds = ds.ScannetReferenceTestDataset.__new__(ds.ScannetReferenceTestDataset)
+    sid = "scene%04d_00" % sseed
+    tds.scanrefer_all_scene = [sid]
+    tds.scene_data = {sid: {"mesh_vertices": scene["mesh_vertices"]}}
+    tds.multiview_data = {mp.current_process().pid: {sid: scene.get("multiview")}}
+    tds.glove = {"sos": np.zeros(300)}
+    tds.num_points = npts
+    for k, v in opts.items():
+        setattr(tds, k, v)
+    np.random.seed(rseed)
+    res = tds[0]
+    out["test_split/point_clouds"] = np.asarray(res["point_clouds"])
+    print("test_split cloud", res["point_clouds"].shape)
     path = os.path.join(HERE, "golden", "scene_items.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")

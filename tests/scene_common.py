@@ -31,6 +31,11 @@ CASES = {
 }
 
 
+# (scene seed, Nv, num_points, multiview width, options, np.random seed) of the TEST dataset
+TEST_CASE = (8, 2600, 1024, 8, dict(use_color=False, use_height=True, use_normal=True,
+                                    use_multiview=True), 105)
+
+
 def make_scene(seed, num_vertices, multiview_width=0, num_instances=14):
     g = np.random.Generator(np.random.PCG64(seed))
     f32 = np.float32

@@ -40,6 +40,15 @@ def test_oracle_matches_reference_item(name, golden):
             got[k].astype(np.float64) - want.astype(np.float64)).max())
 
 
+def test_oracle_matches_reference_test_split_item(golden):
+    sseed, nv, npts, mvw, opts, rseed = sc.TEST_CASE
+    scene = sc.make_scene(sseed, nv, mvw)
+    np.random.seed(rseed)
+    got = osb.build_test_item(scene, osb.draw(nv, npts, False), **opts)["point_clouds"]
+    want = golden["test_split/point_clouds"]
+    assert got.dtype == want.dtype and np.array_equal(got, want)
+
+
 def test_nyu40_class_table_matches_reference(golden):
     # 37 voting ids, 18 classes, "others" = 17 (model_util_scannet.py:83-115)
     assert np.array_equal(golden["nyu40ids"], osb.NYU40IDS)

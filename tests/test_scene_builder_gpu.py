@@ -62,6 +62,28 @@ def test_items_match_reference_golden(name):
     _assert_item(out, 0, want, name)
 
 
+def test_test_split_item_matches_reference_golden():
+    """`build_clouds` over a vertices-only store = the reference's test dataset item."""
+    golden = np.load(GOLDEN)
+    sseed, nv, npts, mvw, opts, rseed = sc.TEST_CASE
+    scene = sc.make_scene(sseed, nv, mvw)
+    sb = _sb()
+    store = sb.SceneStore("cuda:0", multiview_width=mvw)
+    store.add_scene("t", scene["mesh_vertices"], multiview=scene["multiview"])
+    store.finalize()
+    builder = sb.SceneBatchBuilder(store, np.ones((18, 3)), num_points=npts, **opts)
+    np.random.seed(rseed)
+    draws = builder.draw(["t"])
+    got = builder.build_clouds(["t"], draws)["point_clouds"][0].cpu().numpy()
+    assert np.array_equal(got, golden["test_split/point_clouds"])
+    with pytest.raises(ValueError):
+        builder.build(["t"], [0], draws)          # no labels in this store
+    dev = builder.build_clouds(["t", "t"], builder.draw(["t", "t"], device_choices=True))
+    ch = dev["_choices"]
+    assert ch.unique(dim=1).shape[1] == npts or ch[0].unique().numel() == npts
+    assert torch.equal(dev["point_clouds"][1, :, 3:6], store.verts[ch[1], 6:9])
+
+
 @pytest.mark.parametrize("mvw,opts", [
     (16, dict(use_color=False, use_height=True, use_normal=True, use_multiview=True,
               augment=True)),
