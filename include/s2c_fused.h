@@ -331,6 +331,20 @@ int s2c_edge_scatter_grad(int B, int K, int L, int F, const float *d_out, const 
                           const long long *nbr, const unsigned char *slot, float *d_msg,
                           void *stream);
 
+/* Weight gradient of a rows x channels layer (autograd of the reference's 1x1 convolutions /
+ * linears, lib/pointnet2/pytorch_utils.py:11-120): dW (Cout x Cin, row stride lddw) =
+ * dY^T A with dY (M x Cout, row stride ldy) and A (M x Cin, row stride lda), fp32-accurate
+ * bf16x3 MFMA products, deterministic (fixed-order) reduction over the rows.
+ * workspace: s2c_weight_grad_workspace_bytes() bytes (scratch, any content);
+ * counters:  s2c_weight_grad_counter_bytes() bytes that must be ZERO on entry and are
+ * zero again on exit (allocate once, zero once).  Both may be NULL when the plan has a
+ * single slab of rows. */
+long long s2c_weight_grad_workspace_bytes(long long M, int Cout, int Cin);
+long long s2c_weight_grad_counter_bytes(long long M, int Cout, int Cin);
+int s2c_weight_grad(long long M, int Cout, int Cin, const float *dY, long long ldy,
+                    const float *A, long long lda, float *dW, int lddw, void *workspace,
+                    void *counters, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

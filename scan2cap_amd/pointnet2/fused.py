@@ -38,6 +38,7 @@ _C.register("s2c_bn_relu_bwd", [_L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, 
 _C.register("s2c_rows_gemm", [_L, _I, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _P])
 _C.register("s2c_sa_gather_gemm", [_I, _I, _I, _I, _I, _L, _L, _F, _I, _P, _P, _P, _P, _I, _P, _I, _P, _I, _P, _P])
 _C.register("s2c_bn_finalize_partials", [_I, _L, _I, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P])
+_C.register("s2c_weight_grad", [_L, _I, _I, _P, _L, _P, _L, _P, _I, _P, _P, _P])
 _C.register("s2c_bn_relu_max_bwd", [_L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P])
 
 
@@ -452,12 +453,56 @@ def _eval_stack(X, gather, M, dev, specs, pool_ns, params):
     return A
 
 
+# dW = dY^T A by the hand-written kernel (csrc/s2c_dw.hip) instead of a split-K batched
+# library GEMM + a partial-sum kernel.  OFF: measured slower (tools/bench_dw.py) --
+# its register-fed MFMA loop only matches the library (135 vs 123 us at 1M x 64 x 64) and the
+# in-kernel "last workgroup adds up" reduction costs 150-250 us in agent-scope fences.
+USE_DW_KERNEL = False
+DW_KERNEL_MIN_ROWS = 2048
+_dw_counters = {}
+
+
+def _dw_sizes(M, Cout, Cin):
+    lib = _C.load()
+    if not getattr(lib, "_dw_sized", False):
+        for name in ("s2c_weight_grad_workspace_bytes", "s2c_weight_grad_counter_bytes"):
+            fn = getattr(lib, name)
+            fn.restype = ctypes.c_longlong
+            fn.argtypes = [_L, _I, _I]
+        lib._dw_sized = True
+    return (lib.s2c_weight_grad_workspace_bytes(M, Cout, Cin),
+            lib.s2c_weight_grad_counter_bytes(M, Cout, Cin))
+
+
+def weight_grad_kernel(dY, A):
+    """dW (Cout,Cin) = dY^T A through s2c_weight_grad (fp32 rows with unit column stride)."""
+    M, Cout = dY.shape
+    Cin = A.shape[1]
+    dev = dY.device
+    wbytes, cbytes = _dw_sizes(M, Cout, Cin)
+    cnt = _dw_counters.get(dev)
+    if cnt is None or cnt.numel() * 4 < cbytes:
+        # zero once: the kernel leaves its counters zeroed (launches are stream-ordered)
+        cnt = torch.zeros(max(cbytes // 4, 4096), dtype=torch.int32, device=dev)
+        _dw_counters[dev] = cnt
+    work = torch.empty(max(wbytes // 4, 1), dtype=torch.float32, device=dev)
+    dW = torch.empty((Cout, Cin), dtype=torch.float32, device=dev)
+    _call("s2c_weight_grad", dW, M, Cout, Cin, dY.data_ptr(), dY.stride(0), A.data_ptr(),
+          A.stride(0), dW.data_ptr(), Cin, work.data_ptr(), cnt.data_ptr(),
+          alg_bytes=4 * M * (Cout + Cin), alg_flops=2 * M * Cout * Cin)
+    return dW
+
+
 def _weight_grad(dY, A):
     """dW (Cout,Cin) = dY^T (Cout,M) @ A (M,Cin) with M up to ~1e6 and a tiny
     output: a plain GEMM call gives the library ONE output tile and a million-deep
-    K loop (a single workgroup).  Split the row dimension into S independent
-    slabs (strided-batched GEMM fills the chip) and reduce the S partials."""
+    K loop (a single workgroup).  Hand-written kernel (USE_DW_KERNEL); library fallback
+    for exotic layouts: split the row dimension into S independent slabs (strided-batched
+    GEMM fills the chip) and reduce the S partials."""
     M = dY.shape[0]
+    if (USE_DW_KERNEL and dY.is_cuda and M >= DW_KERNEL_MIN_ROWS and dY.dtype == torch.float32
+            and A.dtype == torch.float32 and dY.stride(1) == 1 and A.stride(1) == 1):
+        return weight_grad_kernel(dY, A)
     S = 1
     while S < 512 and M % (2 * S) == 0 and M // (2 * S) >= 1024:
         S *= 2
