@@ -345,6 +345,25 @@ int s2c_weight_grad(long long M, int Cout, int Cin, const float *dY, long long l
                     const float *A, long long lda, float *dW, int lddw, void *workspace,
                     void *counters, void *stream);
 
+/* Box bookkeeping of the proposal stage (models/proposal_module.py:80-144,
+ * model_util_scannet.py:165-172, utils/box_util.py:360-383) from the head output net
+ * (B,K,nout) f32 [2 objectness | 3 centre offset | NH heading scores | NH heading residuals |
+ * NS size scores | NS*3 size residuals (normalised) | num_class semantic scores] and the
+ * decoded centres (B,K,3) f32: bbox_corner (B,K,8,3) f64 for heading 0 (ScanNet),
+ * bbox_mask / sem_cls (B,K) i64 = arg-max of the objectness / semantic scores (first
+ * maximum), size_class (B,K) i64 (may be NULL). */
+int s2c_proposal_decode(int B, int K, int nout, int num_heading_bin, int num_size_cluster,
+                        int num_class, const float *net, const float *center,
+                        const float *mean_size_f32, const double *mean_size_f64,
+                        double *bbox_corner, long long *bbox_mask, long long *sem_cls,
+                        long long *size_class, void *stream);
+
+/* target_ids (B) i64 / target_ious (B) f32: the proposal with the largest axis-aligned IoU
+ * (utils/box_util.py:183-209, float64) against each sample's ground-truth box
+ * (models/caption_module.py:16-38); first maximum. */
+int s2c_select_target(int B, int K, const double *bbox_corner, const double *ref_box_corner,
+                      long long *target_ids, float *target_ious, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

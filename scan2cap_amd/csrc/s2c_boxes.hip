@@ -1,0 +1,156 @@
+// s2c_boxes.hip -- the non-differentiable box bookkeeping of the proposal and caption
+// stages as two launches instead of ~45 framework micro-kernels (each a 3-6 us node of the
+// captured step):
+//   proposal_decode   argmax size class, box size, AABB corners (float64), objectness /
+//                     semantic arg-max     (models/proposal_module.py:80-144,
+//                     data/scannet/model_util_scannet.py:165-172, utils/box_util.py:360-383)
+//   select_target     best-IoU proposal per ground-truth box (models/caption_module.py:16-38,
+//                     utils/box_util.py:183-209)
+// Arithmetic is the reference's: float32 residual * float32 mean size, float64 mean size +
+// residual, corners = +-size/2 + centre (ScanNet heading is 0, so the rotation is the
+// identity), AABB IoU in float64 in the reference's operation order; arg-max = first maximum.
+#include "s2c_common.h"
+#include "../../include/s2c_fused.h"
+
+#include <stdio.h>
+
+namespace {
+
+__device__ __forceinline__ int argmax_first(const float *p, int n) {
+  int best = 0;
+  float bv = p[0];
+  for (int i = 1; i < n; ++i) {
+    const float v = p[i];
+    if (v > bv || (v != v && bv == bv)) { bv = v; best = i; }   // NaN counts as maximal
+  }
+  return best;
+}
+
+// thread = proposal
+__global__ __launch_bounds__(256) void proposal_decode_kernel(
+    int total, int nout, int NH, int NS, int num_class, const float *__restrict__ net,
+    const float *__restrict__ center, const float *__restrict__ mean32,
+    const double *__restrict__ mean64, double *__restrict__ corners,
+    long long *__restrict__ bbox_mask, long long *__restrict__ sem_cls,
+    long long *__restrict__ size_class_out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const float *row = net + (size_t)i * nout;
+  const int o_size = 5 + 2 * NH;
+  const int cls = argmax_first(row + o_size, NS);
+  const float *resn = row + o_size + NS + 3 * cls;       // normalised residual of the class
+  double size[3], c[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float res = resn[d] * mean32[cls * 3 + d];      // data_dict["size_residuals"]
+    size[d] = mean64[cls * 3 + d] + (double)res;          // class2size_batch
+    c[d] = (double)center[(size_t)i * 3 + d];
+  }
+  const double sx[8] = {1, 1, -1, -1, 1, 1, -1, -1};
+  const double sy[8] = {1, -1, -1, 1, 1, -1, -1, 1};
+  const double sz[8] = {1, 1, 1, 1, -1, -1, -1, -1};
+  double *out = corners + (size_t)i * 24;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    out[k * 3 + 0] = (size[0] / 2) * sx[k] + c[0];
+    out[k * 3 + 1] = (size[1] / 2) * sy[k] + c[1];
+    out[k * 3 + 2] = (size[2] / 2) * sz[k] + c[2];
+  }
+  bbox_mask[i] = argmax_first(row, 2);
+  sem_cls[i] = argmax_first(row + o_size + 4 * NS, num_class);
+  if (size_class_out) size_class_out[i] = cls;
+}
+
+// workgroup = sample; thread = proposal (strided when K > 1024)
+__global__ __launch_bounds__(1024) void select_target_kernel(
+    int K, const double *__restrict__ corners, const double *__restrict__ gt,
+    long long *__restrict__ target_ids, float *__restrict__ target_ious) {
+  __shared__ double s_iou[1024];
+  __shared__ int s_idx[1024];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const double *g = gt + (size_t)b * 24;
+  double gmin[3], gmax[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    gmin[d] = gmax[d] = g[d];
+    for (int k = 1; k < 8; ++k) {
+      gmin[d] = fmin(gmin[d], g[k * 3 + d]);
+      gmax[d] = fmax(gmax[d], g[k * 3 + d]);
+    }
+  }
+  double best = -1.0;
+  int bidx = 0x7fffffff;
+  for (int k = t; k < K; k += 1024) {
+    const double *p = corners + ((size_t)b * K + k) * 24;
+    double inter = 1.0, vol1 = 1.0, vol2 = 1.0;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      double lo1 = p[d], hi1 = p[d];
+      for (int q = 1; q < 8; ++q) {
+        lo1 = fmin(lo1, p[q * 3 + d]);
+        hi1 = fmax(hi1, p[q * 3 + d]);
+      }
+      const double lo = fmax(lo1, gmin[d]), hi = fmin(hi1, gmax[d]);
+      const double ext = fmax(hi - lo, 0.0);
+      inter = (d == 0) ? ext : inter * ext;
+      vol1 = (d == 0) ? (hi1 - lo1) : vol1 * (hi1 - lo1);
+      vol2 = (d == 0) ? (gmax[d] - gmin[d]) : vol2 * (gmax[d] - gmin[d]);
+    }
+    const double iou = inter / (vol1 + vol2 - inter + 1e-8);
+    if (iou > best) { best = iou; bidx = k; }        // first maximum of this thread's stride
+  }
+  s_iou[t] = best;
+  s_idx[t] = bidx;
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) {
+    if (t < s) {
+      const double o = s_iou[t + s];
+      const int oi = s_idx[t + s];
+      if (o > s_iou[t] || (o == s_iou[t] && oi < s_idx[t])) { s_iou[t] = o; s_idx[t] = oi; }
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    target_ids[b] = s_idx[0];
+    target_ious[b] = (float)s_iou[0];
+  }
+}
+
+int chk7(const char *k) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    fprintf(stderr, "s2c: %s launch failed: %s\n", k, hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int s2c_proposal_decode(int B, int K, int nout, int num_heading_bin,
+                                   int num_size_cluster, int num_class, const float *net,
+                                   const float *center, const float *mean_size_f32,
+                                   const double *mean_size_f64, double *bbox_corner,
+                                   long long *bbox_mask, long long *sem_cls,
+                                   long long *size_class, void *stream) {
+  if (B <= 0 || K <= 0 || num_heading_bin <= 0 || num_size_cluster <= 0 || num_class <= 0 ||
+      nout != 2 + 3 + 2 * num_heading_bin + 4 * num_size_cluster + num_class || !net ||
+      !center || !mean_size_f32 || !mean_size_f64 || !bbox_corner || !bbox_mask || !sem_cls)
+    return -1;
+  const int total = B * K;
+  hipLaunchKernelGGL(proposal_decode_kernel, dim3((total + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, total, nout, num_heading_bin, num_size_cluster,
+                     num_class, net, center, mean_size_f32, mean_size_f64, bbox_corner,
+                     bbox_mask, sem_cls, size_class);
+  return chk7("proposal_decode");
+}
+
+extern "C" int s2c_select_target(int B, int K, const double *bbox_corner,
+                                 const double *ref_box_corner, long long *target_ids,
+                                 float *target_ious, void *stream) {
+  if (B <= 0 || K <= 0 || !bbox_corner || !ref_box_corner || !target_ids || !target_ious)
+    return -1;
+  hipLaunchKernelGGL(select_target_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, K,
+                     bbox_corner, ref_box_corner, target_ids, target_ious);
+  return chk7("select_target");
+}

@@ -48,6 +48,8 @@ def _split_gemm_available():
         except Exception:
             _split_ok = False
     return _split_ok
+_C.register("s2c_select_target", [_I, _I, _P, _P, _P, _P, _P])
+USE_SELECT_TARGET_KERNEL = True      # one launch instead of ~15 (csrc/s2c_boxes.hip)
 _C.register("s2c_split_bf16x3", [ctypes.c_longlong, _I, _P, ctypes.c_longlong, _P, _P, _P])
 _ORDER_A = (ctypes.c_int * 6)(0, 0, 1, 1, 0, 2)      # activations: hi hi mid mid hi lo
 _ORDER_W = (ctypes.c_int * 6)(0, 1, 0, 1, 2, 0)      # weights:     hi mid hi mid lo hi
@@ -75,6 +77,17 @@ def select_target(data_dict):
     Returns target_ids (B) int64, target_ious (B) float32."""
     pred_bbox = data_dict["bbox_corner"]                    # (B,K,8,3)
     gt_bbox = data_dict["ref_box_corner_label"]             # (B,8,3)
+    if (USE_SELECT_TARGET_KERNEL and pred_bbox.is_cuda and pred_bbox.dtype == torch.float64
+            and gt_bbox.dtype == torch.float64):
+        B, K = pred_bbox.shape[:2]
+        pb = pred_bbox if pred_bbox.is_contiguous() else pred_bbox.contiguous()
+        gb = gt_bbox if gt_bbox.is_contiguous() else gt_bbox.contiguous()
+        ids = torch.empty(B, dtype=torch.int64, device=pb.device)
+        ious = torch.empty(B, dtype=torch.float32, device=pb.device)
+        with torch.cuda.device(pb.device):
+            _C.call("s2c_select_target", B, K, pb.data_ptr(), gb.data_ptr(), ids.data_ptr(),
+                    ious.data_ptr(), _C.stream_ptr())
+        return ids, ious
     ious = box3d_iou_batch_tensor(pred_bbox, gt_bbox.unsqueeze(1).to(pred_bbox.dtype))
     target_ids = ious.argmax(dim=1)
     target_ious = torch.gather(ious, 1, target_ids.view(-1, 1)).squeeze(1).float()

@@ -11,9 +11,18 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+import ctypes
+
+from .. import _C
 from ..box_util import get_3d_box_batch
 from ..pointnet2 import fused
 from ..pointnet2.pointnet2_modules import PointnetSAModuleVotes
+
+_I, _P = ctypes.c_int, ctypes.c_void_p
+_C.register("s2c_proposal_decode", [_I] * 6 + [_P] * 9)
+# box size / corners / arg-max bookkeeping in one launch (csrc/s2c_boxes.hip) instead of ~30
+# framework micro-kernels; identical values (tests/test_fused_gpu.py)
+FUSE_BOX_DECODE = True
 
 
 class ProposalModule(nn.Module):
@@ -109,8 +118,27 @@ class ProposalModule(nn.Module):
             self._mean_size_f32.unsqueeze(0).unsqueeze(0)
         data_dict["sem_cls_scores"] = sem_cls_scores
 
-        data_dict["bbox_corner"] = self.decode_pred_box(data_dict)
         data_dict["bbox_feature"] = data_dict["aggregated_vote_features"]
+        if FUSE_BOX_DECODE and nt.is_cuda and nt.dtype == torch.float32:
+            # one launch for the non-differentiable bookkeeping (csrc/s2c_boxes.hip)
+            dev = nt.device
+            corners = torch.empty((B, K, 8, 3), dtype=torch.float64, device=dev)
+            mask = torch.empty((B, K), dtype=torch.int64, device=dev)
+            sem = torch.empty((B, K), dtype=torch.int64, device=dev)
+            cen = center.detach()
+            if not cen.is_contiguous():
+                cen = cen.contiguous()
+            with torch.cuda.device(dev):
+                _C.call("s2c_proposal_decode", B, K, nt.shape[2], NH, NS, num_class,
+                        nt.data_ptr(), cen.data_ptr(), self._mean_size_f32.data_ptr(),
+                        self._mean_size_f64.data_ptr(), corners.data_ptr(), mask.data_ptr(),
+                        sem.data_ptr(), None, _C.stream_ptr())
+            data_dict["bbox_corner"] = corners
+            data_dict["bbox_mask"] = mask
+            data_dict["bbox_sems"] = sem
+            data_dict["sem_cls"] = sem
+            return data_dict
+        data_dict["bbox_corner"] = self.decode_pred_box(data_dict)
         data_dict["bbox_mask"] = objectness_scores.argmax(-1)
         data_dict["bbox_sems"] = sem_cls_scores.argmax(-1)
         data_dict["sem_cls"] = sem_cls_scores.argmax(-1)

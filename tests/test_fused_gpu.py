@@ -509,3 +509,41 @@ def test_weight_grad_kernel(M, Cout, Cin):
     assert torch.equal(got, again)            # fixed reduction order, clean counters
     cnt = fused._dw_counters[dY.device]
     assert int(cnt.abs().sum()) == 0
+
+
+def test_box_bookkeeping_kernels_equal_the_torch_path():
+    """s2c_proposal_decode / s2c_select_target (csrc/s2c_boxes.hip) against the op-by-op
+    device code they replace (proposal_module.decode_scores, caption_module.select_target):
+    every output identical, ties resolved to the first maximum."""
+    from scan2cap_amd.models import caption_module as cm, proposal_module as pm
+    B, K, NH, NS, NC = 3, 300, 1, 18, 18
+    msa = np.random.Generator(np.random.PCG64(5)).uniform(0.3, 1.5, size=(NS, 3))
+    mod = pm.ProposalModule(NC, NH, NS, msa, K, "vote_fps").cuda()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    net = torch.randn((B, 2 + 3 + 2 * NH + 4 * NS + NC, K), device="cuda", generator=g)
+    net[0, 7:7 + NS, 5] = 0.25                    # all size scores tie -> class 0
+    net[1, 0:2, 9] = 1.0                          # objectness tie -> 0
+    xyz = torch.randn((B, K, 3), device="cuda", generator=g)
+    outs = []
+    for flag in (True, False):
+        pm.FUSE_BOX_DECODE = flag
+        dd = {"aggregated_vote_xyz": xyz, "aggregated_vote_features": xyz}
+        outs.append(mod.decode_scores(net, dd, NC, NH, NS, msa))
+    pm.FUSE_BOX_DECODE = True
+    for k in ("bbox_corner", "bbox_mask", "bbox_sems", "sem_cls", "center", "size_residuals"):
+        assert outs[0][k].dtype == outs[1][k].dtype and outs[0][k].shape == outs[1][k].shape, k
+        assert torch.equal(outs[0][k], outs[1][k]), k
+    assert outs[0]["bbox_corner"].dtype == torch.float64
+    # select_target: boxes around the proposals, one exact duplicate (tie -> first)
+    corners = outs[0]["bbox_corner"].clone()
+    corners[2, 77] = corners[2, 13]
+    gt = corners[:, 13] + 0.05
+    gt[2] = corners[2, 13]
+    res = []
+    for flag in (True, False):
+        cm.USE_SELECT_TARGET_KERNEL = flag
+        res.append(cm.select_target({"bbox_corner": corners, "ref_box_corner_label": gt}))
+    cm.USE_SELECT_TARGET_KERNEL = True
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert res[0][0].dtype == torch.int64 and res[0][1].dtype == torch.float32
+    assert int(res[0][0][2]) == 13
