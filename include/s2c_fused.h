@@ -364,6 +364,19 @@ int s2c_proposal_decode(int B, int K, int nout, int num_heading_bin, int num_siz
 int s2c_select_target(int B, int K, const double *bbox_corner, const double *ref_box_corner,
                       long long *target_ids, float *target_ious, void *stream);
 
+/* Caption loss (lib/loss_helper.py:189-230): masked cross-entropy (ignore_index 0, rows of
+ * samples with good[b] == 0 excluded) and word accuracy of the teacher-forced logits pred
+ * (B,T,V) f32 contiguous against target (B,T) i64 (row stride target_stride elements).
+ * fwd: row_lse (B*T), row_stats (B*T,4) scratch, out[0] = cap_loss, out[1] = cap_acc,
+ * out[2] = 1 / (sum good + 1e-6).  bwd: dpred (B,T,V) = d cap_loss / d pred * gup[0]. */
+int s2c_caption_loss_fwd(int B, int T, int V, const float *pred, const long long *target,
+                         long long target_stride, const unsigned char *good, float *row_lse,
+                         float *row_stats, float *out, void *stream);
+int s2c_caption_loss_bwd(int B, int T, int V, const float *pred, const long long *target,
+                         long long target_stride, const unsigned char *good,
+                         const float *row_lse, const float *fwd_out, const float *gup,
+                         float *dpred, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

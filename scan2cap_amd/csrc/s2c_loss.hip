@@ -352,3 +352,146 @@ extern "C" int s2c_detection_loss_bwd(const s2c_detloss_args *a,
                      *a, *d, gup);
   return chk3("detection_loss_bwd");
 }
+
+// ---------------------------------------------------------------------------------------
+// Caption loss (lib/loss_helper.py:189-230): masked cross-entropy of the teacher-forced
+// logits + word accuracy, forward in two launches and backward in one instead of ~40
+// framework kernels (log_softmax, nll, masks, sums, arg-max, ...).
+//   ce[r]    = -log_softmax(pred[r])[target[r]]           (0 where target == 0: ignore_index)
+//   cap_loss = sum_r ce[r] * good[b(r)] / (sum_r good[b(r)] + 1e-6)
+//   cap_acc  = #(argmax == target, target != 0, good) / #(target != 0, good)   (0 if none)
+namespace {
+
+constexpr int CAP_T = 256;
+
+__device__ __forceinline__ float block_reduce_sum(float v, float *s) {
+  const int t = threadIdx.x;
+  s[t] = v;
+  __syncthreads();
+  for (int k = CAP_T / 2; k > 0; k >>= 1) {
+    if (t < k) s[t] += s[t + k];
+    __syncthreads();
+  }
+  const float r = s[0];
+  __syncthreads();
+  return r;
+}
+
+// block = one (sample, word) row of V logits
+__global__ __launch_bounds__(CAP_T) void caploss_rows_kernel(
+    int V, int T, const float *__restrict__ pred, const long long *__restrict__ target,
+    long long target_stride, const unsigned char *__restrict__ good,
+    float *__restrict__ row_lse, float *__restrict__ row_stats) {
+  __shared__ float s_v[CAP_T];
+  __shared__ int s_i[CAP_T];
+  const int r = blockIdx.x, t = threadIdx.x;
+  const int b = r / T, w = r - b * T;
+  const float *x = pred + (size_t)r * V;
+  const long long tg = target[(size_t)b * target_stride + w];
+  float m = -INFINITY;
+  int am = 0x7fffffff;
+  for (int v = t; v < V; v += CAP_T) {
+    const float xv = x[v];
+    if (xv > m || (xv != xv && m == m)) { m = xv; am = v; }
+  }
+  s_v[t] = m;
+  s_i[t] = am;
+  __syncthreads();
+  for (int k = CAP_T / 2; k > 0; k >>= 1) {
+    if (t < k) {
+      const float o = s_v[t + k];
+      const int oi = s_i[t + k];
+      if (o > s_v[t] || (o == s_v[t] && oi < s_i[t])) { s_v[t] = o; s_i[t] = oi; }
+    }
+    __syncthreads();
+  }
+  m = s_v[0];
+  am = s_i[0];
+  __syncthreads();
+  float s = 0.f;
+  for (int v = t; v < V; v += CAP_T) s += expf(x[v] - m);
+  s = block_reduce_sum(s, s_v);
+  if (t == 0) {
+    const float ls = logf(s);
+    const bool g = good[b] != 0, live = tg != 0;
+    const float ce = live ? -((x[tg] - m) - ls) : 0.0f;
+    row_lse[r] = m + ls;
+    float *o = row_stats + (size_t)r * 4;
+    o[0] = g ? ce : 0.0f;
+    o[1] = g ? 1.0f : 0.0f;
+    o[2] = (g && live && (long long)am == tg) ? 1.0f : 0.0f;
+    o[3] = (g && live) ? 1.0f : 0.0f;
+  }
+}
+
+// out[0] = cap_loss, out[1] = cap_acc, out[2] = 1 / (sum good + 1e-6)
+__global__ __launch_bounds__(CAP_T) void caploss_finalize_kernel(
+    int rows, const float *__restrict__ row_stats, float *__restrict__ out) {
+  __shared__ double s_d[4][CAP_T];
+  const int t = threadIdx.x;
+  double a[4] = {0, 0, 0, 0};
+  for (int r = t; r < rows; r += CAP_T)
+    for (int k = 0; k < 4; ++k) a[k] += (double)row_stats[(size_t)r * 4 + k];
+  for (int k = 0; k < 4; ++k) s_d[k][t] = a[k];
+  __syncthreads();
+  for (int k = CAP_T / 2; k > 0; k >>= 1) {
+    if (t < k)
+      for (int q = 0; q < 4; ++q) s_d[q][t] += s_d[q][t + k];
+    __syncthreads();
+  }
+  if (t == 0) {
+    const float s1 = (float)s_d[0][0], s2 = (float)s_d[1][0];
+    const float hits = (float)s_d[2][0], n = (float)s_d[3][0];
+    out[0] = s1 / (s2 + 1e-6f);
+    out[1] = n > 0.0f ? hits / fmaxf(n, 1.0f) : 0.0f;
+    out[2] = 1.0f / (s2 + 1e-6f);
+  }
+}
+
+// d pred[r, v] = gup * good * [target != 0] / (sum good + 1e-6) * (softmax(pred[r])[v] - [v == target])
+__global__ __launch_bounds__(CAP_T) void caploss_bwd_kernel(
+    int V, int T, const float *__restrict__ pred, const long long *__restrict__ target,
+    long long target_stride, const unsigned char *__restrict__ good,
+    const float *__restrict__ row_lse, const float *__restrict__ fwd_out,
+    const float *__restrict__ gup, float *__restrict__ dpred) {
+  const int r = blockIdx.x, t = threadIdx.x;
+  const int b = r / T, w = r - b * T;
+  const long long tg = target[(size_t)b * target_stride + w];
+  const float coef = (good[b] != 0 && tg != 0) ? gup[0] * fwd_out[2] : 0.0f;
+  const float *x = pred + (size_t)r * V;
+  float *d = dpred + (size_t)r * V;
+  const float lse = row_lse[r];
+  for (int v = t; v < V; v += CAP_T) {
+    float g = 0.0f;
+    if (coef != 0.0f) g = coef * (expf(x[v] - lse) - (v == tg ? 1.0f : 0.0f));
+    d[v] = g;
+  }
+}
+
+}  // namespace
+
+extern "C" int s2c_caption_loss_fwd(int B, int T, int V, const float *pred,
+                                    const long long *target, long long target_stride,
+                                    const unsigned char *good, float *row_lse,
+                                    float *row_stats, float *out, void *stream) {
+  if (B <= 0 || T <= 0 || V <= 0 || !pred || !target || !good || !row_lse || !row_stats || !out)
+    return -1;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(caploss_rows_kernel, dim3(B * T), dim3(CAP_T), 0, st, V, T, pred, target,
+                     target_stride, good, row_lse, row_stats);
+  hipLaunchKernelGGL(caploss_finalize_kernel, dim3(1), dim3(CAP_T), 0, st, B * T, row_stats, out);
+  return chk3("caption_loss_fwd");
+}
+
+extern "C" int s2c_caption_loss_bwd(int B, int T, int V, const float *pred,
+                                    const long long *target, long long target_stride,
+                                    const unsigned char *good, const float *row_lse,
+                                    const float *fwd_out, const float *gup, float *dpred,
+                                    void *stream) {
+  if (B <= 0 || T <= 0 || V <= 0 || !pred || !target || !good || !row_lse || !fwd_out || !gup ||
+      !dpred)
+    return -1;
+  hipLaunchKernelGGL(caploss_bwd_kernel, dim3(B * T), dim3(CAP_T), 0, (hipStream_t)stream, V, T,
+                     pred, target, target_stride, good, row_lse, fwd_out, gup, dpred);
+  return chk3("caption_loss_bwd");
+}

@@ -140,3 +140,52 @@ def detection_loss(data_dict, config, near, far, cls_weights):
         d["vote_xyz"], d["objectness_scores"], d["center"], d["heading_scores"],
         d["heading_residuals_normalized"], d["size_scores"],
         d["size_residuals_normalized"], d["sem_cls_scores"], d, cfg)
+
+
+# ---------------------------------------------------------------------------------------
+# caption loss (loss_helper.py:189-230) -- csrc/s2c_loss.hip
+_L64 = ctypes.c_longlong
+_C.register("s2c_caption_loss_fwd", [_I, _I, _I, _P, _P, _L64, _P, _P, _P, _P, _P])
+_C.register("s2c_caption_loss_bwd", [_I, _I, _I, _P, _P, _L64, _P, _P, _P, _P, _P, _P])
+
+
+class CaptionLoss(Function):
+    """(pred (B,T,V) f32, target (B,T) i64 view, good (B) bool) -> cap_loss, cap_acc."""
+
+    @staticmethod
+    def forward(ctx, pred, target, good):
+        pred = pred if pred.is_contiguous() else pred.contiguous()
+        B, T, V = pred.shape
+        dev = pred.device
+        if target.stride(1) != 1:
+            target = target.contiguous()
+        good8 = good.view(torch.uint8) if good.dtype == torch.bool else \
+            (good != 0).view(torch.uint8)
+        lse = torch.empty(B * T, dtype=torch.float32, device=dev)
+        stats = torch.empty((B * T, 4), dtype=torch.float32, device=dev)
+        out = torch.empty(3, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _C.call("s2c_caption_loss_fwd", B, T, V, pred.data_ptr(), target.data_ptr(),
+                    target.stride(0), good8.data_ptr(), lse.data_ptr(), stats.data_ptr(),
+                    out.data_ptr(), _C.stream_ptr())
+        ctx.save_for_backward(pred, target, good8, lse, out)
+        loss, acc = out[0], out[1]
+        ctx.mark_non_differentiable(acc)
+        return loss, acc
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_acc):
+        pred, target, good8, lse, out = ctx.saved_tensors
+        B, T, V = pred.shape
+        gup = g_loss.reshape(1).to(torch.float32).contiguous()
+        dpred = torch.empty_like(pred)
+        with torch.cuda.device(pred.device):
+            _C.call("s2c_caption_loss_bwd", B, T, V, pred.data_ptr(), target.data_ptr(),
+                    target.stride(0), good8.data_ptr(), lse.data_ptr(), out.data_ptr(),
+                    gup.data_ptr(), dpred.data_ptr(), _C.stream_ptr())
+        return dpred, None, None
+
+
+def caption_loss_available(pred, target, good):
+    return (pred.is_cuda and pred.dtype == torch.float32 and pred.dim() == 3
+            and target.dtype == torch.int64 and good.dim() == 1)

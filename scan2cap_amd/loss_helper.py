@@ -17,6 +17,7 @@ from .consts import array_const, const
 
 # CUDA tensors: detection terms from csrc/s2c_loss.hip (2 + 1 launches)
 FUSED_DETECTION_LOSS = True
+FUSED_CAPTION_LOSS = True        # masked CE + word accuracy: 3 launches (csrc/s2c_loss.hip)
 
 FAR_THRESHOLD = 0.6
 NEAR_THRESHOLD = 0.3
@@ -144,6 +145,10 @@ def compute_cap_loss(data_dict, config, weights):
         num_words = int(data_dict["lang_len"].max())
     target_caps = data_dict["lang_ids"][:, 1:num_words]
     V = pred_caps.shape[-1]
+    if FUSED_CAPTION_LOSS and loss_fused.caption_loss_available(
+            pred_caps, target_caps, data_dict["good_bbox_masks"]):
+        return loss_fused.CaptionLoss.apply(pred_caps, target_caps,
+                                            data_dict["good_bbox_masks"])
     ce = F.cross_entropy(pred_caps.reshape(-1, V), target_caps.reshape(-1),
                          ignore_index=0, reduction="none")
     good = data_dict["good_bbox_masks"]

@@ -547,3 +547,41 @@ def test_box_bookkeeping_kernels_equal_the_torch_path():
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     assert res[0][0].dtype == torch.int64 and res[0][1].dtype == torch.float32
     assert int(res[0][0][2]) == 13
+
+
+def test_fused_caption_loss_matches_torch():
+    """s2c_caption_loss_fwd / _bwd against the op-by-op masked cross-entropy + accuracy
+    (loss_helper.compute_cap_loss): values and the gradient of the logits."""
+    from scan2cap_amd import loss_helper as lh
+    B, T, V, W = 6, 17, 3500, 32
+    g = torch.Generator(device="cuda").manual_seed(1)
+    logits0 = torch.randn((B, T, V), device="cuda", generator=g) * 2.0
+    ids = torch.randint(4, V, (B, W), device="cuda", generator=g)
+    ids[:, 0] = 2
+    ids[1, 9:] = 0                     # padding -> ignore_index
+    ids[4, 3:] = 0
+    # make some predictions correct
+    for b in range(B):
+        for t in range(0, T, 3):
+            logits0[b, t, ids[b, t + 1]] = 30.0
+    good = torch.tensor([True, True, False, True, True, False], device="cuda")
+    res = []
+    for flag in (True, False):
+        lh.FUSED_CAPTION_LOSS = flag
+        x = logits0.clone().requires_grad_(True)
+        dd = {"lang_cap": x, "lang_ids": ids, "good_bbox_masks": good, "_num_words": T + 1}
+        loss, acc = lh.compute_cap_loss(dd, None, None)
+        (loss * 1.7).backward()
+        res.append((loss.detach(), acc.detach(), x.grad.clone()))
+    lh.FUSED_CAPTION_LOSS = True
+    torch.testing.assert_close(res[0][0], res[1][0], rtol=1e-6, atol=1e-6)
+    assert float(res[0][1]) == float(res[1][1]) and 0.2 < float(res[0][1]) < 0.6
+    torch.testing.assert_close(res[0][2], res[1][2], rtol=1e-5, atol=1e-9)
+    assert float(res[0][2][2].abs().sum()) == 0.0          # excluded sample: no gradient
+    # no good sample at all: loss 0, accuracy 0, zero gradient
+    x = logits0.clone().requires_grad_(True)
+    dd = {"lang_cap": x, "lang_ids": ids, "good_bbox_masks": torch.zeros_like(good),
+          "_num_words": T + 1}
+    loss, acc = lh.compute_cap_loss(dd, None, None)
+    loss.backward()
+    assert float(loss) == 0.0 and float(acc) == 0.0 and float(x.grad.abs().sum()) == 0.0
