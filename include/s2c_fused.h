@@ -377,6 +377,19 @@ int s2c_caption_loss_bwd(int B, int T, int V, const float *pred, const long long
                          const float *row_lse, const float *fwd_out, const float *gup,
                          float *dpred, void *stream);
 
+/* Vote head (models/voting_module.py:49-58, models/capnet.py:97-98) on rows: net (M,3+C) =
+ * [xyz offset | feature residual] of the vote MLP, seed_xyz (M,3), seed_feat (M,C) with row
+ * stride seed_ld ->  vote_xyz (M,3) = seed_xyz + offset,  y (M,C) = f / ||f||_2 with
+ * f = seed_feat + residual,  norm (M).  bwd: d_net (M,3+C) = [g_xyz | (g_y - y <g_y,y>) / norm]
+ * (g_xyz may be NULL; g_y addressed as g_y[row*gy_row_stride + c*gy_col_stride]);
+ * d_seed (M,C) = d_net[:, 3:] as a dense copy (may be NULL); d seed_xyz = g_xyz. */
+int s2c_vote_head_fwd(int M, int C, const float *net, const float *seed_xyz,
+                      const float *seed_feat, long long seed_ld, float *vote_xyz, float *y,
+                      float *norm, void *stream);
+int s2c_vote_head_bwd(int M, int C, const float *g_xyz, const float *g_y,
+                      long long gy_row_stride, long long gy_col_stride, const float *y,
+                      const float *norm, float *d_net, float *d_seed, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

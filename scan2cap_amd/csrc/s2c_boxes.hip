@@ -154,3 +154,81 @@ extern "C" int s2c_select_target(int B, int K, const double *bbox_corner,
                      bbox_corner, ref_box_corner, target_ids, target_ious);
   return chk7("select_target");
 }
+
+// ---------------------------------------------------------------------------------------
+// Vote head (models/voting_module.py:49-58 + models/capnet.py:97-98): from the rows of the
+// vote MLP net (M, 3 + C) = [xyz offset | feature residual],
+//     vote_xyz = seed_xyz + net[:, 0:3]
+//     y        = f / ||f||_2,   f = seed_features + net[:, 3:]
+// and its backward, one launch each (the framework path: 6 + ~15 kernels).  Wave per row.
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void vote_head_fwd_kernel(
+    int M, int C, const float *__restrict__ net, const float *__restrict__ seed_xyz,
+    const float *__restrict__ seed_feat, long long seed_ld, float *__restrict__ vote_xyz,
+    float *__restrict__ y, float *__restrict__ norm_out) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float *n = net + (size_t)row * (3 + C);
+  const float *s = seed_feat + (size_t)row * seed_ld;
+  float ss = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float f = s[c] + n[3 + c];
+    ss += f * f;
+  }
+  ss = wave_sum(ss);
+  const float nrm = sqrtf(ss);
+  for (int c = lane; c < C; c += 64) y[(size_t)row * C + c] = (s[c] + n[3 + c]) / nrm;
+  if (lane < 3) vote_xyz[(size_t)row * 3 + lane] = seed_xyz[(size_t)row * 3 + lane] + n[lane];
+  if (lane == 0) norm_out[row] = nrm;
+}
+
+// d_net (M, 3+C) = [g_xyz | (g_y - y <g_y, y>) / norm]
+__global__ __launch_bounds__(256) void vote_head_bwd_kernel(
+    int M, int C, const float *__restrict__ g_xyz, const float *__restrict__ g_y,
+    long long gy_ld, long long gy_cs, const float *__restrict__ y,
+    const float *__restrict__ norm, float *__restrict__ d_net, float *__restrict__ d_seed) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float *yy = y + (size_t)row * C;
+  float dot = 0.f;
+  for (int c = lane; c < C; c += 64) dot += g_y[(size_t)row * gy_ld + (size_t)c * gy_cs] * yy[c];
+  dot = wave_sum(dot);
+  const float inv = 1.0f / norm[row];
+  float *d = d_net + (size_t)row * (3 + C);
+  for (int c = lane; c < C; c += 64) {
+    const float v = (g_y[(size_t)row * gy_ld + (size_t)c * gy_cs] - yy[c] * dot) * inv;
+    d[3 + c] = v;
+    if (d_seed) d_seed[(size_t)row * C + c] = v;
+  }
+  if (lane < 3) d[lane] = g_xyz ? g_xyz[(size_t)row * 3 + lane] : 0.0f;
+}
+
+}  // namespace
+
+extern "C" int s2c_vote_head_fwd(int M, int C, const float *net, const float *seed_xyz,
+                                 const float *seed_feat, long long seed_ld, float *vote_xyz,
+                                 float *y, float *norm, void *stream) {
+  if (M <= 0 || C <= 0 || !net || !seed_xyz || !seed_feat || seed_ld < C || !vote_xyz || !y ||
+      !norm)
+    return -1;
+  hipLaunchKernelGGL(vote_head_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                     M, C, net, seed_xyz, seed_feat, seed_ld, vote_xyz, y, norm);
+  return chk7("vote_head_fwd");
+}
+
+extern "C" int s2c_vote_head_bwd(int M, int C, const float *g_xyz, const float *g_y,
+                                 long long gy_row_stride, long long gy_col_stride,
+                                 const float *y, const float *norm, float *d_net,
+                                 float *d_seed, void *stream) {
+  if (M <= 0 || C <= 0 || !g_y || !y || !norm || !d_net) return -1;
+  hipLaunchKernelGGL(vote_head_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                     M, C, g_xyz, g_y, gy_row_stride, gy_col_stride, y, norm, d_net, d_seed);
+  return chk7("vote_head_bwd");
+}

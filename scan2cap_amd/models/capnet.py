@@ -78,8 +78,12 @@ class CapNet(nn.Module):
         data_dict = self.backbone_net(data_dict)
         for dst, src in self._SEED_KEYS:
             data_dict[dst] = data_dict[src]
-        vote_xyz, vote_feat = self.vgen(data_dict["seed_xyz"], data_dict["seed_features"])
-        vote_feat = vote_feat.div(torch.norm(vote_feat, p=2, dim=1).unsqueeze(1))
+        if hasattr(self.vgen, "forward_normalized"):      # offsets + L2 norm in one kernel
+            vote_xyz, vote_feat = self.vgen.forward_normalized(data_dict["seed_xyz"],
+                                                               data_dict["seed_features"])
+        else:
+            vote_xyz, vote_feat = self.vgen(data_dict["seed_xyz"], data_dict["seed_features"])
+            vote_feat = vote_feat.div(torch.norm(vote_feat, p=2, dim=1).unsqueeze(1))
         data_dict.update(vote_xyz=vote_xyz, vote_features=vote_feat)
         return self.proposal(vote_xyz, vote_feat, data_dict)
 

@@ -503,8 +503,10 @@ def _weight_grad(dY, A):
     if (USE_DW_KERNEL and dY.is_cuda and M >= DW_KERNEL_MIN_ROWS and dY.dtype == torch.float32
             and A.dtype == torch.float32 and dY.stride(1) == 1 and A.stride(1) == 1):
         return weight_grad_kernel(dY, A)
-    S = 1
-    while S < 512 and M % (2 * S) == 0 and M // (2 * S) >= 1024:
+    # slabs of >= 1024 rows (>= 2048 from 256k rows on), at most 256 of them: measured best
+    # trade between the batched GEMM and the partial sum (tools/bench_dw_split.py)
+    S, rows = 1, (2048 if M >= 262144 else 1024)
+    while S < 256 and M % (2 * S) == 0 and M // (2 * S) >= rows:
         S *= 2
     if S == 1:
         return torch.mm(dY.t(), A)

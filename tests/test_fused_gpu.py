@@ -585,3 +585,32 @@ def test_fused_caption_loss_matches_torch():
     loss, acc = lh.compute_cap_loss(dd, None, None)
     loss.backward()
     assert float(loss) == 0.0 and float(acc) == 0.0 and float(x.grad.abs().sum()) == 0.0
+
+
+def test_vote_head_kernel_matches_torch_path():
+    """VotingModule.forward_normalized (s2c_vote_head_fwd / _bwd) against forward() + the
+    L2 normalisation of capnet.py:97-98: outputs and all gradients."""
+    from scan2cap_amd.models import voting_module as vm
+    torch.manual_seed(0)
+    mod = vm.VotingModule(1, 256).cuda().train()
+    B, S = 3, 512
+    g = torch.Generator(device="cuda").manual_seed(2)
+    seed_xyz = torch.randn((B, S, 3), device="cuda", generator=g)
+    feats_rows = torch.randn((B, S, 256), device="cuda", generator=g)
+    w_xyz = torch.randn((B, S, 3), device="cuda", generator=g)
+    w_f = torch.randn((B, 256, S), device="cuda", generator=g)
+    res = []
+    for flag in (True, False):
+        vm.FUSE_VOTE_HEAD = flag
+        mod.zero_grad()
+        fr = feats_rows.clone().requires_grad_(True)
+        xyz, f = mod.forward_normalized(seed_xyz, fr.transpose(2, 1))
+        ((xyz * w_xyz).sum() + (f * w_f).sum()).backward()
+        res.append((xyz.detach(), f.detach().contiguous(), fr.grad.clone(),
+                    mod.conv3.weight.grad.clone(), mod.conv1.weight.grad.clone()))
+    vm.FUSE_VOTE_HEAD = True
+    assert res[0][1].shape == (B, 256, S)
+    for a, b, tol in zip(res[0], res[1], (1e-6, 1e-6, 2e-5, 2e-5, 2e-5)):
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= tol * max(scale, 1.0), (float((a - b).abs().max()), scale)
+    assert torch.allclose(res[0][1].norm(dim=1), torch.ones(B, S, device="cuda"), atol=1e-5)
