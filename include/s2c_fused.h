@@ -390,6 +390,19 @@ int s2c_vote_head_bwd(int M, int C, const float *g_xyz, const float *g_y,
                       long long gy_row_stride, long long gy_col_stride, const float *y,
                       const float *norm, float *d_net, float *d_seed, void *stream);
 
+/* One launch for up to 8 transposes dst[j] (cols x rows, dense) = src[j]^T (rows x cols, row
+ * stride lds[j]) and up to 8 float buffers to zero (the set-up of the decoder's backward). */
+typedef struct s2c_prep_args {
+  int n_transpose, n_zero;
+  const float *src[8];
+  float *dst[8];
+  int rows[8], cols[8];
+  long long lds[8];
+  float *zero[8];
+  long long zero_count[8];
+} s2c_prep_args;
+int s2c_batch_prep(const s2c_prep_args *a, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

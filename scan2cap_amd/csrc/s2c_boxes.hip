@@ -232,3 +232,65 @@ extern "C" int s2c_vote_head_bwd(int M, int C, const float *g_xyz, const float *
                      M, C, g_xyz, g_y, gy_row_stride, gy_col_stride, y, norm, d_net, d_seed);
   return chk7("vote_head_bwd");
 }
+
+// ---------------------------------------------------------------------------------------
+// Batched "prepare" launch: up to 8 matrix transposes (dst (cols x rows) = src^T, src row
+// stride lds) and up to 8 buffers to zero, in ONE launch -- the set-up of the decoder's
+// backward pass (7 transposed weight matrices + 3 accumulators) was 10 framework kernels.
+namespace {
+
+__global__ __launch_bounds__(256) void batch_prep_kernel(s2c_prep_args a) {
+  __shared__ float tile[32][33];
+  int blk = blockIdx.x;
+  for (int j = 0; j < a.n_transpose; ++j) {
+    const int tr = (a.rows[j] + 31) / 32, tc = (a.cols[j] + 31) / 32;
+    const int nb = tr * tc;
+    if (blk < nb) {
+      const int r0 = (blk / tc) * 32, c0 = (blk % tc) * 32;
+      const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+      const float *src = a.src[j];
+      float *dst = a.dst[j];
+      for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < a.rows[j] && c < a.cols[j]) ? src[(size_t)r * a.lds[j] + c] : 0.f;
+      }
+      __syncthreads();
+      for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < a.cols[j] && r < a.rows[j]) dst[(size_t)c * a.rows[j] + r] = tile[tx][i];
+      }
+      return;
+    }
+    blk -= nb;
+  }
+  for (int j = 0; j < a.n_zero; ++j) {
+    const long long nb = (a.zero_count[j] + 1023) / 1024;
+    if (blk < nb) {
+      const long long base = (long long)blk * 1024;
+      for (int i = threadIdx.x; i < 1024; i += 256)
+        if (base + i < a.zero_count[j]) a.zero[j][base + i] = 0.f;
+      return;
+    }
+    blk -= (int)nb;
+  }
+}
+
+}  // namespace
+
+extern "C" int s2c_batch_prep(const s2c_prep_args *a, void *stream) {
+  if (!a || a->n_transpose < 0 || a->n_transpose > 8 || a->n_zero < 0 || a->n_zero > 8) return -1;
+  long long blocks = 0;
+  for (int j = 0; j < a->n_transpose; ++j) {
+    if (!a->src[j] || !a->dst[j] || a->rows[j] <= 0 || a->cols[j] <= 0 || a->lds[j] < a->cols[j])
+      return -1;
+    blocks += (long long)((a->rows[j] + 31) / 32) * ((a->cols[j] + 31) / 32);
+  }
+  for (int j = 0; j < a->n_zero; ++j) {
+    if (!a->zero[j] || a->zero_count[j] <= 0) return -1;
+    blocks += (a->zero_count[j] + 1023) / 1024;
+  }
+  if (blocks == 0) return 0;
+  hipLaunchKernelGGL(batch_prep_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, *a);
+  return chk7("batch_prep");
+}

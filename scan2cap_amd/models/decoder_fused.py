@@ -85,6 +85,30 @@ def supported(emb, hid, feat, K):
             and hid <= 512 and emb <= 512)     # register-resident input slices
 
 
+class _PrepArgs(ctypes.Structure):
+    """s2c_prep_args (include/s2c_fused.h)."""
+    _fields_ = [("n_transpose", ctypes.c_int), ("n_zero", ctypes.c_int),
+                ("src", ctypes.c_void_p * 8), ("dst", ctypes.c_void_p * 8),
+                ("rows", ctypes.c_int * 8), ("cols", ctypes.c_int * 8),
+                ("lds", ctypes.c_longlong * 8), ("zero", ctypes.c_void_p * 8),
+                ("zero_count", ctypes.c_longlong * 8)]
+
+
+_C.register("s2c_batch_prep", [ctypes.c_void_p, ctypes.c_void_p])
+
+
+def _batch_prep(srcs, dsts, zeros):
+    a = _PrepArgs()
+    a.n_transpose, a.n_zero = len(srcs), len(zeros)
+    for j, (w, d) in enumerate(zip(srcs, dsts)):
+        assert w.dim() == 2 and w.stride(1) == 1 and w.dtype == torch.float32
+        a.src[j], a.dst[j] = w.data_ptr(), d.data_ptr()
+        a.rows[j], a.cols[j], a.lds[j] = w.shape[0], w.shape[1], w.stride(0)
+    for j, zt in enumerate(zeros):
+        a.zero[j], a.zero_count[j] = zt.data_ptr(), zt.numel()
+    _C.call("s2c_batch_prep", ctypes.byref(a), _C.stream_ptr())
+
+
 class TopDownDecode(Function):
     """forward(word_embs (R,Tw,E), target_feats (R,F), obj_feats (R,K,F),
     masks (R,K) float, steps, *params) -> logits (R,steps,V), attn (R,K,steps).
@@ -163,15 +187,15 @@ class TopDownDecode(Function):
             dW_cls = torch.mm(dl.t(), H2n.view(R * T, H))
             db_cls = dl.sum(0)
             dH2 = torch.mm(dl, W_cls).view(R, T, H).permute(1, 0, 2).contiguous()
-            # transposed weights: the same small_linear kernel serves W^T products
-            WT_ih2, WT_hh2 = W_ih2.t().contiguous(), W_hh2.t().contiguous()
-            WT_lang, WT_h = W_lang.t().contiguous(), W_h.t().contiguous()
-            WT_ih1, WT_hh1 = W_ih1.t().contiguous(), W_hh1.t().contiguous()
-            WT_td_h2 = W_td[:, E:E + H].t().contiguous()            # (H,E)
-            z = lambda *s: torch.zeros(*s, device=dev)
+            # transposed weights (the same small_linear kernel serves W^T products) and the
+            # zeroed accumulators: one batched launch (s2c_batch_prep) instead of ten
             e = lambda *s: torch.empty(*s, device=dev)
-            dM, dwa_rows = z(R, K, H), z(R, H)
-            dh1c, dh2_part = z(R, H), e(R, H)
+            srcs = (W_ih2, W_hh2, W_lang, W_h, W_ih1, W_hh1, W_td[:, E:E + H])
+            WTs = [e(w.shape[1], w.shape[0]) for w in srcs]
+            dM, dwa_rows, dh1c = e(R, K, H), e(R, H), e(R, H)
+            _batch_prep(srcs, WTs, (dM, dwa_rows, dh1c))
+            WT_ih2, WT_hh2, WT_lang, WT_h, WT_ih1, WT_hh1, WT_td_h2 = WTs
+            dh2_part = e(R, H)
             DA1, DA2 = e(T, R, E), e(T, R, E)
             DGI1, DGH1 = e(T, R, 3 * H), e(T, R, 3 * H)
             DGI2, DGH2 = e(T, R, 3 * H), e(T, R, 3 * H)
