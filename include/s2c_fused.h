@@ -238,6 +238,8 @@ int s2c_attn_local_fwd(int R, int L, int H, int F, const float *mapped, const fl
  * boxes, NH heading bins, NS size clusters, NC classes (each <= 64), K <= 1024. */
 typedef struct s2c_detloss_args {
   int B, S, VF, N, K, G, NH, NS, NC, ld_center_label;
+  int ld_scores;   /* > 0: objectness / heading / size / semantic score arrays (and their
+                      gradients, and d center) are columns of one (B,K,ld_scores) matrix */
   float near_threshold, far_threshold, obj_w0, obj_w1;
   const float *seed_xyz;              /* (B,S,3) */
   const float *vote_xyz;              /* (B,S*VF,3) */

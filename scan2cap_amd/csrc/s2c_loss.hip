@@ -17,6 +17,9 @@
 
 #include <stdio.h>
 
+// row stride of the score arrays: dense (n) or the head-output row (a.ld_scores)
+#define LD(n) ((size_t)(a.ld_scores > 0 ? a.ld_scores : (n)))
+
 namespace {
 
 constexpr int NPART = 14;
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(256) void detloss_fwd_kernel(s2c_detloss_args a) {
     a.objectness_label[bk] = near ? 1 : 0;
     a.objectness_mask[bk] = mask;
     a.object_assignment[bk] = g1;
-    const float *os = a.objectness_scores + bk * 2;
+    const float *os = a.objectness_scores + bk * LD(2);
     const float w = near ? a.obj_w1 : a.obj_w0;
     acc[2] += w * (lse_of(os, 2) - os[near ? 1 : 0]) * mask;
     acc[3] += mask;
@@ -129,23 +132,23 @@ __global__ __launch_bounds__(256) void detloss_fwd_kernel(s2c_detloss_args a) {
     const size_t bg = (size_t)b * G + g1;
     // heading
     const int hc = (int)a.heading_class_label[bg];
-    const float *hs = a.heading_scores + bk * a.NH;
+    const float *hs = a.heading_scores + bk * LD(a.NH);
     acc[8] += (lse_of(hs, a.NH) - hs[hc]) * label;
     const float hres = a.heading_residual_label[bg] / (3.14159265358979323846f / (float)a.NH);
-    acc[9] += huber1(a.heading_res_norm[bk * a.NH + hc] - hres) * label;
+    acc[9] += huber1(a.heading_res_norm[bk * LD(a.NH) + hc] - hres) * label;
     // size
     const int sc = (int)a.size_class_label[bg];
-    const float *ss = a.size_scores + bk * a.NS;
+    const float *ss = a.size_scores + bk * LD(a.NS);
     acc[10] += (lse_of(ss, a.NS) - ss[sc]) * label;
     float sr = 0.0f;
     for (int c = 0; c < 3; ++c) {
       const float lab = a.size_residual_label[bg * 3 + c] / a.mean_size_arr[sc * 3 + c];
-      sr += huber1(a.size_res_norm[(bk * a.NS + sc) * 3 + c] - lab);
+      sr += huber1(a.size_res_norm[bk * LD(a.NS * 3) + sc * 3 + c] - lab);
     }
     acc[11] += (sr / 3.0f) * label;
     // semantic class
     const int cc = (int)a.sem_cls_label[bg];
-    const float *cs = a.sem_cls_scores + bk * a.NC;
+    const float *cs = a.sem_cls_scores + bk * LD(a.NC);
     acc[12] += (lse_of(cs, a.NC) - cs[cc]) * label;
   }
 
@@ -249,13 +252,13 @@ __global__ __launch_bounds__(256) void detloss_bwd_kernel(s2c_detloss_args a,
     const size_t bg = (size_t)b * G + g1;
     // objectness scores (weight 0.5)
     {
-      const float *os = a.objectness_scores + bk * 2;
+      const float *os = a.objectness_scores + bk * LD(2);
       const int y = label > 0.0f ? 1 : 0;
       const float w = y ? a.obj_w1 : a.obj_w0;
       const float l = lse_of(os, 2);
       const float coef = 0.5f * up * w * mask / den_o;
-      d.objectness_scores[bk * 2 + 0] = coef * (expf(os[0] - l) - (y == 0 ? 1.0f : 0.0f));
-      d.objectness_scores[bk * 2 + 1] = coef * (expf(os[1] - l) - (y == 1 ? 1.0f : 0.0f));
+      d.objectness_scores[bk * LD(2) + 0] = coef * (expf(os[0] - l) - (y == 0 ? 1.0f : 0.0f));
+      d.objectness_scores[bk * LD(2) + 1] = coef * (expf(os[1] - l) - (y == 1 ? 1.0f : 0.0f));
     }
     const float cl = up * label / den_l;
     // centre (both chamfer directions)
@@ -272,46 +275,46 @@ __global__ __launch_bounds__(256) void detloss_bwd_kernel(s2c_detloss_args a,
         gy += 2.0f * (c[1] - s_gt[3 * g + 1]) * wgt;
         gz += 2.0f * (c[2] - s_gt[3 * g + 2]) * wgt;
       }
-      d.center[bk * 3 + 0] = up * gx;
-      d.center[bk * 3 + 1] = up * gy;
-      d.center[bk * 3 + 2] = up * gz;
+      d.center[bk * LD(3) + 0] = up * gx;
+      d.center[bk * LD(3) + 1] = up * gy;
+      d.center[bk * LD(3) + 2] = up * gz;
     }
     // heading (class weight 0.1, residual weight 1)
     {
       const int hc = (int)a.heading_class_label[bg];
-      const float *hs = a.heading_scores + bk * a.NH;
+      const float *hs = a.heading_scores + bk * LD(a.NH);
       const float l = lse_of(hs, a.NH);
       const float hres = a.heading_residual_label[bg] / (3.14159265358979323846f / (float)a.NH);
-      const float e = a.heading_res_norm[bk * a.NH + hc] - hres;
+      const float e = a.heading_res_norm[bk * LD(a.NH) + hc] - hres;
       for (int h = 0; h < a.NH; ++h) {
-        d.heading_scores[bk * a.NH + h] = 0.1f * cl * (expf(hs[h] - l) - (h == hc ? 1.0f : 0.0f));
-        d.heading_res_norm[bk * a.NH + h] = h == hc ? cl * huber1_grad(e) : 0.0f;
+        d.heading_scores[bk * LD(a.NH) + h] = 0.1f * cl * (expf(hs[h] - l) - (h == hc ? 1.0f : 0.0f));
+        d.heading_res_norm[bk * LD(a.NH) + h] = h == hc ? cl * huber1_grad(e) : 0.0f;
       }
     }
     // size (class weight 0.1, residual weight 1, mean over 3 axes)
     {
       const int sc = (int)a.size_class_label[bg];
-      const float *ss = a.size_scores + bk * a.NS;
+      const float *ss = a.size_scores + bk * LD(a.NS);
       const float l = lse_of(ss, a.NS);
       for (int s = 0; s < a.NS; ++s) {
-        d.size_scores[bk * a.NS + s] = 0.1f * cl * (expf(ss[s] - l) - (s == sc ? 1.0f : 0.0f));
+        d.size_scores[bk * LD(a.NS) + s] = 0.1f * cl * (expf(ss[s] - l) - (s == sc ? 1.0f : 0.0f));
         for (int c = 0; c < 3; ++c) {
           float g = 0.0f;
           if (s == sc) {
             const float lab = a.size_residual_label[bg * 3 + c] / a.mean_size_arr[sc * 3 + c];
-            g = cl * huber1_grad(a.size_res_norm[(bk * a.NS + sc) * 3 + c] - lab) / 3.0f;
+            g = cl * huber1_grad(a.size_res_norm[bk * LD(a.NS * 3) + sc * 3 + c] - lab) / 3.0f;
           }
-          d.size_res_norm[(bk * a.NS + s) * 3 + c] = g;
+          d.size_res_norm[bk * LD(a.NS * 3) + s * 3 + c] = g;
         }
       }
     }
     // semantic class (weight 0.1)
     {
       const int cc = (int)a.sem_cls_label[bg];
-      const float *cs = a.sem_cls_scores + bk * a.NC;
+      const float *cs = a.sem_cls_scores + bk * LD(a.NC);
       const float l = lse_of(cs, a.NC);
       for (int c = 0; c < a.NC; ++c)
-        d.sem_cls_scores[bk * a.NC + c] = 0.1f * cl * (expf(cs[c] - l) - (c == cc ? 1.0f : 0.0f));
+        d.sem_cls_scores[bk * LD(a.NC) + c] = 0.1f * cl * (expf(cs[c] - l) - (c == cc ? 1.0f : 0.0f));
     }
   }
 }

@@ -18,7 +18,7 @@ from .consts import array_const
 
 _I, _F, _P = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 
-_INTS = ("B", "S", "VF", "N", "K", "G", "NH", "NS", "NC", "ld_center_label")
+_INTS = ("B", "S", "VF", "N", "K", "G", "NH", "NS", "NC", "ld_center_label", "ld_scores")
 _FLOATS = ("near_threshold", "far_threshold", "obj_w0", "obj_w1")
 _PTRS = ("seed_xyz", "vote_xyz", "seed_inds", "vote_label", "vote_label_mask", "agg_xyz",
          "center_label", "objectness_scores", "center", "box_label_mask",
@@ -57,17 +57,24 @@ def _c(t, dtype):
 
 
 class DetectionLoss(Function):
+    """Dense inputs: eight tensors in, eight gradients out.  Head-rows mode (`rows` = the
+    proposal head's (B,K,nout) output whose column groups the score tensors are views of):
+    the kernels read the scores in place (row stride nout) and write ONE gradient tensor
+    d rows -- no contiguous copies of six slices, no slice-gradient assembly."""
+
     @staticmethod
     def forward(ctx, vote_xyz, objectness_scores, center, heading_scores, heading_res_norm,
-                size_scores, size_res_norm, sem_cls_scores, labels, cfg):
+                size_scores, size_res_norm, sem_cls_scores, labels, cfg, rows=None,
+                agg_xyz=None):
         dev = center.device
         f32, i64 = torch.float32, torch.int64
+        keep = (lambda x, dt: x) if rows is not None else _c
         t = {
-            "vote_xyz": _c(vote_xyz, f32), "objectness_scores": _c(objectness_scores, f32),
-            "center": _c(center, f32), "heading_scores": _c(heading_scores, f32),
-            "heading_res_norm": _c(heading_res_norm, f32),
-            "size_scores": _c(size_scores, f32), "size_res_norm": _c(size_res_norm, f32),
-            "sem_cls_scores": _c(sem_cls_scores, f32),
+            "vote_xyz": _c(vote_xyz, f32), "objectness_scores": keep(objectness_scores, f32),
+            "center": _c(center, f32), "heading_scores": keep(heading_scores, f32),
+            "heading_res_norm": keep(heading_res_norm, f32),
+            "size_scores": keep(size_scores, f32), "size_res_norm": keep(size_res_norm, f32),
+            "sem_cls_scores": keep(sem_cls_scores, f32),
             "seed_xyz": _c(labels["seed_xyz"], f32),
             "seed_inds": _c(labels["seed_inds"], torch.int32),
             "vote_label": _c(labels["vote_label"], f32),
@@ -99,12 +106,13 @@ class DetectionLoss(Function):
         w = cfg["objectness_cls_weights"]
         args = _Args(B, S, VF, t["vote_label"].shape[1], K, G, t["heading_scores"].shape[2],
                      t["size_scores"].shape[2], t["sem_cls_scores"].shape[2],
-                     t["center_label"].shape[2], float(cfg["near_threshold"]),
+                     t["center_label"].shape[2], 0 if rows is None else rows.shape[2],
+                     float(cfg["near_threshold"]),
                      float(cfg["far_threshold"]), float(w[0]), float(w[1]),
                      *[t[n].data_ptr() for n in _PTRS])
         with torch.cuda.device(dev):
             _C.call("s2c_detection_loss_fwd", ctypes.addressof(args), _C.stream_ptr())
-        ctx.args, ctx.tensors = args, t
+        ctx.args, ctx.tensors, ctx.rows = args, t, rows
         outs = (t["stats"], t["objectness_label"], t["objectness_mask"],
                 t["object_assignment"])
         ctx.mark_non_differentiable(*outs)
@@ -112,16 +120,34 @@ class DetectionLoss(Function):
 
     @staticmethod
     def backward(ctx, gdet, *_unused):
-        t, args = ctx.tensors, ctx.args
+        t, args, rows = ctx.tensors, ctx.args, ctx.rows
         dev = gdet.device
+        gup = gdet.to(torch.float32).contiguous()
+        if rows is not None:
+            # one gradient tensor for the head rows: every column group is written by the
+            # kernel (d centre lands in the centre-offset columns 2:5)
+            d_rows = torch.empty_like(rows)
+            off = {n: (t[n].data_ptr() - rows.data_ptr()) for n in _GRADS
+                   if n not in ("vote_xyz", "center")}
+            g_vote = torch.empty_like(t["vote_xyz"])
+            ptr = {"vote_xyz": g_vote.data_ptr(), "center": d_rows.data_ptr() + 2 * 4}
+            for n, o in off.items():
+                ptr[n] = d_rows.data_ptr() + o
+            grads = _Grads(*[ptr[n] for n in _GRADS])
+            with torch.cuda.device(dev):
+                _C.call("s2c_detection_loss_bwd", ctypes.addressof(args),
+                        ctypes.addressof(grads), gup.data_ptr(), _C.stream_ptr())
+            ctx.tensors = None
+            # centre = aggregated_vote_xyz + rows[:, :, 2:5]: the same gradient for both
+            d_agg = d_rows[:, :, 2:5] if ctx.needs_input_grad[11] else None
+            return (g_vote,) + (None,) * 9 + (d_rows, d_agg)
         g = {n: torch.empty_like(t[n]) for n in _GRADS}
         grads = _Grads(*[g[n].data_ptr() for n in _GRADS])
-        gup = gdet.to(torch.float32).contiguous()
         with torch.cuda.device(dev):
             _C.call("s2c_detection_loss_bwd", ctypes.addressof(args),
                     ctypes.addressof(grads), gup.data_ptr(), _C.stream_ptr())
         ctx.tensors = None
-        return tuple(g[n] for n in _GRADS) + (None, None)
+        return tuple(g[n] for n in _GRADS) + (None, None, None, None)
 
 
 def available(data_dict):
@@ -136,10 +162,44 @@ def detection_loss(data_dict, config, near, far, cls_weights):
     d = data_dict
     cfg = {"mean_size_arr": config.mean_size_arr, "near_threshold": near,
            "far_threshold": far, "objectness_cls_weights": cls_weights}
+    rows = d.get("_head_rows") if HEAD_ROWS_MODE else None
+    if rows is not None and _views_of_rows(d, rows):
+        det = lambda x: x.detach()
+        return DetectionLoss.apply(
+            d["vote_xyz"], det(d["objectness_scores"]), det(d["center"]),
+            det(d["heading_scores"]), det(d["heading_residuals_normalized"]),
+            det(d["size_scores"]), det(d["size_residuals_normalized"]),
+            det(d["sem_cls_scores"]), d, cfg, rows, d["aggregated_vote_xyz"])
     return DetectionLoss.apply(
         d["vote_xyz"], d["objectness_scores"], d["center"], d["heading_scores"],
         d["heading_residuals_normalized"], d["size_scores"],
         d["size_residuals_normalized"], d["sem_cls_scores"], d, cfg)
+
+
+HEAD_ROWS_MODE = True
+
+
+def _views_of_rows(d, rows):
+    """The score tensors are the column groups [0:2 | 2:5 centre | NH | NH | NS | NS*3 | NC]
+    of the contiguous float32 head output `rows` (B,K,nout) (proposal_module.decode_scores)."""
+    if not (rows.is_cuda and rows.dtype == torch.float32 and rows.is_contiguous()
+            and rows.dim() == 3):
+        return False
+    B, K, nout = rows.shape
+    NH, NS = d["heading_scores"].shape[2], d["size_scores"].shape[2]
+    NC = d["sem_cls_scores"].shape[2]
+    if nout != 5 + 2 * NH + 4 * NS + NC:
+        return False
+    cols = {"objectness_scores": 0, "heading_scores": 5,
+            "heading_residuals_normalized": 5 + NH, "size_scores": 5 + 2 * NH,
+            "size_residuals_normalized": 5 + 2 * NH + NS, "sem_cls_scores": 5 + 2 * NH + 4 * NS}
+    base = rows.data_ptr()
+    for n, c in cols.items():
+        x = d[n]
+        if x.dtype != torch.float32 or x.data_ptr() != base + 4 * c \
+                or x.stride(0) != K * nout or x.stride(1) != nout:
+            return False
+    return True
 
 
 # ---------------------------------------------------------------------------------------

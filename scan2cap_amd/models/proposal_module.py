@@ -107,6 +107,7 @@ class ProposalModule(nn.Module):
         size_residuals_normalized = nt[:, :, o + NS:o + NS * 4].view(B, K, NS, 3)
         sem_cls_scores = nt[:, :, o + NS * 4:]
 
+        data_dict["_head_rows"] = nt       # the loss reads / differentiates the rows in place
         data_dict["objectness_scores"] = objectness_scores
         data_dict["center"] = center
         data_dict["heading_scores"] = heading_scores

@@ -614,3 +614,60 @@ def test_vote_head_kernel_matches_torch_path():
         scale = float(b.abs().max())
         assert float((a - b).abs().max()) <= tol * max(scale, 1.0), (float((a - b).abs().max()), scale)
     assert torch.allclose(res[0][1].norm(dim=1), torch.ones(B, S, device="cuda"), atol=1e-5)
+
+
+def test_detection_loss_head_rows_mode_equals_dense_mode():
+    """The detection loss reading the proposal head's (B,K,nout) rows in place and writing
+    one gradient tensor (loss_fused.HEAD_ROWS_MODE) against the dense-slices mode: same
+    terms, same gradient of the head output and of the votes."""
+    from types import SimpleNamespace
+    from scan2cap_amd import loss_fused as lf, loss_helper as lh
+    from scan2cap_amd.models import proposal_module as pm
+    dev = torch.device("cuda")
+    B, S, N, K, G, NH, NS, NC = 2, 96, 600, 80, 128, 1, 18, 18
+    g = torch.Generator().manual_seed(11)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    nbox = 7
+    centers = torch.zeros(B, G, 3)
+    centers[:, :nbox] = torch.rand(B, nbox, 3, generator=g) * 4 - 2
+    blm = torch.zeros(B, G)
+    blm[:, :nbox] = 1
+    cls = torch.randint(0, NS, (B, G), generator=g)
+    msa = (torch.rand(NS, 3, generator=g) + 0.3).double().numpy()
+    labels = dict(
+        seed_xyz=rnd(B, S, 3), seed_inds=torch.randint(0, N, (B, S), generator=g).int(),
+        vote_label=rnd(B, N, 3).repeat(1, 1, 3),
+        vote_label_mask=(torch.rand(B, N, generator=g) < 0.6).long(),
+        center_label=centers, box_label_mask=blm,
+        heading_class_label=torch.zeros(B, G, dtype=torch.long),
+        heading_residual_label=torch.zeros(B, G), size_class_label=cls,
+        size_residual_label=rnd(B, G, 3) * 0.2, sem_cls_label=cls.clone())
+    agg = centers[:, torch.randint(0, nbox, (K,), generator=g)] + rnd(B, K, 3) * 0.25
+    agg[:, ::5] += 3.0
+    net0 = rnd(B, 5 + 2 * NH + 4 * NS + NC, K)
+    net0[:, 2:5] *= 0.1
+    vote0 = rnd(B, S, 3)
+    mod = pm.ProposalModule(NC, NH, NS, msa, K, "vote_fps").to(dev)
+    cfg = SimpleNamespace(num_heading_bin=NH, num_size_cluster=NS, mean_size_arr=msa)
+    res = []
+    for flag in (True, False):
+        lf.HEAD_ROWS_MODE = flag
+        dd = {k: v.to(dev) for k, v in labels.items()}
+        aggd = agg.to(dev).requires_grad_(True)     # differentiable, as in the model
+        dd["aggregated_vote_xyz"] = aggd
+        dd["aggregated_vote_features"] = agg.to(dev)
+        net = net0.to(dev).requires_grad_(True)
+        vote = vote0.to(dev).requires_grad_(True)
+        dd["vote_xyz"] = vote
+        dd = mod.decode_scores(net, dd, NC, NH, NS, msa)
+        dd = lh.get_scene_cap_loss(dd, dev, cfg, None, detection=True, caption=False)
+        dd["loss"].backward()
+        res.append((dd, net.grad.clone(), vote.grad.clone(), aggd.grad.clone()))
+    lf.HEAD_ROWS_MODE = True
+    for k in ("vote_loss", "objectness_loss", "center_loss", "heading_cls_loss",
+              "heading_reg_loss", "size_cls_loss", "size_reg_loss", "sem_cls_loss", "loss"):
+        assert float(res[0][0][k].detach()) == float(res[1][0][k].detach()), k
+    assert torch.equal(res[0][1], res[1][1])        # same kernel arithmetic, other addressing
+    assert torch.equal(res[0][2], res[1][2])
+    assert torch.equal(res[0][3], res[1][3])        # ... and of the aggregated vote positions
+    assert float(res[0][1][:, 2:5].abs().sum()) > 0           # centre gradient arrived
