@@ -405,6 +405,17 @@ typedef struct s2c_prep_args {
 } s2c_prep_args;
 int s2c_batch_prep(const s2c_prep_args *a, void *stream);
 
+/* Up to 8 partial-sum jobs in one launch: out[j] (n[j]) = sum over the S[j] slabs of
+ * part[j] (S[j] x n[j], dense), fixed order. */
+typedef struct s2c_colsum_args {
+  int n_jobs;
+  int S[8];
+  long long n[8];
+  const float *part[8];
+  float *out[8];
+} s2c_colsum_args;
+int s2c_multi_colsum(const s2c_colsum_args *a, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -294,3 +294,49 @@ extern "C" int s2c_batch_prep(const s2c_prep_args *a, void *stream) {
                      (hipStream_t)stream, *a);
   return chk7("batch_prep");
 }
+
+// ---------------------------------------------------------------------------------------
+// Batched partial-sum: up to 8 jobs out[j][e] = sum_{s < S[j]} part[j][s * n[j] + e] in ONE
+// launch (the split-K partial products of the weight gradients of one layer stack; each was
+// its own framework reduction kernel).  Fixed summation order.
+namespace {
+
+__global__ __launch_bounds__(256) void multi_colsum_kernel(s2c_colsum_args a) {
+  long long blk = blockIdx.x;
+  for (int j = 0; j < a.n_jobs; ++j) {
+    const long long nb = (a.n[j] + 255) / 256;
+    if (blk < nb) {
+      const long long e = blk * 256 + threadIdx.x;
+      if (e >= a.n[j]) return;
+      const float *p = a.part[j] + e;
+      const long long n = a.n[j];
+      const int S = a.S[j];
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      int s = 0;
+      for (; s + 4 <= S; s += 4) {          // four independent chains, fixed order
+        s0 += p[(long long)s * n];
+        s1 += p[(long long)(s + 1) * n];
+        s2 += p[(long long)(s + 2) * n];
+        s3 += p[(long long)(s + 3) * n];
+      }
+      for (; s < S; ++s) s0 += p[(long long)s * n];
+      a.out[j][e] = (s0 + s1) + (s2 + s3);
+      return;
+    }
+    blk -= nb;
+  }
+}
+
+}  // namespace
+
+extern "C" int s2c_multi_colsum(const s2c_colsum_args *a, void *stream) {
+  if (!a || a->n_jobs <= 0 || a->n_jobs > 8) return -1;
+  long long blocks = 0;
+  for (int j = 0; j < a->n_jobs; ++j) {
+    if (!a->part[j] || !a->out[j] || a->S[j] <= 0 || a->n[j] <= 0) return -1;
+    blocks += (a->n[j] + 255) / 256;
+  }
+  hipLaunchKernelGGL(multi_colsum_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, *a);
+  return chk7("multi_colsum");
+}

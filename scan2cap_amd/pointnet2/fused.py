@@ -332,6 +332,7 @@ class _MLPRows(Function):
         saved, specs, pool_ns = ctx.saved, ctx.specs, ctx.pool_ns
         dev = dOut.device
         grads = []          # per layer, reversed
+        pending = []        # split-K partials of the weight gradients, summed in one launch
         dA = dOut.contiguous()
         partial = None
         nl = len(specs)
@@ -380,7 +381,7 @@ class _MLPRows(Function):
                 dY = dA * (rec["Y"] > 0)
             else:
                 dY = dA
-            dW = gather.weight_grad(dY) if lazy_dw else _weight_grad(dY, A_in)
+            dW = gather.weight_grad(dY) if lazy_dw else _weight_grad(dY, A_in, pending)
             dbias = dY.sum(0) if rec["has_bias"] else None
             need_dA = li > 0 or ctx.x_needs_grad
             dA = torch.mm(dY, W) if need_dA else None
@@ -390,6 +391,8 @@ class _MLPRows(Function):
             if sp.bn is not None:
                 g += [dgamma, dbeta]
             grads.append(g)
+        if pending:
+            flush_partial_sums(pending)
         flat = []
         for g in reversed(grads):
             flat += g
@@ -493,7 +496,32 @@ def weight_grad_kernel(dY, A):
     return dW
 
 
-def _weight_grad(dY, A):
+class _ColsumArgs(ctypes.Structure):
+    """s2c_colsum_args (include/s2c_fused.h)."""
+    _fields_ = [("n_jobs", ctypes.c_int), ("S", ctypes.c_int * 8),
+                ("n", ctypes.c_longlong * 8), ("part", ctypes.c_void_p * 8),
+                ("out", ctypes.c_void_p * 8)]
+
+
+_C.register("s2c_multi_colsum", [_P, _P])
+BATCH_PARTIAL_SUMS = True
+
+
+def flush_partial_sums(pending):
+    """[(part (S,Cout,Cin), dW (Cout,Cin))...] -> every dW filled, 8 jobs per launch."""
+    for i in range(0, len(pending), 8):
+        chunk = pending[i:i + 8]
+        a = _ColsumArgs()
+        a.n_jobs = len(chunk)
+        for j, (part, dW) in enumerate(chunk):
+            a.S[j], a.n[j] = part.shape[0], dW.numel()
+            a.part[j], a.out[j] = part.data_ptr(), dW.data_ptr()
+        with torch.cuda.device(chunk[0][1].device):
+            _C.call("s2c_multi_colsum", ctypes.byref(a), _C.stream_ptr())
+    del pending[:]
+
+
+def _weight_grad(dY, A, pending=None):
     """dW (Cout,Cin) = dY^T (Cout,M) @ A (M,Cin) with M up to ~1e6 and a tiny
     output: a plain GEMM call gives the library ONE output tile and a million-deep
     K loop (a single workgroup).  Hand-written kernel (USE_DW_KERNEL); library fallback
@@ -511,6 +539,12 @@ def _weight_grad(dY, A):
     if S == 1:
         return torch.mm(dY.t(), A)
     part = torch.bmm(dY.view(S, M // S, -1).transpose(1, 2), A.view(S, M // S, -1))
+    if pending is not None and BATCH_PARTIAL_SUMS and part.is_cuda \
+            and part.dtype == torch.float32:
+        # the caller adds up the slabs of all its layers in one launch (flush_partial_sums)
+        dW = torch.empty(part.shape[1:], dtype=torch.float32, device=part.device)
+        pending.append((part, dW))
+        return dW
     return part.sum(0)
 
 

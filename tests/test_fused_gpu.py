@@ -671,3 +671,22 @@ def test_detection_loss_head_rows_mode_equals_dense_mode():
     assert torch.equal(res[0][2], res[1][2])
     assert torch.equal(res[0][3], res[1][3])        # ... and of the aggregated vote positions
     assert float(res[0][1][:, 2:5].abs().sum()) > 0           # centre gradient arrived
+
+
+def test_batched_partial_sums():
+    """s2c_multi_colsum (one launch for all split-K partials of a layer stack) vs torch.sum,
+    more than 8 jobs, odd sizes."""
+    from scan2cap_amd.pointnet2 import fused
+    g = torch.Generator(device="cuda").manual_seed(0)
+    shapes = [(256, 64, 64), (128, 128, 131), (7, 3, 5), (1, 97, 128), (33, 259, 256)] * 2
+    pending, want = [], []
+    for S, co, ci in shapes:
+        part = torch.randn((S, co, ci), device="cuda", generator=g)
+        dW = torch.full((co, ci), float("nan"), device="cuda")
+        pending.append((part, dW))
+        want.append(part.double().sum(0))
+    outs = [dW for _, dW in pending]
+    fused.flush_partial_sums(pending)
+    assert pending == []
+    for o, w in zip(outs, want):
+        assert torch.allclose(o.double(), w, rtol=0, atol=2e-5 * float(w.abs().max() + 1))
