@@ -569,8 +569,8 @@ def main():
                          "avg_launch_us": top["avg_us"],
                          "share_of_step": top["ms_per_step"] / ms_per_step})
         out = {
-            "metric": "scenes/sec forward+backward, B=8 N=40000 pts" if wl["train"]
-                      else "scenes/sec forward, B=%d N=%d pts" % (wl["B"], wl["N"]),
+            "metric": ("scenes/sec forward+backward, B=%d N=%d pts" if wl["train"]
+                       else "scenes/sec forward, B=%d N=%d pts") % (wl["B"], wl["N"]),
             "value": value, "unit": "scenes/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
