@@ -323,3 +323,41 @@ def test_builder_batch_trains_a_step_like_a_host_built_batch():
     want = float(step2(host).detach())
     assert np.isfinite(got)
     np.testing.assert_allclose(got, want, rtol=1e-5)
+
+
+def test_batch_feeder_fills_static_buffer_sets():
+    """BatchFeeder (the producer behind `bench.py --feed builder`): three static buffer sets,
+    host-paced hand-over; every set ends up holding exactly the batch a direct `build` with
+    the same draws gives, including after the sets have been recycled."""
+    sb = _sb()
+    scenes = [sc.make_scene(70 + i, 5000 + 500 * i, num_instances=20) for i in range(3)]
+    store = _store(scenes, 0)
+    N, B = 1024, 2
+    msa = np.full((18, 3), 0.7)
+    builder = sb.SceneBatchBuilder(store, msa, num_points=N, use_normal=True, augment=True)
+    ids0 = ["s0", "s1"]
+    oid = lambda ids: [int(scenes[int(s[1])]["instance_bboxes"][0, 7]) for s in ids]
+    template = builder.build(ids0, oid(ids0), builder.draw(ids0, rng=np.random.RandomState(0)))
+    keys = [k for k in template if not k.startswith("_")]
+    sets = [{k: torch.zeros_like(template[k]) for k in keys} for _ in range(3)]
+    feeder = sb.BatchFeeder(builder, None, sets, device_choices=True,
+                            rng=np.random.RandomState(5))
+    mirror = np.random.RandomState(5)
+    picks = [["s%d" % ((k + b) % 3) for b in range(B)] for k in range(7)]
+    want = []
+    for k, ids in enumerate(picks):
+        p = k % 3
+        feeder.produce(p, ids, oid(ids), host_wait=True)
+        feeder.acquire(p)                                  # consumer side
+        snap = {key: sets[p][key].clone() for key in keys}
+        feeder.release(p)
+        draws = builder.draw(ids, rng=mirror, device_choices=True)
+        ref = builder.build(ids, oid(ids), draws)
+        want.append((snap, ref))
+    torch.cuda.synchronize()
+    for k, (snap, ref) in enumerate(want):
+        for key in keys:
+            assert torch.equal(snap[key], ref[key]), (k, key)
+    with pytest.raises(ValueError):
+        builder.build(ids0, oid(ids0), builder.draw(ids0),
+                      out={"point_clouds": torch.zeros(1, device="cuda")})
