@@ -416,6 +416,17 @@ typedef struct s2c_colsum_args {
 } s2c_colsum_args;
 int s2c_multi_colsum(const s2c_colsum_args *a, void *stream);
 
+/* Up to 16 row-sum jobs in one launch: out[j] (C[j]) = sum over the M[j] rows of X[j]
+ * (M[j] x C[j], row stride ld[j]) -- bias gradients.  Fixed summation order. */
+typedef struct s2c_rowsum_args {
+  int n_jobs;
+  int C[16];
+  long long M[16], ld[16];
+  const float *X[16];
+  float *out[16];
+} s2c_rowsum_args;
+int s2c_multi_rowsum(const s2c_rowsum_args *a, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -340,3 +340,50 @@ extern "C" int s2c_multi_colsum(const s2c_colsum_args *a, void *stream) {
                      (hipStream_t)stream, *a);
   return chk7("multi_colsum");
 }
+
+// ---------------------------------------------------------------------------------------
+// Batched row sums: up to 16 jobs out[j][c] = sum_{m < M[j]} X[j][m * ld[j] + c] (the bias
+// gradients of a layer stack / of the decoder: each was its own framework reduction).
+// Workgroup = (job, 64 columns): 64 columns x 16 row phases, fixed combination order.
+namespace {
+
+__global__ __launch_bounds__(1024) void multi_rowsum_kernel(s2c_rowsum_args a) {
+  __shared__ float s_part[16][64];
+  int blk = blockIdx.x;
+  for (int j = 0; j < a.n_jobs; ++j) {
+    const int nb = (a.C[j] + 63) / 64;
+    if (blk < nb) {
+      const int col = blk * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+      float s = 0.f;
+      if (col < a.C[j]) {
+        const float *x = a.X[j] + col;
+        const long long ld = a.ld[j], M = a.M[j];
+        for (long long m = ph; m < M; m += 16) s += x[m * ld];
+      }
+      s_part[ph][threadIdx.x & 63] = s;
+      __syncthreads();
+      if (ph == 0 && col < a.C[j]) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += s_part[q][threadIdx.x];
+        a.out[j][col] = t;
+      }
+      return;
+    }
+    blk -= nb;
+  }
+}
+
+}  // namespace
+
+extern "C" int s2c_multi_rowsum(const s2c_rowsum_args *a, void *stream) {
+  if (!a || a->n_jobs <= 0 || a->n_jobs > 16) return -1;
+  long long blocks = 0;
+  for (int j = 0; j < a->n_jobs; ++j) {
+    if (!a->X[j] || !a->out[j] || a->M[j] <= 0 || a->C[j] <= 0 || a->ld[j] < a->C[j]) return -1;
+    blocks += (a->C[j] + 63) / 64;
+  }
+  hipLaunchKernelGGL(multi_rowsum_kernel, dim3((unsigned)blocks), dim3(1024), 0,
+                     (hipStream_t)stream, *a);
+  return chk7("multi_rowsum");
+}

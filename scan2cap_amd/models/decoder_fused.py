@@ -18,6 +18,7 @@ import torch
 from torch.autograd import Function
 
 from .. import _C
+from ..pointnet2 import fused
 
 _I, _P = ctypes.c_int, ctypes.c_void_p
 _C.register("s2c_small_linear", [_I, _I, _I, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _P, _I, _P])
@@ -185,7 +186,6 @@ class TopDownDecode(Function):
         with torch.cuda.device(dev):
             dl = dlogits.contiguous().view(R * T, -1)
             dW_cls = torch.mm(dl.t(), H2n.view(R * T, H))
-            db_cls = dl.sum(0)
             dH2 = torch.mm(dl, W_cls).view(R, T, H).permute(1, 0, 2).contiguous()
             # transposed weights (the same small_linear kernel serves W^T products) and the
             # zeroed accumulators: one batched launch (s2c_batch_prep) instead of ten
@@ -232,33 +232,31 @@ class TopDownDecode(Function):
                                        add1=dh2_part, ld1=H, add2=dH2[t - 1], ld2=H),
                               gates=_gates(S2, t - 1, H2[t - 1], DGI2[t - 1],
                                            DGH2[t - 1], dh2_direct))
+            # every bias gradient (and the sum over time of DA1) in ONE launch
+            TR = T * R
+            da1, da2 = DA1.view(TR, E), DA2.view(TR, E)
+            gi1, gh1 = DGI1.view(TR, 3 * H), DGH1.view(TR, 3 * H)
+            gi2, gh2 = DGI2.view(TR, 3 * H), DGH2.view(TR, 3 * H)
+            (db_cls, DA1s, db_td, db_ih1, db_hh1, db_lang, db_ih2, db_hh2, dwa) = \
+                fused.row_sums([dl, DA1.view(T, R * E), da1, gi1, gh1, da2, gi2, gh2, dwa_rows])
+            DA1s = DA1s.view(R, E)
             # no recurrence through these two: hoisted out of the time loop
-            DA1s = DA1.sum(0)
             dtf = torch.mm(DA1s, W_td[:, E + H:])                             # (R,F)
             dO = torch.bmm(ALPHA.permute(1, 2, 0), DV[:, :, :F].permute(1, 0, 2))
             # ---- every weight gradient: one stacked GEMM each ------------------
-            TR = T * R
-            da1 = DA1.view(TR, E)
             dW_td = torch.empty_like(W_td)
             dW_td[:, :E] = torch.mm(da1.t(), words.permute(1, 0, 2).reshape(TR, E))
             dW_td[:, E:E + H] = torch.mm(da1.t(), H2[:-1].reshape(TR, H))
             dW_td[:, E + H:] = torch.mm(DA1s.t(), tf)
-            db_td = da1.sum(0)
-            gi1, gh1 = DGI1.view(TR, 3 * H), DGH1.view(TR, 3 * H)
             dW_ih1 = torch.mm(gi1.t(), X1.view(TR, E))
             dW_hh1 = torch.mm(gh1.t(), H1[:-1].reshape(TR, H))
-            db_ih1, db_hh1 = gi1.sum(0), gh1.sum(0)
             h1n = H1[1:].reshape(TR, H)
             dW_h = torch.mm(DQ.view(TR, H).t(), h1n)
-            da2 = DA2.view(TR, E)
             dW_lang = torch.empty_like(W_lang)
             dW_lang[:, :F] = torch.mm(da2.t(), ATT.view(TR, F))
             dW_lang[:, F:] = torch.mm(da2.t(), h1n)
-            db_lang = da2.sum(0)
-            gi2, gh2 = DGI2.view(TR, 3 * H), DGH2.view(TR, 3 * H)
             dW_ih2 = torch.mm(gi2.t(), X2.view(TR, E))
             dW_hh2 = torch.mm(gh2.t(), H2[:-1].reshape(TR, H))
-            db_ih2, db_hh2 = gi2.sum(0), gh2.sum(0)
             dMf = dM.view(R * K, H)
             dW_f = torch.mm(dMf.t(), O.view(R * K, F))
             dO = dO + torch.mm(dMf, W_f).view(R, K, F)
@@ -267,7 +265,7 @@ class TopDownDecode(Function):
                 dwords = torch.matmul(DA1.permute(1, 0, 2), W_td[:, :E])
         ctx.stash = None
         return (dwords, dtf, dO, None, None, dW_td, db_td, dW_ih1, dW_hh1, db_ih1,
-                db_hh1, dW_f, dW_h, dwa_rows.sum(0).view_as(w_a), dW_lang, db_lang, dW_ih2, dW_hh2,
+                db_hh1, dW_f, dW_h, dwa.view_as(w_a), dW_lang, db_lang, dW_ih2, dW_hh2,
                 db_ih2, db_hh2, dW_cls, db_cls)
 
 

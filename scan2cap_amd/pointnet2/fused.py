@@ -333,6 +333,7 @@ class _MLPRows(Function):
         dev = dOut.device
         grads = []          # per layer, reversed
         pending = []        # split-K partials of the weight gradients, summed in one launch
+        bias_jobs = []      # (dY, layer slot): bias gradients, summed in one launch
         dA = dOut.contiguous()
         partial = None
         nl = len(specs)
@@ -382,7 +383,13 @@ class _MLPRows(Function):
             else:
                 dY = dA
             dW = gather.weight_grad(dY) if lazy_dw else _weight_grad(dY, A_in, pending)
-            dbias = dY.sum(0) if rec["has_bias"] else None
+            dbias = None
+            if rec["has_bias"]:
+                if BATCH_PARTIAL_SUMS and dY.is_cuda and dY.dtype == torch.float32 \
+                        and dY.stride(1) == 1 and dY.shape[0] <= 4096:   # short columns only
+                    bias_jobs.append((dY, len(grads)))      # summed after the loop
+                else:
+                    dbias = dY.sum(0)
             need_dA = li > 0 or ctx.x_needs_grad
             dA = torch.mm(dY, W) if need_dA else None
             g = [dW]
@@ -393,6 +400,9 @@ class _MLPRows(Function):
             grads.append(g)
         if pending:
             flush_partial_sums(pending)
+        if bias_jobs:
+            for (_, slot), db in zip(bias_jobs, row_sums([x for x, _ in bias_jobs])):
+                grads[slot][1] = db
         flat = []
         for g in reversed(grads):
             flat += g
@@ -519,6 +529,31 @@ def flush_partial_sums(pending):
         with torch.cuda.device(chunk[0][1].device):
             _C.call("s2c_multi_colsum", ctypes.byref(a), _C.stream_ptr())
     del pending[:]
+
+
+class _RowsumArgs(ctypes.Structure):
+    """s2c_rowsum_args (include/s2c_fused.h)."""
+    _fields_ = [("n_jobs", ctypes.c_int), ("C", ctypes.c_int * 16),
+                ("M", ctypes.c_longlong * 16), ("ld", ctypes.c_longlong * 16),
+                ("X", ctypes.c_void_p * 16), ("out", ctypes.c_void_p * 16)]
+
+
+_C.register("s2c_multi_rowsum", [_P, _P])
+
+
+def row_sums(mats):
+    """[X (M,C) float32, unit column stride, ...] -> [X.sum(0), ...] in one launch per 16."""
+    outs = [torch.empty(x.shape[1], dtype=torch.float32, device=x.device) for x in mats]
+    for i in range(0, len(mats), 16):
+        a = _RowsumArgs()
+        a.n_jobs = len(mats[i:i + 16])
+        for j, (x, o) in enumerate(zip(mats[i:i + 16], outs[i:i + 16])):
+            assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.float32
+            a.M[j], a.C[j], a.ld[j] = x.shape[0], x.shape[1], x.stride(0)
+            a.X[j], a.out[j] = x.data_ptr(), o.data_ptr()
+        with torch.cuda.device(mats[0].device):
+            _C.call("s2c_multi_rowsum", ctypes.byref(a), _C.stream_ptr())
+    return outs
 
 
 def _weight_grad(dY, A, pending=None):

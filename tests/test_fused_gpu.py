@@ -690,3 +690,21 @@ def test_batched_partial_sums():
     assert pending == []
     for o, w in zip(outs, want):
         assert torch.allclose(o.double(), w, rtol=0, atol=2e-5 * float(w.abs().max() + 1))
+
+
+def test_batched_row_sums():
+    """s2c_multi_rowsum (bias gradients of a stack / of the decoder in one launch) vs
+    torch.sum(0): strided rows, more than 16 jobs, tall and wide matrices."""
+    from scan2cap_amd.pointnet2 import fused
+    g = torch.Generator(device="cuda").manual_seed(4)
+    shapes = [(240, 3500), (30, 2400), (240, 300), (240, 1536), (8, 512), (20480, 128),
+              (8192, 259), (1, 7), (2048, 97)] * 2
+    mats = []
+    for M, C in shapes:
+        base = torch.randn((M, C + 5), device="cuda", generator=g)
+        mats.append(base[:, 2:2 + C])
+    outs = fused.row_sums(mats)
+    for x, o in zip(mats, outs):
+        w = x.double().sum(0)
+        assert o.shape == (x.shape[1],)
+        assert torch.allclose(o.double(), w, rtol=0, atol=3e-5 * float(x.abs().sum(0).max() + 1))
