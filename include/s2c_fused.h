@@ -417,9 +417,12 @@ typedef struct s2c_colsum_args {
 int s2c_multi_colsum(const s2c_colsum_args *a, void *stream);
 
 /* Up to 16 row-sum jobs in one launch: out[j] (C[j]) = sum over the M[j] rows of X[j]
- * (M[j] x C[j], row stride ld[j]) -- bias gradients.  Fixed summation order. */
+ * (M[j] x C[j], row stride ld[j]) -- bias gradients.  Fixed summation order.
+ * chunk_rows > 0: slabs of chunk_rows rows are summed separately, slab q of job j into
+ * out[j] + q*C[j] (ceil(M/chunk_rows) x C floats; add them up with s2c_multi_colsum). */
 typedef struct s2c_rowsum_args {
   int n_jobs;
+  int chunk_rows;
   int C[16];
   long long M[16], ld[16];
   const float *X[16];

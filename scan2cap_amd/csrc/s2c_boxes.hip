@@ -348,17 +348,25 @@ extern "C" int s2c_multi_colsum(const s2c_colsum_args *a, void *stream) {
 namespace {
 
 __global__ __launch_bounds__(1024) void multi_rowsum_kernel(s2c_rowsum_args a) {
+  // chunk_rows > 0: a job is cut into slabs of chunk_rows rows, slab q of job j writes its
+  // sums to out[j] + q * C[j] (the caller adds the slabs up, s2c_multi_colsum)
   __shared__ float s_part[16][64];
   int blk = blockIdx.x;
   for (int j = 0; j < a.n_jobs; ++j) {
-    const int nb = (a.C[j] + 63) / 64;
+    const int ncg = (a.C[j] + 63) / 64;
+    const long long rows = a.chunk_rows > 0 ? a.chunk_rows : a.M[j];
+    const int nslab = (int)((a.M[j] + rows - 1) / rows);
+    const int nb = ncg * nslab;
     if (blk < nb) {
-      const int col = blk * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+      const int slab = blk / ncg, cg = blk - slab * ncg;
+      const int col = cg * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+      const long long m0 = (long long)slab * rows;
+      const long long m1 = m0 + rows < a.M[j] ? m0 + rows : a.M[j];
       float s = 0.f;
       if (col < a.C[j]) {
         const float *x = a.X[j] + col;
-        const long long ld = a.ld[j], M = a.M[j];
-        for (long long m = ph; m < M; m += 16) s += x[m * ld];
+        const long long ld = a.ld[j];
+        for (long long m = m0 + ph; m < m1; m += 16) s += x[m * ld];
       }
       s_part[ph][threadIdx.x & 63] = s;
       __syncthreads();
@@ -366,7 +374,7 @@ __global__ __launch_bounds__(1024) void multi_rowsum_kernel(s2c_rowsum_args a) {
         float t = 0.f;
 #pragma unroll
         for (int q = 0; q < 16; ++q) t += s_part[q][threadIdx.x];
-        a.out[j][col] = t;
+        a.out[j][(size_t)slab * a.C[j] + col] = t;
       }
       return;
     }
@@ -381,7 +389,8 @@ extern "C" int s2c_multi_rowsum(const s2c_rowsum_args *a, void *stream) {
   long long blocks = 0;
   for (int j = 0; j < a->n_jobs; ++j) {
     if (!a->X[j] || !a->out[j] || a->M[j] <= 0 || a->C[j] <= 0 || a->ld[j] < a->C[j]) return -1;
-    blocks += (a->C[j] + 63) / 64;
+    const long long rows = a->chunk_rows > 0 ? a->chunk_rows : a->M[j];
+    blocks += (long long)((a->C[j] + 63) / 64) * ((a->M[j] + rows - 1) / rows);
   }
   hipLaunchKernelGGL(multi_rowsum_kernel, dim3((unsigned)blocks), dim3(1024), 0,
                      (hipStream_t)stream, *a);

@@ -386,7 +386,7 @@ class _MLPRows(Function):
             dbias = None
             if rec["has_bias"]:
                 if BATCH_PARTIAL_SUMS and dY.is_cuda and dY.dtype == torch.float32 \
-                        and dY.stride(1) == 1 and dY.shape[0] <= 4096:   # short columns only
+                        and dY.stride(1) == 1:
                     bias_jobs.append((dY, len(grads)))      # summed after the loop
                 else:
                     dbias = dY.sum(0)
@@ -533,7 +533,8 @@ def flush_partial_sums(pending):
 
 class _RowsumArgs(ctypes.Structure):
     """s2c_rowsum_args (include/s2c_fused.h)."""
-    _fields_ = [("n_jobs", ctypes.c_int), ("C", ctypes.c_int * 16),
+    _fields_ = [("n_jobs", ctypes.c_int), ("chunk_rows", ctypes.c_int),
+                ("C", ctypes.c_int * 16),
                 ("M", ctypes.c_longlong * 16), ("ld", ctypes.c_longlong * 16),
                 ("X", ctypes.c_void_p * 16), ("out", ctypes.c_void_p * 16)]
 
@@ -541,18 +542,35 @@ class _RowsumArgs(ctypes.Structure):
 _C.register("s2c_multi_rowsum", [_P, _P])
 
 
+ROWSUM_CHUNK = 1024
+
+
 def row_sums(mats):
-    """[X (M,C) float32, unit column stride, ...] -> [X.sum(0), ...] in one launch per 16."""
-    outs = [torch.empty(x.shape[1], dtype=torch.float32, device=x.device) for x in mats]
+    """[X (M,C) float32, unit column stride, ...] -> [X.sum(0), ...]: one launch per 16
+    matrices; tall matrices go through slabs of ROWSUM_CHUNK rows + one partial-sum launch."""
+    dev = mats[0].device
+    tall = max(x.shape[0] for x in mats) > 2 * ROWSUM_CHUNK
+    outs = [torch.empty(x.shape[1], dtype=torch.float32, device=dev) for x in mats]
+    pending = []
     for i in range(0, len(mats), 16):
         a = _RowsumArgs()
         a.n_jobs = len(mats[i:i + 16])
+        a.chunk_rows = ROWSUM_CHUNK if tall else 0
         for j, (x, o) in enumerate(zip(mats[i:i + 16], outs[i:i + 16])):
             assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.float32
             a.M[j], a.C[j], a.ld[j] = x.shape[0], x.shape[1], x.stride(0)
-            a.X[j], a.out[j] = x.data_ptr(), o.data_ptr()
-        with torch.cuda.device(mats[0].device):
+            a.X[j] = x.data_ptr()
+            if tall:
+                nslab = (x.shape[0] + ROWSUM_CHUNK - 1) // ROWSUM_CHUNK
+                part = torch.empty((nslab, x.shape[1]), dtype=torch.float32, device=dev)
+                pending.append((part, o))
+                a.out[j] = part.data_ptr()
+            else:
+                a.out[j] = o.data_ptr()
+        with torch.cuda.device(dev):
             _C.call("s2c_multi_rowsum", ctypes.byref(a), _C.stream_ptr())
+    if pending:
+        flush_partial_sums(pending)
     return outs
 
 
