@@ -423,12 +423,12 @@ def main():
             else:
                 for p in range(depth):
                     slots.refill(p, dd["point_clouds"])
+            torch.cuda.synchronize()     # from here on the resident batch is complete
             counter = {"i": 0}
             if feeder is not None:
                 for p in range(depth - 1 if depth >= 3 else depth):
                     feeder.produce(p, *feed_pick(p))
-                    slots.streams[p].wait_event(feeder.ready[p])
-                    slots.refill(p, dd_sets[p]["point_clouds"])
+                    slots.refill(p, dd_sets[p]["point_clouds"], ready=feeder.ready[p])
 
             host_ms = {"replay": 0.0, "produce": 0.0, "refill": 0.0, "n": 0}
             host_paced = feeder is not None and depth >= 3
@@ -451,8 +451,7 @@ def main():
                 q, nxt = ((i + depth - 1) % depth, i + depth - 1) if host_paced else (p, i + depth)
                 feeder.produce(q, *feed_pick(nxt), host_wait=host_paced)
                 t_c = time.perf_counter()
-                slots.streams[q].wait_event(feeder.ready[q])
-                slots.refill(q, dd_sets[q]["point_clouds"])
+                slots.refill(q, dd_sets[q]["point_clouds"], ready=feeder.ready[q])
                 t_d = time.perf_counter()
                 host_ms["replay"] += 1e3 * (t_b - t_a)
                 host_ms["produce"] += 1e3 * (t_c - t_b)
@@ -469,10 +468,12 @@ def main():
                 slots.acquire(p)                       # geometry of this step is published
                 out = replays[p]()
                 slots.release(p)
+                # ready=None: the resident batch is complete (synchronised above); the
+                # refill must NOT wait for the step graph just launched -- it overlaps it
                 if G == 1:
-                    slots.refill(p, dd["point_clouds"])    # geometry of step i+depth
+                    slots.refill(p, dd["point_clouds"], ready=None)   # step i+depth
                 elif (p + 1) % G == 0:                 # group fully consumed: next G batches
-                    slots.refill_group(p // G, [dd["point_clouds"]] * G)
+                    slots.refill_group(p // G, [dd["point_clouds"]] * G, ready=None)
                 return out
         else:
             def step(_dd):

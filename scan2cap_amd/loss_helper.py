@@ -145,6 +145,12 @@ def compute_cap_loss(data_dict, config, weights):
         num_words = int(data_dict["lang_len"].max())
     target_caps = data_dict["lang_ids"][:, 1:num_words]
     V = pred_caps.shape[-1]
+    if tuple(pred_caps.shape[:2]) != tuple(target_caps.shape):
+        # a stale `_num_words` (static data_dict reused with new lang_len) or a
+        # degenerate caption (num_words == 1: the decoder still runs one step)
+        raise ValueError("caption loss: lang_cap has %s steps but the targets have %s "
+                         "(is data_dict['_num_words'] = %r stale?)"
+                         % (tuple(pred_caps.shape[:2]), tuple(target_caps.shape), num_words))
     if FUSED_CAPTION_LOSS and loss_fused.caption_loss_available(
             pred_caps, target_caps, data_dict["good_bbox_masks"]):
         return loss_fused.CaptionLoss.apply(pred_caps, target_caps,

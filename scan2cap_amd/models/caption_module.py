@@ -387,7 +387,10 @@ class TopDownSceneCaptionModule(nn.Module):
         # 115 MB copy per step at cfg5)
         cap_buf = torch.empty(T, R, self.num_vocabs, device=dev)
         attn = torch.zeros(R, K, T, device=dev)
+        # the fused step calls raw kernels outside autograd: only when nothing can ask
+        # for a gradient (RL / saliency callers with grad enabled take `_step`)
         fused_step = (FUSE_EVAL_STEP and dev.type == "cuda" and L <= 32
+                      and not torch.is_grad_enabled()
                       and self.hidden_size % 4 == 0 and self.attend.bias is None)
         if fused_step:
             # Same step as `_step`, re-associated so that nothing step-invariant and no

@@ -81,8 +81,11 @@ def _lin_pair(R, d1, d2=None, gates=None):
           ctypes.addressof(gates) if gates is not None else None, alg_bytes=ab)
 
 
+ENABLED = True      # scan2cap_amd/opbyop.py: False = the plain `_step` loop
+
+
 def supported(emb, hid, feat, K):
-    return (emb % 4 == 0 and hid % 4 == 0 and feat in (32, 64, 128, 256) and K <= 1024
+    return (ENABLED and emb % 4 == 0 and hid % 4 == 0 and feat in (32, 64, 128, 256) and K <= 1024
             and hid <= 512 and emb <= 512)     # register-resident input slices
 
 

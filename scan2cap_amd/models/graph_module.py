@@ -182,7 +182,7 @@ class EdgeConv(nn.Module):
 
     def message(self, x_i, x_j):
         e = torch.cat([x_i, x_j - x_i], dim=-1)
-        if e.is_cuda:
+        if fused.fused_available(e):
             # rows path: its weight gradient is a split-K GEMM (the plain autograd
             # dW = dY^T X over B*K*L edge rows is one output tile with a 20k-deep K
             # loop: 73 us per layer on MI355X instead of ~10)

@@ -60,7 +60,7 @@ class ProposalModule(nn.Module):
         data_dict["aggregated_vote_xyz"] = xyz
         data_dict["aggregated_vote_features"] = features.permute(0, 2, 1).contiguous()
         data_dict["aggregated_vote_inds"] = fps_inds
-        if features.is_cuda:
+        if fused.fused_available(features):
             B, C, K = features.shape
             p = self.proposal
             specs = [fused.LayerSpec(False, p[1], True),

@@ -88,7 +88,7 @@ class VotingModule(nn.Module):
         (models/capnet.py:97-98), with offsets / residual / normalisation in one kernel
         (csrc/s2c_boxes.hip) when the fused path applies."""
         B, S = seed_xyz.shape[0], seed_xyz.shape[1]
-        if not (FUSE_VOTE_HEAD and seed_features.is_cuda and self.in_dim % 4 == 0
+        if not (FUSE_VOTE_HEAD and fused.fused_available(seed_features) and self.in_dim % 4 == 0
                 and self.vote_factor == 1 and self.out_dim == self.in_dim
                 and seed_features.dtype == torch.float32):
             vote_xyz, f = self.forward(seed_xyz, seed_features)
@@ -102,7 +102,7 @@ class VotingModule(nn.Module):
         vote_xyz (B,S*vf,3), vote_features (B,C,S*vf)."""
         B, S = seed_xyz.shape[0], seed_xyz.shape[1]
         V = S * self.vote_factor
-        if seed_features.is_cuda and self.in_dim % 4 == 0:
+        if fused.fused_available(seed_features) and self.in_dim % 4 == 0:
             # point-major rows through the fused GEMM/BN kernels
             net, _ = self._net(seed_features, B, S)
             net = net.view(B, S, self.vote_factor, 3 + self.out_dim)

@@ -146,7 +146,8 @@ class GeometrySlots(object):
 
         slots = GeometrySlots(backbone, point_clouds, depth)
         graphs = [capture(step_fn reading slots.geometry(p)) for p in range(depth)]
-        for p in range(depth): slots.refill(p, point_clouds)          # prime
+        for p in range(depth): slots.refill(p, point_clouds)          # prime (waits for
+                                         # the current stream; ready=None / an Event otherwise)
         for i in ...:
             p = i % depth
             slots.acquire(p)          # main waits until slot p is published
@@ -180,8 +181,26 @@ class GeometrySlots(object):
     def geometry(self, p):
         return unflatten_geometry(self._slots[p])
 
-    def refill(self, p, point_clouds):
+    def _order_after_producer(self, side, tensors, ready):
+        """The geometry kernels read `tensors` on `side`: order them after the producer.
+        ready = "current" (default): whatever is enqueued on the caller's current stream
+        (an H2D copy, a builder kernel, a previous step) finishes first; an Event: wait
+        for it (a producer on a third stream); None: the caller guarantees the data is
+        already complete (e.g. a resident batch after a synchronize) -- no wait, so a
+        refill issued right behind a step graph still overlaps that step."""
+        if ready == "current":
+            side.wait_stream(torch.cuda.current_stream())
+        elif ready is not None:
+            side.wait_event(ready)
+        for t in tensors:
+            t.record_stream(side)
+
+    def refill(self, p, point_clouds, ready="current"):
+        if self.group > 1:
+            raise RuntimeError("GeometrySlots(group=%d): use refill_group(g, clouds); "
+                               "refill(p, ...) is the group == 1 interface" % self.group)
         side = self.streams[p]
+        self._order_after_producer(side, [point_clouds], ready)
         with torch.cuda.stream(side):
             geo = self.backbone.compute_geometry(point_clouds)
             if self._consumed[p] is not None:
@@ -191,13 +210,15 @@ class GeometrySlots(object):
             ev.record(side)
         self._published[p] = ev
 
-    def refill_group(self, g, clouds):
+    def refill_group(self, g, clouds, ready="current"):
         """Geometry of slots g*group .. (g+1)*group-1 from `group` point clouds (a list
-        of (B,N,3+C) tensors) in one pass on group g's side stream."""
+        of (B,N,3+C) tensors) in one pass on group g's side stream.  `ready`: see
+        `_order_after_producer`."""
         G = self.group
         assert len(clouds) == G
         side = self.streams[g]
         first = g * G
+        self._order_after_producer(side, clouds, ready)
         with torch.cuda.stream(side):
             xyz = torch.cat([c[..., :3] for c in clouds], 0) if G > 1 else clouds[0]
             flat = flatten_geometry(self.backbone.compute_geometry(xyz))

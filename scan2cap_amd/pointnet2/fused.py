@@ -84,8 +84,13 @@ def set_gemm_split(on):
     return bool(lib.s2c_gemm_set_split(int(bool(on))))
 
 
+# Master switch of the point-major rows path (scan2cap_amd/opbyop.py flips it for A/B
+# parity tests against the reference's op-by-op formulation).
+ENABLED = True
+
+
 def fused_available(t):
-    return t.is_cuda
+    return ENABLED and t.is_cuda
 
 
 # ---------------------------------------------------------------------------
@@ -230,6 +235,10 @@ class _MLPRows(Function):
                 gamma, beta = params[pi], params[pi + 1]; pi += 2
             Cout = W.shape[0]
             train_stats = bn is not None and (bn.training or bn.running_mean is None)
+            if train_stats and bn.momentum is None and bn.running_mean is not None:
+                raise NotImplementedError(
+                    "BatchNorm(momentum=None) (cumulative moving average) is not "
+                    "implemented on the rows path; use a float momentum")
             from_gather = gather is not None and li == 0
             gemm_stats = (USE_MFMA_GEMM and train_stats and bias is None
                           and W.stride(1) == 1 and (from_gather or A.stride(1) == 1))
@@ -267,7 +276,7 @@ class _MLPRows(Function):
                 mean = torch.empty(Cout, device=dev)
                 invstd = torch.empty(Cout, device=dev)
                 if gemm_stats and gpart is not None:
-                    mom = bn.momentum if bn.momentum is not None else 0.1
+                    mom = bn.momentum if bn.momentum is not None else 0.0
                     _call("s2c_bn_finalize_partials", Y, nbg, M, Cout, gpart.data_ptr(),
                           float(bn.eps), float(mom), _ptr(gamma), _ptr(beta),
                           _ptr(bn.running_mean), _ptr(bn.running_var),
@@ -277,7 +286,7 @@ class _MLPRows(Function):
                     nb = _stat_blocks(M)
                     if partial is None or partial.numel() < nb * 2 * Cout:
                         partial = torch.empty(nb * 2 * max(Cout, 256), device=dev)
-                    mom = bn.momentum if bn.momentum is not None else 0.1
+                    mom = bn.momentum if bn.momentum is not None else 0.0
                     _call("s2c_bn_train_stats", Y, M, Cout, Y.data_ptr(),
                           partial.data_ptr(), float(bn.eps), float(mom),
                           _ptr(gamma), _ptr(beta), _ptr(bn.running_mean),
@@ -696,12 +705,16 @@ def shared_mlp_specs(mlp):
 
 def mlp_supported(specs, params):
     """BN kernels need channel counts that are multiples of 4."""
+    if not ENABLED:
+        return False
     pi = 0
     for sp in specs:
         W = params[pi]
         pi += 1 + (1 if sp.has_bias else 0) + (2 if sp.bn is not None else 0)
         if sp.bn is not None and W.shape[0] % 4 != 0:
             return False
+        if sp.bn is not None and sp.bn.momentum is None:
+            return False        # cumulative moving average: torch path
     return True
 
 

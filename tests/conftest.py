@@ -12,6 +12,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """Plain `pytest tests` on a GPU-less host: GPU tests are skipped, not failed."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="needs a real MI355X (no GPU on this host)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The CPU parity oracle (oracle/s2c_oracle.c via ctypes) -- checker only."""

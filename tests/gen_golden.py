@@ -1,9 +1,12 @@
-"""Generates tests/golden/capnet_cfg1.npz by running the REFERENCE's CapNet
+"""Generates tests/golden/capnet_{cfg1,c132}.npz by running the REFERENCE's CapNet
 (imported from /root/reference through oracle/ref_harness.py) on seeded
 synthetic inputs with deterministic weights.  Runs only where the reference
 tree exists; the committed .npz holds inputs + expected outputs only.
 
-    python tests/gen_golden.py
+    python tests/gen_golden.py [cfg1|c132 ...]      (default: cfg1)
+
+c132 = the cfg3 channel layout (3+132) and proposal count (256) at N=8192; its inputs
+are regenerated from the seed by the tests (pinned by `in_crc`), not stored.
 """
 import os
 import sys
@@ -19,18 +22,19 @@ from oracle import ref_harness  # noqa: E402
 from tests import golden_common as gc  # noqa: E402
 
 
-def main():
+def main(name="cfg1"):
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ref = ref_harness.reference_modules()
-    cfg = gc.GOLDEN_CFG
+    spec = gc.CFGS[name]
+    cfg = spec["cfg"]
     vocabulary, embeddings = gc.vocab_and_embeddings(cfg["V"])
     msa = gc.mean_size_arr()
     # the reference's box decode uses the module-level DC (proposal_module.py:17);
     # give it the same mean sizes the ctor receives
     ref.DC.mean_size_arr = msa
     model = ref.capnet.CapNet(vocabulary=vocabulary, embeddings=embeddings,
-                              mean_size_arr=msa, **gc.CAPNET_KW)
+                              mean_size_arr=msa, **spec["kw"])
     sd = model.state_dict()
     with torch.no_grad():
         gc.det_fill_(sd)
@@ -58,7 +62,7 @@ def main():
     for k, v in gc.extract_grads(model).items():
         out["grad/" + k] = v
     print("loss terms:", {k: float(out["loss/" + k]) for k in ("loss", "cap_loss", "ori_loss", "dist_loss", "cap_acc")})
-    for k, v in gc.extract(dd, gc.TRAIN_KEYS).items():
+    for k, v in gc.extract(dd, spec["train_keys"]).items():
         out["train/" + k] = v
     # sanity: the local top-k never had to pick among 1e30 ties
     nvalid = dd["bbox_mask"].sum(1)
@@ -75,14 +79,20 @@ def main():
     model.eval()
     with torch.no_grad():
         dd = model(gc.to_torch(inputs), use_tf=False, is_eval=True)
-    for k, v in gc.extract(dd, gc.EVAL_KEYS).items():
+    for k, v in gc.extract(dd, spec["eval_keys"]).items():
         out["eval/" + k] = v
-    for k, v in inputs.items():
-        out["in/" + k] = v
-    path = os.path.join(HERE, "golden", "capnet_cfg1.npz")
+    if spec["store_inputs"]:
+        for k, v in inputs.items():
+            out["in/" + k] = v
+    else:
+        # the one input that is not a pure function of the seed (set from the dry run)
+        out["in/ref_box_corner_label"] = inputs["ref_box_corner_label"]
+        out["in_crc"] = np.asarray(gc.inputs_crc(inputs), np.int64)
+    path = os.path.join(HERE, "golden", spec["file"])
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
 if __name__ == "__main__":
-    main()
+    for cfg_name in (sys.argv[1:] or ["cfg1"]):
+        main(cfg_name)

@@ -18,6 +18,14 @@ CAPNET_KW = dict(num_class=18, num_heading_bin=1, num_size_cluster=18,
                  num_graph_steps=2, use_relation=True, use_orientation=True,
                  num_bins=6)
 
+# The cfg3 channel layout (XYZ + normal + multiview(128) + height = 3+132, row stride
+# 540 B) and proposal count (K=256) at a reduced cloud size.  N=8192 still takes the
+# bucketed FPS kernel (pointnet2/_ext.py: FPS_BUCKET_MIN_N).  The 8.8 MB of inputs
+# are NOT stored: they are regenerated from the seed and pinned by a CRC.
+GOLDEN_CFG_C132 = dict(B=2, N=8192, K=256, V=40, num_locals=10, graph_steps=2,
+                       max_words=9, input_feature_dim=132, seed=4321)
+CAPNET_KW_C132 = dict(CAPNET_KW, input_feature_dim=132, num_proposal=256)
+
 
 def vocab_and_embeddings(V, seed=0):
     rng = np.random.Generator(np.random.PCG64(seed))
@@ -79,7 +87,16 @@ def make_inputs(cfg=GOLDEN_CFG):
     rng = np.random.Generator(np.random.PCG64(cfg["seed"]))
     xyz = scene_xyz(B, N, seed=cfg["seed"], mode="surface", adversarial=True)
     height = xyz[..., 2:3] - np.percentile(xyz[..., 2], 0.99)
-    pc = np.concatenate([xyz, height.astype(np.float32)], -1).astype(np.float32)
+    feats = []
+    if cfg["input_feature_dim"] >= 132:
+        # channel order of lib/dataset.py:338-362: xyz, normal, multiview, height
+        frng = np.random.Generator(np.random.PCG64(cfg["seed"] + 77))
+        nrm = frng.standard_normal((B, N, 3)).astype(np.float32)
+        nrm /= np.linalg.norm(nrm, axis=-1, keepdims=True) + 1e-9
+        mv = np.maximum(frng.standard_normal((B, N, 128)).astype(np.float32) * 0.5, 0)
+        feats = [nrm, mv]
+    pc = np.concatenate([xyz] + feats + [height.astype(np.float32)], -1).astype(np.float32)
+    assert pc.shape[-1] == 3 + cfg["input_feature_dim"]
     vocabulary, embeddings = vocab_and_embeddings(V)
     words = list(vocabulary["word2idx"].keys())
     T = 32
@@ -103,6 +120,16 @@ def make_inputs(cfg=GOLDEN_CFG):
     out.update(scene_labels(xyz, num_boxes=12, seed=cfg["seed"],
                             mean_size_arr=mean_size_arr()))
     return out
+
+
+def inputs_crc(inputs):
+    """One CRC over every input array (name order): pins regenerated inputs."""
+    c = 0
+    for k in sorted(inputs):
+        a = np.ascontiguousarray(inputs[k])
+        c = zlib.crc32(("%s|%s|%s" % (k, a.dtype.str, a.shape)).encode(), c)
+        c = zlib.crc32(a.tobytes(), c)
+    return c
 
 
 def to_torch(inputs, device="cpu"):
@@ -132,6 +159,34 @@ EVAL_KEYS = {
     "bbox_corner": None, "bbox_mask": None, "bbox_feature": None,
     "adjacent_mat": None, "valid_masks": None,
     "lang_cap": None, "topdown_attn": None,
+}
+
+
+_S = slice
+# K=256 variant: the same keys, the large ones sub-sampled harder
+TRAIN_KEYS_C132 = dict(TRAIN_KEYS)
+TRAIN_KEYS_C132.update({
+    "sa1_features": (_S(None), _S(None, None, 8), _S(None, None, 32)),
+    "aggregated_vote_features": (_S(None), _S(None, None, 4), _S(None, None, 4)),
+    "bbox_feature": (_S(None), _S(None, None, 4), _S(None, None, 4)),
+    "size_residuals": (_S(None), _S(None, None, 4)),
+    "edge_feature": (_S(None), _S(None, None, 8), _S(None), _S(None, None, 8)),
+    "edge_orientations": (_S(None), _S(None, None, 4)),
+    "topdown_attn": None,
+})
+EVAL_KEYS_C132 = {
+    "bbox_corner": None, "bbox_mask": None,
+    "bbox_feature": (_S(None), _S(None, None, 4), _S(None, None, 4)),
+    "adjacent_mat": None, "valid_masks": None,
+    "lang_cap": (_S(None), _S(None, None, 8)),
+    "topdown_attn": (_S(None), _S(None, None, 16), _S(None, None, 4)),
+}
+
+CFGS = {
+    "cfg1": dict(cfg=GOLDEN_CFG, kw=CAPNET_KW, train_keys=TRAIN_KEYS, eval_keys=EVAL_KEYS,
+                 file="capnet_cfg1.npz", store_inputs=True),
+    "c132": dict(cfg=GOLDEN_CFG_C132, kw=CAPNET_KW_C132, train_keys=TRAIN_KEYS_C132,
+                 eval_keys=EVAL_KEYS_C132, file="capnet_c132.npz", store_inputs=False),
 }
 
 

@@ -7,7 +7,10 @@ native ops supplied by the oracle).
   op layer (a test double; the product never does this).
 * GPU flavour (-m gpu): the real path, HIP kernels through the C ABI.
 
-Tolerance 1e-4 on float features (north_star); integer outputs exact.
+Tolerance 1e-4 of each tensor's scale on float outputs (north_star) unless a key is
+listed in TOL_KEY with its measured bound; integer outputs exact.  Fixtures: cfg1
+(BASELINE configs[0] shapes) and c132 (cfg3's 3+132 channels and 256 proposals at
+N=8192).
 """
 import os
 
@@ -17,25 +20,38 @@ import torch
 
 from tests import golden_common as gc
 
-GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "capnet_cfg1.npz")
-# Per-op parity is held to 1e-4 / bit-exact in tests/test_ops_gpu.py.  Here a
-# whole network is chained (train-mode BN, L2-normalisation, 2 graph layers that
-# grow activations to ~1e3 with these random weights), so the bound is relative
-# to each tensor's scale: |got - want| <= TOL * max(1, max|want|).
-# Train mode additionally divides by per-batch BN standard deviations (11 BN
-# layers, some channels with tiny variance under these random weights), which
-# amplifies fp32 re-association noise between the CPU reference run and the GPU:
-# measured 3.5e-4 of scale on lang_cap; eval mode (running stats) stays < 1e-5.
-TOL = {("cpu", "train"): 1e-4, ("cpu", "eval"): 1e-4,
-       ("cuda", "train"): 1e-3, ("cuda", "eval"): 1e-4,
-       ("cpu", "grad"): 1e-4, ("cuda", "grad"): 5e-3}
+GOLDEN_DIR = os.path.join(os.path.dirname(__file__), "golden")
+
+# Bound per key: |got - want| <= tol * max(1, max|want|), tol = 1e-4 (north_star) unless the
+# key is listed below with a MEASURED bound (worst case over the fixtures, x ~2 headroom)
+# and the reason.  Integer / bool outputs are always exact.
+TOL_DEFAULT = 1e-4
+# Train-mode tensors behind the whole BN chain: 11+ batch-norm layers divide by per-batch
+# standard deviations (some channels have tiny variance under the deterministic random
+# weights), which amplifies fp32 re-association differences between the CPU reference run
+# (MKL / oracle order) and the GPU kernels; the graph module then sums ~10 un-normalised
+# messages per node twice.  Eval mode (running statistics) holds 1e-4 everywhere.
+TOL_KEY = {
+    # (device, section/key): bound  -- filled from gpurun_out/golden_report_*.json
+}
+TOL_GRAD_DEFAULT = {"cpu": 1e-4, "cuda": 1e-4}
 
 
-def build_model(device):
+def tol_of(device, key):
+    t = TOL_KEY.get((device, key))
+    if t is not None:
+        return t
+    if key.startswith("grad/"):
+        return TOL_GRAD_DEFAULT[device]
+    return TOL_DEFAULT
+
+
+def build_model(device, name="cfg1"):
     from scan2cap_amd.models import CapNet
-    vocabulary, embeddings = gc.vocab_and_embeddings(gc.GOLDEN_CFG["V"])
+    spec = gc.CFGS[name]
+    vocabulary, embeddings = gc.vocab_and_embeddings(spec["cfg"]["V"])
     model = CapNet(vocabulary=vocabulary, embeddings=embeddings,
-                   mean_size_arr=gc.mean_size_arr(), **gc.CAPNET_KW)
+                   mean_size_arr=gc.mean_size_arr(), **spec["kw"])
     sd = model.state_dict()
     with torch.no_grad():
         gc.det_fill_(sd)
@@ -44,61 +60,100 @@ def build_model(device):
     return model.to(device), sd
 
 
-def check(got, want, key, tol):
-    g = got.detach().cpu().numpy()
-    assert g.shape == want.shape, (key, g.shape, want.shape)
-    if want.dtype.kind in "iub":
-        np.testing.assert_array_equal(g, want, err_msg=key)
-    else:
+class Report(object):
+    """Collects every key's error before failing, so one run shows the whole table."""
+
+    def __init__(self, device, name):
+        self.device, self.name, self.rows, self.bad = device, name, {}, []
+
+    def check(self, got, want, key):
+        g = got.detach().cpu().numpy()
+        assert g.shape == want.shape, (key, g.shape, want.shape)
+        if want.dtype.kind in "iub":
+            ok = np.array_equal(g, want)
+            self.rows[key] = {"exact": bool(ok)}
+            if not ok:
+                self.bad.append("%s: %d integer mismatches" % (key, int((g != want).sum())))
+            return
         w = want.astype(np.float64)
-        bound = tol * max(1.0, float(np.abs(w).max()))
-        err = float(np.abs(g.astype(np.float64) - w).max())
-        assert err <= bound, "%s: max|diff| %.3e > %.3e" % (key, err, bound)
+        scale = max(1.0, float(np.abs(w).max()))
+        err = float(np.abs(g.astype(np.float64) - w).max()) / scale
+        tol = tol_of(self.device, key)
+        self.rows[key] = {"rel_err": err, "tol": tol}
+        if not err <= tol:
+            self.bad.append("%s: %.3e of scale > %.1e" % (key, err, tol))
+
+    def finish(self):
+        out = os.environ.get("S2C_GOLDEN_REPORT")
+        if out:
+            import json
+            os.makedirs(out, exist_ok=True)
+            with open(os.path.join(out, "golden_report_%s_%s.json"
+                                   % (self.name, self.device)), "w") as f:
+                json.dump(self.rows, f, indent=1, sort_keys=True)
+        assert not self.bad, "\n".join(self.bad)
 
 
-def run_and_compare(device):
-    ref = np.load(GOLDEN)
-    inputs = {k[3:]: ref[k] for k in ref.files if k.startswith("in/")}
-    model, sd = build_model(device)
+def load_fixture(name):
+    spec = gc.CFGS[name]
+    ref = np.load(os.path.join(GOLDEN_DIR, spec["file"]))
+    if spec["store_inputs"]:
+        inputs = {k[3:]: ref[k] for k in ref.files if k.startswith("in/")}
+    else:
+        inputs = gc.make_inputs(spec["cfg"])
+        inputs["ref_box_corner_label"] = ref["in/ref_box_corner_label"]
+        assert gc.inputs_crc(inputs) == int(ref["in_crc"]), \
+            "regenerated inputs differ from the ones the fixture was made with"
+    return spec, ref, inputs
+
+
+def run_and_compare(device, name="cfg1"):
+    spec, ref, inputs = load_fixture(name)
+    model, sd = build_model(device, name)
+    rep = Report(device, name)
 
     from scan2cap_amd.loss_helper import get_scene_cap_loss
     model.train()
     model.zero_grad()
     dd = model(gc.to_torch(inputs, device), use_tf=True, is_eval=False)
-    for key, sl in gc.TRAIN_KEYS.items():
+    for key, sl in spec["train_keys"].items():
         v = dd[key]
-        check(v[sl] if sl is not None else v, ref["train/" + key], "train/" + key, TOL[(device, "train")])
+        rep.check(v[sl] if sl is not None else v, ref["train/" + key], "train/" + key)
     # loss restatement + backward (autograd through the custom grad kernels)
     dd = get_scene_cap_loss(dd, torch.device(device), gc.LossConfig(gc.mean_size_arr()),
                             None, **gc.LOSS_FLAGS)
     dd["loss"].backward()
     for key in gc.LOSS_KEYS:
-        check(dd[key].detach().reshape(()), ref["loss/" + key].reshape(()),
-              "loss/" + key, TOL[(device, "train")])
+        rep.check(dd[key].detach().reshape(()), ref["loss/" + key].reshape(()),
+                  "loss/" + key)
     for key, g in gc.extract_grads(model).items():
-        check(torch.from_numpy(g), ref["grad/" + key], "grad/" + key,
-              TOL[(device, "grad")])
+        rep.check(torch.from_numpy(g), ref["grad/" + key], "grad/" + key)
 
     model.load_state_dict(sd)
     model.eval()
     with torch.no_grad():
         dd = model(gc.to_torch(inputs, device), use_tf=False, is_eval=True)
-    for key, sl in gc.EVAL_KEYS.items():
+    for key, sl in spec["eval_keys"].items():
         v = dd[key]
-        check(v[sl] if sl is not None else v, ref["eval/" + key], "eval/" + key, TOL[(device, "eval")])
+        rep.check(v[sl] if sl is not None else v, ref["eval/" + key], "eval/" + key)
     # greedy tokens identical
-    np.testing.assert_array_equal(dd["lang_cap"].argmax(-1).cpu().numpy(),
-                                  ref["eval/lang_cap"].argmax(-1))
+    sl = spec["eval_keys"]["lang_cap"]
+    lc = dd["lang_cap"][sl] if sl is not None else dd["lang_cap"]
+    if not np.array_equal(lc.argmax(-1).cpu().numpy(), ref["eval/lang_cap"].argmax(-1)):
+        rep.bad.append("eval/lang_cap: greedy tokens differ")
+    rep.finish()
 
 
-def test_capnet_host_logic_cpu(monkeypatch):
+@pytest.mark.parametrize("name", sorted(gc.CFGS))
+def test_capnet_host_logic_cpu(monkeypatch, name):
     from oracle import torch_ext
     from scan2cap_amd.pointnet2 import _ext
-    for name in torch_ext.NAMES:
-        monkeypatch.setattr(_ext, name, getattr(torch_ext, name))
-    run_and_compare("cpu")
+    for n in torch_ext.NAMES:
+        monkeypatch.setattr(_ext, n, getattr(torch_ext, n))
+    run_and_compare("cpu", name)
 
 
 @pytest.mark.gpu
-def test_capnet_gpu():
-    run_and_compare("cuda")
+@pytest.mark.parametrize("name", sorted(gc.CFGS))
+def test_capnet_gpu(name):
+    run_and_compare("cuda", name)
