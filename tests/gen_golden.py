@@ -8,6 +8,7 @@ tree exists; the committed .npz holds inputs + expected outputs only.
 c132 = the cfg3 channel layout (3+132) and proposal count (256) at N=8192; its inputs
 are regenerated from the seed by the tests (pinned by `in_crc`), not stored.
 """
+import contextlib
 import os
 import sys
 
@@ -20,6 +21,49 @@ sys.path.insert(0, ROOT)
 
 from oracle import ref_harness  # noqa: E402
 from tests import golden_common as gc  # noqa: E402
+
+
+N_TRIALS = 3
+
+
+def sensitivity(ref, model, sd, inputs, spec, msa, forced_inds, base):
+    """Per stored key: the largest deviation (same metric as the tests: max |diff| over
+    max(1, max|want|)) of the REFERENCE's own train-mode outputs / losses / gradients over
+    N_TRIALS evaluations with one-rounding noise after every layer (golden_common.ulp_noise)
+    and N_TRIALS with the input features perturbed below float32 resolution
+    (golden_common.perturb_features), vote sampling held fixed.  The parity tests bound each key by
+    max(1e-4, SENS_FACTOR x this) -- a measured conditioning bound instead of one blanket
+    tolerance."""
+    def rel(g, w):
+        w = np.asarray(w, np.float64)
+        return float(np.abs(np.asarray(g, np.float64) - w).max() / max(1.0, np.abs(w).max()))
+    sens = {}
+    for trial in range(2 * N_TRIALS):
+        model.load_state_dict(sd)
+        model.train()
+        model.zero_grad()
+        tin = gc.to_torch(inputs)
+        if trial < N_TRIALS:        # one rounding error of noise after every layer
+            probe = gc.ulp_noise(model, 1000 + trial)
+        else:                       # ... or on the input features (coherent per point)
+            probe = contextlib.nullcontext()
+            tin["point_clouds"] = gc.perturb_features(tin["point_clouds"], 2000 + trial)
+        with probe, gc.forced_vote_sampling(model, forced_inds):
+            dd = model(tin, use_tf=True, is_eval=False)
+            dd = ref.loss_helper.get_scene_cap_loss(
+                dd, torch.device("cpu"), gc.LossConfig(msa), None, **gc.LOSS_FLAGS)
+            dd["loss"].backward()
+        cur = {}
+        for k, v in gc.extract(dd, spec["train_keys"]).items():
+            cur["train/" + k] = v
+        for k in gc.LOSS_KEYS:
+            cur["loss/" + k] = np.asarray(dd[k].detach().cpu().numpy(), np.float64)
+        for k, v in gc.extract_grads(model).items():
+            cur["grad/" + k] = v
+        for k, v in cur.items():
+            if base[k].dtype.kind == "f":
+                sens[k] = max(sens.get(k, 0.0), rel(v, base[k]))
+    return sens
 
 
 def main(name="cfg1"):
@@ -75,6 +119,12 @@ def main(name="cfg1"):
     print("adjacency picks that hit invalid objects: %d, self picks: %d "
           "(both must be 0: no 1e30 tie-breaks)" % (bad, diag))
     assert bad == 0 and diag == 0
+    sens = sensitivity(ref, model, sd, inputs, spec, msa,
+                       dd["aggregated_vote_inds"].detach().clone(), dict(out))
+    for k, v in sens.items():
+        out["sens/" + k] = np.asarray(v, np.float64)
+    print("conditioning (one-ulp noise per layer), worst keys:",
+          sorted(((round(v, 6), k) for k, v in sens.items()), reverse=True)[:8])
     model.load_state_dict(sd)  # reset BN running stats touched by the train pass
     model.eval()
     with torch.no_grad():

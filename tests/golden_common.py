@@ -2,6 +2,7 @@
 (tests/gen_golden.py, runs the REFERENCE here) and the parity tests (run the
 build's CapNet, on the GPU or -- with the oracle injected as `_ext` -- on CPU).
 """
+import contextlib
 import zlib
 
 import numpy as np
@@ -132,6 +133,104 @@ def inputs_crc(inputs):
     return c
 
 
+@contextlib.contextmanager
+def forced_vote_sampling(model, inds):
+    """Teacher-force the ONE discrete decision that sits behind float features: the vote
+    aggregation's FPS picks (proposal_module.py:60 -> pointnet2_modules.py:226-231 sample
+    the model's own vote_xyz).  A 1e-6 difference in vote_xyz can legitimately flip a pick
+    between two near-tied votes, after which every proposal-level tensor describes a
+    different set of boxes; parity of the float stages downstream is therefore checked with
+    the picks of the run being compared against, and the picks themselves are checked
+    separately, bit-exactly, against the oracle's FPS on the very same vote_xyz."""
+    sa = model.proposal.vote_aggregation
+    orig = sa.forward
+
+    def forward(xyz, features=None, inds_=None, **kw):      # (the reference's has no geom=)
+        return orig(xyz, features, inds=inds.to(device=xyz.device, dtype=torch.int32), **kw)
+    sa.forward = forward
+    try:
+        yield
+    finally:
+        del sa.forward
+
+
+ULP_NOISE = 1.0e-7      # relative, rms: about one float32 rounding error per value
+# A K-term fp32 dot product summed in another order (another GEMM tiling, another
+# reduction tree) differs by up to ~sqrt(K)/2 roundings, K = 64..512 on this path, and a
+# BatchNorm statistic over 1e3..1e6 rows likewise: the allowance over the response to ONE
+# rounding per value.
+SENS_FACTOR = 8.0
+
+
+@contextlib.contextmanager
+def ulp_noise(model, seed):
+    """Conditioning probe: while active, every leaf layer of `model` that runs as an
+    nn.Module call is evaluated "as another correct fp32 implementation would":
+
+    * its output (and, through a tensor hook, the incoming gradient) is multiplied by
+      (1 + ULP_NOISE * N(0,1)) element-wise -- one rounding error per value;
+    * a train-mode BatchNorm additionally gets its batch statistics perturbed by one
+      rounding error relative to their own magnitude: per channel, mean += eps*|mean|,
+      std *= (1 + eps), i.e. y += gamma * eps * n_c * |mean|/std and y *= (1 + eps * n'_c).
+      This error is COHERENT over all rows of a channel (a differently ordered sum over
+      1e3..1e6 rows), does not average out in the sums the backward pass forms, and moves
+      every ReLU threshold of the channel the same way.
+
+    How far a result moves under it is a MEASURED bound on how far two correct fp32
+    implementations may differ there."""
+    gens = {}
+
+    def randn(shape, like):
+        g = gens.get(like.device)
+        if g is None:
+            g = gens[like.device] = torch.Generator(device=like.device).manual_seed(seed)
+        return torch.randn(shape, generator=g, dtype=like.dtype, device=like.device)
+
+    def perturb(t):
+        return t * (1.0 + ULP_NOISE * randn(t.shape, t))
+
+    def fwd(mod, inp, out):
+        if not (torch.is_tensor(out) and out.is_floating_point()):
+            return None
+        if isinstance(mod, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)) and mod.training:
+            x = inp[0].detach()
+            dims = [d for d in range(x.dim()) if d != 1]
+            ratio = (x.mean(dims).abs() / x.std(dims).clamp_min(1e-20)).clamp(max=1e4)
+            shape = [1, -1] + [1] * (x.dim() - 2)
+            gamma = mod.weight.detach().abs() if mod.weight is not None else 1.0
+            out = out * (1.0 + ULP_NOISE * randn(ratio.shape, x)).view(shape) \
+                + (ULP_NOISE * randn(ratio.shape, x) * ratio * gamma).view(shape)
+        out = perturb(out)
+        if out.requires_grad:
+            out.register_hook(perturb)
+        return out
+    leaf = (torch.nn.Conv1d, torch.nn.Conv2d, torch.nn.Linear, torch.nn.BatchNorm1d,
+            torch.nn.BatchNorm2d, torch.nn.GRUCell)
+    hooks = [m.register_forward_hook(fwd) for m in model.modules() if isinstance(m, leaf)]
+    try:
+        yield
+    finally:
+        for h in hooks:
+            h.remove()
+
+
+def perturb_features(point_clouds, seed, eps=ULP_NOISE):
+    """Second conditioning probe: the per-point feature channels of the input cloud times
+    (1 + eps * N(0,1)) -- below float32 resolution of the data, xyz untouched (the sampled /
+    grouped indices stay the same).  Unlike per-layer noise this perturbation is COHERENT
+    over every ball a point belongs to, passes the max-pools coherently, and at the
+    BASELINE sizes (1e6 grouped rows x 64..256 channels of arg-maxes) it always finds a
+    few decisions within 1e-7 of a tie; one re-routed arg-max moves a whole gradient path.
+    (Measured at cfg3: this probe reproduces the fused-vs-op-by-op gradient difference of
+    every parameter to three digits -- tools/diag_bisect.py.)"""
+    g = torch.Generator(device=point_clouds.device).manual_seed(seed)
+    pc = point_clouds.clone()
+    if pc.shape[-1] > 3:
+        pc[..., 3:] *= 1.0 + eps * torch.randn(pc[..., 3:].shape, generator=g,
+                                               device=pc.device, dtype=pc.dtype)
+    return pc
+
+
 def to_torch(inputs, device="cpu"):
     return {k: torch.from_numpy(v).to(device) for k, v in inputs.items()}
 
@@ -175,6 +274,7 @@ TRAIN_KEYS_C132.update({
     "topdown_attn": None,
 })
 EVAL_KEYS_C132 = {
+    "vote_xyz": None, "aggregated_vote_inds": None,
     "bbox_corner": None, "bbox_mask": None,
     "bbox_feature": (_S(None), _S(None, None, 4), _S(None, None, 4)),
     "adjacent_mat": None, "valid_masks": None,

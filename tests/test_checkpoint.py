@@ -148,6 +148,43 @@ def _graphed(bench, wl, model, dd, cfg, dev):
     return opt, run
 
 
+LR = 1e-3
+
+
+def _snapshot(model, opt):
+    w = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    names = {id(p): n for n, p in model.named_parameters()}
+    st = {names[id(p)]: {k: v.detach().clone() for k, v in s.items() if torch.is_tensor(v)}
+          for p, s in opt.state.items() if s}
+    return w, st
+
+
+def _assert_continues(model, opt, loss, ref_loss, ref_w, ref_st, what):
+    """One step after a resume vs the original run's same step.  The loss is a function of
+    the restored weights / BN statistics only; the weights and Adam moments after the step
+    additionally prove the optimizer state was restored.  (Trajectories are NOT compared
+    beyond one step: at random init one last-bit difference of the float atomics moves a
+    discrete label assignment, cf. tests/test_train_loop_gpu.py.)"""
+    np.testing.assert_allclose(loss, ref_loss, rtol=1e-4, err_msg=what)
+    w, st = _snapshot(model, opt)
+    for k, b in ref_w.items():
+        if not b.is_floating_point():
+            assert torch.equal(w[k], b), (what, k)
+            continue
+        d = (w[k] - b).abs()
+        # Adam moves a weight by ~lr per step whatever the gradient's size: an entry whose
+        # gradient is rounding noise (e.g. a BN bias in front of another BN) may step the
+        # other way (2 lr apart); most entries must agree closely
+        assert float(d.max()) <= 2.5 * LR + 1e-4 * float(b.abs().max()), (what, k)
+        assert float((d > 0.1 * LR).float().mean()) <= 0.5, (what, k)
+    assert set(st) == set(ref_st), what
+    for n, s in ref_st.items():
+        assert float(st[n]["step"]) == float(s["step"]), (what, n)
+        for k in ("exp_avg", "exp_avg_sq"):
+            scale = max(1e-12, float(s[k].abs().max()))
+            assert float((st[n][k] - s[k]).abs().max()) <= 2e-3 * scale, (what, n, k)
+
+
 @pytest.mark.gpu
 def test_checkpoint_tar_resumes_a_graphed_run(tmp_path):
     from scan2cap_amd import checkpoint as ck
@@ -160,35 +197,37 @@ def test_checkpoint_tar_resumes_a_graphed_run(tmp_path):
     saved = torch.load(os.path.join(root, "checkpoint.tar"), map_location="cpu")
     assert sorted(saved) == ["best", "epoch", "model_state_dict", "optimizer_state_dict"]
     assert os.path.exists(os.path.join(root, "model_last.pth"))
-    want = run(2)                                           # steps 3, 4 of the original run
-    w_want = {k: v.clone() for k, v in model.state_dict().items()}
+    (want,) = run(1)                                         # step 3 of the original run
+    w_want, st_want = _snapshot(model, opt)
 
     # (a) resume INTO the live captured graph: weights and Adam state copied in place
     for p in model.parameters():
         p.data.add_(0.05)                                   # wreck the live state first
+    for s in opt.state.values():
+        for v in s.values():
+            if torch.is_tensor(v):
+                v.add_(1.0)
     epoch, best = ck.load_checkpoint(root, model, opt, inplace=True)
     assert epoch == 0 and best["sum"] == -1.0
-    got_a = run(2)
-    np.testing.assert_allclose(got_a, want, rtol=2e-3)      # float atomics: last-bit noise
-    for k in ("backbone_net.sa1.mlp_module.layer0.bn.bn.running_mean",
-              "caption.classifier.bias", "vgen.conv3.weight"):
-        a, b = model.state_dict()[k], w_want[k]
-        assert float((a - b).abs().max()) <= 2e-3 * max(1.0, float(b.abs().max())), k
+    (got,) = run(1)
+    _assert_continues(model, opt, got, want, w_want, st_want, "in-place resume, live graph")
 
-    # (b) a fresh model + optimizer (different init), the reference's resume calls, then a
-    # newly captured graph
+    # (b) a fresh model + optimizer (different init) with its own captured graph, resumed
+    # in place
     bench2, wl2, model2, dd2, cfg2, dev2 = _train_setup(seed=123)
     opt2, run2 = _graphed(bench2, wl2, model2, dd2, cfg2, dev2)
     ck.load_checkpoint(root, model2, opt2, inplace=True)
-    got_b = run2(2)
-    np.testing.assert_allclose(got_b, want, rtol=2e-3)
-    # and the plain (replacing) optimizer load followed by a re-capture
+    (got,) = run2(1)
+    _assert_continues(model2, opt2, got, want, w_want, st_want, "fresh process, in place")
+
+    # (c) the reference's own resume calls (scripts/train.py:138-145: optimizer state
+    # REPLACED), then the step is built / captured afterwards
     bench3, wl3, model3, dd3, cfg3, dev3 = _train_setup(seed=321)
     ckpt = torch.load(os.path.join(root, "checkpoint.tar"))
     model3.load_state_dict(ckpt["model_state_dict"])
-    opt3 = torch.optim.Adam(model3.parameters(), lr=1e-3, weight_decay=1e-5, capturable=True,
+    opt3 = torch.optim.Adam(model3.parameters(), lr=LR, weight_decay=1e-5, capturable=True,
                             fused=True)
     opt3.load_state_dict(ckpt["optimizer_state_dict"])
     step3 = bench3.make_step(model3, wl3, cfg3, opt3, None, dev3)
-    got_c = [float(step3(dd3).detach()) for _ in range(2)]  # eager, loaded state
-    np.testing.assert_allclose(got_c, want, rtol=2e-3)
+    got = float(step3(dd3).detach())
+    _assert_continues(model3, opt3, got, want, w_want, st_want, "reference resume calls")
