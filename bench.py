@@ -17,7 +17,10 @@ Scenes shard data-parallel: one process per GPU, B scenes each (weak scaling),
 one flat-bucket gradient all-reduce per step over RCCL (scan2cap_amd/parallel.py).
 
 Prints ONE JSON line (rank 0).  `roofline` describes the kernel with the largest
-share of the timed region (HIP events on the launch stream, live in this run);
+total time per step -- whichever stream it runs on -- (HIP events on the launch stream,
+live in this run); `roofline_main_stream` the largest one of the main stream when the top
+one is overlapped on a side stream; `roofline_named` north_star's ball_query + grouping
+pair; `fed` the same step on a new device-assembled batch every step;
 `cpu_baseline` is the same step run through the CPU oracle ops + torch CPU on a
 bounded sample (rank 0, N=1 only) -- a reported baseline, not the target.
 """
@@ -95,18 +98,24 @@ KERNELS_OF = {
     "s2c_gru_fwd": ("gru_fwd_kernel",),
     "s2c_attn_bwd": ("attn_bwd_kernel",),
     "s2c_ball_query": ("ball_query_kernel",),
+    "s2c_ball_query_grid": ("bq_grid_build_kernel", "ball_query_grid_kernel"),
+    "s2c_furthest_point_sampling_bucketed": ("fps_bucket_kernel",),
+    "s2c_furthest_point_sampling_cells": ("fps_cells_prep_kernel", "fps_cells_rounds_kernel"),
+    "s2c_furthest_point_sampling_small": ("fps_small_kernel",),
 }
 
 
 def pmc_traffic(entry):
     """Mean HBM bytes per launch of `entry` from the committed rocprofv3 PMC
-    summary (profiles/r01_pmc_bench.json: FETCH_SIZE and WRITE_SIZE collected in
+    summary (profiles/rNN_pmc_bench.json, newest round: FETCH_SIZE and WRITE_SIZE collected in
     separate passes over `bench.py --no-graph --steps 2 --warmup 1`).  gfx950
     correction (MI355X_MICROARCH.md, re-calibrated in
     profiles/r01_pmc_sa_kernels_calibration.json on bn_relu, whose byte count is
     exact): FETCH_SIZE counts half of a 16-byte-per-lane streaming read, so
     bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.  None when not available."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_bench.json")
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_bench.json")))
+    path = found[-1] if found else ""          # the newest round's summary
     keys = KERNELS_OF.get(entry)
     if not keys or not os.path.exists(path):
         return None
@@ -290,6 +299,69 @@ def cpu_baseline(wl, vocabulary, embeddings, table, msa, sample_B=1):
                       % (sample_B, wl["N"], wl["C"], wl["K"], dt)}
 
 
+# FPS is a chain of dependent rounds: per round one pick -> min-distance update of the points
+# it can affect -> arg-max.  Floor used for the latency regime: the register-resident
+# single-barrier kernel of csrc/s2c_fps_small.hip sustains 0.5 us per round at N <= 8192
+# (DESIGN 4.1), i.e. the dependent-instruction chain of one round with no memory traffic.
+FPS_ROUND_FLOOR_US = 0.5
+_FPS_ROUNDS = {"s2c_furthest_point_sampling_bucketed": 2047,       # SA1: npoint - 1
+               "s2c_furthest_point_sampling_cells": 2047}
+
+
+def roofline_of(top, ms_per_step, wl):
+    """`roofline` object of one kernel-table entry (the contract's keys; `traffic` from the
+    committed PMC summary).  GEMM kernels report the roof they sit closer to; FPS reports
+    its HBM fraction (as the contract asks: algorithmic bytes / duration) AND the regime it
+    is really in: a latency-bound chain of rounds."""
+    hbm = {"bound": "hbm", "achieved": top["alg_GBps"], "peak": HBM_PEAK_GBS,
+           "unit": "GB/s", "frac": top["alg_GBps"] / HBM_PEAK_GBS}
+    roof = dict(hbm)
+    if top["alg_TFLOPs"] > 0:
+        mfma = {"bound": "mfma", "achieved": top["alg_TFLOPs"],
+                "peak": MFMA_GEMM_PEAK_TF, "unit": "TFLOP/s",
+                "frac": top["alg_TFLOPs"] / MFMA_GEMM_PEAK_TF,
+                "note": ("fp32-equivalent FLOPs; peak = bf16 MFMA peak / 6 (bf16x3 "
+                         "split products)") if GEMM_SPLIT else "fp32 MFMA"}
+        roof = dict(mfma, other_roof=hbm) if mfma["frac"] > hbm["frac"] \
+            else dict(hbm, other_roof=mfma)
+    roof = dict({"kernel": top["kernel"]}, **roof)
+    roof.update({"traffic": pmc_traffic(top["kernel"]),
+                 "alg_bytes_per_launch": top["alg_bytes_per_launch"],
+                 "avg_launch_us": top["avg_us"],
+                 "share_of_step": top["ms_per_step"] / ms_per_step})
+    rounds = _FPS_ROUNDS.get(top["kernel"])
+    if rounds:
+        us = top["avg_us"] / rounds
+        roof["regime"] = {"kind": "latency", "rounds_per_launch": rounds,
+                          "us_per_round": us, "rounds_per_s": 1e6 / us,
+                          "floor_us_per_round": FPS_ROUND_FLOOR_US,
+                          "frac_of_floor": FPS_ROUND_FLOOR_US / us,
+                          "note": "serial rounds (one workgroup per scene, %d scenes in "
+                                  "flight); overlapped with the previous step on a side "
+                                  "stream" % wl["B"]}
+    return roof
+
+
+def named_roofline(table_k):
+    """north_star's named target: ball_query + grouping as a fraction of the HBM roof.
+    Grouping is fused into the first GEMM of every set-abstraction stage
+    (s2c_sa_gather_gemm: the gathered (rows, 3+C) operand is never materialised), so the
+    pair is  s2c_ball_query (+ its grid variant for SA1) + s2c_sa_gather_gemm  with the op-contract algorithmic bytes
+    of both (xyz + centres + idx;  unique source rows + idx + Y)."""
+    parts = [k for k in table_k if k["kernel"] in ("s2c_ball_query", "s2c_ball_query_grid",
+                                                   "s2c_sa_gather_gemm")]
+    if not parts:
+        return None
+    ms = sum(k["ms_per_step"] for k in parts)
+    nbytes = sum(k["alg_bytes_per_launch"] * k["calls_per_step"] for k in parts)
+    gbs = nbytes / max(ms, 1e-9) / 1e6
+    return {"kernels": [k["kernel"] for k in parts], "bound": "hbm", "achieved": gbs,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "ms_per_step": ms, "alg_bytes_per_step": nbytes,
+            "parts": {k["kernel"]: {"ms_per_step": k["ms_per_step"],
+                                    "alg_GBps": k["alg_GBps"]} for k in parts}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -311,6 +383,8 @@ def main():
                          "the device from HBM-resident synthetic scenes "
                          "(scan2cap_amd/scene_builder.py, SURVEY 8 f3), one batch ahead")
     ap.add_argument("--feed-scenes", type=int, default=12)
+    ap.add_argument("--no-fed", action="store_true",
+                    help="skip the second measurement (builder-fed step) of the default run")
     args = ap.parse_args()
 
     rank, world, local_rank = init_from_env()
@@ -350,137 +424,6 @@ def main():
     eager_step = make_step(model, wl, cfg_loss, optimizer, ddp, device)
     dd = to_device(make_batch(wl, B, 42 + rank, table, msa), device)
 
-    overlap = use_graph and not args.no_overlap
-    slots, depth = None, 0
-    if overlap:
-        # software pipeline across batches: geometry of step i+depth on a side
-        # stream while step i runs; each slot has its own captured step graph that
-        # reads the slot's static geometry tensors (scan2cap_amd/pipeline.py)
-        from scan2cap_amd.pipeline import GeometrySlots
-        # a forward-only step is shorter than one FPS chain: keep 3 batches of
-        # geometry in flight; a train step (~12.6 ms) hides one chain (~5.8 ms)
-        depth = 1 if wl["train"] else 3
-        if args.feed == "builder":
-            depth = 3          # three static batch sets / graphs: host-paced hand-over
-        depth = int(os.environ.get("S2C_GEO_DEPTH", depth))
-        # forward-only steps are shorter than one FPS chain even with 3 chains in
-        # flight: compute the geometry of `group` batches per pass (stacked clouds),
-        # two groups alternating
-        group = int(os.environ.get("S2C_GEO_GROUP", 1 if wl["train"] else 3))
-        if group > 1:
-            depth = 2 * group
-        slots = GeometrySlots(model.backbone_net, dd["point_clouds"], depth, group)
-
-    feeder = None
-    dd_sets = [dd] * max(depth, 1)
-    if args.feed == "builder":
-        if not (overlap and wl["train"] and slots.group == 1 and wl["C"] in (1, 4, 132)):
-            raise SystemExit("--feed builder needs the default graphed train step")
-        from scan2cap_amd.pipeline import independent_streams
-        feeder, dd_sets, feed_pick = make_feeder(
-            wl, dd, depth, msa, device, args.feed_scenes, rank,
-            independent_streams(1, avoid=slots.streams)[0])
-    if use_graph:
-        # whole step = one hipGraph replay (fwd + loss + bwd [+ Adam]); with N>1
-        # the RCCL all-reduce stays an eager call between two graphs
-        from scan2cap_amd.graphs import GraphedCallable
-
-        def with_geometry(p):
-            d = dict(dd_sets[p])
-            if slots is not None:
-                d["_geometry"] = slots.geometry(p)
-            return d
-
-        replays = []
-        g2 = None
-        for p in range(max(depth, 1)):
-            if wl["train"] and ddp is not None:
-                def fwd_bwd(p=p):
-                    d = with_geometry(p)
-                    ddp.drop_grads()
-                    d = model(d, use_tf=True, is_eval=False)
-                    d = get_scene_cap_loss(d, device, cfg_loss, None)
-                    d["loss"].backward()
-                    ddp.pack_grads()      # one multi-tensor copy into the flat bucket
-                    return d["loss"]
-                g1 = GraphedCallable(fwd_bwd).capture()
-                if g2 is None:
-                    g2 = GraphedCallable(lambda: optimizer.step()).capture()
-
-                def replay(g1=g1):
-                    loss = g1()
-                    ddp.reduce()
-                    g2()
-                    return loss
-            else:
-                replay = GraphedCallable(lambda p=p: eager_step(with_geometry(p))).capture()
-            replays.append(replay)
-        if overlap:
-            G = slots.group
-            if G > 1:
-                for g in range(depth // G):
-                    slots.refill_group(g, [dd["point_clouds"]] * G)
-            else:
-                for p in range(depth):
-                    slots.refill(p, dd["point_clouds"])
-            torch.cuda.synchronize()     # from here on the resident batch is complete
-            counter = {"i": 0}
-            if feeder is not None:
-                for p in range(depth - 1 if depth >= 3 else depth):
-                    feeder.produce(p, *feed_pick(p))
-                    slots.refill(p, dd_sets[p]["point_clouds"], ready=feeder.ready[p])
-
-            host_ms = {"replay": 0.0, "produce": 0.0, "refill": 0.0, "n": 0}
-            host_paced = feeder is not None and depth >= 3
-
-            def fed_step(_dd):
-                """Step i trains on buffer set i % depth; batch i + depth - 1 (host-paced,
-                depth 3: the host waits for step i-1 itself, so that no stream parks on an
-                event) or i + depth (stream-paced) is assembled and its geometry computed
-                while the following steps run."""
-                i = counter["i"]
-                p = i % depth
-                counter["i"] += 1
-                t_a = time.perf_counter()
-                feeder.acquire(p)                      # batch i is assembled
-                slots.acquire(p)                       # ... and its geometry published
-                out = replays[p]()
-                slots.release(p)
-                feeder.release(p)
-                t_b = time.perf_counter()
-                q, nxt = ((i + depth - 1) % depth, i + depth - 1) if host_paced else (p, i + depth)
-                feeder.produce(q, *feed_pick(nxt), host_wait=host_paced)
-                t_c = time.perf_counter()
-                slots.refill(q, dd_sets[q]["point_clouds"], ready=feeder.ready[q])
-                t_d = time.perf_counter()
-                host_ms["replay"] += 1e3 * (t_b - t_a)
-                host_ms["produce"] += 1e3 * (t_c - t_b)
-                host_ms["refill"] += 1e3 * (t_d - t_c)
-                host_ms["n"] += 1
-                return out
-
-            def step(_dd):
-                if feeder is not None:
-                    return fed_step(_dd)
-                i = counter["i"]
-                p = i % depth
-                counter["i"] += 1
-                slots.acquire(p)                       # geometry of this step is published
-                out = replays[p]()
-                slots.release(p)
-                # ready=None: the resident batch is complete (synchronised above); the
-                # refill must NOT wait for the step graph just launched -- it overlaps it
-                if G == 1:
-                    slots.refill(p, dd["point_clouds"], ready=None)   # step i+depth
-                elif (p + 1) % G == 0:                 # group fully consumed: next G batches
-                    slots.refill_group(p // G, [dd["point_clouds"]] * G, ready=None)
-                return out
-        else:
-            def step(_dd):
-                return replays[0]()
-    else:
-        step = eager_step
-
     def barrier():
         if world > 1:
             dist.barrier()
@@ -493,23 +436,164 @@ def main():
             torch.cuda.synchronize()
             print("[bench] ok:", msg, file=sys.stderr, flush=True)
 
-    trace("setup / capture done")
-    for _ in range(args.warmup):
-        step(dd)
-        trace("warmup step")
-    barrier()
-    if not use_graph:
-        _C.TIMER.start()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(dd)
-        trace("timed step")
-    barrier()
-    elapsed = time.perf_counter() - t0
-    trace("timed region done")
-    if feeder is not None and os.environ.get("S2C_DEBUG_HOST") == "1":
-        print("[bench] host ms per step:", {k: round(v / host_ms["n"], 3) for k, v in
-                                            host_ms.items() if k != "n"}, file=sys.stderr)
+    def measure(feed, steps, warmup):
+        """Set up the pipeline for `feed` ("resident": one batch in HBM replayed; "builder":
+        a new device-assembled batch per step), run `warmup` + `steps` steps, return the
+        timing and a description of what ran."""
+        overlap = use_graph and not args.no_overlap
+        slots, depth = None, 0
+        if overlap:
+            # software pipeline across batches: geometry of step i+depth on a side
+            # stream while step i runs; each slot has its own captured step graph that
+            # reads the slot's static geometry tensors (scan2cap_amd/pipeline.py)
+            from scan2cap_amd.pipeline import GeometrySlots
+            # a forward-only step is shorter than one FPS chain: keep 3 batches of
+            # geometry in flight; a train step (~12.6 ms) hides one chain (~5.8 ms)
+            depth = 1 if wl["train"] else 3
+            if feed == "builder":
+                depth = 3          # three static batch sets / graphs: host-paced hand-over
+            depth = int(os.environ.get("S2C_GEO_DEPTH", depth))
+            # forward-only steps are shorter than one FPS chain even with 3 chains in
+            # flight: compute the geometry of `group` batches per pass (stacked clouds),
+            # two groups alternating
+            group = int(os.environ.get("S2C_GEO_GROUP", 1 if wl["train"] else 3))
+            if group > 1:
+                depth = 2 * group
+            slots = GeometrySlots(model.backbone_net, dd["point_clouds"], depth, group)
+
+        feeder = None
+        dd_sets = [dd] * max(depth, 1)
+        if feed == "builder":
+            if not (overlap and wl["train"] and slots.group == 1 and wl["C"] in (1, 4, 132)):
+                raise SystemExit("--feed builder needs the default graphed train step")
+            from scan2cap_amd.pipeline import independent_streams
+            feeder, dd_sets, feed_pick = make_feeder(
+                wl, dd, depth, msa, device, args.feed_scenes, rank,
+                independent_streams(1, avoid=slots.streams)[0])
+        if use_graph:
+            # whole step = one hipGraph replay (fwd + loss + bwd [+ Adam]); with N>1
+            # the RCCL all-reduce stays an eager call between two graphs
+            from scan2cap_amd.graphs import GraphedCallable
+
+            def with_geometry(p):
+                d = dict(dd_sets[p])
+                if slots is not None:
+                    d["_geometry"] = slots.geometry(p)
+                return d
+
+            replays = []
+            g2 = None
+            for p in range(max(depth, 1)):
+                if wl["train"] and ddp is not None:
+                    def fwd_bwd(p=p):
+                        d = with_geometry(p)
+                        ddp.drop_grads()
+                        d = model(d, use_tf=True, is_eval=False)
+                        d = get_scene_cap_loss(d, device, cfg_loss, None)
+                        d["loss"].backward()
+                        ddp.pack_grads()      # one multi-tensor copy into the flat bucket
+                        return d["loss"]
+                    g1 = GraphedCallable(fwd_bwd).capture()
+                    if g2 is None:
+                        g2 = GraphedCallable(lambda: optimizer.step()).capture()
+
+                    def replay(g1=g1):
+                        loss = g1()
+                        ddp.reduce()
+                        g2()
+                        return loss
+                else:
+                    replay = GraphedCallable(lambda p=p: eager_step(with_geometry(p))).capture()
+                replays.append(replay)
+            if overlap:
+                G = slots.group
+                if G > 1:
+                    for g in range(depth // G):
+                        slots.refill_group(g, [dd["point_clouds"]] * G)
+                else:
+                    for p in range(depth):
+                        slots.refill(p, dd["point_clouds"])
+                torch.cuda.synchronize()     # from here on the resident batch is complete
+                counter = {"i": 0}
+                if feeder is not None:
+                    for p in range(depth - 1 if depth >= 3 else depth):
+                        feeder.produce(p, *feed_pick(p))
+                        slots.refill(p, dd_sets[p]["point_clouds"], ready=feeder.ready[p])
+
+                host_ms = {"replay": 0.0, "produce": 0.0, "refill": 0.0, "n": 0}
+                host_paced = feeder is not None and depth >= 3
+
+                def fed_step(_dd):
+                    """Step i trains on buffer set i % depth; batch i + depth - 1 (host-paced,
+                    depth 3: the host waits for step i-1 itself, so that no stream parks on an
+                    event) or i + depth (stream-paced) is assembled and its geometry computed
+                    while the following steps run."""
+                    i = counter["i"]
+                    p = i % depth
+                    counter["i"] += 1
+                    t_a = time.perf_counter()
+                    feeder.acquire(p)                      # batch i is assembled
+                    slots.acquire(p)                       # ... and its geometry published
+                    out = replays[p]()
+                    slots.release(p)
+                    feeder.release(p)
+                    t_b = time.perf_counter()
+                    q, nxt = ((i + depth - 1) % depth, i + depth - 1) if host_paced else (p, i + depth)
+                    feeder.produce(q, *feed_pick(nxt), host_wait=host_paced)
+                    t_c = time.perf_counter()
+                    slots.refill(q, dd_sets[q]["point_clouds"], ready=feeder.ready[q])
+                    t_d = time.perf_counter()
+                    host_ms["replay"] += 1e3 * (t_b - t_a)
+                    host_ms["produce"] += 1e3 * (t_c - t_b)
+                    host_ms["refill"] += 1e3 * (t_d - t_c)
+                    host_ms["n"] += 1
+                    return out
+
+                def step(_dd):
+                    if feeder is not None:
+                        return fed_step(_dd)
+                    i = counter["i"]
+                    p = i % depth
+                    counter["i"] += 1
+                    slots.acquire(p)                       # geometry of this step is published
+                    out = replays[p]()
+                    slots.release(p)
+                    # ready=None: the resident batch is complete (synchronised above); the
+                    # refill must NOT wait for the step graph just launched -- it overlaps it
+                    if G == 1:
+                        slots.refill(p, dd["point_clouds"], ready=None)   # step i+depth
+                    elif (p + 1) % G == 0:                 # group fully consumed: next G batches
+                        slots.refill_group(p // G, [dd["point_clouds"]] * G, ready=None)
+                    return out
+            else:
+                def step(_dd):
+                    return replays[0]()
+        else:
+            step = eager_step
+
+        trace("setup / capture done")
+        for _ in range(warmup):
+            step(dd)
+            trace("warmup step")
+        barrier()
+        if not use_graph:
+            _C.TIMER.start()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(dd)
+            trace("timed step")
+        barrier()
+        elapsed = time.perf_counter() - t0
+        trace("timed region done")
+        if feeder is not None and os.environ.get("S2C_DEBUG_HOST") == "1":
+            print("[bench] host ms per step:", {k: round(v / host_ms["n"], 3) for k, v in
+                                                host_ms.items() if k != "n"}, file=sys.stderr)
+        return {"elapsed": elapsed, "overlap": overlap, "depth": depth,
+                "group": slots.group if slots is not None else 1,
+                "fed": feeder is not None}
+
+    head = measure(args.feed, args.steps, args.warmup)
+    elapsed, overlap, depth = head["elapsed"], head["overlap"], head["depth"]
     if use_graph:
         # per-kernel durations: HIP events cannot be read back from inside a graph
         # replay, so the same steps are run once more eagerly, un-timed for the
@@ -527,17 +611,26 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # the same step on a NEW device-assembled batch every step, in the same
+    # line: the headline replays one resident 187 MB batch, which fits the 256 MiB
+    # Infinity Cache
+    fed = None
+    if (world == 1 and args.feed == "resident" and not args.no_fed and head["overlap"]
+            and wl["train"] and wl["C"] in (1, 4, 132)):
+        try:
+            f = measure("builder", args.steps, args.warmup)
+            fed = {"value": B * args.steps / f["elapsed"], "unit": "scenes/s",
+                   "ms_per_step": f["elapsed"] / args.steps * 1e3,
+                   "feed": "a new batch per step assembled on the device from %d HBM-resident "
+                           "synthetic scenes (150k vertices each), geometry %d batches ahead"
+                           % (args.feed_scenes, f["depth"])}
+        except Exception as e:          # reported, never fatal for the headline
+            fed = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = B * world * args.steps / elapsed
-        # dominant hand-written kernel of the timed region.  When the geometry stage
-        # runs ahead on side streams its kernels are off the critical path, so the
-        # roofline describes the dominant kernel of the main stream instead (the
-        # geometry kernels stay listed under "kernels").
-        off_path = ("s2c_furthest_point_sampling", "s2c_ball_query", "s2c_three_nn") \
-            if overlap else ()
-        roof, table_k = None, []
+        table_k = []
         for name, r in sorted(kern.items(), key=lambda kv: -kv[1]["total_ms"]):
             avg_us = r["total_ms"] / max(r["calls"], 1) * 1e3
             gbs = r["alg_bytes"] / max(r["total_ms"], 1e-9) / 1e6
@@ -546,29 +639,12 @@ def main():
                             "avg_us": avg_us, "alg_GBps": gbs,
                             "alg_TFLOPs": r.get("alg_flops", 0) / max(r["total_ms"], 1e-9) / 1e9,
                             "alg_bytes_per_launch": r["alg_bytes"] / max(r["calls"], 1)})
-        if table_k:
-            on_path = [k for k in table_k if not k["kernel"].startswith(off_path)] \
-                if off_path else table_k
-            top = (on_path or table_k)[0]
-            hbm = {"bound": "hbm", "achieved": top["alg_GBps"], "peak": HBM_PEAK_GBS,
-                   "unit": "GB/s", "frac": top["alg_GBps"] / HBM_PEAK_GBS}
-            roof = dict(hbm)
-            if top["alg_TFLOPs"] > 0:
-                # a GEMM kernel: the binding roof is the one it sits closer to
-                mfma = {"bound": "mfma", "achieved": top["alg_TFLOPs"],
-                        "peak": MFMA_GEMM_PEAK_TF, "unit": "TFLOP/s",
-                        "frac": top["alg_TFLOPs"] / MFMA_GEMM_PEAK_TF,
-                        "note": ("fp32-equivalent FLOPs; peak = bf16 MFMA peak / 6 (bf16x3 "
-                                 "split products)") if GEMM_SPLIT else "fp32 MFMA"}
-                if mfma["frac"] > hbm["frac"]:
-                    roof = dict(mfma, other_roof=hbm)
-                else:
-                    roof = dict(hbm, other_roof=mfma)
-            roof = dict({"kernel": top["kernel"]}, **roof)
-            roof.update({"traffic": pmc_traffic(top["kernel"]),
-                         "alg_bytes_per_launch": top["alg_bytes_per_launch"],
-                         "avg_launch_us": top["avg_us"],
-                         "share_of_step": top["ms_per_step"] / ms_per_step})
+        roof = roofline_of(table_k[0], ms_per_step, wl) if table_k else None
+        # the dominant kernel of the MAIN stream as well when the top one runs ahead on a
+        # side stream (the geometry stage, overlapped with the previous step)
+        side = ("s2c_furthest_point_sampling", "s2c_ball_query", "s2c_three_nn")
+        main_k = [k for k in table_k if not k["kernel"].startswith(side)]
+        roof_main = roofline_of(main_k[0], ms_per_step, wl) if (overlap and main_k) else None
         out = {
             "metric": ("scenes/sec forward+backward, B=%d N=%d pts" if wl["train"]
                        else "scenes/sec forward, B=%d N=%d pts") % (wl["B"], wl["N"]),
@@ -579,17 +655,24 @@ def main():
             "config": {"workload": "%s: %s" % (args.workload, wl["desc"]),
                        "scenes_per_gpu": B, "global_batch": B * world,
                        "parallelism": "dp%d" % world,
+                       "arithmetic": ("fp32 in / fp32 accumulate everywhere; the rows GEMMs form "
+                                      "each fp32 product from 6 bf16 MFMA products of a 3-way "
+                                      "split (error = an fp32 FMA chain's, tests/test_fused_gpu.py)"
+                                      if GEMM_SPLIT else "fp32 MFMA chain"),
                        "launch": "hipGraph replay" if use_graph else "eager",
                        "geometry": ("%d batch(es) ahead on side stream(s)%s" % (
-                           depth, ", %d batches per geometry pass" % slots.group
-                           if slots is not None and slots.group > 1 else ""))
+                           depth, ", %d batches per geometry pass" % head["group"]
+                           if head["group"] > 1 else ""))
                                    if overlap else "in-line",
                        "feed": ("a new batch per step assembled on the device from %d "
                                 "HBM-resident scenes, one batch ahead" % args.feed_scenes)
-                               if feeder is not None else "one batch resident in HBM",
+                               if head["fed"] else "one batch resident in HBM",
                        "grad_allreduce_bytes": ddp.nbytes if ddp else 0},
             "roofline": roof,
-            "kernels": table_k[:8],
+            "roofline_main_stream": roof_main,
+            "roofline_named": named_roofline(table_k),
+            "fed": fed,
+            "kernels": table_k[:10],
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, vocabulary, embeddings, table, msa,

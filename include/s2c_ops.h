@@ -65,6 +65,13 @@ int s2c_furthest_point_sampling_bucketed(int b, int n, int m, const float *xyz,
                                          void *workspace, int *idx,
                                          s2c_stream_t stream);
 
+/* The same with every grid cell owned by one wave and a single workgroup barrier per round
+ * (csrc/s2c_fps_cells.hip); identical output.  Scratch of s2c_fps_cells_workspace_bytes(b, n)
+ * bytes; waves = workgroup size of the rounds kernel in waves (4, 8, 16; 0 = default). */
+long long s2c_fps_cells_workspace_bytes(int b, int n);
+int s2c_furthest_point_sampling_cells(int b, int n, int m, const float *xyz, void *workspace,
+                                      int *idx, int waves, s2c_stream_t stream);
+
 /* Latency-optimised register-resident FPS for n <= s2c_fps_small_limit() points
  * (csrc/s2c_fps_small.hip); identical output.  threads = 0 picks the geometry. */
 int s2c_fps_small_limit(void);
@@ -87,6 +94,17 @@ int s2c_gather_points_grad(int b, int c, int n, int npoints,
 int s2c_ball_query(int b, int n, int m, float radius, int nsample,
                    const float *new_xyz, const float *xyz, int *idx,
                    s2c_stream_t stream);
+
+/* The same operator for large point sets (csrc/s2c_bq_grid.hip): identical output; the
+ * points are counting-sorted into a uniform grid of edge >= radius in a caller-owned,
+ * 16-byte aligned scratch of s2c_ball_query_workspace_bytes(b, n) bytes and a centre
+ * visits the <= 27 cells its ball can touch.  nsample <=
+ * s2c_ball_query_grid_max_nsample(); radius > 0. */
+long long s2c_ball_query_workspace_bytes(int b, int n);
+int s2c_ball_query_grid_max_nsample(void);
+int s2c_ball_query_grid(int b, int n, int m, float radius, int nsample,
+                        const float *new_xyz, const float *xyz, void *workspace,
+                        int *idx, s2c_stream_t stream);
 
 /* replaces group_points_kernel_wrapper (group_points.cpp:4-6,
  * group_points_gpu.cu:30-39).  points (b,c,n), idx (b,npoints,nsample) ->

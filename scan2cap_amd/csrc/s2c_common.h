@@ -54,6 +54,43 @@ __device__ __forceinline__ u64 wave_max_u64(u64 v) {
   return umax64(umax64(a, b), umax64(c, d));
 }
 
+// ---- the same reductions as two 32-bit passes -------------------------------------------
+// A 64-bit max step costs two DPP moves, a 64-bit compare and two selects; a 32-bit one is
+// a single v_max_u32 with a DPP operand.  max over (hi, lo) pairs = max over hi, then max
+// over lo among the lanes that hold that hi.
+template <int CTRL>
+__device__ __forceinline__ u32 dpp_umax32(u32 v) {
+  const u32 o = (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+  return v > o ? v : o;
+}
+__device__ __forceinline__ u32 row16_umax32(u32 v) {
+  v = dpp_umax32<DPP_QUAD_1032>(v);
+  v = dpp_umax32<DPP_QUAD_2301>(v);
+  v = dpp_umax32<DPP_ROW_HALF_MIRROR>(v);
+  v = dpp_umax32<DPP_ROW_MIRROR>(v);
+  return v;
+}
+__device__ __forceinline__ u32 wave_umax32(u32 v) {
+  v = row16_umax32(v);
+  const u32 a = (u32)__builtin_amdgcn_readlane((int)v, 0), b = (u32)__builtin_amdgcn_readlane((int)v, 16);
+  const u32 c = (u32)__builtin_amdgcn_readlane((int)v, 32), d = (u32)__builtin_amdgcn_readlane((int)v, 48);
+  const u32 ab = a > b ? a : b, cd = c > d ? c : d;
+  return ab > cd ? ab : cd;
+}
+__device__ __forceinline__ u64 wave_max_u64_2x32(u64 v) {
+  const u32 hi = (u32)(v >> 32);
+  const u32 mhi = wave_umax32(hi);
+  const u32 mlo = wave_umax32(hi == mhi ? (u32)v : 0u);
+  return ((u64)mhi << 32) | mlo;
+}
+// every lane of each 16-lane row gets that row's maximum
+__device__ __forceinline__ u64 row16_max_u64_2x32(u64 v) {
+  const u32 hi = (u32)(v >> 32);
+  const u32 mhi = row16_umax32(hi);
+  const u32 mlo = row16_umax32(hi == mhi ? (u32)v : 0u);
+  return ((u64)mhi << 32) | mlo;
+}
+
 // number of set bits of `mask` strictly below the calling lane
 __device__ __forceinline__ int mask_rank_below(u64 mask) {
   return (int)__builtin_amdgcn_mbcnt_hi(
@@ -61,5 +98,39 @@ __device__ __forceinline__ int mask_rank_below(u64 mask) {
 }
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// Zero fill as an ordinary KERNEL launch.  Not hipMemsetAsync: inside a captured hipGraph a
+// memset node followed by the kernel that accumulates into the buffer (float atomics) was
+// observed NOT to be ordered on ROCm 7.2 / gfx950 -- replays of the training step returned
+// non-finite gradients in 88 % of the steps (tools/stress_nan.py), eager launches never;
+// a kernel node behind a kernel node is ordered.
+static __global__ void __launch_bounds__(256) zero_fill_kernel(uint4 *__restrict__ p16, size_t n16,
+                                                        u32 *__restrict__ tail, int ntail) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t k = i; k < n16; k += stride) p16[k] = make_uint4(0u, 0u, 0u, 0u);
+  if (i < (size_t)ntail) tail[i] = 0u;
+}
+
+// `bytes` a multiple of 4, `p` 4-byte aligned (16-byte aligned bulk, dword head/tail).
+inline hipError_t zero_async(void *p, size_t bytes, hipStream_t st) {
+  if (bytes == 0) return hipSuccess;
+  uintptr_t a = (uintptr_t)p;
+  size_t head = (16 - (a & 15)) & 15;             // bytes up to 16-byte alignment
+  if (head > bytes) head = bytes;
+  if (head) {                                      // rare: unaligned start
+    hipLaunchKernelGGL(zero_fill_kernel, dim3(1), dim3(256), 0, st, (uint4 *)nullptr, (size_t)0,
+                       (u32 *)p, (int)(head / 4));
+    a += head; bytes -= head;
+  }
+  const size_t n16 = bytes / 16;
+  const int ntail = (int)((bytes - n16 * 16) / 4);
+  size_t blocks = (n16 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (uint4 *)a, n16,
+                     (u32 *)(a + n16 * 16), ntail);
+  return hipGetLastError();
+}
 
 }  // namespace s2c

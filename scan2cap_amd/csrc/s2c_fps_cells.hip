@@ -1,0 +1,432 @@
+// s2c_fps_cells.hip -- exact furthest point sampling on wave-owned grid cells.
+//
+// Same result, bit for bit, as the brute-force kernel in s2c_ops.hip (and hence as the
+// reference, sampling_gpu.cu:69-173) and as s2c_fps_bucket.hip, whose pruning rule it
+// keeps: points are counting-sorted into <= 1024 grid cells with tight bounding boxes; a
+// pick can lower a min-distance in a cell only if a conservative lower bound of
+// dist2(pick, box) does not exceed the cell's current maximum, so a round re-evaluates
+// ~15 cells (~600 points) instead of 40000, with exactly the reference's float expression.
+//
+// What changed is the ROUND, which is a latency chain (2047 of them per SA1 call):
+// s2c_fps_bucket.hip builds a list of active cells with LDS atomics, deals the list out to
+// the 16 waves and needs three workgroup barriers per round (2.1 us).  Here every cell is
+// OWNED by one wave -- cell c by wave c % NW, so that the 27 neighbours of a pick spread
+// over all waves -- and a wave tests, re-evaluates and keeps the keys of its own cells in
+// registers without talking to anybody: no list, no atomics, and ONE barrier per round
+// (the cross-wave arg-max, double-buffered like s2c_fps_small.hip).
+//
+//   prep    (1024 threads / scene) bounding box, grid, counting sort of {x,y,z,d2} + rank
+//           records, per-cell start / count / tight box -> workspace
+//   rounds  (NW waves / scene) per round and wave: bound test of its SL = 1024/(64 NW) cells
+//           per lane -> ballot -> its active cells, the 16-byte point records of up to four
+//           of them requested from L2 at once, each evaluated by all 64 lanes, DPP arg-max,
+//           result handed to the owning lane by readlane -> arg-max over own keys (DPP) ->
+//           LDS slot -> barrier -> arg-max over the NW slots, pivot coordinates ride along.
+#include "s2c_common.h"
+#include "../../include/s2c_ops.h"
+
+#include <math.h>
+#include <stdio.h>
+
+using namespace s2c;
+
+namespace {
+
+constexpr int PT = 1024;          // prep threads
+constexpr int PNW = PT / 64;
+constexpr int MAXC = 1024;        // cells
+constexpr int TAB_WORDS = 9;      // start, cnt, cand, box lo[3], box hi[3]
+
+__device__ __forceinline__ u32 bitrev_n(u32 v, int nbits) {
+  return nbits == 0 ? 0u : (__builtin_bitreverse32(v) >> (32 - nbits));
+}
+__device__ __forceinline__ u32 ord_of(float f) {
+  const u32 b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ord_inv(u32 o) {
+  return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);
+}
+
+struct __attribute__((aligned(16))) Pt { float x, y, z, d2; };
+struct __attribute__((aligned(16))) Slot { u64 key; float x, y, z, pad; };
+
+__host__ __device__ inline size_t cells_scene_bytes(int n) {
+  // Pt[n] | rank[n] | table[TAB_WORDS][MAXC]
+  return (((size_t)n * (sizeof(Pt) + 4) + 15) & ~(size_t)15) + (size_t)TAB_WORDS * MAXC * 4;
+}
+
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(PT) void fps_cells_prep_kernel(
+    int n, int bs, int log2bs, int target_cells, const float *__restrict__ xyz,
+    char *__restrict__ ws, size_t stride) {
+  __shared__ int s_cnt[MAXC], s_cursor[MAXC], s_cand[MAXC];
+  __shared__ u32 s_bb[6][MAXC];
+  __shared__ u32 s_red[6][PNW];
+  __shared__ float s_grid[6];
+  __shared__ int s_dims[4];
+  __shared__ int s_wsum[PNW];
+  const int b = blockIdx.x;
+  xyz += (size_t)b * n * 3;
+  ws += (size_t)b * stride;
+  Pt *spt = (Pt *)ws;
+  u32 *srank = (u32 *)(ws + (size_t)n * sizeof(Pt));
+  u32 *tab = (u32 *)(ws + (((size_t)n * (sizeof(Pt) + 4) + 15) & ~(size_t)15));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  {  // scene bounding box
+    u32 lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
+    for (int k = tid; k < n; k += PT) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const u32 o = ord_of(xyz[k * 3 + a]);
+        lo[a] = min(lo[a], o);
+        hi[a] = max(hi[a], o);
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        lo[a] = min(lo[a], (u32)__shfl_xor((int)lo[a], off, 64));
+        hi[a] = max(hi[a], (u32)__shfl_xor((int)hi[a], off, 64));
+      }
+      if (lane == 0) { s_red[a][wave] = lo[a]; s_red[3 + a][wave] = hi[a]; }
+    }
+    s_cnt[tid] = 0; s_cand[tid] = 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { s_bb[a][tid] = 0xFFFFFFFFu; s_bb[3 + a][tid] = 0u; }
+    __syncthreads();
+    if (tid == 0) {
+      float flo[3], fhi[3], ext[3];
+      for (int a = 0; a < 3; ++a) {
+        u32 l = 0xFFFFFFFFu, h = 0u;
+        for (int w = 0; w < PNW; ++w) { l = min(l, s_red[a][w]); h = max(h, s_red[3 + a][w]); }
+        flo[a] = ord_inv(l); fhi[a] = ord_inv(h);
+        ext[a] = fmaxf(fhi[a] - flo[a], 1e-6f);
+      }
+      const float vol = ext[0] * ext[1] * ext[2];
+      float e = cbrtf(vol / (float)target_cells);
+      int g[3];
+      for (int it = 0; it < 64; ++it) {
+        for (int a = 0; a < 3; ++a) g[a] = max(1, min(1024, (int)(ext[a] / e) + 1));
+        if ((long long)g[0] * g[1] * g[2] <= MAXC) break;
+        e *= 1.05f;
+      }
+      if ((long long)g[0] * g[1] * g[2] > MAXC) { g[0] = g[1] = g[2] = 1; }
+      for (int a = 0; a < 3; ++a) {
+        s_grid[a] = flo[a];
+        s_grid[3 + a] = (float)g[a] / ext[a];
+        s_dims[a] = g[a];
+      }
+      s_dims[3] = g[0] * g[1] * g[2];
+    }
+    __syncthreads();
+  }
+  const float glx = s_grid[0], gly = s_grid[1], glz = s_grid[2];
+  const float gix = s_grid[3], giy = s_grid[4], giz = s_grid[5];
+  const int gx = s_dims[0], gy = s_dims[1], gz = s_dims[2];
+  auto cell_of = [&](float x, float y, float z) {
+    const int ix = min(gx - 1, max(0, (int)((x - glx) * gix)));
+    const int iy = min(gy - 1, max(0, (int)((y - gly) * giy)));
+    const int iz = min(gz - 1, max(0, (int)((z - glz) * giz)));
+    return ix + gx * (iy + gy * iz);
+  };
+
+  for (int k = tid; k < n; k += PT)
+    atomicAdd(&s_cnt[cell_of(xyz[k * 3], xyz[k * 3 + 1], xyz[k * 3 + 2])], 1);
+  __syncthreads();
+  int my_start;
+  {
+    const int v = s_cnt[tid];
+    int inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += t;
+    }
+    if (lane == 63) s_wsum[wave] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += s_wsum[w];
+    my_start = base + inc - v;
+    s_cursor[tid] = my_start;
+  }
+  __syncthreads();
+  for (int k = tid; k < n; k += PT) {
+    const float x = xyz[k * 3], y = xyz[k * 3 + 1], z = xyz[k * 3 + 2];
+    const int c = cell_of(x, y, z);
+    const int pos = atomicAdd(&s_cursor[c], 1);
+    const float mag = (x * x) + (y * y) + (z * z);
+    const bool skip = (double)mag <= 1e-3;  // sampling_gpu.cu:100-101
+    Pt p; p.x = x; p.y = y; p.z = z; p.d2 = skip ? -1.0f : 1e10f;
+    spt[pos] = p;
+    srank[pos] = (bitrev_n((u32)k & (u32)(bs - 1), log2bs) << 22) | ((u32)k >> log2bs);
+    if (!skip) {
+      atomicAdd(&s_cand[c], 1);
+      atomicMin(&s_bb[0][c], ord_of(x)); atomicMax(&s_bb[3][c], ord_of(x));
+      atomicMin(&s_bb[1][c], ord_of(y)); atomicMax(&s_bb[4][c], ord_of(y));
+      atomicMin(&s_bb[2][c], ord_of(z)); atomicMax(&s_bb[5][c], ord_of(z));
+    }
+  }
+  __syncthreads();
+  // cell table (SoA, one coalesced row per field)
+  const bool has = s_cand[tid] > 0;
+  tab[0 * MAXC + tid] = (u32)my_start;
+  tab[1 * MAXC + tid] = (u32)s_cnt[tid];
+  tab[2 * MAXC + tid] = (u32)s_cand[tid];
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+    tab[(3 + a) * MAXC + tid] = has ? __float_as_uint(ord_inv(s_bb[a][tid])) : 0u;
+}
+
+// ---------------------------------------------------------------------------------
+template <int NW, bool PROFILE = false>
+__global__ __launch_bounds__(NW * 64) void fps_cells_rounds_kernel(
+    int n, int m, int log2bs, const float *__restrict__ xyz, char *__restrict__ ws,
+    size_t stride, int *__restrict__ idx, long long *__restrict__ prof = nullptr) {
+  // PROFILE: cycle sums per phase (s_memtime) of every wave of scene 0 -> prof[wave][8]
+  long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  constexpr int SL = MAXC / (64 * NW);      // cells per lane
+  __shared__ Slot s_slot[2][NW];
+  if (m <= 0) return;
+  const int b = blockIdx.x;
+  xyz += (size_t)b * n * 3;
+  ws += (size_t)b * stride;
+  idx += (size_t)b * m;
+  Pt *spt = (Pt *)ws;
+  const u32 *srank = (const u32 *)(ws + (size_t)n * sizeof(Pt));
+  const u32 *tab = (const u32 *)(ws + (((size_t)n * (sizeof(Pt) + 4) + 15) & ~(size_t)15));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  // ---- own cells: c = wave + NW * (lane + 64 s) ------------------------------------------
+  int c_start[SL], c_cnt[SL];
+  bool own[SL];
+  float blx[SL], bly[SL], blz[SL], bhx[SL], bhy[SL], bhz[SL];
+  u64 key[SL];
+  float kx[SL], ky[SL], kz[SL];
+#pragma unroll
+  for (int s = 0; s < SL; ++s) {
+    const int c = wave + NW * (lane + 64 * s);
+    c_start[s] = (int)tab[0 * MAXC + c];
+    c_cnt[s] = (int)tab[1 * MAXC + c];
+    own[s] = tab[2 * MAXC + c] > 0u;        // cells with no candidate never compete
+    blx[s] = __uint_as_float(tab[3 * MAXC + c]); bly[s] = __uint_as_float(tab[4 * MAXC + c]);
+    blz[s] = __uint_as_float(tab[5 * MAXC + c]); bhx[s] = __uint_as_float(tab[6 * MAXC + c]);
+    bhy[s] = __uint_as_float(tab[7 * MAXC + c]); bhz[s] = __uint_as_float(tab[8 * MAXC + c]);
+    key[s] = own[s] ? ((u64)(__float_as_uint(1e10f) + 1u) << 32) : 0ull;
+    kx[s] = 0.f; ky[s] = 0.f; kz[s] = 0.f;
+  }
+  // pivot coordinates travel with the arg-max through LDS; point 0 = first pivot and the
+  // "nothing selectable" case (the reference's besti = 0 initialisation, :90)
+  const float x0 = xyz[0], y0 = xyz[1], z0 = xyz[2];
+  float px = x0, py = y0, pz = z0;
+  if (tid == 0) idx[0] = 0;
+
+  for (int j = 1; j < m; ++j) {
+    const int par = j & 1;
+    long long t0 = 0;
+    if (PROFILE) t0 = (long long)__builtin_amdgcn_s_memtime();
+#pragma unroll
+    for (int s = 0; s < SL; ++s) {
+      // ---- which of my cells can change? --------------------------------------------------
+      bool active = false;
+      if (own[s]) {
+        const float ddx = fmaxf(fmaxf(blx[s] - px, px - bhx[s]), 0.0f);
+        const float ddy = fmaxf(fmaxf(bly[s] - py, py - bhy[s]), 0.0f);
+        const float ddz = fmaxf(fmaxf(blz[s] - pz, pz - bhz[s]), 0.0f);
+        const float lb = (ddx * ddx + ddy * ddy + ddz * ddz) * 0.99999f;
+        const float cmax = __uint_as_float((u32)(key[s] >> 32) - 1u);
+        active = !(lb > cmax);
+      }
+      u64 amask = __ballot(active);
+      if (PROFILE) pc[4] += (long long)__builtin_popcountll(amask);
+      // ---- re-evaluate them: the whole wave on one cell at a time (a ~40-point cell is ONE
+      // 64-lane pass), but the point records of up to four cells are requested before the
+      // first one is looked at -- one L2 round trip per group instead of one per cell, and
+      // the min-distance write-backs are issued behind all the loads
+      while (amask) {
+        int L[4], st[4], nc[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          L[r] = amask ? (int)__builtin_ctzll(amask) : -1;
+          amask = amask ? (amask & (amask - 1)) : 0ull;
+          const int src = L[r] < 0 ? 0 : L[r];
+          st[r] = __builtin_amdgcn_readlane(c_start[s], src);
+          nc[r] = L[r] < 0 ? 0 : __builtin_amdgcn_readlane(c_cnt[s], src);
+        }
+        Pt pa[4], pb[4];
+        u32 ra[4], rb[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (nc[r] > 0) {                       // wave-uniform
+            const int qa = st[r] + min(lane, nc[r] - 1);
+            const int qb = st[r] + min(lane + 64, nc[r] - 1);
+            pa[r] = spt[qa]; ra[r] = srank[qa];
+            pb[r] = spt[qb]; rb[r] = srank[qb];
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (nc[r] <= 0) continue;              // wave-uniform
+          u64 best = 0ull;
+          float bx = 0.f, by = 0.f, bz = 0.f;
+          auto visit = [&](const Pt &p, u32 rk, int q) {
+            const float d = (p.x - px) * (p.x - px) + (p.y - py) * (p.y - py) +
+                            (p.z - pz) * (p.z - pz);
+            const float d2 = fminf(d, p.d2);
+            if (d2 != p.d2) spt[st[r] + q].d2 = d2;
+            const u64 k = d2 < 0.0f ? 0ull
+                                    : ((u64)(__float_as_uint(d2) + 1u) << 32) |
+                                          (u64)(0xFFFFFFFFu - rk);
+            if (k > best) { best = k; bx = p.x; by = p.y; bz = p.z; }
+          };
+          if (lane < nc[r]) visit(pa[r], ra[r], lane);
+          if (lane + 64 < nc[r]) visit(pb[r], rb[r], lane + 64);
+          for (int q = lane + 128; q < nc[r]; q += 64) {      // crowded cells (rare)
+            const Pt p = spt[st[r] + q];
+            visit(p, srank[st[r] + q], q);
+          }
+          const u64 wbest = wave_max_u64_2x32(best);
+          // a cell with candidates always has a non-zero key; ranks make the winner unique
+          const int src = (int)__builtin_ctzll(__ballot(best == wbest));
+          const float wx = __uint_as_float((u32)__builtin_amdgcn_readlane((int)__float_as_uint(bx), src));
+          const float wy = __uint_as_float((u32)__builtin_amdgcn_readlane((int)__float_as_uint(by), src));
+          const float wz = __uint_as_float((u32)__builtin_amdgcn_readlane((int)__float_as_uint(bz), src));
+          if (lane == L[r]) { key[s] = wbest; kx[s] = wx; ky[s] = wy; kz[s] = wz; }
+        }
+      }
+    }
+    // ---- arg-max over my cells, over the wave, over the workgroup -------------------------
+    long long t1 = 0;
+    if (PROFILE) { t1 = (long long)__builtin_amdgcn_s_memtime(); pc[0] += t1 - t0; }
+    u64 best = key[0];
+    float bx = kx[0], by = ky[0], bz = kz[0];
+#pragma unroll
+    for (int s = 1; s < SL; ++s) {
+      const bool gt = key[s] > best;
+      best = gt ? key[s] : best;
+      bx = gt ? kx[s] : bx; by = gt ? ky[s] : by; bz = gt ? kz[s] : bz;
+    }
+    const u64 wmax = wave_max_u64_2x32(best);
+    Slot *slots = s_slot[par];
+    if (wmax == 0ull) {
+      if (lane == 0) slots[wave].key = 0ull;
+    } else if (best == wmax) {
+      Slot sl; sl.key = wmax; sl.x = bx; sl.y = by; sl.z = bz; sl.pad = 0.f;
+      slots[wave] = sl;
+    }
+    long long t2 = 0;
+    if (PROFILE) { t2 = (long long)__builtin_amdgcn_s_memtime(); pc[1] += t2 - t1; }
+    __syncthreads();
+    long long t3 = 0;
+    if (PROFILE) { t3 = (long long)__builtin_amdgcn_s_memtime(); pc[2] += t3 - t2; }
+    u64 v = lane < NW ? slots[lane].key : 0ull;
+    const u64 mine = v;
+    v = row16_max_u64_2x32(v);
+    const u64 gkey = readlane_u64(v, 0);
+    int old = 0;
+    if ((gkey >> 32) == 0ull) {
+      px = x0; py = y0; pz = z0;
+    } else {
+      const u32 r = 0xFFFFFFFFu - (u32)gkey;
+      old = (int)(((r & 0x3FFFFFu) << log2bs) | bitrev_n(r >> 22, log2bs));
+      const u64 wl = __ballot(lane < NW && mine == gkey);
+      const int w = (int)__builtin_ctzll(wl);
+      px = slots[w].x; py = slots[w].y; pz = slots[w].z;
+    }
+    if (tid == 0) idx[j] = old;
+    if (PROFILE) pc[3] += (long long)__builtin_amdgcn_s_memtime() - t3;
+  }
+  if (PROFILE && prof && b == 0 && lane == 0) {
+    for (int q = 0; q < 8; ++q) prof[wave * 8 + q] = pc[q];
+  }
+}
+
+}  // namespace
+
+// Diagnostics: the 16-wave rounds kernel with per-phase cycle counters of scene 0
+// (prof[16][8]: cells phase, own arg-max, barrier wait, decode, active cells; device memory).
+extern "C" int s2c_fps_cells_profile(int b, int n, int m, const float *xyz, void *workspace,
+                                     int *idx, int waves, long long *prof, s2c_stream_t stream) {
+  const int pow_2 = (int)(log((double)n) / log(2.0));
+  int bs = 1 << pow_2;
+  if (bs > 512) bs = 512;
+  int log2bs = 0;
+  while ((1 << log2bs) < bs) ++log2bs;
+  int target = n / 40;
+  if (target > MAXC) target = MAXC;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t stride = cells_scene_bytes(n);
+  hipLaunchKernelGGL(fps_cells_prep_kernel, dim3(b), dim3(PT), 0, st, n, bs, log2bs, target,
+                     xyz, (char *)workspace, stride);
+  if (waves == 4)
+    hipLaunchKernelGGL((fps_cells_rounds_kernel<4, true>), dim3(b), dim3(256), 0, st, n, m,
+                       log2bs, xyz, (char *)workspace, stride, idx, prof);
+  else if (waves == 8)
+    hipLaunchKernelGGL((fps_cells_rounds_kernel<8, true>), dim3(b), dim3(512), 0, st, n, m,
+                       log2bs, xyz, (char *)workspace, stride, idx, prof);
+  else
+    hipLaunchKernelGGL((fps_cells_rounds_kernel<16, true>), dim3(b), dim3(1024), 0, st, n, m,
+                       log2bs, xyz, (char *)workspace, stride, idx, prof);
+  return (int)hipGetLastError();
+}
+
+static thread_local char g_err5[256] = "";
+extern "C" const char *s2c_fps_cells_last_error_string(void) { return g_err5; }
+
+extern "C" long long s2c_fps_cells_workspace_bytes(int b, int n) {
+  if (b <= 0 || n <= 0) return 16;
+  return (long long)b * (long long)cells_scene_bytes(n);
+}
+
+// Same contract as s2c_furthest_point_sampling_bucketed; `waves` = workgroup size of the
+// rounds kernel in waves (4, 8 or 16; 0 = library default).
+extern "C" int s2c_furthest_point_sampling_cells(int b, int n, int m, const float *xyz,
+                                                 void *workspace, int *idx, int waves,
+                                                 s2c_stream_t stream) {
+  if (b < 0 || n <= 0 || m < 0 || !xyz || !idx || !workspace ||
+      ((uintptr_t)workspace & 15)) {
+    snprintf(g_err5, sizeof(g_err5), "s2c: fps_cells: invalid argument");
+    return S2C_EINVAL;
+  }
+  if (b == 0 || m == 0) return 0;
+  const int pow_2 = (int)(log((double)n) / log(2.0));  // cuda_utils.h:13-19
+  int bs = 1 << pow_2;
+  if (bs > 512) bs = 512;
+  if (bs < 1) bs = 1;
+  int log2bs = 0;
+  while ((1 << log2bs) < bs) ++log2bs;
+  int target = n / 40;
+  if (target > MAXC) target = MAXC;
+  if (target < 1) target = 1;
+  if (waves == 0) waves = 16;   // measured: 1.84 us/round vs 2.23 (8) and 3.27 (4) at N = 40000
+  hipStream_t st = (hipStream_t)stream;
+  const size_t stride = cells_scene_bytes(n);
+  hipLaunchKernelGGL(fps_cells_prep_kernel, dim3(b), dim3(PT), 0, st, n, bs, log2bs, target,
+                     xyz, (char *)workspace, stride);
+  switch (waves) {
+    case 4:
+      hipLaunchKernelGGL((fps_cells_rounds_kernel<4>), dim3(b), dim3(256), 0, st, n, m, log2bs,
+                         xyz, (char *)workspace, stride, idx, nullptr);
+      break;
+    case 8:
+      hipLaunchKernelGGL((fps_cells_rounds_kernel<8>), dim3(b), dim3(512), 0, st, n, m, log2bs,
+                         xyz, (char *)workspace, stride, idx, nullptr);
+      break;
+    case 16:
+      hipLaunchKernelGGL((fps_cells_rounds_kernel<16>), dim3(b), dim3(1024), 0, st, n, m,
+                         log2bs, xyz, (char *)workspace, stride, idx, nullptr);
+      break;
+    default:
+      snprintf(g_err5, sizeof(g_err5), "s2c: fps_cells: waves must be 4, 8 or 16");
+      return S2C_EINVAL;
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_err5, sizeof(g_err5), "s2c: fps_cells launch failed: %s",
+             hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}

@@ -270,7 +270,7 @@ extern "C" int s2c_edge_rows_grad(int B, int K, int L, int F, const float *d_row
                                   const long long *nbr, float *dx, void *stream) {
   if (B <= 0 || K <= 0 || L <= 0 || F <= 0 || !d_rows || !nbr || !dx) return -1;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(dx, 0, sizeof(float) * (size_t)B * K * F, st) != hipSuccess) return -1;
+  if (zero_async(dx, sizeof(float) * (size_t)B * K * F, st) != hipSuccess) return -1;
   const long long E = (long long)B * K * L;
   hipLaunchKernelGGL(edge_rows_grad_kernel, dim3(edge_grid(E)), dim3(256), 0, st, K, L, F,
                      d_rows, nbr, dx, E);
@@ -282,7 +282,7 @@ extern "C" int s2c_edge_scatter(int B, int K, int L, int F, const float *msg,
                                 float *msgm, void *stream) {
   if (B <= 0 || K <= 0 || L <= 0 || F <= 0 || !msg || !nbr || !slot || !out || !msgm) return -1;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * K * F, st) != hipSuccess) return -1;
+  if (zero_async(out, sizeof(float) * (size_t)B * K * F, st) != hipSuccess) return -1;
   const long long E = (long long)B * K * L;
   hipLaunchKernelGGL(edge_scatter_kernel, dim3(edge_grid(E)), dim3(256), 0, st, K, L, F, msg,
                      nbr, slot, out, msgm, E);

@@ -356,7 +356,7 @@ extern "C" int s2c_gather_points_grad(int b, int c, int n, int npoints,
   const long long nout = (long long)b * c * n;
   if (nout == 0) return 0;
   if (!grad_points) return fail_args("gather_points_grad: null pointer");
-  hipError_t e = hipMemsetAsync(grad_points, 0, sizeof(float) * nout, st);
+  hipError_t e = zero_async(grad_points, sizeof(float) * nout, st);
   if (e != hipSuccess) return (int)e;
   const long long total = (long long)b * c * npoints;
   if (total == 0) return 0;
@@ -545,7 +545,7 @@ extern "C" int s2c_group_points_grad(int b, int c, int n, int npoints,
   const long long nout = (long long)b * c * n;
   if (nout == 0) return 0;
   if (!grad_points) return fail_args("group_points_grad: null pointer");
-  hipError_t e = hipMemsetAsync(grad_points, 0, sizeof(float) * nout, st);
+  hipError_t e = zero_async(grad_points, sizeof(float) * nout, st);
   if (e != hipSuccess) return (int)e;
   const long long mk = (long long)npoints * nsample;
   const long long total = (long long)b * c * mk;
@@ -699,7 +699,7 @@ extern "C" int s2c_three_interpolate_grad(int b, int c, int n, int m,
   const long long nout = (long long)b * c * m;
   if (nout == 0) return 0;
   if (!grad_points) return fail_args("three_interpolate_grad: null pointer");
-  hipError_t e = hipMemsetAsync(grad_points, 0, sizeof(float) * nout, st);
+  hipError_t e = zero_async(grad_points, sizeof(float) * nout, st);
   if (e != hipSuccess) return (int)e;
   const long long total = (long long)b * c * n;
   if (total == 0) return 0;

@@ -135,7 +135,7 @@ extern "C" int s2c_boxes_count_points(int b, int n, int K, const float *pts,
       pt_stride < 3)
     return -1;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(counts, 0, sizeof(int) * (size_t)b * K, st) != hipSuccess) return -1;
+  if (s2c::zero_async(counts, sizeof(int) * (size_t)b * K, st) != hipSuccess) return -1;
   hipLaunchKernelGGL(boxes_count_points_kernel, dim3((n + PIB_TILE - 1) / PIB_TILE, b),
                      dim3(256), 0, st, n, K, pts, pt_stride, pt_batch_stride, center, size,
                      angle, counts);

@@ -133,12 +133,12 @@ extern "C" int s2c_sa_scatter_rows(int b, int n, int m, int ns, int C,
   if (b < 0 || n <= 0 || m < 0 || ns < 0 || C < 0) return fail2("sa_scatter_rows sizes");
   hipStream_t st = (hipStream_t)stream;
   if (d_feats && (long long)b * n * C > 0)
-    if (hipMemsetAsync(d_feats, 0, sizeof(float) * (size_t)b * n * C, st) != hipSuccess)
+    if (zero_async(d_feats, sizeof(float) * (size_t)b * n * C, st) != hipSuccess)
       return fail2("memset");
   if (d_xyz) {
     if (!d_new_xyz) return fail2("sa_scatter_rows: d_xyz needs d_new_xyz");
-    if (hipMemsetAsync(d_xyz, 0, sizeof(float) * (size_t)b * n * 3, st) != hipSuccess ||
-        hipMemsetAsync(d_new_xyz, 0, sizeof(float) * (size_t)b * m * 3, st) != hipSuccess)
+    if (zero_async(d_xyz, sizeof(float) * (size_t)b * n * 3, st) != hipSuccess ||
+        zero_async(d_new_xyz, sizeof(float) * (size_t)b * m * 3, st) != hipSuccess)
       return fail2("memset");
   }
   const long long rows = (long long)b * m * ns;
@@ -190,7 +190,7 @@ extern "C" int s2c_sa_scatter_sum(int b, int n, int m, int ns, int C, const floa
   if (b <= 0 || n <= 0 || m <= 0 || ns <= 0 || C <= 0 || C > 1024 || !dY || !idx || !Z || !S)
     return fail2("sa_scatter_sum: sizes / null pointer");
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(Z, 0, sizeof(float) * (size_t)b * n * C, st) != hipSuccess)
+  if (zero_async(Z, sizeof(float) * (size_t)b * n * C, st) != hipSuccess)
     return fail2("memset");
   hipLaunchKernelGGL(sa_scatter_sum_kernel, dim3((unsigned)(b * m)), dim3(256), 0, st, n, m,
                      ns, C, dY, idx, Z, S);
@@ -267,7 +267,7 @@ extern "C" int s2c_fp_interp_rows_grad(int b, int n, int m, int C2, int ld,
   if (b <= 0 || n <= 0 || m <= 0 || C2 <= 0 || ld < C2 || !dOut || !idx || !weight || !d_known)
     return fail2("fp_interp_rows_grad: sizes / null pointer");
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(d_known, 0, sizeof(float) * (size_t)b * m * C2, st) != hipSuccess)
+  if (zero_async(d_known, sizeof(float) * (size_t)b * m * C2, st) != hipSuccess)
     return fail2("memset");
   const long long rows = (long long)b * n;
   hipLaunchKernelGGL(fp_interp_rows_grad_kernel, dim3(grid1d(rows, 4, 256 * 32)), dim3(256),

@@ -75,6 +75,14 @@ def furthest_point_sampling(points, nsamples):
     b, n, _ = points.shape
     out = torch.empty((b, nsamples), dtype=torch.int32, device=points.device)
     ab = 4 * (3 * b * n + b * nsamples)
+    if n >= FPS_BUCKET_MIN_N and FPS_LARGE_IMPL == "cells":
+        # wave-owned grid cells, one barrier per round (csrc/s2c_fps_cells.hip)
+        ws = torch.empty(_C.load().s2c_fps_cells_workspace_bytes(b, n), dtype=torch.uint8,
+                         device=points.device)
+        _run("s2c_furthest_point_sampling_cells", points, b, n, int(nsamples),
+             points.data_ptr(), ws.data_ptr(), out.data_ptr(), int(FPS_CELLS_WAVES),
+             alg_bytes=ab)
+        return out
     if n >= FPS_BUCKET_MIN_N:
         ws = torch.empty(_C.load().s2c_fps_workspace_bytes(b, n), dtype=torch.uint8,
                          device=points.device)
@@ -87,6 +95,8 @@ def furthest_point_sampling(points, nsamples):
 
 
 FPS_SMALL_THREADS = 0   # 0 = library heuristic (tests sweep 64..1024)
+FPS_LARGE_IMPL = "cells"   # "cells" (s2c_fps_cells.hip) | "bucket" (s2c_fps_bucket.hip)
+FPS_CELLS_WAVES = 0        # rounds-kernel workgroup in waves: 4 / 8 / 16, 0 = library default
 
 
 def furthest_point_sampling_bruteforce(points, nsamples):
@@ -142,6 +152,23 @@ def three_interpolate_grad(grad_out, idx, weight, m):
     return out
 
 
+# point sets at least this large take the grid kernel; smaller ones the LDS-tiled
+# brute-force kernel (csrc/s2c_ops.hip), which is faster there
+BQ_GRID_MIN_N = 4096
+
+
+def ball_query_bruteforce(new_xyz, xyz, radius, nsample):
+    """The brute-force kernel regardless of size (A/B parity tests)."""
+    _chk_f(new_xyz, "new_xyz")
+    _chk_f(xyz, "xyz")
+    b, m, _ = new_xyz.shape
+    n = xyz.shape[1]
+    idx = torch.empty((b, m, nsample), dtype=torch.int32, device=new_xyz.device)
+    _run("s2c_ball_query", new_xyz, b, n, m, float(radius), int(nsample),
+         new_xyz.data_ptr(), xyz.data_ptr(), idx.data_ptr())
+    return idx
+
+
 def ball_query(new_xyz, xyz, radius, nsample):
     """ball_query.cpp:8-32.  NOTE the C++ argument order (new_xyz, xyz, radius,
     nsample) differs from the Python wrapper's (pointnet2_utils.py:262,282)."""
@@ -150,6 +177,14 @@ def ball_query(new_xyz, xyz, radius, nsample):
     b, m, _ = new_xyz.shape
     n = xyz.shape[1]
     idx = torch.empty((b, m, nsample), dtype=torch.int32, device=new_xyz.device)
+    ab = 4 * (3 * b * n + 3 * b * m + b * m * nsample)
+    if n >= BQ_GRID_MIN_N and 0 < nsample <= 64 and radius > 0 and b > 0 and m > 0:
+        # large clouds: uniform grid, a centre visits <= 27 cells (csrc/s2c_bq_grid.hip)
+        ws = torch.empty(_C.load().s2c_ball_query_workspace_bytes(b, n), dtype=torch.uint8,
+                         device=new_xyz.device)
+        _run("s2c_ball_query_grid", new_xyz, b, n, m, float(radius), int(nsample),
+             new_xyz.data_ptr(), xyz.data_ptr(), ws.data_ptr(), idx.data_ptr(), alg_bytes=ab)
+        return idx
     _run("s2c_ball_query", new_xyz, b, n, m, float(radius), int(nsample),
          new_xyz.data_ptr(), xyz.data_ptr(), idx.data_ptr(),
          alg_bytes=4 * (3 * b * n + 3 * b * m + b * m * nsample))

@@ -42,7 +42,21 @@ def test_fps_bit_exact(ext, oracle, B, N, m, mode):
     np.testing.assert_array_equal(got, want)
 
 
-def test_fps_bucketed_adversarial(ext, oracle):
+@pytest.mark.parametrize("impl,waves", [("cells", 4), ("cells", 8), ("cells", 16), ("bucket", 0)])
+@pytest.mark.parametrize("B,N,m,mode", [(2, 40000, 2048, "volume"), (2, 40000, 2048, "surface"),
+                                        (1, 80000, 2048, "surface"), (3, 9000, 700, "volume")])
+def test_fps_large_every_kernel(ext, oracle, monkeypatch, impl, waves, B, N, m, mode):
+    """Both large-set kernels (wave-owned cells with 4 / 8 / 16 waves; the bucket-list
+    kernel of round 1) give the oracle's picks."""
+    monkeypatch.setattr(ext, "FPS_LARGE_IMPL", impl)
+    monkeypatch.setattr(ext, "FPS_CELLS_WAVES", waves)
+    xyz = scene_xyz(B, N, seed=31 + N, mode=mode, adversarial=True)
+    np.testing.assert_array_equal(ext.furthest_point_sampling(dev(xyz), m).cpu().numpy(),
+                                  oracle.furthest_point_sampling(xyz, m))
+
+
+@pytest.mark.parametrize("impl", ["cells", "bucket"])
+def test_fps_bucketed_adversarial(ext, oracle, monkeypatch, impl):
     """Inputs built to stress the bucket pruning: tight clusters (many points per
     cell), all points identical (one cell, ties everywhere), a regular lattice
     (masses of bit-equal distances across cells), mostly-skipped scenes."""
@@ -57,6 +71,7 @@ def test_fps_bucketed_adversarial(ext, oracle):
     lattice = (g.astype(np.float32) * 0.125 + 0.5)
     skipped = rng.uniform(-0.02, 0.02, size=(1, N, 3)).astype(np.float32)
     skipped[0, 5000:5040] = rng.uniform(1, 2, size=(40, 3))
+    monkeypatch.setattr(ext, "FPS_LARGE_IMPL", impl)
     for name, xyz in (("clustered", clustered), ("same", same),
                       ("lattice", lattice), ("skipped", skipped)):
         want = oracle.furthest_point_sampling(xyz, 300)
@@ -123,6 +138,44 @@ def test_ball_query_bit_exact(ext, oracle, B, N, m, radius, ns, mode):
     want = oracle.ball_query(new_xyz, xyz, radius, ns)
     got = ext.ball_query(dev(new_xyz), dev(xyz), radius, ns).cpu().numpy()
     np.testing.assert_array_equal(got, want)
+
+
+BQ_GRID_CASES = [
+    # (B, N, m, radius, nsample, mode, centres)
+    (8, 40000, 2048, 0.2, 64, "volume", "subset"),    # SA1 of cfg3 (XCD-swizzled grid)
+    (3, 40000, 2048, 0.2, 64, "surface", "subset"),   # B not a multiple of 8; ~50 hits
+    (16, 80000, 2048, 0.2, 64, "volume", "subset"),   # SA1 of cfg5
+    (2, 8192, 1024, 0.8, 16, "surface", "subset"),    # hundreds of hits: bisection path
+    (2, 8192, 777, 0.8, 64, "volume", "random"),      # centres not in the cloud, some outside
+    (1, 5000, 300, 0.45, 32, "tiny", "subset"),       # every ball holds all points: overflow
+    (2, 4096, 512, 0.05, 8, "volume", "subset"),      # only the centre itself hits
+    (1, 4100, 130, 0.3, 1, "surface", "random"),      # nsample = 1
+    (2, 6000, 256, 5.0, 64, "volume", "subset"),      # radius > scene: one cell, overflow
+]
+
+
+@pytest.mark.parametrize("B,N,m,radius,ns,mode,centres", BQ_GRID_CASES)
+def test_ball_query_grid_bit_exact(ext, oracle, B, N, m, radius, ns, mode, centres):
+    """csrc/s2c_bq_grid.hip (N >= _ext.BQ_GRID_MIN_N) against the oracle and against the
+    brute-force kernel: identical rows, including order, padding and empty rows."""
+    assert N >= ext.BQ_GRID_MIN_N
+    if mode == "tiny":
+        rng0 = np.random.default_rng(5)
+        xyz = (rng0.random((B, N, 3), dtype=np.float32) * 0.1 + 1.0).astype(np.float32)
+    else:
+        xyz = scene_xyz(B, N, seed=21 + N + m, mode=mode, adversarial=True)
+    rng = np.random.default_rng(m)
+    if centres == "subset":
+        sel = np.stack([rng.choice(N, m, replace=False) for _ in range(B)])
+        new_xyz = np.take_along_axis(xyz, sel[..., None], 1)
+    else:
+        lo, hi = xyz.min((0, 1)) - 0.5, xyz.max((0, 1)) + 0.5
+        new_xyz = (rng.random((B, m, 3)) * (hi - lo) + lo).astype(np.float32)
+    got = ext.ball_query(dev(new_xyz), dev(xyz), radius, ns).cpu().numpy()
+    ref = ext.ball_query_bruteforce(dev(new_xyz), dev(xyz), radius, ns).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+    if B * N * m <= 3e9:
+        np.testing.assert_array_equal(got, oracle.ball_query(new_xyz, xyz, radius, ns))
 
 
 def test_ball_query_no_hit_rows_are_zero(ext, oracle):
