@@ -40,7 +40,8 @@ sys.path.insert(0, ROOT)
 from scan2cap_amd import _C  # noqa: E402
 from scan2cap_amd.loss_helper import get_scene_cap_loss  # noqa: E402
 from scan2cap_amd.models import CapNet  # noqa: E402
-from scan2cap_amd.parallel import FlatGradAllReduce, init_from_env  # noqa: E402
+from scan2cap_amd.parallel import (BucketedGradAllReduce, FlatGradAllReduce,  # noqa: E402
+                                   TwoStageBackward, init_from_env, split_detector_captioner)
 from scan2cap_amd.synthetic import scene_labels, scene_xyz  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -237,7 +238,7 @@ def to_device(batch, device):
     return dd
 
 
-def make_step(model, wl, cfg_loss, optimizer, ddp, device):
+def make_step(model, wl, cfg_loss, optimizer, ddp, device, two_stage=None):
     """Eager step (also the un-captured body of the graphed step)."""
     def train_step(dd):
         dd = dict(dd)
@@ -251,7 +252,13 @@ def make_step(model, wl, cfg_loss, optimizer, ddp, device):
         dd = get_scene_cap_loss(dd, device, cfg_loss, None, detection=True,
                                 caption=True, orientation=False, distance=False)
         dd["loss"].backward()
-        if ddp is not None:
+        if two_stage is not None:
+            ddp.pack_grads(0)
+            ddp.pack_grads(1)
+            ddp.reduce(0)
+            ddp.reduce(1)
+            ddp.wait()
+        elif ddp is not None:
             ddp.pack_grads()
             ddp.reduce()
         optimizer.step()
@@ -418,10 +425,21 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=0, world_size=1)
-    ddp = FlatGradAllReduce(model) if ((world > 1 or force_ddp) and wl["train"]) else None
+    # N > 1: two gradient buckets -- captioner + relation graph (80 % of the bytes, complete
+    # early in backward) and detector -- the first one all-reduced on RCCL's stream while the
+    # detector's backward still runs (S2C_DDP_OVERLAP=0: one flat bucket after backward)
+    ddp_overlap = os.environ.get("S2C_DDP_OVERLAP", "1") != "0" and use_graph
+    ddp, two_stage = None, None
+    if (world > 1 or force_ddp) and wl["train"]:
+        if ddp_overlap:
+            early, late = split_detector_captioner(model)
+            ddp = BucketedGradAllReduce(model, [early, late])
+            two_stage = TwoStageBackward(early, late)
+        else:
+            ddp = FlatGradAllReduce(model)
     if ddp is not None and force_ddp:
         ddp.world = 2          # make reduce() issue the collective
-    eager_step = make_step(model, wl, cfg_loss, optimizer, ddp, device)
+    eager_step = make_step(model, wl, cfg_loss, optimizer, ddp, device, two_stage)
     dd = to_device(make_batch(wl, B, 42 + rank, table, msa), device)
 
     def barrier():
@@ -484,7 +502,34 @@ def main():
             replays = []
             g2 = None
             for p in range(max(depth, 1)):
-                if wl["train"] and ddp is not None:
+                if wl["train"] and two_stage is not None:
+                    from scan2cap_amd.graphs import GraphedPair
+
+                    def first(p=p):
+                        d = with_geometry(p)
+                        ddp.drop_grads()
+                        d = model(d, use_tf=True, is_eval=False)
+                        d = get_scene_cap_loss(d, device, cfg_loss, None)
+                        two_stage.stage1(d)       # captioner + graph gradients, d loss / d X
+                        ddp.pack_grads(0)
+                        return d["loss"]
+
+                    def second():
+                        two_stage.stage2()        # ... through the detector
+                        ddp.pack_grads(1)
+                    pair = GraphedPair(first, second).capture()
+                    if g2 is None:
+                        g2 = GraphedCallable(lambda: optimizer.step()).capture()
+
+                    def replay(pair=pair):
+                        loss = pair.replay_first()
+                        ddp.reduce(0, async_op=True)   # 80 % of the bytes: on the wire while
+                        pair.replay_second()           # the detector's backward runs
+                        ddp.reduce(1, async_op=True)
+                        ddp.wait()
+                        g2()
+                        return loss
+                elif wl["train"] and ddp is not None:
                     def fwd_bwd(p=p):
                         d = with_geometry(p)
                         ddp.drop_grads()
@@ -667,7 +712,12 @@ def main():
                        "feed": ("a new batch per step assembled on the device from %d "
                                 "HBM-resident scenes, one batch ahead" % args.feed_scenes)
                                if head["fed"] else "one batch resident in HBM",
-                       "grad_allreduce_bytes": ddp.nbytes if ddp else 0},
+                       "grad_allreduce_bytes": ddp.nbytes if ddp else 0,
+                       "grad_allreduce": (("2 buckets (captioner+graph %d B async under the "
+                                           "detector's backward, detector %d B)"
+                                           % (ddp.flats[0].numel() * 4, ddp.flats[1].numel() * 4))
+                                          if two_stage is not None else "1 flat bucket after "
+                                          "backward") if ddp else "none"},
             "roofline": roof,
             "roofline_main_stream": roof_main,
             "roofline_named": named_roofline(table_k),

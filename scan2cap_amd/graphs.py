@@ -59,3 +59,40 @@ class GraphCache(object):
             g = GraphedCallable(self.make_fn(key), self.warmup).capture()
             self.graphs[key] = g
         return g()
+
+
+class GraphedPair(object):
+    """Two functions that must run back to back (`second` consumes state `first` leaves
+    behind, e.g. the autograd graph of a two-stage backward), captured as TWO hipGraphs so
+    that the host can enqueue something between them on every replay -- the asynchronous
+    all-reduce of the gradients the first half has finished (scan2cap_amd/parallel.py).
+    Both graphs allocate from one memory pool."""
+
+    def __init__(self, first, second, warmup=3):
+        self.first, self.second, self.warmup = first, second, warmup
+        self.g1 = self.g2 = None
+        self.out = None
+
+    def capture(self):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(self.warmup):
+                self.first()
+                self.second()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g1):
+            self.out = self.first()
+        self.g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g2, pool=self.g1.pool()):
+            self.second()
+        return self
+
+    def replay_first(self):
+        self.g1.replay()
+        return self.out
+
+    def replay_second(self):
+        self.g2.replay()

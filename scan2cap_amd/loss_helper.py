@@ -268,7 +268,21 @@ def _get_scene_cap_loss_fused(data_dict, device, config, weights, detection, cap
     if distance:
         loss = loss + 0.1 * data_dict["dist_loss"]
     data_dict["loss"] = loss
+    _publish_parts(data_dict, det if detection else None, caption, orientation, distance)
     return data_dict
+
+
+def _publish_parts(data_dict, det, caption, orientation, distance):
+    """loss = _loss_det + _loss_rest (the detector part / everything that flows through the
+    relation graph and the captioner) for parallel.backward_in_two_stages."""
+    rest = None
+    if caption:
+        rest = data_dict["cap_loss"]
+    if orientation:
+        rest = 0.1 * data_dict["ori_loss"] if rest is None else rest + 0.1 * data_dict["ori_loss"]
+    if distance:
+        rest = 0.1 * data_dict["dist_loss"] if rest is None else rest + 0.1 * data_dict["dist_loss"]
+    data_dict["_loss_det"], data_dict["_loss_rest"] = det, rest
 
 
 def get_scene_cap_loss(data_dict, device, config, weights, detection=True,
@@ -323,10 +337,12 @@ def get_scene_cap_loss(data_dict, device, config, weights, detection=True,
         data_dict["ori_acc"] = zero
     data_dict["dist_loss"] = compute_node_distance_loss(data_dict) if distance else zero
 
+    det = None
     if detection:
         loss = data_dict["vote_loss"] + 0.5 * data_dict["objectness_loss"] + \
             data_dict["box_loss"] + 0.1 * data_dict["sem_cls_loss"]
         loss = loss * 10  # amplify
+        det = loss
         if caption:
             loss = loss + data_dict["cap_loss"]
     else:
@@ -336,4 +352,5 @@ def get_scene_cap_loss(data_dict, device, config, weights, detection=True,
     if distance:
         loss = loss + 0.1 * data_dict["dist_loss"]
     data_dict["loss"] = loss
+    _publish_parts(data_dict, det, caption, orientation, distance)
     return data_dict

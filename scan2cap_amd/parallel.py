@@ -112,3 +112,137 @@ class FlatGradAllReduce(object):
     @property
     def nbytes(self):
         return self.flat.numel() * 4
+
+
+def split_detector_captioner(model):
+    """Parameter groups in the order their gradients complete in backward: the captioner +
+    relation graph first (~80 % of CapNet's parameter bytes: GRUs, classifier), the detector
+    (backbone, voting, proposal) last."""
+    late = [p for n in ("backbone_net", "vgen", "proposal") if hasattr(model, n)
+            for p in getattr(model, n).parameters() if p.requires_grad]
+    late_ids = {id(p) for p in late}
+    early = [p for p in model.parameters() if p.requires_grad and id(p) not in late_ids]
+    return early, late
+
+
+class BucketedGradAllReduce(object):
+    """Several flat buckets, reduced independently: bucket i can be on the wire (RCCL's own
+    stream, `async_op=True`) while the backward pass of the later buckets still runs.
+    Same drop / pack / reduce protocol as FlatGradAllReduce, per bucket."""
+
+    def __init__(self, module, groups, process_group=None, broadcast=True):
+        self.module, self.group = module, process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.groups = [list(g) for g in groups]
+        self.params = [p for g in self.groups for p in g]
+        assert len({id(p) for p in self.params}) == len(self.params)
+        assert {id(p) for p in self.params} == {id(p) for p in module.parameters()
+                                                if p.requires_grad}, "groups must partition"
+        dev = self.params[0].device
+        self.flats = [torch.zeros(sum(p.numel() for p in g), dtype=torch.float32, device=dev)
+                      for g in self.groups]
+        self._work = [None] * len(self.groups)
+        if broadcast and self.world > 1:
+            with torch.no_grad():
+                for t in list(module.parameters()) + list(module.buffers()):
+                    dist.broadcast(t, src=0, group=self.group)
+
+    def drop_grads(self):
+        for p in self.params:
+            p.grad = None
+
+    def pack_grads(self, i):
+        views, grads, off = [], [], 0
+        flat = self.flats[i]
+        for p in self.groups[i]:
+            n = p.numel()
+            v = flat[off:off + n].view_as(p)
+            off += n
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                views.append(v)
+                grads.append(p.grad)
+            p.grad = v
+        if views:
+            torch._foreach_copy_(views, grads)
+
+    def reduce(self, i, async_op=True):
+        """Average bucket i across the ranks.  async_op: the collective is enqueued behind
+        the work already on the current stream and runs on the process group's stream;
+        `wait(i)` orders the current stream behind it."""
+        if self.world <= 1:
+            return
+        self.flats[i].div_(self.world)
+        self._work[i] = dist.all_reduce(self.flats[i], op=dist.ReduceOp.SUM, group=self.group,
+                                        async_op=async_op)
+
+    def wait(self, i=None):
+        for k in (range(len(self.groups)) if i is None else (i,)):
+            if self._work[k] is not None:
+                self._work[k].wait()
+                self._work[k] = None
+
+    @property
+    def nbytes(self):
+        return sum(f.numel() for f in self.flats) * 4
+
+
+class TwoStageBackward(object):
+    """backward_in_two_stages as two separately callable halves (each half is captured in
+    its own hipGraph by bench.py, with the early bucket's all-reduce launched in between)."""
+
+    def __init__(self, early_params, late_params):
+        self.early, self.late = list(early_params), list(late_params)
+        self._pending = None
+
+    def stage1(self, data_dict):
+        det, rest = data_dict.get("_loss_det"), data_dict.get("_loss_rest")
+        X = data_dict.get("aggregated_vote_features")
+        if det is None or rest is None or X is None or not rest.requires_grad \
+                or not self.early or not X.requires_grad:
+            data_dict["loss"].backward()
+            self._pending = None
+            return
+        torch.autograd.backward([rest], inputs=self.early + [X], retain_graph=True)
+        dX = X.grad
+        X.grad = None
+        self._pending = (det, X, dX)
+
+    def stage2(self):
+        if self._pending is None:
+            return
+        det, X, dX = self._pending
+        self._pending = None
+        roots, seeds = [det], [None]
+        if dX is not None:
+            roots.append(X)
+            seeds.append(dX)
+        torch.autograd.backward(roots, seeds, inputs=self.late)
+
+
+def backward_in_two_stages(data_dict, early_params, late_params, between=None):
+    """loss = det + rest, where `rest` (caption + relation losses) reaches the detector only
+    through X = data_dict["aggregated_vote_features"] (the proposal features the graph and
+    caption modules consume; box corners / masks / target ids are non-differentiable).
+    Stage 1 differentiates `rest` down to X and the captioner / graph parameters;
+    `between()` runs (e.g. starts their all-reduce); stage 2 carries d rest / d X and `det`
+    through the detector.  The parameter gradients equal those of loss.backward()."""
+    det, rest = data_dict.get("_loss_det"), data_dict.get("_loss_rest")
+    X = data_dict.get("aggregated_vote_features")
+    if det is None or rest is None or X is None or not rest.requires_grad \
+            or not early_params or not X.requires_grad:
+        data_dict["loss"].backward()
+        if between is not None:
+            between()
+        return
+    torch.autograd.backward([rest], inputs=list(early_params) + [X], retain_graph=True)
+    dX = X.grad
+    X.grad = None
+    if between is not None:
+        between()
+    roots, seeds = [det], [None]
+    if dX is not None:
+        roots.append(X)
+        seeds.append(dX)
+    torch.autograd.backward(roots, seeds, inputs=list(late_params))

@@ -10,12 +10,22 @@ import torch.nn as nn
 from torch.autograd import Function
 
 from . import _ext
+from . import ops as _ops  # noqa: F401  (registers torch.ops.s2c.*)
+
+
+def _op(name, ref):
+    """CUDA tensors go through the registered custom op `torch.ops.s2c.<name>`; anything
+    else reaches `_ext.<name>`, which rejects it like the reference ("CPU not supported",
+    ball_query.cpp:27-29) -- or is the oracle when a CPU test has injected it there."""
+    if ref.is_cuda:
+        return getattr(torch.ops.s2c, name)
+    return getattr(_ext, name)
 
 
 class FurthestPointSampling(Function):
     @staticmethod
     def forward(ctx, xyz, npoint):
-        inds = _ext.furthest_point_sampling(xyz, npoint)
+        inds = _op("furthest_point_sampling", xyz)(xyz, npoint)
         ctx.mark_non_differentiable(inds)
         return inds
 
@@ -32,12 +42,13 @@ class GatherOperation(Function):
     def forward(ctx, features, idx):
         ctx.n = features.size(2)
         ctx.save_for_backward(idx)
-        return _ext.gather_points(features, idx)
+        return _op("gather_points", features)(features, idx)
 
     @staticmethod
     def backward(ctx, grad_out):
         (idx,) = ctx.saved_tensors
-        return _ext.gather_points_grad(grad_out.contiguous(), idx, ctx.n), None
+        g = grad_out.contiguous()
+        return _op("gather_points_grad", g)(g, idx, ctx.n), None
 
 
 gather_operation = GatherOperation.apply
@@ -46,7 +57,7 @@ gather_operation = GatherOperation.apply
 class ThreeNN(Function):
     @staticmethod
     def forward(ctx, unknown, known):
-        dist2, idx = _ext.three_nn(unknown, known)
+        dist2, idx = _op("three_nn", unknown)(unknown, known)
         ctx.mark_non_differentiable(idx)
         return torch.sqrt(dist2), idx  # pointnet2_utils.py:142
 
@@ -63,12 +74,13 @@ class ThreeInterpolate(Function):
     def forward(ctx, features, idx, weight):
         ctx.m = features.size(2)
         ctx.save_for_backward(idx, weight)
-        return _ext.three_interpolate(features, idx, weight)
+        return _op("three_interpolate", features)(features, idx, weight)
 
     @staticmethod
     def backward(ctx, grad_out):
         idx, weight = ctx.saved_tensors
-        g = _ext.three_interpolate_grad(grad_out.contiguous(), idx, weight, ctx.m)
+        go = grad_out.contiguous()
+        g = _op("three_interpolate_grad", go)(go, idx, weight, ctx.m)
         return g, None, None
 
 
@@ -80,12 +92,13 @@ class GroupingOperation(Function):
     def forward(ctx, features, idx):
         ctx.n = features.size(2)
         ctx.save_for_backward(idx)
-        return _ext.group_points(features, idx)
+        return _op("group_points", features)(features, idx)
 
     @staticmethod
     def backward(ctx, grad_out):
         (idx,) = ctx.saved_tensors
-        return _ext.group_points_grad(grad_out.contiguous(), idx, ctx.n), None
+        g = grad_out.contiguous()
+        return _op("group_points_grad", g)(g, idx, ctx.n), None
 
 
 grouping_operation = GroupingOperation.apply
@@ -94,7 +107,7 @@ grouping_operation = GroupingOperation.apply
 class BallQuery(Function):
     @staticmethod
     def forward(ctx, radius, nsample, xyz, new_xyz):
-        inds = _ext.ball_query(new_xyz, xyz, radius, nsample)
+        inds = _op("ball_query", new_xyz)(new_xyz, xyz, radius, nsample)
         ctx.mark_non_differentiable(inds)
         return inds
 

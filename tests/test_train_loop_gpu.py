@@ -104,3 +104,55 @@ def test_graphed_training_replays_eager_steps():
     # float atomics make two runs differ in the last bits; by the third step the
     # discontinuous label assignment may amplify that (see above)
     np.testing.assert_allclose(losses[:2], ref[:2], rtol=2e-3)
+
+
+def test_two_stage_graph_pair_matches_single_backward():
+    """The N>1 step of bench.py -- forward + captioner/graph backward in one hipGraph, the
+    detector's backward in a second one (the early gradient bucket goes on the wire in
+    between), gradients packed into two flat buckets -- gives the gradients of the plain
+    eager `loss.backward()`."""
+    from scan2cap_amd.graphs import GraphedPair
+    from scan2cap_amd.loss_helper import get_scene_cap_loss
+    from scan2cap_amd.parallel import (BucketedGradAllReduce, TwoStageBackward,
+                                       split_detector_captioner)
+    bench, wl, model, opt, dd, cfg, dev = _setup()
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    model.zero_grad(set_to_none=True)
+    d = model(dict(dd), use_tf=True, is_eval=False)
+    d = get_scene_cap_loss(d, dev, cfg, None)
+    d["loss"].backward()
+    want = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    want_loss = float(d["loss"])
+
+    early, late = split_detector_captioner(model)
+    ddp = BucketedGradAllReduce(model, [early, late])
+    two = TwoStageBackward(early, late)
+
+    def first():
+        model.load_state_dict(state)              # (captured: identical weights every replay)
+        ddp.drop_grads()
+        x = model(dict(dd), use_tf=True, is_eval=False)
+        x = get_scene_cap_loss(x, dev, cfg, None)
+        two.stage1(x)
+        ddp.pack_grads(0)
+        return x["loss"]
+
+    def second():
+        two.stage2()
+        ddp.pack_grads(1)
+    pair = GraphedPair(first, second).capture()
+    for _ in range(3):
+        loss = pair.replay_first()
+        ddp.reduce(0, async_op=True)              # world == 1: no-op, same call sequence
+        pair.replay_second()
+        ddp.reduce(1, async_op=True)
+        ddp.wait()
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(float(loss), want_loss, rtol=1e-5)
+        for n, p in model.named_parameters():
+            if n not in want:
+                assert float(p.grad.abs().max()) == 0.0, n       # unused: reduced as zeros
+                continue
+            scale = max(1.0, float(want[n].abs().max()))
+            # float atomics: last-bit noise between two evaluations of the same backward
+            assert float((p.grad - want[n]).abs().max()) <= 2e-3 * scale, n
