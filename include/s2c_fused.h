@@ -99,6 +99,24 @@ int s2c_bn_relu_bwd(long long M, int C, const float *dA, const float *Y,
                     float *partial, float *coef, float *dgamma, float *dbeta,
                     float *dY, void *stream);
 
+/* The same split in two: (1) the statistics half -- dgamma, dbeta and the three per-channel
+ * coefficient rows `coef` (3*C floats) of the apply formula; (2) the apply half fused into
+ * the operand load of the layer's input-gradient GEMM (csrc/s2c_gemm.hip, PRO_BNBWD):
+ *   dY = bn_relu_backward(dA, Y)  (side output, bit-identical to s2c_bn_relu_bwd's dY)
+ *   dX = dY Wt^T,  Wt = W^T stored (N x C) row-major with row stride ldw
+ * -- one pass over (dA, Y) instead of an apply pass plus a GEMM that re-reads dY (reference:
+ * autograd of Conv -> BatchNorm -> ReLU, lib/pointnet2/pytorch_utils.py:67-120).
+ * s2c_bn_bwd_gemm returns -2 when the bf16x3 GEMM is switched off. */
+int s2c_bn_relu_bwd_stats(long long M, int C, const float *dA, const float *Y,
+                          const float *scale, const float *shift, const float *mean,
+                          const float *invstd, const float *gamma, int relu, int frozen,
+                          float *partial, float *coef, float *dgamma, float *dbeta,
+                          void *stream);
+int s2c_bn_bwd_gemm(long long M, int C, int N, const float *dA, const float *Y,
+                    const float *scale, const float *shift, const float *mean,
+                    const float *invstd, const float *coef, int relu, const float *Wt,
+                    int ldw, float *dY, float *dX, int ldx, void *stream);
+
 /* backward of BN+ReLU+max-pool given dOut (J x C) and arg (J x C): dY (J*ns x C) */
 int s2c_bn_relu_max_bwd(long long J, int ns, int C, const float *dOut,
                         const int *arg, const float *ymax, const float *Y,
@@ -343,6 +361,10 @@ int s2c_edge_scatter_grad(int B, int K, int L, int F, const float *d_out, const 
  * single slab of rows. */
 long long s2c_weight_grad_workspace_bytes(long long M, int Cout, int Cin);
 long long s2c_weight_grad_counter_bytes(long long M, int Cout, int Cin);
+/* counters == NULL: the kernel only writes one partial (Cout x Cin) tile per row slab into
+ * `workspace` (s2c_weight_grad_slabs(M, Cout, Cin) of them; one slab: straight into dW) and the
+ * caller adds them up behind a kernel boundary (s2c_multi_colsum). */
+int s2c_weight_grad_slabs(long long M, int Cout, int Cin);
 int s2c_weight_grad(long long M, int Cout, int Cin, const float *dY, long long ldy,
                     const float *A, long long lda, float *dW, int lddw, void *workspace,
                     void *counters, void *stream);

@@ -266,6 +266,15 @@ extern "C" long long s2c_weight_grad_workspace_bytes(long long M, int Cout, int 
   return 4ll * ((long long)nslab + ngroups) * Cout * Cin;
 }
 
+// number of row slabs = partial (Cout x Cin) tiles the kernel writes into `workspace` when
+// called with counters == NULL (the caller adds them up, e.g. s2c_multi_colsum)
+extern "C" int s2c_weight_grad_slabs(long long M, int Cout, int Cin) {
+  if (M <= 0 || Cout <= 0 || Cin <= 0) return 0;
+  int rps, nslab, nt;
+  dw_plan(M, Cout, Cin, &rps, &nslab, &nt);
+  return nslab;
+}
+
 extern "C" long long s2c_weight_grad_counter_bytes(long long M, int Cout, int Cin) {
   if (M <= 0 || Cout <= 0 || Cin <= 0) return 0;
   int rps, nslab, nt;

@@ -43,7 +43,7 @@ namespace {
 constexpr int BK = 32;
 constexpr int LDS_LD = 36;  // floats per LDS row (32 + 4 pad, 16-byte aligned)
 
-enum { PRO_NONE = 0, PRO_BNRELU = 1, PRO_GATHER = 2 };
+enum { PRO_NONE = 0, PRO_BNRELU = 1, PRO_GATHER = 2, PRO_BNBWD = 3 };
 
 // 16 bytes, 4-byte aligned (rows of the (B,N,3+C) cloud are not 16-byte aligned)
 struct __attribute__((packed, aligned(4))) F4U { float x, y, z, w; };
@@ -70,6 +70,20 @@ struct EpiArgs {
   int relu, pool_ns;                         // pool_ns in {0, 16, 32, 64}
   float *out;
   int ldo;
+};
+
+// PRO_BNBWD: the operand is the BatchNorm(+ReLU) BACKWARD of the upstream gradient, formed
+// while the tile is staged (the arithmetic of bn_bwd_apply_kernel in s2c_sa.hip, bit for
+// bit):   dz = dA * [Y*scale + shift > 0];  dY = k0 * (dz - k1 - ((Y - mean) * invstd) * k2)
+// with k0 = gamma*invstd, k1 = sum(dz)/M, k2 = sum(dz*xhat)/M from the statistics pass.
+// The GEMM is then  dX = dY W  (the layer's input gradient), and dY itself leaves as a side
+// output of the column-block-0 workgroups (the weight / bias gradients read it): one pass
+// over (dA, Y) instead of an apply pass plus a GEMM that re-reads dY.
+struct BwdArgs {
+  const float *Y;                 // (M x K) pre-BN activations of the layer; nullptr: off
+  const float *scale, *shift, *mean, *invstd, *coef;   // K each; coef = 3 K
+  float *dY;                      // (M x K) side output, may be nullptr
+  int relu;
 };
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -406,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_x3_kernel(
     long long M, int N, int K, const float *__restrict__ A, int lda,
     const float *__restrict__ W, int ldw, const float *__restrict__ pscale,
     const float *__restrict__ pshift, GatherArgs ga, float *__restrict__ Y, int ldy,
-    float *__restrict__ partial, int avec, int wvec, EpiArgs ep) {
+    float *__restrict__ partial, int avec, int wvec, EpiArgs ep, BwdArgs bw) {
   constexpr int BM = 64 * WM, BN = 64 * WN;
   // three bf16 planes (hi, mid, lo) per operand tile, rows of X3_LD bf16 (32 + 8 pad)
   extern __shared__ __attribute__((aligned(16))) unsigned char x3_smem[];
@@ -454,6 +468,17 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_x3_kernel(
         if (k + 2 < K) { sc.z = pscale[k + 2]; sh.z = pshift[k + 2]; }
       }
     }
+    // PRO_BNBWD (K % 4 == 0): the seven per-channel quads of this k-quad
+    float4 b_mu = sh, b_is = sh, b_k0 = sh, b_k1 = sh, b_k2 = sh;
+    if (PRO == PRO_BNBWD && k < K) {
+      sc = *reinterpret_cast<const float4 *>(bw.scale + k);
+      sh = *reinterpret_cast<const float4 *>(bw.shift + k);
+      b_mu = *reinterpret_cast<const float4 *>(bw.mean + k);
+      b_is = *reinterpret_cast<const float4 *>(bw.invstd + k);
+      b_k0 = *reinterpret_cast<const float4 *>(bw.coef + k);
+      b_k1 = *reinterpret_cast<const float4 *>(bw.coef + K + k);
+      b_k2 = *reinterpret_cast<const float4 *>(bw.coef + 2 * K + k);
+    }
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       const long long row = m0 + sr + 32 * i;
@@ -483,6 +508,23 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_x3_kernel(
               e[c] = x;
             }
             v = make_float4(e[0], e[1], e[2], e[3]);
+          }
+        } else if (PRO == PRO_BNBWD) {
+          if (k < K) {
+            float4 g = *reinterpret_cast<const float4 *>(A + row * lda + k);
+            const float4 y = *reinterpret_cast<const float4 *>(bw.Y + row * (long long)K + k);
+            if (bw.relu) {
+              if (!(y.x * sc.x + sh.x > 0.f)) g.x = 0.f;
+              if (!(y.y * sc.y + sh.y > 0.f)) g.y = 0.f;
+              if (!(y.z * sc.z + sh.z > 0.f)) g.z = 0.f;
+              if (!(y.w * sc.w + sh.w > 0.f)) g.w = 0.f;
+            }
+            v.x = b_k0.x * (g.x - b_k1.x - ((y.x - b_mu.x) * b_is.x) * b_k2.x);
+            v.y = b_k0.y * (g.y - b_k1.y - ((y.y - b_mu.y) * b_is.y) * b_k2.y);
+            v.z = b_k0.z * (g.z - b_k1.z - ((y.z - b_mu.z) * b_is.z) * b_k2.z);
+            v.w = b_k0.w * (g.w - b_k1.w - ((y.w - b_mu.w) * b_is.w) * b_k2.w);
+            if (bw.dY != nullptr && blockIdx.y == 0)
+              *reinterpret_cast<float4 *>(bw.dY + row * (long long)K + k) = v;
           }
         } else {
           const float *p = A + row * lda + k;
@@ -674,7 +716,8 @@ constexpr size_t x3_lds_bytes() {
 template <int PRO>
 int launch_x3(long long M, int N, int K, const float *A, int lda, const float *W, int ldw,
               const float *pscale, const float *pshift, const GatherArgs &ga, float *Y,
-              int ldy, float *partial, hipStream_t st, const EpiArgs &ep = EpiArgs()) {
+              int ldy, float *partial, hipStream_t st, const EpiArgs &ep = EpiArgs(),
+              const BwdArgs &bw = BwdArgs()) {
   const int avec = A && ((lda & 3) == 0) && (((uintptr_t)A & 15) == 0);
   const int wvec = ((ldw & 3) == 0) && (((uintptr_t)W & 15) == 0);
   static bool attr_done = false;
@@ -693,12 +736,12 @@ int launch_x3(long long M, int N, int K, const float *A, int lda, const float *W
     dim3 grid((unsigned)((M + 255) / 256), 1);
     hipLaunchKernelGGL((rows_gemm_x3_kernel<4, 1, PRO>), grid, dim3(256), lds41,
                        st, M, N, K, A, lda, W, ldw, pscale, pshift, ga, Y, ldy, partial, avec,
-                       wvec, ep);
+                       wvec, ep, bw);
   } else {
     dim3 grid((unsigned)((M + 127) / 128), (unsigned)((N + 127) / 128));
     hipLaunchKernelGGL((rows_gemm_x3_kernel<2, 2, PRO>), grid, dim3(256), lds22,
                        st, M, N, K, A, lda, W, ldw, pscale, pshift, ga, Y, ldy, partial, avec,
-                       wvec, ep);
+                       wvec, ep, bw);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -778,6 +821,30 @@ extern "C" int s2c_sa_gather_gemm(int b, int n, int m, int ns, int C,
                                  partial, (hipStream_t)stream);
   return launch<PRO_GATHER>(M, N, K, nullptr, K, W, ldw, nullptr, nullptr, ga, Y, ldy,
                             partial, (hipStream_t)stream);
+}
+
+// Backward of one BatchNorm(+ReLU) + linear layer in one pass over (dA, Y):
+//   dY = bn_relu_backward(dA, Y)           (side output, M x C; the arithmetic of s2c_bn_relu_bwd)
+//   dX = dY Wt^T,  Wt = W^T (N x C row-major, N = the layer's input channels)
+// coef (3 C floats) comes from s2c_bn_relu_bwd_stats.  C % 4 == 0, all pointers 16-byte
+// aligned.  Needs the bf16x3 GEMM (returns -2 when S2C_GEMM_SPLIT=0: use the separate passes).
+extern "C" int s2c_bn_bwd_gemm(long long M, int C, int N, const float *dA, const float *Y,
+                               const float *scale, const float *shift, const float *mean,
+                               const float *invstd, const float *coef, int relu,
+                               const float *Wt, int ldw, float *dY, float *dX, int ldx,
+                               void *stream) {
+  if (!use_split()) return -2;
+  if (M <= 0 || C <= 0 || (C & 3) || N <= 0 || !dA || !Y || !scale || !shift || !mean ||
+      !invstd || !coef || !Wt || !dX || ldw < C || ldx < N ||
+      (((uintptr_t)dA | (uintptr_t)Y | (uintptr_t)scale | (uintptr_t)shift | (uintptr_t)mean |
+        (uintptr_t)invstd | (uintptr_t)coef | (uintptr_t)dY) & 15)) {
+    fprintf(stderr, "s2c_bn_bwd_gemm: bad arguments\n");
+    return -1;
+  }
+  GatherArgs ga = {};
+  BwdArgs bw = {Y, scale, shift, mean, invstd, coef, dY, relu};
+  return launch_x3<PRO_BNBWD>(M, N, C, dA, C, Wt, ldw, nullptr, nullptr, ga, dX, ldx, nullptr,
+                              (hipStream_t)stream, EpiArgs(), bw);
 }
 
 /* 1: bf16x3 split products (default), 0: exact fp32 MFMA chain.  Returns the previous

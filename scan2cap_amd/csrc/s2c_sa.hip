@@ -691,6 +691,25 @@ extern "C" int s2c_bn_relu_bwd(long long M, int C, const float *dA, const float 
   return check2("bn_relu_bwd");
 }
 
+// The statistics half only (stats + finalize: dgamma, dbeta, coef); the apply half is then
+// the operand prologue of s2c_bn_bwd_gemm (csrc/s2c_gemm.hip).
+extern "C" int s2c_bn_relu_bwd_stats(long long M, int C, const float *dA, const float *Y,
+                                     const float *scale, const float *shift,
+                                     const float *mean, const float *invstd,
+                                     const float *gamma, int relu, int frozen,
+                                     float *partial, float *coef, float *dgamma,
+                                     float *dbeta, void *stream) {
+  if (M <= 0 || C <= 0 || (C & 3) || C > 1024) return fail2("bn_relu_bwd_stats: C%4==0");
+  hipStream_t st = (hipStream_t)stream;
+  long long rpb;
+  const int nb = stat_blocks(M, &rpb);
+  hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(nb), dim3(STAT_BLOCK), 0, st, dA, Y,
+                     scale, shift, mean, invstd, M, C, relu, partial, rpb);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(FIN_BLOCK), 0, st,
+                     partial, nb, C, M, frozen, gamma, invstd, dgamma, dbeta, coef);
+  return check2("bn_relu_bwd_stats");
+}
+
 // max-pool variant: upstream dOut (J x C), arg (J x C); rows M = J*ns.
 __global__ __launch_bounds__(STAT_BLOCK) void pool_bwd_stats_kernel(
     const float *__restrict__ dOut, const float *__restrict__ ymax,

@@ -40,6 +40,8 @@ _C.register("s2c_sa_gather_gemm", [_I, _I, _I, _I, _I, _L, _L, _F, _I, _P, _P, _
 _C.register("s2c_bn_finalize_partials", [_I, _L, _I, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_weight_grad", [_L, _I, _I, _P, _L, _P, _L, _P, _I, _P, _P, _P])
 _C.register("s2c_bn_relu_max_bwd", [_L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P])
+_C.register("s2c_bn_relu_bwd_stats", [_L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P])
+_C.register("s2c_bn_bwd_gemm", [_L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _I, _P])
 
 
 def _ptr(t):
@@ -73,6 +75,59 @@ USE_MFMA_GEMM = True
 # weight gradient of a gather-fused first layer from point-indexed sums when its
 # inputs need no gradient (no re-materialised operand)
 SCATTER_DW = True
+
+
+# Backward of a BN(+ReLU) layer: statistics pass, then ONE kernel that forms dY in the operand
+# load of the input-gradient GEMM dX = dY W (s2c_bn_bwd_gemm) -- no apply pass, no library GEMM
+import os as _os
+FUSE_BWD_GEMM = _os.environ.get("S2C_FUSE_BWD_GEMM", "1") != "0"
+# input gradients of the remaining layers (pooled / BN-free) through the hand-written GEMM
+# instead of torch.mm (hipBLASLt)
+HAND_DA_GEMM = _os.environ.get("S2C_HAND_DA", "1") != "0"
+# weight gradients through csrc/s2c_dw.hip (slab partials + the multi_colsum launch) instead of
+# a split-K batched library GEMM
+HAND_DW_GEMM = _os.environ.get("S2C_HAND_DW", "1") != "0"
+
+
+# S2C_HAND_EVERYWHERE=1: no library GEMM anywhere in the layer-stack backward (costs ~0.5 ms
+# of the 11.5 ms cfg3 step).  Default: each hand-written kernel where it is at least as fast
+# as hipBLASLt on MI355X (tools/bench_bwd.py, us, apply pass + library vs fused / hand):
+#   (M, C, N) = (1M, 64, 64): 324 vs 244 | (1M, 128, 64): 556 vs 421 | (262144, 128, 128): 168 vs
+#   148 | (65536, 256, 128): 70 vs 58 | (262144, 128, 131): 200 vs 265 (N % 4 != 0: 4-byte
+#   operand loads) | (8192, 256, 256): 21 vs 40 (too few row blocks to fill 256 CUs);
+#   plain dX = dY W: (1M, 64, 64) 155 vs 143, otherwise the library is 3-20 % ahead;
+#   dW = dY^T A: library split-K 120 vs 146 at (1M, 64, 64), hand 25 vs 35 at 8192 rows.
+HAND_EVERYWHERE = _os.environ.get("S2C_HAND_EVERYWHERE", "0") == "1"
+
+
+def _fused_bwd_pays(M, C, N):
+    return HAND_EVERYWHERE or (M >= 32768 and N % 4 == 0)
+
+
+def _hand_da_pays(M, C, N):
+    return HAND_EVERYWHERE or (M >= 262144 and N <= 64)
+
+
+def _gemm_split_on():
+    lib = _C.load()
+    lib.s2c_gemm_set_split.argtypes = [_I]
+    lib.s2c_gemm_set_split.restype = _I
+    on = lib.s2c_gemm_set_split(1)
+    lib.s2c_gemm_set_split(on)
+    return bool(on)
+
+
+def _input_grad_gemm(dY, W):
+    """dX (M, Cin) = dY (M, Cout) @ W (Cout, Cin) on the hand-written rows GEMM
+    (Y = A Wt^T with Wt = W^T)."""
+    M, Cout = dY.shape
+    Cin = W.shape[1]
+    Wt = W.t().contiguous()
+    dX = torch.empty((M, Cin), device=dY.device)
+    _call("s2c_rows_gemm", dX, M, Cin, Cout, dY.data_ptr(), dY.stride(0), Wt.data_ptr(),
+          Wt.stride(0), None, None, dX.data_ptr(), Cin, None,
+          alg_bytes=4 * M * (Cout + Cin), alg_flops=2 * M * Cout * Cin)
+    return dX
 
 
 def set_gemm_split(on):
@@ -351,6 +406,7 @@ class _MLPRows(Function):
             rec, sp = saved[li], specs[li]
             W, A_in = rec["W"], rec["A_in"]
             lazy_dw = False
+            fused_dA = None
             if A_in is None:
                 if gather.needs_grad or not SCATTER_DW:
                     # first layer of a gather-fused stack: rebuild its operand now
@@ -380,6 +436,26 @@ class _MLPRows(Function):
                           int(rec["frozen"]), partial.data_ptr(), coef.data_ptr(),
                           _ptr(dgamma), _ptr(dbeta), dY.data_ptr(),
                           alg_bytes=4 * (2 * M * Cout + 2 * J * Cout))
+                elif (FUSE_BWD_GEMM and (li > 0 or ctx.x_needs_grad) and W.dtype == torch.float32
+                      and dA.dtype == torch.float32 and dA.stride(1) == 1
+                      and dA.stride(0) == Cout and _fused_bwd_pays(M, Cout, W.shape[1])
+                      and _gemm_split_on()):
+                    # statistics, then dY and the input gradient dX = dY W in ONE pass
+                    _call("s2c_bn_relu_bwd_stats", Y, M, Cout, dA.data_ptr(), Y.data_ptr(),
+                          rec["scale"].data_ptr(), rec["shift"].data_ptr(),
+                          rec["mean"].data_ptr(), rec["invstd"].data_ptr(),
+                          _ptr(rec["gamma"]), int(rec["relu"]), int(rec["frozen"]),
+                          partial.data_ptr(), coef.data_ptr(), _ptr(dgamma),
+                          _ptr(dbeta), alg_bytes=4 * 2 * M * Cout)
+                    Cin = W.shape[1]
+                    Wt = W.t().contiguous()
+                    fused_dA = torch.empty((M, Cin), device=dev)
+                    _call("s2c_bn_bwd_gemm", Y, M, Cout, Cin, dA.data_ptr(), Y.data_ptr(),
+                          rec["scale"].data_ptr(), rec["shift"].data_ptr(),
+                          rec["mean"].data_ptr(), rec["invstd"].data_ptr(), coef.data_ptr(),
+                          int(rec["relu"]), Wt.data_ptr(), Wt.stride(0), dY.data_ptr(),
+                          fused_dA.data_ptr(), Cin,
+                          alg_bytes=4 * M * (3 * Cout + Cin), alg_flops=2 * M * Cout * Cin)
                 else:
                     _call("s2c_bn_relu_bwd", Y, M, Cout, dA.data_ptr(), Y.data_ptr(),
                           rec["scale"].data_ptr(), rec["shift"].data_ptr(),
@@ -400,7 +476,16 @@ class _MLPRows(Function):
                 else:
                     dbias = dY.sum(0)
             need_dA = li > 0 or ctx.x_needs_grad
-            dA = torch.mm(dY, W) if need_dA else None
+            if not need_dA:
+                dA = None
+            elif fused_dA is not None:
+                dA = fused_dA
+            elif (HAND_DA_GEMM and dY.is_cuda and dY.dtype == torch.float32
+                  and W.dtype == torch.float32 and dY.stride(1) == 1
+                  and _hand_da_pays(M, Cout, W.shape[1])):
+                dA = _input_grad_gemm(dY, W)
+            else:
+                dA = torch.mm(dY, W)
             g = [dW]
             if rec["has_bias"]:
                 g.append(dbias)
@@ -515,6 +600,29 @@ def weight_grad_kernel(dY, A):
     return dW
 
 
+def _weight_grad_partials(dY, A, pending):
+    """dW = dY^T A: the register-fed MFMA kernel of csrc/s2c_dw.hip writes one partial tile per
+    row slab; the caller's single multi_colsum launch adds them (kernel boundary instead of
+    an in-kernel hand-off)."""
+    M, Cout = dY.shape
+    Cin = A.shape[1]
+    dev = dY.device
+    lib = _C.load()
+    if not getattr(lib, "_dw_slabs_sized", False):
+        lib.s2c_weight_grad_slabs.restype = _I
+        lib.s2c_weight_grad_slabs.argtypes = [_L, _I, _I]
+        lib._dw_slabs_sized = True
+    nslab = lib.s2c_weight_grad_slabs(M, Cout, Cin)
+    dW = torch.empty((Cout, Cin), dtype=torch.float32, device=dev)
+    part = torch.empty((nslab, Cout, Cin), dtype=torch.float32, device=dev) if nslab > 1 else None
+    _call("s2c_weight_grad", dW, M, Cout, Cin, dY.data_ptr(), dY.stride(0), A.data_ptr(),
+          A.stride(0), dW.data_ptr(), Cin, _ptr(part), None,
+          alg_bytes=4 * M * (Cout + Cin), alg_flops=2 * M * Cout * Cin)
+    if part is not None:
+        pending.append((part, dW))
+    return dW
+
+
 class _ColsumArgs(ctypes.Structure):
     """s2c_colsum_args (include/s2c_fused.h)."""
     _fields_ = [("n_jobs", ctypes.c_int), ("S", ctypes.c_int * 8),
@@ -593,6 +701,10 @@ def _weight_grad(dY, A, pending=None):
     if (USE_DW_KERNEL and dY.is_cuda and M >= DW_KERNEL_MIN_ROWS and dY.dtype == torch.float32
             and A.dtype == torch.float32 and dY.stride(1) == 1 and A.stride(1) == 1):
         return weight_grad_kernel(dY, A)
+    if (HAND_DW_GEMM and dY.is_cuda and dY.dtype == torch.float32 and A.dtype == torch.float32
+            and dY.stride(1) == 1 and A.stride(1) == 1 and pending is not None
+            and BATCH_PARTIAL_SUMS and (HAND_EVERYWHERE or M <= 16384)):
+        return _weight_grad_partials(dY, A, pending)
     # slabs of >= 1024 rows (>= 2048 from 256k rows on), at most 256 of them: measured best
     # trade between the batched GEMM and the partial sum (tools/bench_dw_split.py)
     S, rows = 1, (2048 if M >= 262144 else 1024)

@@ -708,3 +708,65 @@ def test_batched_row_sums():
         w = x.double().sum(0)
         assert o.shape == (x.shape[1],)
         assert torch.allclose(o.double(), w, rtol=0, atol=3e-5 * float(x.abs().sum(0).max() + 1))
+
+
+@pytest.mark.parametrize("M,C,N,relu", [(4096, 64, 64, 1), (5000, 128, 131, 1), (1000, 256, 259, 0),
+                                         (70000, 64, 135, 1)])
+def test_bn_bwd_gemm_matches_the_separate_passes(M, C, N, relu):
+    """s2c_bn_relu_bwd_stats + s2c_bn_bwd_gemm (BN backward formed in the operand load of the
+    input-gradient GEMM) against s2c_bn_relu_bwd (stats + apply) followed by torch.mm: dY
+    bit-identical, dX within 1e-5 of scale (fp32-accurate bf16x3 products), dgamma / dbeta
+    identical."""
+    from scan2cap_amd.pointnet2 import fused
+    g = torch.Generator(device="cuda").manual_seed(M + C)
+    r = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    Y, dA, W = r(M, C) * 2 + 0.5, r(M, C), r(C, N) * 0.2
+    gamma, mean = torch.rand(C, device="cuda", generator=g) + 0.5, Y.mean(0)
+    invstd = 1.0 / torch.sqrt(Y.var(0, unbiased=False) + 1e-5)
+    scale = gamma * invstd
+    shift = r(C) * 0.1 - mean * scale
+    nb = fused._stat_blocks(M)
+    outs = []
+    for fusedp in (False, True):
+        partial = torch.empty(nb * 2 * max(C, 256), device="cuda")
+        coef, dgamma, dbeta = (torch.empty(3 * C, device="cuda"), torch.empty(C, device="cuda"),
+                               torch.empty(C, device="cuda"))
+        dY = torch.empty_like(Y)
+        common = (dA.data_ptr(), Y.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                  mean.data_ptr(), invstd.data_ptr())
+        if not fusedp:
+            fused._call("s2c_bn_relu_bwd", Y, M, C, *common, gamma.data_ptr(), relu, 0,
+                        partial.data_ptr(), coef.data_ptr(), dgamma.data_ptr(),
+                        dbeta.data_ptr(), dY.data_ptr())
+            dX = torch.mm(dY, W)
+        else:
+            fused._call("s2c_bn_relu_bwd_stats", Y, M, C, *common, gamma.data_ptr(), relu, 0,
+                        partial.data_ptr(), coef.data_ptr(), dgamma.data_ptr(),
+                        dbeta.data_ptr())
+            Wt = W.t().contiguous()
+            dX = torch.empty(M, N, device="cuda")
+            fused._call("s2c_bn_bwd_gemm", Y, M, C, N, *common, coef.data_ptr(), relu,
+                        Wt.data_ptr(), Wt.stride(0), dY.data_ptr(), dX.data_ptr(), N)
+        outs.append((dY, dX, dgamma, dbeta))
+    (dY0, dX0, dg0, db0), (dY1, dX1, dg1, db1) = outs
+    assert torch.equal(dY0, dY1)
+    assert torch.equal(dg0, dg1) and torch.equal(db0, db1)
+    ref = torch.mm(dY0.double(), W.double())
+    assert _rel(dX1.double(), ref) < 1e-5
+    assert _rel(dX0.double(), ref) < 1e-5
+
+
+def test_weight_grad_partials_and_hand_input_grad_match_torch():
+    from scan2cap_amd.pointnet2 import fused
+    torch.manual_seed(2)
+    for (M, Cout, Cin) in ((262144, 128, 131), (8192, 256, 256), (1000, 97, 128), (70000, 64, 64)):
+        dY, A = torch.randn(M, Cout, device="cuda"), torch.randn(M, Cin, device="cuda")
+        pending = []
+        dW = fused._weight_grad_partials(dY, A, pending)
+        if pending:
+            fused.flush_partial_sums(pending)
+        want = torch.mm(dY.double().t(), A.double())
+        assert _rel(dW.double(), want) < 1e-5, (M, Cout, Cin)
+        W = torch.randn(Cout, Cin, device="cuda") * 0.1
+        dX = fused._input_grad_gemm(dY, W)
+        assert _rel(dX.double(), torch.mm(dY.double(), W.double())) < 1e-5
