@@ -663,12 +663,22 @@ def main():
     if (world == 1 and args.feed == "resident" and not args.no_fed and head["overlap"]
             and wl["train"] and wl["C"] in (1, 4, 132)):
         try:
-            f = measure("builder", args.steps, args.warmup)
-            fed = {"value": B * args.steps / f["elapsed"], "unit": "scenes/s",
-                   "ms_per_step": f["elapsed"] / args.steps * 1e3,
-                   "feed": "a new batch per step assembled on the device from %d HBM-resident "
-                           "synthetic scenes (150k vertices each), geometry %d batches ahead"
-                           % (args.feed_scenes, f["depth"])}
+            # in a fresh process, after this one has gone idle: a second pipeline set up next
+            # to the first one's graphs / slots / side streams measured 8 % low (639 vs 693
+            # scenes/s standalone), whatever was freed in between
+            import subprocess
+            torch.cuda.synchronize()
+            cmd = [sys.executable, os.path.abspath(__file__), "--feed", "builder", "--no-fed",
+                   "--no-cpu-baseline", "--workload", args.workload, "--steps", str(args.steps),
+                   "--warmup", str(args.warmup), "--feed-scenes", str(args.feed_scenes)]
+            env = {k: v for k, v in os.environ.items()
+                   if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "S2C_FORCE_DDP")}
+            res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+            f = json.loads(res.stdout.strip().splitlines()[-1])
+            fed = {"value": f["value"], "unit": "scenes/s", "ms_per_step": f["ms_per_step"],
+                   "feed": f["config"]["feed"] + "; geometry " + f["config"]["geometry"],
+                   "how": "python bench.py --feed builder (own process, same GPU, run after "
+                          "the headline measurement)"}
         except Exception as e:          # reported, never fatal for the headline
             fed = {"error": "%s: %s" % (type(e).__name__, e)}
 
