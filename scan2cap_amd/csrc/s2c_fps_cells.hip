@@ -343,6 +343,260 @@ __global__ __launch_bounds__(NW * 64) void fps_cells_rounds_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------
+// Several exact picks per round.
+//
+// A round of the kernel above is ~4000 cycles of dependent latency (L2 round trip for the
+// active cells, three cross-lane reductions, one barrier) for ONE pick.  But the arg-max the
+// round computes anyway usually determines the next few picks too.  Let c_1 > c_2 > ... be the
+// 16 waves' best points (keys are unique: they carry the tie-break rank) and theta the
+// largest key of any OTHER point (per wave: its second-best cell key and the runner-up
+// inside its best cell).  c_1 is this round's pick.  Then c_t (t > 1) is exactly the t-th
+// pick iff (a) key(c_t) > theta and (b) no pick accepted before it in this round lowers its
+// min-distance, i.e. !(dist2(c_s, c_t) < d2(c_t)) for s < t with the reference's float
+// expression: every other point's key can only fall, c_t's does not, so c_t is the maximum
+// the reference's next round would find, tie rule included.  The min-distance updates of
+// the accepted picks are applied together (min is associative: the same values as the
+// reference's one-pick rounds).  Simulated and measured: 3.7-3.9 picks per round at N=40000.
+// NOT the default (see the launcher): bit-exact, 3.9x fewer rounds, but each round is 4x as
+// expensive -- the scene's single CU is instruction-issue bound once 16 waves each run the
+// 8-pick update and the candidate selection (tools/prof_fps.py).
+constexpr int MAXP = 8;           // picks per round
+struct __attribute__((aligned(16))) MSlot { u64 key; float x, y, z; int pad; u64 bound; u64 pad2; };
+
+template <bool LDSD2>
+__global__ __launch_bounds__(1024) void fps_cells_multi_kernel(
+    int n, int m, int log2bs, const float *__restrict__ xyz, char *__restrict__ ws,
+    size_t stride, int *__restrict__ idx, long long *__restrict__ prof = nullptr) {
+  // LDSD2 (n <= ~40000): the running min-distances live in LDS (4 n bytes of the 160 KB) and
+  // the sorted records carry the tie-break rank in their 4th word: ONE 16-byte read-only load
+  // per point and no global store in the round loop at all -- vmcnt counts stores too on
+  // CDNA4, so a min-distance write-back in front of the next group's loads put the store's
+  // acknowledgement on the critical path of every group.
+  constexpr int NW = 16;
+  long long n_cells = 0, n_rounds = 0, t_upd = 0, t_cand = 0;
+  __shared__ MSlot s_slot[2][NW];
+  extern __shared__ __attribute__((aligned(16))) float s_d2[];
+  if (m <= 0) return;
+  const int b = blockIdx.x;
+  xyz += (size_t)b * n * 3;
+  ws += (size_t)b * stride;
+  idx += (size_t)b * m;
+  Pt *spt = (Pt *)ws;
+  const u32 *srank = (const u32 *)(ws + (size_t)n * sizeof(Pt));
+  const u32 *tab = (const u32 *)(ws + (((size_t)n * (sizeof(Pt) + 4) + 15) & ~(size_t)15));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  // own cell: c = wave + 16 * lane
+  const int c = wave + NW * lane;
+  const int c_start = (int)tab[0 * MAXC + c], c_cnt = (int)tab[1 * MAXC + c];
+  const bool own = tab[2 * MAXC + c] > 0u;
+  const float blx = __uint_as_float(tab[3 * MAXC + c]), bly = __uint_as_float(tab[4 * MAXC + c]);
+  const float blz = __uint_as_float(tab[5 * MAXC + c]), bhx = __uint_as_float(tab[6 * MAXC + c]);
+  const float bhy = __uint_as_float(tab[7 * MAXC + c]), bhz = __uint_as_float(tab[8 * MAXC + c]);
+  u64 key1 = own ? ((u64)(__float_as_uint(1e10f) + 1u) << 32) : 0ull, key2 = key1;
+  float kx = 0.f, ky = 0.f, kz = 0.f;
+
+  if (LDSD2) {
+    for (int q = tid; q < n; q += 1024) s_d2[q] = spt[q].d2;
+    __syncthreads();
+  }
+  const float x0 = xyz[0], y0 = xyz[1], z0 = xyz[2];
+  // accepted picks of the current round live in lanes 0 .. P-1 of every wave
+  float ax = x0, ay = y0, az = z0;
+  int P = 1;                        // round 0: the reference's first pick, point 0
+  if (tid == 0) idx[0] = 0;
+  int j = 1;                        // picks written so far
+
+  for (int round = 0;; ++round) {
+    const int par = round & 1;
+    // ---- update: which of my cells can any of the P picks change? ------------------------
+    bool active = false;
+    if (own) {
+      const float cmax = __uint_as_float((u32)(key1 >> 32) - 1u);
+      for (int s = 0; s < P; ++s) {
+        const float px = __uint_as_float((u32)__builtin_amdgcn_readlane((int)__float_as_uint(ax), s));
+        const float py = __uint_as_float((u32)__builtin_amdgcn_readlane((int)__float_as_uint(ay), s));
+        const float pz = __uint_as_float((u32)__builtin_amdgcn_readlane((int)__float_as_uint(az), s));
+        const float ddx = fmaxf(fmaxf(blx - px, px - bhx), 0.0f);
+        const float ddy = fmaxf(fmaxf(bly - py, py - bhy), 0.0f);
+        const float ddz = fmaxf(fmaxf(blz - pz, pz - bhz), 0.0f);
+        const float lb = (ddx * ddx + ddy * ddy + ddz * ddz) * 0.99999f;
+        active = active || !(lb > cmax);
+      }
+    }
+    u64 amask = __ballot(active);
+    long long tp0 = 0;
+    if (prof) { n_cells += __builtin_popcountll(amask); ++n_rounds; tp0 = (long long)__builtin_amdgcn_s_memtime(); }
+    // four active cells at a time, one per 16-lane row: three 16-point chunks of each cell are
+    // requested before the first is looked at (one L2 round trip per group of four cells), the
+    // per-cell arg-max and runner-up are DPP row reductions (no cross-row traffic)
+    const int row = lane >> 4, rl = lane & 15;
+    while (amask) {
+      int L[4], st = 0, nc = 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        L[r] = amask ? (int)__builtin_ctzll(amask) : -1;
+        amask = amask ? (amask & (amask - 1)) : 0ull;
+        const int src = L[r] < 0 ? 0 : L[r];
+        const int a = __builtin_amdgcn_readlane(c_start, src);
+        const int q = __builtin_amdgcn_readlane(c_cnt, src);
+        if (row == r) { st = a; nc = L[r] < 0 ? 0 : q; }
+      }
+      Pt pp[3];
+      u32 rr[3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int q = st + min(rl + 16 * u, max(nc - 1, 0));
+        pp[u] = spt[q];
+        rr[u] = srank[q];
+        if (LDSD2) pp[u].d2 = s_d2[q];
+      }
+      u64 b1 = 0ull, b2 = 0ull;          // this lane's best and second-best key
+      float bx = 0.f, by = 0.f, bz = 0.f;
+      auto visit = [&](const Pt &p, u32 rk, int q) {
+        float d2 = p.d2;
+        for (int s = 0; s < P; ++s) {
+          const float px = __uint_as_float((u32)__builtin_amdgcn_readlane((int)__float_as_uint(ax), s));
+          const float py = __uint_as_float((u32)__builtin_amdgcn_readlane((int)__float_as_uint(ay), s));
+          const float pz = __uint_as_float((u32)__builtin_amdgcn_readlane((int)__float_as_uint(az), s));
+          const float d = (p.x - px) * (p.x - px) + (p.y - py) * (p.y - py) +
+                          (p.z - pz) * (p.z - pz);
+          d2 = fminf(d, d2);
+        }
+        if (d2 != p.d2) {
+          if (LDSD2) s_d2[st + q] = d2; else spt[st + q].d2 = d2;
+        }
+        const u64 k = d2 < 0.0f ? 0ull
+                                : ((u64)(__float_as_uint(d2) + 1u) << 32) |
+                                      (u64)(0xFFFFFFFFu - rk);
+        if (k > b1) { b2 = b1; b1 = k; bx = p.x; by = p.y; bz = p.z; }
+        else if (k > b2) { b2 = k; }
+      };
+#pragma unroll
+      for (int u = 0; u < 3; ++u)
+        if (rl + 16 * u < nc) visit(pp[u], rr[u], rl + 16 * u);
+      for (int q = rl + 48; q < nc; q += 16) {        // crowded cells
+        Pt p = spt[st + q];
+        if (LDSD2) p.d2 = s_d2[st + q];
+        visit(p, srank[st + q], q);
+      }
+      const u64 w1 = row16_max_u64_2x32(b1);
+      const bool win = (b1 == w1) && (w1 != 0ull);
+      const u64 w2 = row16_max_u64_2x32(win ? b2 : b1);
+      const u64 winners = __ballot(win);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (L[r] < 0) continue;                         // wave-uniform
+        const u64 wr = (winners >> (16 * r)) & 0xFFFFull;
+        // a cell with candidates always yields a non-zero key; ranks make the winner unique
+        const int src = 16 * r + (int)__builtin_ctzll(wr | 0x10000ull);
+        const u64 k1 = readlane_u64(w1, 16 * r), k2 = readlane_u64(w2, 16 * r);
+        const float wx = __uint_as_float((u32)__builtin_amdgcn_readlane((int)__float_as_uint(bx), src & 63));
+        const float wy = __uint_as_float((u32)__builtin_amdgcn_readlane((int)__float_as_uint(by), src & 63));
+        const float wz = __uint_as_float((u32)__builtin_amdgcn_readlane((int)__float_as_uint(bz), src & 63));
+        if (lane == L[r]) { key1 = k1; key2 = k2; kx = wx; ky = wy; kz = wz; }
+      }
+    }
+    if (j >= m) break;
+    long long tp1 = 0;
+    if (prof) { tp1 = (long long)__builtin_amdgcn_s_memtime(); t_upd += tp1 - tp0; }
+
+    // ---- candidates: my wave's best point, and a bound on all its other points ------------
+    const u64 wmax = wave_max_u64_2x32(key1);
+    MSlot *slots = s_slot[par];
+    if (wmax == 0ull) {
+      if (lane == 0) { slots[wave].key = 0ull; slots[wave].bound = 0ull; }
+    } else {
+      const int src = (int)__builtin_ctzll(__ballot(key1 == wmax));
+      const u64 bound = wave_max_u64_2x32(lane == src ? key2 : key1);
+      if (lane == src) {
+        MSlot sl; sl.key = wmax; sl.x = kx; sl.y = ky; sl.z = kz; sl.pad = 0; sl.bound = bound;
+        sl.pad2 = 0ull;
+        slots[wave] = sl;
+      }
+    }
+    __syncthreads();
+    // ---- every wave derives the same pick sequence from the 16 slots ----------------------
+    u64 ckey = 0ull, cbound = 0ull;
+    float cx = 0.f, cy = 0.f, cz = 0.f;
+    if (lane < NW) {
+      const MSlot sl = slots[lane];
+      ckey = sl.key; cbound = sl.bound; cx = sl.x; cy = sl.y; cz = sl.z;
+    }
+    const u64 theta = readlane_u64(row16_max_u64_2x32(cbound), 0);
+    int rank = 0;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) rank += (readlane_u64(ckey, q) > ckey) ? 1 : 0;
+    const int room = min(MAXP, m - j);
+    u64 akey = 0ull;                 // lane s: key of accepted pick s
+    P = 0;
+    for (int t = 0; t < NW && P < room; ++t) {
+      const u64 who = __ballot(lane < NW && rank == t && ckey != 0ull);
+      if (who == 0ull) break;
+      const int src = (int)__builtin_ctzll(who);
+      const u64 kt = readlane_u64(ckey, src);
+      // a candidate with d2 == 0 (key >> 32 == 1) is an already-picked point: later picks of
+      // this round (whose keys fall to d2 == 0 too) need not stay below it
+      if (t > 0 && (!(kt > theta) || (kt >> 32) <= 1ull)) break;
+      const float px = __uint_as_float((u32)__builtin_amdgcn_readlane((int)__float_as_uint(cx), src));
+      const float py = __uint_as_float((u32)__builtin_amdgcn_readlane((int)__float_as_uint(cy), src));
+      const float pz = __uint_as_float((u32)__builtin_amdgcn_readlane((int)__float_as_uint(cz), src));
+      const float d2t = __uint_as_float((u32)(kt >> 32) - 1u);
+      // would an earlier pick of this round lower its min-distance?  (x2 = candidate, x1 = pick)
+      const float d = (px - ax) * (px - ax) + (py - ay) * (py - ay) + (pz - az) * (pz - az);
+      if (__ballot(lane < P && d < d2t) != 0ull) break;
+      if (lane == P) { ax = px; ay = py; az = pz; akey = kt; }
+      ++P;
+      if ((kt >> 32) <= 1ull) {
+        // the maximum has d2 == 0: picking it changes nothing, so the reference picks this
+        // same point in every following round -- fill the rest of the round with it
+        if (lane >= 1 && lane < room) { ax = px; ay = py; az = pz; akey = kt; }
+        P = room;
+        break;
+      }
+    }
+    if (P == 0) {                    // nothing selectable: the reference's besti = 0 (:90)
+      if (lane == 0) { ax = x0; ay = y0; az = z0; akey = 0ull; }
+      P = 1;
+    }
+    if (wave == 0 && lane < P) {
+      int old = 0;
+      if ((akey >> 32) != 0ull) {
+        const u32 r = 0xFFFFFFFFu - (u32)akey;
+        old = (int)(((r & 0x3FFFFFu) << log2bs) | bitrev_n(r >> 22, log2bs));
+      }
+      idx[j + lane] = old;
+    }
+    j += P;
+    if (prof) t_cand += (long long)__builtin_amdgcn_s_memtime() - tp1;
+    if (j >= m) break;               // the last picks need no update
+  }
+  if (prof && b == 0 && lane == 0) {
+    prof[wave * 8 + 0] = n_rounds; prof[wave * 8 + 1] = n_cells;
+    prof[wave * 8 + 2] = t_upd; prof[wave * 8 + 3] = t_cand;
+  }
+}
+
+// n * 4 bytes of min-distances + the static slots must fit the 160 KB of one CU
+void launch_multi(int b, int n, int m, int log2bs, const float *xyz, void *workspace,
+                  size_t stride, int *idx, long long *prof, hipStream_t st) {
+  const size_t lds = (size_t)n * 4;
+  if (lds + 4096 <= 160 * 1024) {
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void *)fps_cells_multi_kernel<true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+      attr = true;
+    }
+    hipLaunchKernelGGL((fps_cells_multi_kernel<true>), dim3(b), dim3(1024), lds, st, n, m,
+                       log2bs, xyz, (char *)workspace, stride, idx, prof);
+  } else {
+    hipLaunchKernelGGL((fps_cells_multi_kernel<false>), dim3(b), dim3(1024), 0, st, n, m,
+                       log2bs, xyz, (char *)workspace, stride, idx, prof);
+  }
+}
+
 }  // namespace
 
 // Diagnostics: the 16-wave rounds kernel with per-phase cycle counters of scene 0
@@ -360,7 +614,9 @@ extern "C" int s2c_fps_cells_profile(int b, int n, int m, const float *xyz, void
   const size_t stride = cells_scene_bytes(n);
   hipLaunchKernelGGL(fps_cells_prep_kernel, dim3(b), dim3(PT), 0, st, n, bs, log2bs, target,
                      xyz, (char *)workspace, stride);
-  if (waves == 4)
+  if (waves == -16)
+    launch_multi(b, n, m, log2bs, xyz, workspace, stride, idx, prof, st);
+  else if (waves == 4)
     hipLaunchKernelGGL((fps_cells_rounds_kernel<4, true>), dim3(b), dim3(256), 0, st, n, m,
                        log2bs, xyz, (char *)workspace, stride, idx, prof);
   else if (waves == 8)
@@ -400,7 +656,11 @@ extern "C" int s2c_furthest_point_sampling_cells(int b, int n, int m, const floa
   int target = n / 40;
   if (target > MAXC) target = MAXC;
   if (target < 1) target = 1;
-  if (waves == 0) waves = 16;   // measured: 1.84 us/round vs 2.23 (8) and 3.27 (4) at N = 40000
+  // 0: default = one pick per round on 16 waves (1.84 us/round at N = 40000; 8 waves 2.23,
+  // 4 waves 3.27); -16 = several exact picks per round: 3.9 picks per round, but a round then
+  // costs 19k cycles instead of 4.7k -- one CU issues every instruction of the scene, and the
+  // 16 waves x ~1500 instructions of a multi-pick round are issue-bound (2.04 us per pick)
+  if (waves == 0) waves = 16;
   hipStream_t st = (hipStream_t)stream;
   const size_t stride = cells_scene_bytes(n);
   hipLaunchKernelGGL(fps_cells_prep_kernel, dim3(b), dim3(PT), 0, st, n, bs, log2bs, target,
@@ -418,8 +678,11 @@ extern "C" int s2c_furthest_point_sampling_cells(int b, int n, int m, const floa
       hipLaunchKernelGGL((fps_cells_rounds_kernel<16>), dim3(b), dim3(1024), 0, st, n, m,
                          log2bs, xyz, (char *)workspace, stride, idx, nullptr);
       break;
+    case -16:
+      launch_multi(b, n, m, log2bs, xyz, workspace, stride, idx, nullptr, st);
+      break;
     default:
-      snprintf(g_err5, sizeof(g_err5), "s2c: fps_cells: waves must be 4, 8 or 16");
+      snprintf(g_err5, sizeof(g_err5), "s2c: fps_cells: waves must be 4, 8, 16 or -16");
       return S2C_EINVAL;
   }
   hipError_t e = hipGetLastError();

@@ -42,12 +42,14 @@ def test_fps_bit_exact(ext, oracle, B, N, m, mode):
     np.testing.assert_array_equal(got, want)
 
 
-@pytest.mark.parametrize("impl,waves", [("cells", 4), ("cells", 8), ("cells", 16), ("bucket", 0)])
+@pytest.mark.parametrize("impl,waves", [("cells", 0), ("cells", -16), ("cells", 4), ("cells", 8),
+                                        ("cells", 16), ("bucket", 0)])
 @pytest.mark.parametrize("B,N,m,mode", [(2, 40000, 2048, "volume"), (2, 40000, 2048, "surface"),
                                         (1, 80000, 2048, "surface"), (3, 9000, 700, "volume")])
 def test_fps_large_every_kernel(ext, oracle, monkeypatch, impl, waves, B, N, m, mode):
-    """Both large-set kernels (wave-owned cells with 4 / 8 / 16 waves; the bucket-list
-    kernel of round 1) give the oracle's picks."""
+    """Every large-set kernel (wave-owned cells: one pick per round with 4 / 8 / 16 waves (16 =
+    the default 0), several exact picks per round (-16); the bucket-list kernel of round 1)
+    gives the oracle's picks."""
     monkeypatch.setattr(ext, "FPS_LARGE_IMPL", impl)
     monkeypatch.setattr(ext, "FPS_CELLS_WAVES", waves)
     xyz = scene_xyz(B, N, seed=31 + N, mode=mode, adversarial=True)

@@ -11,12 +11,12 @@ for (B, N, m) in ((8, 40000, 2048), (16, 80000, 2048)):
         xyz = torch.from_numpy(scene_xyz(B, N, mode=mode)).cuda()
         res = []
         ref = None
-        for impl, waves in (("bucket", 0), ("cells", 4), ("cells", 8), ("cells", 16)):
+        for impl, waves in (("bucket", 0), ("cells", 16), ("cells", -16)):
             _ext.FPS_LARGE_IMPL, _ext.FPS_CELLS_WAVES = impl, waves
             out = _ext.furthest_point_sampling(xyz, m)
             if ref is None:
                 ref = out
             assert torch.equal(out, ref), (impl, waves)
             t = timeit(lambda: _ext.furthest_point_sampling(xyz, m), iters=3, warmup=1)
-            res.append("%s%s %7.0f us (%.2f us/round)" % (impl, waves or "", t, t / (m - 1)))
+            res.append("%s%s %7.0f us (%.2f us/pick)" % (impl, waves or "", t, t / (m - 1)))
         print("B=%d N=%d %-7s: %s" % (B, N, mode, " | ".join(res)))
