@@ -19,6 +19,8 @@ def step():
     return d["loss"]
 if mode == "graph":
     from scan2cap_amd.graphs import GraphedCallable
+    # (the eager reference below runs on a side stream too: a default-stream backward before a
+    # capture binds AccumulateGrad nodes to the legacy stream and crashes the capture)
     g = GraphedCallable(step).capture()
     fn = g
 elif mode == "slots":
@@ -34,14 +36,28 @@ else:
     fn = step
 bad = 0
 first = None
+# the replayed graph writes its gradients into the tensors p.grad pointed at when the capture ended
+gg = {n: p.grad for n, p in model.named_parameters() if p.grad is not None} if mode != "eager" else None
+# eager reference gradients from the same weights (graph replays must reproduce them up to the
+# last-bit noise of the float atomics: a mis-ordered memset / memcpy node shows up here even
+# when the garbage happens to be finite)
+model.load_state_dict(state)
+float(step().detach())
+ref = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+worst = 0.0
 for i in range(iters):
     model.load_state_dict(state)
     loss = float(fn().detach())
-    if i < 14:
-        print(i, "loss %.6f" % loss, "nan-grad params", sum(1 for n, p in model.named_parameters() if p.grad is not None and not torch.isfinite(p.grad).all()))
-    ng = [n for n, p in model.named_parameters() if p.grad is not None and not torch.isfinite(p.grad).all()]
+    cur = gg if gg is not None else {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    for n, g in cur.items():
+        if n in ref:
+            e = float((g - ref[n]).abs().max()) / max(1.0, float(ref[n].abs().max()))
+            if e == e:
+                worst = max(worst, e)
+    ng = [n for n, g in cur.items() if not torch.isfinite(g).all()]
     if ng:
         bad += 1
         if first is None:
             first = (i, loss, len(ng), ng[:2], ng[-2:])
-print(mode, sys.argv[3:] , "steps", iters, "steps with non-finite grads:", bad, "first:", first)
+print(mode, sys.argv[3:] , "steps", iters, "steps with non-finite grads:", bad, "first:", first,
+      "| worst gradient deviation from the eager step: %.2e of scale" % worst)
