@@ -146,9 +146,19 @@ def _install_pyg_shim():
                     "index": edge_index[1], "dim_size": n, "ptr": None}
 
         def aggregate(self, inputs, index, ptr=None, dim_size=None):
-            assert self.aggr == "add"
+            # torch_scatter's reductions: "add"; "mean" = sum / max(count, 1); "max" with
+            # 0 for nodes that receive nothing
             out = torch.zeros(dim_size, inputs.size(1), dtype=inputs.dtype)
-            return out.index_add(0, index, inputs)
+            if self.aggr == "add":
+                return out.index_add(0, index, inputs)
+            cnt = torch.zeros(dim_size, dtype=inputs.dtype).index_add(
+                0, index, torch.ones_like(index, dtype=inputs.dtype))
+            if self.aggr == "mean":
+                return out.index_add(0, index, inputs) / cnt.clamp(min=1).unsqueeze(-1)
+            assert self.aggr == "max"
+            ix = index.view(-1, 1).expand_as(inputs)
+            red = out.scatter_reduce(0, ix, inputs, reduce="amax", include_self=False)
+            return torch.where((cnt > 0).unsqueeze(-1), red, out)
 
         def update(self, inputs):
             return inputs

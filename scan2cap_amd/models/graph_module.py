@@ -168,13 +168,17 @@ _EDGE_SPECS = (fused.LayerSpec(True, None, True), fused.LayerSpec(True, None, Fa
 
 class EdgeConv(nn.Module):
     """message = MLP(cat[x_i, x_j - x_i]) (graph_module.py:102-109), update =
-    identity (:111-115), aggregation "add".  Same parameter names
-    (`map_edge.{0,2}`) as the reference's MessagePassing subclass."""
+    identity (:111-115).  Same parameter names (`map_edge.{0,2}`) as the reference's
+    MessagePassing subclass.  `aggregation` is MessagePassing's `aggr` (:92): "add" (the
+    value every CapNet configuration uses) runs on the HIP scatter kernel; "mean" divides
+    that sum by the number of incoming edges and "max" takes the per-channel maximum over
+    them, nodes without incoming edges getting 0 in both (torch_scatter's convention)."""
 
     def __init__(self, in_size, out_size, aggregation="add"):
         super().__init__()
-        if aggregation != "add":
-            raise NotImplementedError("only graph_aggr='add' is on the hot path")
+        if aggregation not in ("add", "mean", "max"):
+            raise ValueError("invalid aggregation, choices: [\"add\", \"mean\", \"max\"]")
+        self.aggr = aggregation
         self.in_size, self.out_size = in_size, out_size
         self.map_edge = nn.Sequential(
             nn.Linear(2 * in_size, out_size), nn.ReLU(),
@@ -203,7 +207,8 @@ class EdgeConv(nn.Module):
             rows = _EdgeRows.apply(x, nbr)
             m = fused.mlp_rows(rows, _EDGE_SPECS, (l1.weight, l1.bias, l2.weight, l2.bias))
             out, msgm = _EdgeScatter.apply(m, nbr, slot)
-            return out, msgm.view(B, K, L, -1)
+            msgm = msgm.view(B, K, L, -1)
+            return self._reaggregate(out, msgm, nbr, slot), msgm
         x_j = x.unsqueeze(2).expand(B, K, L, F)                        # source=row
         x_i = torch.gather(x, 1, nbr.view(B, K * L, 1).expand(B, K * L, F)
                            ).view(B, K, L, F)                          # target=col
@@ -212,7 +217,24 @@ class EdgeConv(nn.Module):
         out = torch.zeros(B, K, msg.shape[-1], device=x.device, dtype=msg.dtype)
         out.scatter_add_(1, nbr.view(B, K * L, 1).expand(B, K * L, msg.shape[-1]),
                          msg.view(B, K * L, -1))
-        return out, msg
+        return self._reaggregate(out, msg, nbr, slot), msg
+
+    def _reaggregate(self, summed, msg, nbr, slot):
+        """`summed` = scatter-add of the masked messages.  "mean" / "max" from it."""
+        if self.aggr == "add":
+            return summed
+        B, K, L = nbr.shape
+        cnt = torch.zeros(B, K, device=msg.device, dtype=msg.dtype)
+        cnt.scatter_add_(1, nbr.view(B, K * L), slot.view(B, K * L).to(msg.dtype))
+        if self.aggr == "mean":
+            return summed / cnt.clamp(min=1.0).unsqueeze(-1)
+        F = msg.shape[-1]
+        low = torch.finfo(msg.dtype).min
+        cand = torch.where(slot.unsqueeze(-1), msg, msg.new_full((), low)).view(B, K * L, F)
+        out = msg.new_full((B, K, F), low)
+        out = out.scatter_reduce(1, nbr.view(B, K * L, 1).expand(B, K * L, F), cand,
+                                 reduce="amax", include_self=True)
+        return torch.where((cnt > 0).unsqueeze(-1), out, torch.zeros_like(out))
 
 
 class GCNConv(nn.Module):

@@ -29,6 +29,7 @@ class PointnetSAModuleVotes(nn.Module):
         self.sigma = sigma if sigma is not None else (
             radius / 2 if radius is not None else None)
         self.normalize_xyz = normalize_xyz
+        self.sample_uniformly = sample_uniformly
         self.ret_unique_cnt = ret_unique_cnt
         if npoint is not None:
             self.grouper = pointnet2_utils.QueryAndGroup(
@@ -44,6 +45,8 @@ class PointnetSAModuleVotes(nn.Module):
 
     def _fused_ok(self, xyz):
         if not (xyz.is_cuda and self.npoint is not None and self.pooling == "max"):
+            return False
+        if self.sample_uniformly:        # host-side draws (pointnet2_utils.uniform_resample)
             return False
         specs, params = fused.shared_mlp_specs(self.mlp_module)
         return len(specs) > 0 and specs[-1].bn is not None and specs[-1].relu \
@@ -81,7 +84,8 @@ class PointnetSAModuleVotes(nn.Module):
     def forward(self, xyz, features=None, inds=None, geom=None):
         """xyz (B,N,3), features (B,C,N) -> new_xyz (B,npoint,3),
         new_features (B,mlp[-1],npoint), inds (B,npoint) int32.
-        `geom` = precomputed (inds, new_xyz, idx) from `geometry()` (optional)."""
+        `geom` = precomputed (inds, new_xyz, idx) from `geometry()` (optional).
+        With `ret_unique_cnt` a fourth output (B,npoint) follows."""
         if self._fused_ok(xyz):
             return self._forward_fused(xyz, features, inds, geom)
         if geom is not None:
@@ -95,7 +99,11 @@ class PointnetSAModuleVotes(nn.Module):
             xyz_flipped, inds).transpose(1, 2).contiguous() \
             if self.npoint is not None else None
 
-        grouped_features, grouped_xyz = self.grouper(xyz, new_xyz, features)
+        unique_cnt = None
+        if self.ret_unique_cnt:                       # pointnet2_modules.py:242-249
+            grouped_features, grouped_xyz, unique_cnt = self.grouper(xyz, new_xyz, features)
+        else:
+            grouped_features, grouped_xyz = self.grouper(xyz, new_xyz, features)
         new_features = self.mlp_module(grouped_features)  # (B,C',npoint,nsample)
         if self.pooling == "max":
             new_features = F.max_pool2d(
@@ -109,6 +117,8 @@ class PointnetSAModuleVotes(nn.Module):
             new_features = torch.sum(new_features * rbf.unsqueeze(1), -1,
                                      keepdim=True) / float(self.nsample)
         new_features = new_features.squeeze(-1)
+        if self.ret_unique_cnt:                       # pointnet2_modules.py:269-272
+            return new_xyz, new_features, inds, unique_cnt
         return new_xyz, new_features, inds
 
 

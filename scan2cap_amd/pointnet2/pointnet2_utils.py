@@ -119,29 +119,64 @@ class BallQuery(Function):
 ball_query = BallQuery.apply
 
 
+def uniform_resample(idx, nsample):
+    """`sample_uniformly` of the reference (pointnet2_utils.py:336-345): every ball's index
+    row is replaced by its sorted distinct ids followed by `nsample - n_unique` of them drawn
+    with replacement.  The reference loops over all B*npoint rows on the host with
+    `torch.unique`; here the distinct ids are found for all rows at once on the device
+    (sort + first-occurrence compaction) and only the draws stay on the host: ONE
+    `torch.randint(0, n_unique, (nsample - n_unique,))` per row from the global CPU
+    generator, in the reference's row order, so that the same `torch.manual_seed` gives the
+    same groups.  Returns (idx (B,npoint,nsample) int32, unique_cnt (B,npoint) float32 on the
+    CPU, as the reference's `torch.zeros((B, npoint))`)."""
+    B, P, S = idx.shape
+    assert S == nsample
+    srt, _ = torch.sort(idx.long(), dim=-1)
+    first = torch.ones_like(srt, dtype=torch.bool)
+    first[..., 1:] = srt[..., 1:] != srt[..., :-1]
+    n_unique = first.sum(-1)                                           # (B,P)
+    # compact the distinct ids to the front of each row (stable: they stay sorted)
+    slot = torch.where(first, torch.cumsum(first.long(), -1) - 1, torch.full_like(srt, S))
+    uniq = torch.zeros(B, P, S + 1, dtype=torch.long, device=idx.device)
+    uniq.scatter_(-1, slot, srt)
+    counts = n_unique.cpu()
+    pick = torch.arange(S).repeat(B * P, 1)                            # host
+    flat = counts.view(-1).tolist()
+    for r, nu in enumerate(flat):                                      # the reference's order
+        pick[r, nu:] = torch.randint(0, nu, (S - nu,), dtype=torch.long)
+    pick = pick.view(B, P, S).to(idx.device)
+    out = torch.gather(uniq[..., :S], -1, pick).to(idx.dtype)
+    return out, counts.to(torch.float32)
+
+
 class QueryAndGroup(nn.Module):
     """Ball query + grouping (pointnet2_utils.py:294-376).
 
-    Returns (B, 3+C, npoint, nsample) [, grouped_xyz (B,3,npoint,nsample)].
+    Returns (B, 3+C, npoint, nsample) [, grouped_xyz (B,3,npoint,nsample)]
+    [, unique_cnt (B,npoint)].
     The centring / radius normalisation are two separate ops exactly as the
     reference (:350, :352): (p - c) / r is not bit-equal to (p - c) * (1/r).
-    `sample_uniformly` (:336-345, a CPU loop never enabled by CapNet) is not
-    provided.
+    `sample_uniformly` (:336-345; never enabled by CapNet) goes through
+    `uniform_resample`.
     """
 
     def __init__(self, radius, nsample, use_xyz=True, ret_grouped_xyz=False,
                  normalize_xyz=False, sample_uniformly=False,
                  ret_unique_cnt=False):
         super().__init__()
-        if sample_uniformly or ret_unique_cnt:
-            raise NotImplementedError(
-                "sample_uniformly is outside the CapNet hot path")
         self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
         self.ret_grouped_xyz = ret_grouped_xyz
         self.normalize_xyz = normalize_xyz
+        self.sample_uniformly = sample_uniformly
+        self.ret_unique_cnt = ret_unique_cnt
+        if self.ret_unique_cnt:
+            assert self.sample_uniformly
 
     def forward(self, xyz, new_xyz, features=None):
         idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
+        unique_cnt = None
+        if self.sample_uniformly:
+            idx, unique_cnt = uniform_resample(idx, self.nsample)
         xyz_trans = xyz.transpose(1, 2).contiguous()
         grouped_xyz = grouping_operation(xyz_trans, idx)  # (B,3,npoint,nsample)
         grouped_xyz = grouped_xyz - new_xyz.transpose(1, 2).unsqueeze(-1)
@@ -155,9 +190,12 @@ class QueryAndGroup(nn.Module):
             assert self.use_xyz, \
                 "Cannot have not features and not use xyz as a feature!"
             new_features = grouped_xyz
+        ret = [new_features]
         if self.ret_grouped_xyz:
-            return new_features, grouped_xyz
-        return new_features
+            ret.append(grouped_xyz)
+        if self.ret_unique_cnt:
+            ret.append(unique_cnt)
+        return ret[0] if len(ret) == 1 else tuple(ret)
 
 
 class GroupAll(nn.Module):
