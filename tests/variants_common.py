@@ -19,6 +19,9 @@ GRAPH_OUT_KEYS = ("bbox_feature", "adjacent_mat", "edge_index", "edge_feature",
                   "num_edge_source", "num_edge_target", "edge_orientations", "edge_distances")
 
 
+TIE_FREE_SCENES = slice(0, 2)      # every target there has >= num_locals finite candidates
+
+
 def graph_inputs(seed=3, B=3, K=24, F=32):
     g = np.random.Generator(np.random.PCG64(seed))
     centers = g.uniform(-2.0, 2.0, size=(B, K, 1, 3))
