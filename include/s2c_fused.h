@@ -132,6 +132,13 @@ int s2c_bn_relu_max_bwd(long long J, int ns, int C, const float *dOut,
  * [sum | sumsq] of Y, s2c_rows_gemm_blocks(M,N) * 2N floats, to be reduced by
  * s2c_bn_finalize_partials (BN batch statistics without another pass over Y). */
 int s2c_rows_gemm_blocks(long long M, int N);
+/* 1 when s2c_rows_gemm (gather = 0) / s2c_sa_gather_gemm (gather = 1, K = 3 + C) run this
+ * shape on the streaming kernel of csrc/s2c_gemm2.hip (persistent waves, LDS-DMA ring; tall
+ * operands with N <= 128 whose W planes leave room for the rings in LDS), 0 when on the
+ * tiled kernel.  Same results contract either way.  S2C_GEMM_STREAM=0 switches it off. */
+int s2c_rows_stream_supported(long long M, int N, int K, int gather);
+/* switch the streaming kernel on / off at run time; returns the previous setting */
+int s2c_gemm_set_stream(int on);
 /* Inference layers (frozen BatchNorm): out = [max over groups of pool_ns rows of]
  * relu?(Y * scale + shift), Y = A W^T, scale = gamma / sqrt(var + eps), shift = beta -
  * mean * scale -- BN, ReLU and the set-abstraction max-pool (pointnet2_modules.py:

@@ -104,6 +104,31 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 // observed NOT to be ordered on ROCm 7.2 / gfx950 -- replays of the training step returned
 // non-finite gradients in 88 % of the steps (tools/stress_nan.py), eager launches never;
 // a kernel node behind a kernel node is ordered.
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+      0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
+// a[i] = element (row i, column = lane & 3 of the quad)  ->  a[c] = element (row = lane & 3,
+// column c): a 4x4 transpose inside every quad of lanes (2 x 2 exchanges).
+__device__ __forceinline__ void quad_transpose(float (&a)[4], int lane) {
+  const bool o1 = lane & 1, o2 = lane & 2;
+#pragma unroll
+  for (int i = 0; i < 4; i += 2) {
+    const float x = o1 ? a[i] : a[i + 1];
+    const float y = dpp_quad<0xB1>(x);              // quad_perm [1,0,3,2]
+    if (o1) a[i] = y; else a[i + 1] = y;
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const float x = o2 ? a[k] : a[k + 2];
+    const float y = dpp_quad<0x4E>(x);              // quad_perm [2,3,0,1]
+    if (o2) a[k] = y; else a[k + 2] = y;
+  }
+}
+
+
 static __global__ void __launch_bounds__(256) zero_fill_kernel(uint4 *__restrict__ p16, size_t n16,
                                                         u32 *__restrict__ tail, int ntail) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;

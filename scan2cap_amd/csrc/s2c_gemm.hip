@@ -386,10 +386,20 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(
 // `v_mfma_f32_32x32x16_bf16` runs at 16x the fp32 MFMA rate (6 MFMAs = 2.7x faster).
 // The split happens once per staged element on the VALU (v_cvt_pk_bf16_f32).
 // ---------------------------------------------------------------------------
+// Diagnostics (tools/prof_gemm.py): when set, wave 0 of workgroup `g_prof_block` writes
+// s_memtime stamps of its phases to g_prof (device memory, 64 slots).
+__device__ long long *g_prof = nullptr;
+__device__ int g_prof_block = 0;
+#define X3_STAMP() do { if (prof_on && nstamp < 64) { __builtin_amdgcn_sched_barrier(0); \
+    pr[nstamp++] = (long long)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int X3_LD = 40;   // bf16 per LDS row: 32 + 8 pad (80 bytes, conflict-free b128)
+__host__ __device__ constexpr size_t x3_tile_bytes(int WM, int WN) {
+  return (size_t)3 * (64 * WM + 64 * WN) * X3_LD * sizeof(unsigned short);
+}
 
 __device__ __forceinline__ void x3_split2(f32x2 v, unsigned &hi, unsigned &mid, unsigned &lo) {
   const bf16x2 h = __builtin_convertvector(v, bf16x2);
@@ -426,12 +436,16 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_x3_kernel(
   extern __shared__ __attribute__((aligned(16))) unsigned char x3_smem[];
   unsigned short *As = reinterpret_cast<unsigned short *>(x3_smem);
   unsigned short *Ws = As + 3 * BM * X3_LD;
-  float (*s_stat)[WM][BN] = reinterpret_cast<float (*)[WM][BN]>(Ws + 3 * BN * X3_LD);
+  float (*s_stat)[WM][BN] = reinterpret_cast<float (*)[WM][BN]>(x3_smem + x3_tile_bytes(WM, WN));
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const long long m0 = (long long)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
+  long long *pr = g_prof;
+  const bool prof_on = pr != nullptr && (int)blockIdx.x == g_prof_block && blockIdx.y == 0 && tid == 0;
+  int nstamp = 0;
+  X3_STAMP();
 
   // staging map: thread -> (row = tid / 8 + 32*i, k-quad = tid % 8)
   const int sq = tid & 7, sr = tid >> 3;
@@ -620,20 +634,32 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_x3_kernel(
   // Two slices of loads are in flight at any time (the MFMA phase of a slice is now
   // shorter than one memory round trip): slice s+2 is requested as soon as the
   // registers of slice s have been drained into LDS.
+  X3_STAMP();                  // [1] set-up done (gather: idx fetched)
   load_slice(ra, rw, 0);
   if (K > BK) load_slice(rb, rwb, BK);
+  X3_STAMP();                  // [2] two slices of loads issued
   for (int k0 = 0; k0 < K; k0 += 2 * BK) {
     __syncthreads();           // previous slice fully consumed
+    X3_STAMP();                // per slice: barrier
     store_slice(ra, rw);
+    X3_STAMP();                //   loads landed + split + LDS stores
     __syncthreads();
+    X3_STAMP();                //   barrier
     if (k0 + 2 * BK < K) load_slice(ra, rw, k0 + 2 * BK);
+    X3_STAMP();                //   next loads issued
     mfma_slice();
+    X3_STAMP();                //   MFMAs
     if (k0 + BK >= K) break;
     __syncthreads();
+    X3_STAMP();
     store_slice(rb, rwb);
+    X3_STAMP();
     __syncthreads();
+    X3_STAMP();
     if (k0 + 3 * BK < K) load_slice(rb, rwb, k0 + 3 * BK);
+    X3_STAMP();
     mfma_slice();
+    X3_STAMP();
   }
 
   if (ep.mean != nullptr) {    // inference: BN + ReLU (+ max-pool) leave with the GEMM
@@ -642,6 +668,9 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_x3_kernel(
   }
   // ---- epilogue: store Y, column statistics -------------------------------
   // C/D layout of 32x32: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+  // (Wide stores were tried here -- the tile transposed through LDS or with 4x4 DPP
+  // exchanges into dwordx4 row pieces -- and LOSE in this skeleton: (1M,64,64) 136 -> 154 us,
+  // (262144,128,128) 94 -> 107 us.  They pay in the streaming kernel of s2c_gemm2.hip.)
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = n0 + wn * 64 + j * 32 + li;
@@ -667,6 +696,12 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_x3_kernel(
         s_stat[1][wm][wn * 64 + j * 32 + li] = s2;
       }
     }
+  }
+  X3_STAMP();                  // epilogue stores issued
+  if (prof_on) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    X3_STAMP();                // ... and acknowledged
+    pr[63] = nstamp;
   }
   if (partial != nullptr) {
     __syncthreads();
@@ -709,8 +744,7 @@ int launch(long long M, int N, int K, const float *A, int lda, const float *W, i
 
 template <int WM, int WN>
 constexpr size_t x3_lds_bytes() {
-  return (size_t)3 * (64 * WM + 64 * WN) * X3_LD * sizeof(unsigned short) +
-         sizeof(float) * 2 * WM * 64 * WN;
+  return x3_tile_bytes(WM, WN) + sizeof(float) * 2 * WM * 64 * WN;
 }
 
 template <int PRO>
@@ -763,6 +797,17 @@ static bool use_split() {
 
 }  // namespace
 
+// streaming variant for the tall SA1-type layers (s2c_gemm2.hip); -2 = shape not taken
+extern "C" int s2c_rows_stream_gemm(long long M, int N, int K, const float *A, int lda,
+                                    const float *W, int ldw, float *Y, int ldy, float *partial,
+                                    int partial_rows, void *stream);
+extern "C" int s2c_sa_gather_stream_gemm(int b, int n, int m, int ns, int C,
+                                         long long feat_row_stride, long long feat_batch_stride,
+                                         float radius, int normalize, const float *xyz,
+                                         const float *new_xyz, const float *feats, const int *idx,
+                                         int N, const float *W, int ldw, float *Y, int ldy,
+                                         float *partial, int partial_rows, void *stream);
+
 extern "C" int s2c_rows_gemm_blocks(long long M, int N) {
   const int BM = N <= 64 ? 256 : 128;
   return (int)((M + BM - 1) / BM);
@@ -788,9 +833,13 @@ extern "C" int s2c_rows_gemm(long long M, int N, int K, const float *A, int lda,
     return launch<PRO_BNRELU>(M, N, K, A, lda, W, ldw, pscale, pshift, ga, Y, ldy,
                               partial, (hipStream_t)stream);
   }
-  if (use_split())
+  if (use_split()) {
+    const int rc = s2c_rows_stream_gemm(M, N, K, A, lda, W, ldw, Y, ldy, partial,
+                                        s2c_rows_gemm_blocks(M, N), stream);
+    if (rc != -2) return rc;
     return launch_x3<PRO_NONE>(M, N, K, A, lda, W, ldw, nullptr, nullptr, ga, Y, ldy, partial,
                                (hipStream_t)stream);
+  }
   return launch<PRO_NONE>(M, N, K, A, lda, W, ldw, nullptr, nullptr, ga, Y, ldy, partial,
                           (hipStream_t)stream);
 }
@@ -816,6 +865,13 @@ extern "C" int s2c_sa_gather_gemm(int b, int n, int m, int ns, int C,
   ga.xyz = xyz; ga.new_xyz = new_xyz; ga.feats = feats; ga.idx = idx;
   ga.frs = feat_row_stride; ga.fbs = feat_batch_stride;
   ga.n = n; ga.m = m; ga.ns = ns; ga.radius = radius; ga.normalize = normalize;
+  if (use_split()) {
+    const int rc = s2c_sa_gather_stream_gemm(b, n, m, ns, C, feat_row_stride, feat_batch_stride,
+                                             radius, normalize, xyz, new_xyz, feats, idx, N, W,
+                                             ldw, Y, ldy, partial, s2c_rows_gemm_blocks(M, N),
+                                             stream);
+    if (rc != -2) return rc;
+  }
   if (use_split())
     return launch_x3<PRO_GATHER>(M, N, K, nullptr, K, W, ldw, nullptr, nullptr, ga, Y, ldy,
                                  partial, (hipStream_t)stream);
@@ -845,6 +901,14 @@ extern "C" int s2c_bn_bwd_gemm(long long M, int C, int N, const float *dA, const
   BwdArgs bw = {Y, scale, shift, mean, invstd, coef, dY, relu};
   return launch_x3<PRO_BNBWD>(M, N, C, dA, C, Wt, ldw, nullptr, nullptr, ga, dX, ldx, nullptr,
                               (hipStream_t)stream, EpiArgs(), bw);
+}
+
+// Diagnostics: phase stamps of workgroup `block` (wave 0) of every following bf16x3 GEMM
+// launch go to prof[0..62], prof[63] = number of stamps.  prof == NULL switches it off.
+extern "C" int s2c_gemm_set_profile(long long *prof, int block) {
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), &prof, sizeof(prof)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof_block), &block, sizeof(block)) != hipSuccess) return -1;
+  return 0;
 }
 
 /* 1: bf16x3 split products (default), 0: exact fp32 MFMA chain.  Returns the previous

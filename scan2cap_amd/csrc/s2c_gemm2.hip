@@ -1,0 +1,475 @@
+// s2c_gemm2.hip -- streaming variant of the bf16x3 rows GEMM for the tall layers of the
+// first set-abstraction stage (M ~ 1M rows, N <= 128, K <= 160):
+//
+//     Y[M x N] = pro(A)[M x K] * W^T  (+ per-column [sum | sumsq] partials)
+//
+// Same arithmetic as rows_gemm_x3_kernel (s2c_gemm.hip): every fp32 product is the six
+// bf16 plane products with i + j <= 2 of a 3-way split, accumulated in fp32 in the same
+// term order.  What changes is the skeleton.  The phase timeline of the tiled kernel
+// (tools/prof_gemm.py) shows its workgroups stalled at the ISSUE of their loads and stores
+// for 2/3 of their life: one tile per workgroup, barrier-separated phases, two workgroups
+// per CU -- nothing is in flight while a workgroup computes or stores.  Here:
+//
+//   * persistent workgroups (one per CU, 8 waves), every WAVE an independent pipeline over
+//     32-row tiles: no workgroup barrier after the weight staging;
+//   * the operand never passes through VGPRs: `global_load_lds_dwordx4` (LDS-DMA) fills a
+//     wave-private ring of 4 KB chunks (32 rows x 32 k, fp32), DEPTH chunks ahead, counted
+//     with `s_waitcnt vmcnt(N)` -- loads of the next tile are in flight under the MFMAs and
+//     the stores of the current one (tools/bench_stream.py: the bare ring copies
+//     268 MB -> 268 MB at 5.1-5.3 TB/s);
+//   * the DMA writes lane-linear, so the XOR swizzle that makes the operand reads
+//     (ds_read_b128, one row per lane) conflict-free sits on the SOURCE address;
+//   * W is split to bf16 planes once per workgroup and stays resident in LDS in operand
+//     order ([plane][k-block of 8][column] x 16 B);
+//   * the fp32 -> 3 x bf16 split of the activations happens on the operand read;
+//   * the accumulator tile leaves through 4x4 DPP transposes as dwordx4 stores (8 rows x
+//     128 B per instruction) -- no LDS round trip, no dword stores;
+//   * PRO_GATHER: the ball-query grouping is fused as in s2c_gemm.hip, now entirely by DMA:
+//     the neighbour ids of the next tile, the xyz rows (dword pieces) and the feature rows (only
+//     4-byte aligned in the (B,N,3+C) cloud: LDS-DMA takes dword-aligned dwordx4 sources)
+//     land in LDS without a VGPR load in the loop.  K is walked feature columns first, the
+//     three centred coordinates last (W is permuted to match while it is staged).
+//
+// LDS (160 KB) decides the shapes this kernel takes: W planes 6 B per element plus 8 rings of
+// 3 chunks (s2c_rows_stream_supported); everything else stays on the tiled kernel.
+#include "s2c_common.h"
+#include "../../include/s2c_fused.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+
+using namespace s2c;
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int WAVES = 8;
+constexpr int SLOTS = 3;          // ring slots per wave
+constexpr int DEPTH = SLOTS - 1;  // chunks requested ahead of the one being consumed
+constexpr int CHUNK_BYTES = 4096; // 32 rows x 32 floats
+constexpr int AUX_BYTES = 1088;   // gather: idx[2][32] int, xyz[2][32][3], centres[2][2][3] float
+
+enum { SPRO_NONE = 0, SPRO_GATHER = 2 };
+
+struct StreamArgs {
+  long long M;
+  int N, K;                 // K = columns of the logical operand (gather: 3 + C)
+  const float *A; int lda;  // SPRO_NONE
+  const float *W; int ldw;
+  float *Y; int ldy;
+  float *partial; int partial_rows;
+  // SPRO_GATHER
+  const float *xyz, *new_xyz, *feats;
+  const int *idx;
+  long long frs, fbs;
+  int n, m, ns, C;
+  float radius; int normalize;
+};
+
+__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void glds4(const void *gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+               "global_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+__device__ __forceinline__ void split2(f32x2 v, unsigned &hi, unsigned &mid, unsigned &lo) {
+  const bf16x2 h = __builtin_convertvector(v, bf16x2);
+  const f32x2 r1 = v - __builtin_convertvector(h, f32x2);
+  const bf16x2 m = __builtin_convertvector(r1, bf16x2);
+  const f32x2 r2 = r1 - __builtin_convertvector(m, f32x2);
+  const bf16x2 l = __builtin_convertvector(r2, bf16x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  mid = __builtin_bit_cast(unsigned, m);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+
+// 8 consecutive-k fp32 values -> the three bf16x8 operand planes
+__device__ __forceinline__ void split8(const float4 &va, const float4 &vb, bf16x8 (&pl)[3]) {
+  uint4 h, m, l;
+  split2((f32x2){va.x, va.y}, h.x, m.x, l.x);
+  split2((f32x2){va.z, va.w}, h.y, m.y, l.y);
+  split2((f32x2){vb.x, vb.y}, h.z, m.z, l.z);
+  split2((f32x2){vb.z, vb.w}, h.w, m.w, l.w);
+  pl[0] = __builtin_bit_cast(bf16x8, h);
+  pl[1] = __builtin_bit_cast(bf16x8, m);
+  pl[2] = __builtin_bit_cast(bf16x8, l);
+}
+
+template <int NT, int PRO>
+__global__ __launch_bounds__(64 * WAVES, 2) void rows_stream_gemm_kernel(StreamArgs p) {
+  constexpr int NP = 32 * NT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lk = lane >> 5;
+  const long long M = p.M;
+  const int N = p.N, K = p.K;
+  const int KA = PRO == SPRO_GATHER ? p.C : K;   // columns that arrive by DMA (multiple of 4)
+  const int KC = (KA + 31) >> 5;                 // DMA chunks per tile
+  const int KS = (K + 15) >> 4;                  // k16 steps per tile
+  const int KB = 2 * KS;                         // k-blocks of 8 in the W planes
+  const int KCT = (KS + 1) >> 1;                 // chunk iterations (the last may be xyz only)
+
+  unsigned char *wp = smem;
+  const unsigned wbytes = 3u * KB * NP * 16u;
+  unsigned char *mine = smem + wbytes + (unsigned)wave * (SLOTS * CHUNK_BYTES + AUX_BYTES);
+  unsigned char *ring = mine;
+  int *idxbuf = reinterpret_cast<int *>(mine + SLOTS * CHUNK_BYTES);          // [2][32]
+  float *xyzbuf = reinterpret_cast<float *>(mine + SLOTS * CHUNK_BYTES + 256); // [2][32][3]
+  const unsigned ring_lds = (unsigned)(size_t)ring;
+  float *ctrbuf = reinterpret_cast<float *>(mine + SLOTS * CHUNK_BYTES + 1024);  // [2][2][3]
+  const unsigned idx_lds = (unsigned)(size_t)idxbuf, xyz_lds = (unsigned)(size_t)xyzbuf;
+  const unsigned ctr_lds = (unsigned)(size_t)ctrbuf;
+
+  // ---- stage W: split to planes, operand order, k permuted for the gather ----------------
+  {
+    const int quads = KB * 2;                    // k-quads per row of W'
+    for (int e = tid; e < NP * quads; e += 64 * WAVES) {
+      const int n = e / quads, k0 = (e - n * quads) * 4;
+      float w[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int k = k0 + c;
+        int src = -1;
+        if (PRO == SPRO_GATHER) {
+          if (k < KA) src = 3 + k; else if (k < KA + 3) src = k - KA;
+        } else if (k < K) {
+          src = k;
+        }
+        w[c] = (n < N && src >= 0) ? p.W[(long long)n * p.ldw + src] : 0.f;
+      }
+      unsigned h0, m0, l0, h1, m1, l1;
+      split2((f32x2){w[0], w[1]}, h0, m0, l0);
+      split2((f32x2){w[2], w[3]}, h1, m1, l1);
+      unsigned char *d = wp + ((unsigned)(k0 >> 3) * NP + n) * 16u + (k0 & 7) * 2;
+      *reinterpret_cast<uint2 *>(d) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2 *>(d + (unsigned)KB * NP * 16u) = make_uint2(m0, m1);
+      *reinterpret_cast<uint2 *>(d + 2u * KB * NP * 16u) = make_uint2(l0, l1);
+    }
+    // ring + aux start as zeros: positions the DMA never writes (k >= KA of the last chunk)
+    // only ever hold zeros or stale FINITE activations, and meet zero weights
+    for (int e = lane; e < (SLOTS * CHUNK_BYTES + AUX_BYTES) / 16; e += 64)
+      reinterpret_cast<uint4 *>(mine)[e] = make_uint4(0, 0, 0, 0);
+  }
+  __syncthreads();
+
+  const long long tiles = (M + 31) >> 5;
+  const long long wid = (long long)blockIdx.x * WAVES + wave, nw = (long long)gridDim.x * WAVES;
+
+  // ---- issue cursor ---------------------------------------------------------------------
+  long long it_tile = wid;
+  int it_c = 0, it_slot = 0, it_par = 0;
+  const float *rp[4];                            // source rows of this lane's 4 DMA pieces
+  const int dma_r0 = lane >> 3;                  // row of piece i: 8 i + dma_r0
+  // piece i, lane: physical quad (lane & 7) of row r holds logical quad (lane & 7) ^ ((r >> 1) & 7)
+  auto issue_idx = [&](long long t, int par) {   // neighbour ids of tile t -> idxbuf[par]
+    if (lane < 32) {
+      long long row = t * 32 + lane;
+      if (row >= M) row = M - 1;
+      glds4(p.idx + row, idx_lds + par * 128);
+    }
+  };
+  auto setup_rows = [&](long long t, int par) {
+    if (PRO == SPRO_GATHER) {
+      // neighbour ids of tile t landed a tile ago (covered by the chunk waits since)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        long long row = t * 32 + 8 * i + dma_r0;
+        if (row >= M) row = M - 1;
+        const long long b = row / ((long long)p.m * p.ns);
+        const int pt = idxbuf[par * 32 + 8 * i + dma_r0];
+        rp[i] = p.feats + b * p.fbs + (long long)pt * p.frs;
+      }
+      if (lane < 32) {
+        long long row = t * 32 + lane;
+        if (row >= M) row = M - 1;
+        const long long b = row / ((long long)p.m * p.ns);
+        const int pt = idxbuf[par * 32 + lane];
+        const float *src = p.xyz + (b * p.n + pt) * 3;      // -> xyzbuf[par][component][row]
+        glds4(src, xyz_lds + par * 384);
+        glds4(src + 1, xyz_lds + par * 384 + 128);
+        glds4(src + 2, xyz_lds + par * 384 + 256);
+      }
+      if (lane < 2) {                            // the (one or two) centres of the tile
+        long long row = t * 32 + 16 * lane;
+        if (row >= M) row = M - 1;
+        const float *src = p.new_xyz + (row / p.ns) * 3;    // -> ctrbuf[par][component][2]
+        glds4(src, ctr_lds + par * 24);
+        glds4(src + 1, ctr_lds + par * 24 + 8);
+        glds4(src + 2, ctr_lds + par * 24 + 16);
+      }
+      if (t + nw < tiles) issue_idx(t + nw, par ^ 1);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        long long row = t * 32 + 8 * i + dma_r0;
+        if (row >= M) row = M - 1;
+        rp[i] = p.A + row * p.lda;
+      }
+    }
+  };
+  auto issue_next = [&]() -> bool {
+    if (it_tile >= tiles) return false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 8 * i + dma_r0;
+      const int q = (lane & 7) ^ ((r >> 1) & 7);
+      const int k = it_c * 32 + q * 4;
+      if (k < KA) glds16(rp[i] + k, ring_lds + it_slot * CHUNK_BYTES + i * 1024);
+    }
+    it_slot = it_slot + 1 == SLOTS ? 0 : it_slot + 1;
+    if (++it_c == KC) {
+      it_c = 0;
+      it_tile += nw;
+      it_par ^= 1;
+      if (it_tile < tiles) setup_rows(it_tile, it_par);
+    }
+    return true;
+  };
+
+  if (it_tile < tiles) {
+    if (PRO == SPRO_GATHER) {
+      issue_idx(it_tile, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    setup_rows(it_tile, 0);
+  }
+#pragma unroll 1
+  for (int d = 0; d < DEPTH; ++d) issue_next();
+
+  float s1[NT], s2[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
+
+  const int swz = (li >> 1) & 7;
+  int slot = 0, par = 0;
+#pragma unroll 1
+  for (long long t = wid; t < tiles; t += nw) {
+    f32x16 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    const long long r0 = t * 32;
+
+#pragma unroll 1
+    for (int c = 0; c < KCT; ++c) {
+      const unsigned char *sl = ring + slot * CHUNK_BYTES;
+      if (c < KC) {
+        if (issue_next()) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * DEPTH) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int ks = 2 * c + s;
+        if (ks < KS) {
+          float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+          if (c < KC) {
+            const int qa = 4 * s + 2 * lk;
+            va = *reinterpret_cast<const float4 *>(sl + li * 128 + ((qa ^ swz) << 4));
+            vb = *reinterpret_cast<const float4 *>(sl + li * 128 + (((qa + 1) ^ swz) << 4));
+          }
+          if (PRO == SPRO_GATHER) {
+            // the quad holding the centred coordinates: logical k = KA .. KA + 2
+            const int kx = KA - ks * 16 - lk * 8;          // offset inside this lane's 8 values
+            if (kx == 0 || kx == 4) {
+              const float *cx = ctrbuf + par * 6 + (li >> 4);       // rows 0-15 / 16-31
+              const float *px = xyzbuf + par * 96 + li;
+              float x = px[0] - cx[0], y = px[32] - cx[2], z = px[64] - cx[4];
+              if (p.normalize) { x = x / p.radius; y = y / p.radius; z = z / p.radius; }
+              const float4 q = make_float4(x, y, z, 0.f);
+              if (kx == 0) { va = q; vb = make_float4(0.f, 0.f, 0.f, 0.f); } else { vb = q; }
+            } else if (kx < 0) {
+              va = make_float4(0.f, 0.f, 0.f, 0.f); vb = va;
+            }
+          }
+          bf16x8 a[3];
+          split8(va, vb, a);
+          bf16x8 b[NT][3];
+          const unsigned char *wk = wp + ((unsigned)(2 * ks + lk) * NP + li) * 16u;
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+              b[j][pl] = *reinterpret_cast<const bf16x8 *>(wk + (unsigned)pl * KB * NP * 16u + j * 512);
+          // the 6 plane products with i + j <= 2, small terms first (as rows_gemm_x3_kernel)
+          constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+          for (int tt = 0; tt < 6; ++tt)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[tt]], b[j][TB[tt]], acc[j], 0, 0, 0);
+        }
+      }
+      if (c < KC) slot = slot + 1 == SLOTS ? 0 : slot + 1;
+    }
+    par ^= 1;
+
+    // ---- epilogue: statistics, 4x4 DPP transposes, dwordx4 stores -------------------------
+    // C/D layout of 32x32: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = 32 * j + li;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float a4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float v = acc[j][4 * g + i];
+          a4[i] = v;
+          if (r0 + 8 * g + 4 * lk + i < M && col < N) { s1[j] += v; s2[j] += v * v; }
+        }
+        quad_transpose(a4, lane);
+        const long long row = r0 + 8 * g + 4 * lk + (lane & 3);
+        const int c0 = 32 * j + (li & ~3);
+        if (row < M) {
+          float *dst = p.Y + row * p.ldy + c0;
+          if (c0 + 3 < N) {
+            *reinterpret_cast<float4 *>(dst) = make_float4(a4[0], a4[1], a4[2], a4[3]);
+          } else {
+            if (c0 < N) dst[0] = a4[0];
+            if (c0 + 1 < N) dst[1] = a4[1];
+            if (c0 + 2 < N) dst[2] = a4[2];
+          }
+        }
+      }
+    }
+  }
+
+  if (p.partial != nullptr) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const float t1 = s1[j] + __shfl_xor(s1[j], 32, 64);
+      const float t2 = s2[j] + __shfl_xor(s2[j], 32, 64);
+      const int col = 32 * j + li;
+      if (lk == 0 && col < N && wid < p.partial_rows) {
+        p.partial[wid * 2 * N + col] = t1;
+        p.partial[wid * 2 * N + N + col] = t2;
+      }
+    }
+    // rows of the partial table this grid does not own stay zero
+    for (long long r = wid + nw; r < p.partial_rows; r += nw)
+      for (int c = lane; c < 2 * N; c += 64) p.partial[r * 2 * N + c] = 0.f;
+  }
+}
+
+size_t stream_lds_bytes(int NT, int K) {
+  const int KS = (K + 15) / 16;
+  return (size_t)3 * 2 * KS * 32 * NT * 16 + (size_t)WAVES * (SLOTS * CHUNK_BYTES + AUX_BYTES);
+}
+
+int g_stream_on = -1, g_stream_grid = 0;
+bool stream_on() {
+  if (g_stream_on < 0) {
+    const char *e = getenv("S2C_GEMM_STREAM");
+    g_stream_on = e ? atoi(e) : 1;
+    const char *g = getenv("S2C_GEMM_STREAM_GRID");
+    g_stream_grid = g ? atoi(g) : 240;
+    if (g_stream_grid <= 0) g_stream_grid = 240;
+  }
+  return g_stream_on != 0;
+}
+
+constexpr long long STREAM_MIN_ROWS = 131072;
+constexpr size_t LDS_LIMIT = 160 * 1024;
+
+bool shape_ok(long long M, int N, int K) {
+  if (M < STREAM_MIN_ROWS || N <= 0 || N > 128 || K <= 0) return false;
+  const int NT = N <= 64 ? 2 : 4;
+  return stream_lds_bytes(NT, K) <= LDS_LIMIT;
+}
+
+template <int PRO>
+int launch_stream(const StreamArgs &a, int blocks, hipStream_t st) {
+  const int NT = a.N <= 64 ? 2 : 4;
+  const size_t lds = stream_lds_bytes(NT, a.K);
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void *)rows_stream_gemm_kernel<2, PRO>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT) != hipSuccess ||
+        hipFuncSetAttribute((const void *)rows_stream_gemm_kernel<4, PRO>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT) != hipSuccess)
+      return -1;
+    attr_done = true;
+  }
+  if (NT == 2)
+    hipLaunchKernelGGL((rows_stream_gemm_kernel<2, PRO>), dim3(blocks), dim3(64 * WAVES), lds, st, a);
+  else
+    hipLaunchKernelGGL((rows_stream_gemm_kernel<4, PRO>), dim3(blocks), dim3(64 * WAVES), lds, st, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    fprintf(stderr, "s2c_rows_stream_gemm launch failed: %s\n", hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
+int grid_for(int partial_rows) {
+  int g = g_stream_grid;
+  if (partial_rows > 0 && g * WAVES > partial_rows) g = partial_rows / WAVES;
+  return g < 1 ? 1 : g;
+}
+
+}  // namespace
+
+// 1 when s2c_rows_gemm / s2c_sa_gather_gemm hand this shape to the streaming kernel
+// (plain operand: K, lda multiples of 4 and 16-byte aligned A; gather: C a multiple of 4,
+// C >= 100, ns in {16, 32, 64}).
+extern "C" int s2c_rows_stream_supported(long long M, int N, int K, int gather) {
+  if (!stream_on() || !shape_ok(M, N, K)) return 0;
+  if (gather) return (K - 3) % 4 == 0 && K - 3 >= 100;
+  return K % 4 == 0;
+}
+
+// 1: tall eligible shapes run on the streaming kernel (default), 0: everything on the tiled
+// kernel.  Returns the previous setting.  (Also: environment S2C_GEMM_STREAM at first use.)
+extern "C" int s2c_gemm_set_stream(int on) {
+  const int old = stream_on() ? 1 : 0;
+  g_stream_on = on ? 1 : 0;
+  return old;
+}
+
+// Internal entry points used by s2c_gemm.hip's dispatch (same contracts as s2c_rows_gemm /
+// s2c_sa_gather_gemm; `partial_rows` = s2c_rows_gemm_blocks(M, N)).  Return -2: shape not taken.
+extern "C" int s2c_rows_stream_gemm(long long M, int N, int K, const float *A, int lda,
+                                    const float *W, int ldw, float *Y, int ldy, float *partial,
+                                    int partial_rows, void *stream) {
+  if (!s2c_rows_stream_supported(M, N, K, 0) || (lda & 3) || ((uintptr_t)A & 15) ||
+      (ldy & 3) || ((uintptr_t)Y & 15))
+    return -2;
+  StreamArgs a = {};
+  a.M = M; a.N = N; a.K = K; a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.Y = Y; a.ldy = ldy;
+  a.partial = partial; a.partial_rows = partial_rows;
+  return launch_stream<SPRO_NONE>(a, grid_for(partial ? partial_rows : 0), (hipStream_t)stream);
+}
+
+extern "C" int s2c_sa_gather_stream_gemm(int b, int n, int m, int ns, int C,
+                                         long long feat_row_stride, long long feat_batch_stride,
+                                         float radius, int normalize, const float *xyz,
+                                         const float *new_xyz, const float *feats, const int *idx,
+                                         int N, const float *W, int ldw, float *Y, int ldy,
+                                         float *partial, int partial_rows, void *stream) {
+  const long long M = (long long)b * m * ns;
+  const int K = 3 + C;
+  if (!s2c_rows_stream_supported(M, N, K, 1) || !(ns == 16 || ns == 32 || ns == 64) ||
+      (ldy & 3) || ((uintptr_t)Y & 15) || ((uintptr_t)feats & 3))
+    return -2;
+  StreamArgs a = {};
+  a.M = M; a.N = N; a.K = K; a.W = W; a.ldw = ldw; a.Y = Y; a.ldy = ldy;
+  a.partial = partial; a.partial_rows = partial_rows;
+  a.xyz = xyz; a.new_xyz = new_xyz; a.feats = feats; a.idx = idx;
+  a.frs = feat_row_stride; a.fbs = feat_batch_stride;
+  a.n = n; a.m = m; a.ns = ns; a.C = C; a.radius = radius; a.normalize = normalize;
+  return launch_stream<SPRO_GATHER>(a, grid_for(partial ? partial_rows : 0), (hipStream_t)stream);
+}

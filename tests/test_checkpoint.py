@@ -184,7 +184,10 @@ def _assert_continues(model, opt, loss, ref_loss, ref_w, ref_st, what):
         # noise of ~1e-7, hence the absolute floors)
         for k, floor in (("exp_avg", 1e-6), ("exp_avg_sq", 1e-10)):
             scale = float(s[k].abs().max())
-            assert float((st[n][k] - s[k]).abs().max()) <= 2e-3 * scale + floor, (what, n, k)
+            # (float atomics: two runs of the same step differ in the last bits, and at random
+            # init a flipped arg-max moves single entries by ~1e-3 of the scale; moments that
+            # were NOT restored would be off by the scale itself)
+            assert float((st[n][k] - s[k]).abs().max()) <= 1e-2 * scale + floor, (what, n, k)
 
 
 @pytest.mark.gpu

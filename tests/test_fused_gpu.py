@@ -770,3 +770,87 @@ def test_weight_grad_partials_and_hand_input_grad_match_torch():
         W = torch.randn(Cout, Cin, device="cuda") * 0.1
         dX = fused._input_grad_gemm(dY, W)
         assert _rel(dX.double(), torch.mm(dY.double(), W.double())) < 1e-5
+
+
+# ---- streaming rows GEMM (csrc/s2c_gemm2.hip) -------------------------------------------------
+def _stream_lib():
+    import ctypes
+    from scan2cap_amd import _C
+    I, L, P, F = ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_float
+    _C.register("s2c_rows_gemm", [L, I, I, P, I, P, I, P, P, P, I, P, P])
+    _C.register("s2c_sa_gather_gemm", [I, I, I, I, I, L, L, F, I, P, P, P, P, I, P, I, P, I, P, P])
+    lib = _C.load()
+    lib.s2c_rows_gemm_blocks.argtypes = [L, I]; lib.s2c_rows_gemm_blocks.restype = I
+    lib.s2c_rows_stream_supported.argtypes = [L, I, I, I]; lib.s2c_rows_stream_supported.restype = I
+    return _C, lib
+
+
+@pytest.mark.parametrize("M,N,K,lda", [(131072, 64, 64, 64), (262144 + 37, 64, 128, 128),
+                                       (140000, 128, 64, 64), (131072 + 31, 48, 36, 40),
+                                       (200000, 100, 64, 72), (131073, 64, 144, 144)])
+def test_stream_gemm_matches_fp64_and_the_tiled_kernel(M, N, K, lda):
+    """Y = A W^T + BatchNorm partials on the persistent LDS-DMA kernel: ragged last tile
+    (M % 32 != 0), N not a multiple of 32, K not a multiple of 32, padded rows (lda > K);
+    against a float64 product and against the tiled kernel (S2C_GEMM_STREAM off = same
+    bf16x3 products in the same order: identical values expected up to the statistics' order)."""
+    _C, lib = _stream_lib()
+    assert lib.s2c_rows_stream_supported(M, N, K, 0) == 1 and lib.s2c_rows_stream_supported(1000, N, K, 0) == 0
+    torch.manual_seed(M % 1000 + N + K)
+    A = torch.randn(M, lda, device="cuda")[:, :K]
+    W = torch.randn(N, K, device="cuda") * 0.2
+    nb = lib.s2c_rows_gemm_blocks(M, N)
+    outs = []
+    for stream in (1, 0):
+        Y = torch.full((M, N), float("nan"), device="cuda")
+        part = torch.full((nb * 2 * N,), float("nan"), device="cuda")
+        prev = lib.s2c_gemm_set_stream(stream)
+        try:
+            _C.call("s2c_rows_gemm", M, N, K, A.data_ptr(), lda, W.data_ptr(), K, None, None,
+                    Y.data_ptr(), N, part.data_ptr(), _C.stream_ptr())
+        finally:
+            lib.s2c_gemm_set_stream(prev)
+        torch.cuda.synchronize()
+        outs.append((Y, part.view(nb, 2, N).double().sum(0)))
+    ref = A.double() @ W.double().t()
+    for Y, p in outs:
+        assert torch.isfinite(Y).all()
+        assert float((Y.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+        assert float((p[0] - ref.sum(0)).abs().max()) <= 1e-4 * float(ref.abs().sum(0).max())
+        assert float((p[1] - (ref * ref).sum(0)).abs().max()) <= 1e-5 * float((ref * ref).sum(0).max())
+    assert torch.equal(outs[0][0], outs[1][0])        # same products, same order
+
+
+@pytest.mark.parametrize("B,n,m,ns,C,N,normalize", [(2, 20000, 1024, 64, 132, 64, 1),
+                                                   (8, 2048, 1024, 32, 128, 128, 1),
+                                                   (3, 5000, 1400, 32, 100, 64, 0),
+                                                   (16, 1024, 512, 16, 128, 96, 1)])
+def test_stream_gather_gemm_matches_gathered_rows(B, n, m, ns, C, N, normalize):
+    """Ball-query grouping fused into the streaming kernel (neighbour ids, xyz and feature
+    rows by LDS-DMA; features only 4-byte aligned inside the (B,n,3+C) cloud) vs the
+    materialised rows of s2c_sa_gather_rows times W in float64."""
+    from scan2cap_amd.pointnet2 import fused
+    _C, lib = _stream_lib()
+    M = B * m * ns
+    assert lib.s2c_rows_stream_supported(M, N, 3 + C, 1) == 1
+    torch.manual_seed(B + n + C)
+    pc = torch.randn(B, n, 3 + C, device="cuda")
+    xyz = pc[..., :3].contiguous()
+    feats = pc[..., 3:]                                   # view: rows 4-byte aligned only
+    inds = torch.stack([torch.randperm(n, device="cuda")[:m] for _ in range(B)])
+    new_xyz = torch.gather(xyz, 1, inds.unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    idx = torch.randint(0, n, (B, m, ns), device="cuda", dtype=torch.int32)
+    W = torch.randn(N, 3 + C, device="cuda") * 0.1
+    Y = torch.full((M, N), float("nan"), device="cuda")
+    nb = lib.s2c_rows_gemm_blocks(M, N)
+    part = torch.full((nb * 2 * N,), float("nan"), device="cuda")
+    _C.call("s2c_sa_gather_gemm", B, n, m, ns, C, feats.stride(1), feats.stride(0), 0.25, normalize,
+            xyz.data_ptr(), new_xyz.data_ptr(), feats.data_ptr(), idx.data_ptr(), N,
+            W.data_ptr(), 3 + C, Y.data_ptr(), N, part.data_ptr(), _C.stream_ptr())
+    torch.cuda.synchronize()
+    X = fused._GatherRows.apply(xyz, new_xyz, feats, idx, 0.25, bool(normalize))
+    ref = X.double() @ W.double().t()
+    assert torch.isfinite(Y).all()
+    assert float((Y.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    p = part.view(nb, 2, N).double().sum(0)
+    assert float((p[0] - ref.sum(0)).abs().max()) <= 1e-4 * float(ref.abs().sum(0).max())
+    assert float((p[1] - (ref * ref).sum(0)).abs().max()) <= 1e-5 * float((ref * ref).sum(0).max())
