@@ -30,8 +30,9 @@
 //     land in LDS without a VGPR load in the loop.  K is walked feature columns first, the
 //     three centred coordinates last (W is permuted to match while it is staged).
 //
-// LDS (160 KB) decides the shapes this kernel takes: W planes 6 B per element plus 8 rings of
-// 3 chunks (s2c_rows_stream_supported); everything else stays on the tiled kernel.
+// LDS (160 KB) decides the shapes this kernel takes: W planes 6 B per element plus one ring per
+// wave -- 8 waves x 3 chunks when W is small, 4 waves x 4, 3 or 2 chunks for N = 128 with
+// K ~ 128 (s2c_rows_stream_supported); everything else stays on the tiled kernel.
 #include "s2c_common.h"
 #include "../../include/s2c_fused.h"
 
@@ -47,9 +48,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int WAVES = 8;
-constexpr int SLOTS = 3;          // ring slots per wave
-constexpr int DEPTH = SLOTS - 1;  // chunks requested ahead of the one being consumed
 constexpr int CHUNK_BYTES = 4096; // 32 rows x 32 floats
 constexpr int AUX_BYTES = 1088;   // gather: idx[2][32] int, xyz[2][32][3], centres[2][2][3] float
 
@@ -106,9 +104,13 @@ __device__ __forceinline__ void split8(const float4 &va, const float4 &vb, bf16x
   pl[2] = __builtin_bit_cast(bf16x8, l);
 }
 
-template <int NT, int PRO>
-__global__ __launch_bounds__(64 * WAVES, 2) void rows_stream_gemm_kernel(StreamArgs p) {
+// NT: 32-column MFMA tiles per wave (N <= 32 NT); WAVES per workgroup (one workgroup per CU);
+// SLOTS: ring slots per wave, SLOTS - 1 chunks requested ahead of the one being consumed.
+template <int NT, int PRO, int WAVES, int SLOTS>
+__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void rows_stream_gemm_kernel(StreamArgs p) {
   constexpr int NP = 32 * NT;
+  constexpr int DEPTH = SLOTS - 1;
+  constexpr int AUXB = PRO == SPRO_GATHER ? AUX_BYTES : 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rows_stream_gemm_kernel(StreamA
 
   unsigned char *wp = smem;
   const unsigned wbytes = 3u * KB * NP * 16u;
-  unsigned char *mine = smem + wbytes + (unsigned)wave * (SLOTS * CHUNK_BYTES + AUX_BYTES);
+  unsigned char *mine = smem + wbytes + (unsigned)wave * (SLOTS * CHUNK_BYTES + AUXB);
   unsigned char *ring = mine;
   int *idxbuf = reinterpret_cast<int *>(mine + SLOTS * CHUNK_BYTES);          // [2][32]
   float *xyzbuf = reinterpret_cast<float *>(mine + SLOTS * CHUNK_BYTES + 256); // [2][32][3]
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rows_stream_gemm_kernel(StreamA
     }
     // ring + aux start as zeros: positions the DMA never writes (k >= KA of the last chunk)
     // only ever hold zeros or stale FINITE activations, and meet zero weights
-    for (int e = lane; e < (SLOTS * CHUNK_BYTES + AUX_BYTES) / 16; e += 64)
+    for (int e = lane; e < (SLOTS * CHUNK_BYTES + AUXB) / 16; e += 64)
       reinterpret_cast<uint4 *>(mine)[e] = make_uint4(0, 0, 0, 0);
   }
   __syncthreads();
@@ -364,9 +366,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rows_stream_gemm_kernel(StreamA
   }
 }
 
-size_t stream_lds_bytes(int NT, int K) {
+size_t stream_lds_bytes(int NT, int K, int waves, int slots, bool gather) {
   const int KS = (K + 15) / 16;
-  return (size_t)3 * 2 * KS * 32 * NT * 16 + (size_t)WAVES * (SLOTS * CHUNK_BYTES + AUX_BYTES);
+  return (size_t)3 * 2 * KS * 32 * NT * 16 +
+         (size_t)waves * (slots * CHUNK_BYTES + (gather ? AUX_BYTES : 0));
 }
 
 int g_stream_on = -1, g_stream_grid = 0;
@@ -384,29 +387,56 @@ bool stream_on() {
 constexpr long long STREAM_MIN_ROWS = 131072;
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
-bool shape_ok(long long M, int N, int K) {
-  if (M < STREAM_MIN_ROWS || N <= 0 || N > 128 || K <= 0) return false;
+// Workgroup shapes in order of preference: more waves (latency hiding on the compute side),
+// then more ring slots (bytes in flight).  LDS is what decides.
+struct StreamCfg { int waves, slots; };
+constexpr StreamCfg CFGS[4] = {{8, 3}, {4, 4}, {4, 3}, {4, 2}};   // (8,4) measured slower than (8,3)
+
+int pick_cfg(long long M, int N, int K, bool gather) {
+  if (M < STREAM_MIN_ROWS || N <= 0 || N > 128 || K <= 0) return -1;
   const int NT = N <= 64 ? 2 : 4;
-  return stream_lds_bytes(NT, K) <= LDS_LIMIT;
+  for (int c = 0; c < 4; ++c)
+    if (stream_lds_bytes(NT, K, CFGS[c].waves, CFGS[c].slots, gather) <= LDS_LIMIT) return c;
+  return -1;
 }
 
-template <int PRO>
-int launch_stream(const StreamArgs &a, int blocks, hipStream_t st) {
-  const int NT = a.N <= 64 ? 2 : 4;
-  const size_t lds = stream_lds_bytes(NT, a.K);
+template <int NT, int PRO, int WAVES, int SLOTS>
+int launch_one(const StreamArgs &a, int blocks, size_t lds, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute((const void *)rows_stream_gemm_kernel<2, PRO>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT) != hipSuccess ||
-        hipFuncSetAttribute((const void *)rows_stream_gemm_kernel<4, PRO>,
+    if (hipFuncSetAttribute((const void *)rows_stream_gemm_kernel<NT, PRO, WAVES, SLOTS>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT) != hipSuccess)
       return -1;
     attr_done = true;
   }
-  if (NT == 2)
-    hipLaunchKernelGGL((rows_stream_gemm_kernel<2, PRO>), dim3(blocks), dim3(64 * WAVES), lds, st, a);
-  else
-    hipLaunchKernelGGL((rows_stream_gemm_kernel<4, PRO>), dim3(blocks), dim3(64 * WAVES), lds, st, a);
+  hipLaunchKernelGGL((rows_stream_gemm_kernel<NT, PRO, WAVES, SLOTS>), dim3(blocks), dim3(64 * WAVES),
+                     lds, st, a);
+  return 0;
+}
+
+template <int NT, int PRO>
+int launch_cfg(const StreamArgs &a, int cfg, int blocks, size_t lds, hipStream_t st) {
+  switch (cfg) {
+    case 0: return launch_one<NT, PRO, 8, 3>(a, blocks, lds, st);
+    case 1: return launch_one<NT, PRO, 4, 4>(a, blocks, lds, st);
+    case 2: return launch_one<NT, PRO, 4, 3>(a, blocks, lds, st);
+    default: return launch_one<NT, PRO, 4, 2>(a, blocks, lds, st);
+  }
+}
+
+template <int PRO>
+int launch_stream(const StreamArgs &a, hipStream_t st) {
+  const int NT = a.N <= 64 ? 2 : 4;
+  const int cfg = pick_cfg(a.M, a.N, a.K, PRO == SPRO_GATHER);
+  if (cfg < 0) return -2;
+  const int waves = CFGS[cfg].waves;
+  const size_t lds = stream_lds_bytes(NT, a.K, waves, CFGS[cfg].slots, PRO == SPRO_GATHER);
+  int blocks = g_stream_grid;
+  if (a.partial != nullptr && blocks * waves > a.partial_rows) blocks = a.partial_rows / waves;
+  if (blocks < 1) return -2;
+  const int rc = NT == 2 ? launch_cfg<2, PRO>(a, cfg, blocks, lds, st)
+                         : launch_cfg<4, PRO>(a, cfg, blocks, lds, st);
+  if (rc != 0) return rc;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     fprintf(stderr, "s2c_rows_stream_gemm launch failed: %s\n", hipGetErrorString(e));
@@ -415,19 +445,13 @@ int launch_stream(const StreamArgs &a, int blocks, hipStream_t st) {
   return 0;
 }
 
-int grid_for(int partial_rows) {
-  int g = g_stream_grid;
-  if (partial_rows > 0 && g * WAVES > partial_rows) g = partial_rows / WAVES;
-  return g < 1 ? 1 : g;
-}
-
 }  // namespace
 
 // 1 when s2c_rows_gemm / s2c_sa_gather_gemm hand this shape to the streaming kernel
 // (plain operand: K, lda multiples of 4 and 16-byte aligned A; gather: C a multiple of 4,
 // C >= 100, ns in {16, 32, 64}).
 extern "C" int s2c_rows_stream_supported(long long M, int N, int K, int gather) {
-  if (!stream_on() || !shape_ok(M, N, K)) return 0;
+  if (!stream_on() || pick_cfg(M, N, K, gather != 0) < 0) return 0;
   if (gather) return (K - 3) % 4 == 0 && K - 3 >= 100;
   return K % 4 == 0;
 }
@@ -451,7 +475,7 @@ extern "C" int s2c_rows_stream_gemm(long long M, int N, int K, const float *A, i
   StreamArgs a = {};
   a.M = M; a.N = N; a.K = K; a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.Y = Y; a.ldy = ldy;
   a.partial = partial; a.partial_rows = partial_rows;
-  return launch_stream<SPRO_NONE>(a, grid_for(partial ? partial_rows : 0), (hipStream_t)stream);
+  return launch_stream<SPRO_NONE>(a, (hipStream_t)stream);
 }
 
 extern "C" int s2c_sa_gather_stream_gemm(int b, int n, int m, int ns, int C,
@@ -471,5 +495,5 @@ extern "C" int s2c_sa_gather_stream_gemm(int b, int n, int m, int ns, int C,
   a.xyz = xyz; a.new_xyz = new_xyz; a.feats = feats; a.idx = idx;
   a.frs = feat_row_stride; a.fbs = feat_batch_stride;
   a.n = n; a.m = m; a.ns = ns; a.C = C; a.radius = radius; a.normalize = normalize;
-  return launch_stream<SPRO_GATHER>(a, grid_for(partial ? partial_rows : 0), (hipStream_t)stream);
+  return launch_stream<SPRO_GATHER>(a, (hipStream_t)stream);
 }

@@ -787,7 +787,8 @@ def _stream_lib():
 
 @pytest.mark.parametrize("M,N,K,lda", [(131072, 64, 64, 64), (262144 + 37, 64, 128, 128),
                                        (140000, 128, 64, 64), (131072 + 31, 48, 36, 40),
-                                       (200000, 100, 64, 72), (131073, 64, 144, 144)])
+                                       (200000, 100, 64, 72), (131073, 64, 144, 144),
+                                       (262144, 128, 128, 128), (150000, 128, 144, 144)])
 def test_stream_gemm_matches_fp64_and_the_tiled_kernel(M, N, K, lda):
     """Y = A W^T + BatchNorm partials on the persistent LDS-DMA kernel: ragged last tile
     (M % 32 != 0), N not a multiple of 32, K not a multiple of 32, padded rows (lda > K);
@@ -823,7 +824,8 @@ def test_stream_gemm_matches_fp64_and_the_tiled_kernel(M, N, K, lda):
 @pytest.mark.parametrize("B,n,m,ns,C,N,normalize", [(2, 20000, 1024, 64, 132, 64, 1),
                                                    (8, 2048, 1024, 32, 128, 128, 1),
                                                    (3, 5000, 1400, 32, 100, 64, 0),
-                                                   (16, 1024, 512, 16, 128, 96, 1)])
+                                                   (16, 1024, 512, 16, 128, 96, 1),
+                                                   (8, 2048, 1024, 32, 128, 128, 0)])
 def test_stream_gather_gemm_matches_gathered_rows(B, n, m, ns, C, N, normalize):
     """Ball-query grouping fused into the streaming kernel (neighbour ids, xyz and feature
     rows by LDS-DMA; features only 4-byte aligned inside the (B,n,3+C) cloud) vs the
