@@ -137,6 +137,14 @@ int s2c_rows_gemm_blocks(long long M, int N);
  * operands with N <= 128 whose W planes leave room for the rings in LDS), 0 when on the
  * tiled kernel.  Same results contract either way.  S2C_GEMM_STREAM=0 switches it off. */
 int s2c_rows_stream_supported(long long M, int N, int K, int gather);
+/* Y = relu?(A * scale[k] + shift[k]) W^T (+ partials as s2c_rows_gemm) with the activated
+ * operand also written to side (M x K, row stride ld_side; may be NULL): the previous layer's
+ * s2c_bn_relu pass folded into this layer's streaming GEMM (pytorch_utils.py:100-120 between
+ * two convs).  Returns -2 when the shape is not one the streaming kernel takes. */
+int s2c_rows_gemm_bn_relu_side(long long M, int N, int K, const float *A, int lda,
+                               const float *scale, const float *shift, int relu, float *side,
+                               int ld_side, const float *W, int ldw, float *Y, int ldy,
+                               float *partial, void *stream);
 /* switch the streaming kernel on / off at run time; returns the previous setting */
 int s2c_gemm_set_stream(int on);
 /* Inference layers (frozen BatchNorm): out = [max over groups of pool_ns rows of]

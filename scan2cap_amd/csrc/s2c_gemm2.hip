@@ -51,12 +51,17 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int CHUNK_BYTES = 4096; // 32 rows x 32 floats
 constexpr int AUX_BYTES = 1088;   // gather: idx[2][32] int, xyz[2][32][3], centres[2][2][3] float
 
-enum { SPRO_NONE = 0, SPRO_GATHER = 2 };
+enum { SPRO_NONE = 0, SPRO_BNRELU = 1, SPRO_GATHER = 2 };
 
 struct StreamArgs {
   long long M;
   int N, K;                 // K = columns of the logical operand (gather: 3 + C)
-  const float *A; int lda;  // SPRO_NONE
+  const float *A; int lda;  // SPRO_NONE / SPRO_BNRELU
+  // SPRO_BNRELU: operand = relu?(A * scale[k] + shift[k]) (the previous layer's BatchNorm +
+  // ReLU, the arithmetic of bn_relu_kernel), written back to `side` (M x K, row stride lds_)
+  // when side != nullptr -- the activation the backward pass needs leaves with the GEMM that
+  // consumes it instead of through a separate pass over the pre-activation tensor
+  const float *scale, *shift; int relu; float *side; int ld_side;
   const float *W; int ldw;
   float *Y; int ldy;
   float *partial; int partial_rows;
@@ -125,7 +130,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void rows_stream_gemm_kernel
 
   unsigned char *wp = smem;
   const unsigned wbytes = 3u * KB * NP * 16u;
-  unsigned char *mine = smem + wbytes + (unsigned)wave * (SLOTS * CHUNK_BYTES + AUXB);
+  const unsigned ssbytes = PRO == SPRO_BNRELU ? 2u * KB * 8u * 4u : 0u;   // scale | shift, KB*8 floats each
+  float *s_scale = reinterpret_cast<float *>(smem + wbytes);
+  float *s_shift = s_scale + KB * 8;
+  unsigned char *mine = smem + wbytes + ssbytes + (unsigned)wave * (SLOTS * CHUNK_BYTES + AUXB);
   unsigned char *ring = mine;
   int *idxbuf = reinterpret_cast<int *>(mine + SLOTS * CHUNK_BYTES);          // [2][32]
   float *xyzbuf = reinterpret_cast<float *>(mine + SLOTS * CHUNK_BYTES + 256); // [2][32][3]
@@ -159,6 +167,11 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void rows_stream_gemm_kernel
       *reinterpret_cast<uint2 *>(d + (unsigned)KB * NP * 16u) = make_uint2(m0, m1);
       *reinterpret_cast<uint2 *>(d + 2u * KB * NP * 16u) = make_uint2(l0, l1);
     }
+    if (PRO == SPRO_BNRELU)
+      for (int k = tid; k < KB * 8; k += 64 * WAVES) {
+        s_scale[k] = k < K ? p.scale[k] : 1.f;
+        s_shift[k] = k < K ? p.shift[k] : 0.f;
+      }
     // ring + aux start as zeros: positions the DMA never writes (k >= KA of the last chunk)
     // only ever hold zeros or stale FINITE activations, and meet zero weights
     for (int e = lane; e < (SLOTS * CHUNK_BYTES + AUXB) / 16; e += 64)
@@ -271,6 +284,33 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void rows_stream_gemm_kernel
       if (c < KC) {
         if (issue_next()) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * DEPTH) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (PRO == SPRO_BNRELU) {
+          // BatchNorm + ReLU applied in place on the landed chunk, every lane on the four
+          // 16-byte pieces it requested (row-coalesced for the side store), before any
+          // operand read of this wave (same wave: LDS operations stay in program order)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int r = 8 * i + dma_r0;
+            const int q = (lane & 7) ^ ((r >> 1) & 7);
+            const int k = c * 32 + q * 4;
+            if (k < KA) {
+              float4 *pos = reinterpret_cast<float4 *>(const_cast<unsigned char *>(sl) + i * 1024 + lane * 16);
+              float4 v = *pos;
+              const float4 sc = *reinterpret_cast<const float4 *>(s_scale + k);
+              const float4 sh = *reinterpret_cast<const float4 *>(s_shift + k);
+              v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y;
+              v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+              if (p.relu) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
+                v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+              }
+              *pos = v;
+              const long long row = r0 + r;
+              if (p.side != nullptr && row < M)
+                *reinterpret_cast<float4 *>(p.side + row * p.ld_side + k) = v;
+            }
+          }
+        }
       }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -366,10 +406,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void rows_stream_gemm_kernel
   }
 }
 
-size_t stream_lds_bytes(int NT, int K, int waves, int slots, bool gather) {
+size_t stream_lds_bytes(int NT, int K, int waves, int slots, int pro) {
   const int KS = (K + 15) / 16;
-  return (size_t)3 * 2 * KS * 32 * NT * 16 +
-         (size_t)waves * (slots * CHUNK_BYTES + (gather ? AUX_BYTES : 0));
+  return (size_t)3 * 2 * KS * 32 * NT * 16 + (pro == SPRO_BNRELU ? (size_t)2 * 2 * KS * 8 * 4 : 0) +
+         (size_t)waves * (slots * CHUNK_BYTES + (pro == SPRO_GATHER ? AUX_BYTES : 0));
 }
 
 int g_stream_on = -1, g_stream_grid = 0;
@@ -392,11 +432,11 @@ constexpr size_t LDS_LIMIT = 160 * 1024;
 struct StreamCfg { int waves, slots; };
 constexpr StreamCfg CFGS[4] = {{8, 3}, {4, 4}, {4, 3}, {4, 2}};   // (8,4) measured slower than (8,3)
 
-int pick_cfg(long long M, int N, int K, bool gather) {
+int pick_cfg(long long M, int N, int K, int pro) {
   if (M < STREAM_MIN_ROWS || N <= 0 || N > 128 || K <= 0) return -1;
   const int NT = N <= 64 ? 2 : 4;
   for (int c = 0; c < 4; ++c)
-    if (stream_lds_bytes(NT, K, CFGS[c].waves, CFGS[c].slots, gather) <= LDS_LIMIT) return c;
+    if (stream_lds_bytes(NT, K, CFGS[c].waves, CFGS[c].slots, pro) <= LDS_LIMIT) return c;
   return -1;
 }
 
@@ -427,10 +467,10 @@ int launch_cfg(const StreamArgs &a, int cfg, int blocks, size_t lds, hipStream_t
 template <int PRO>
 int launch_stream(const StreamArgs &a, hipStream_t st) {
   const int NT = a.N <= 64 ? 2 : 4;
-  const int cfg = pick_cfg(a.M, a.N, a.K, PRO == SPRO_GATHER);
+  const int cfg = pick_cfg(a.M, a.N, a.K, PRO);
   if (cfg < 0) return -2;
   const int waves = CFGS[cfg].waves;
-  const size_t lds = stream_lds_bytes(NT, a.K, waves, CFGS[cfg].slots, PRO == SPRO_GATHER);
+  const size_t lds = stream_lds_bytes(NT, a.K, waves, CFGS[cfg].slots, PRO);
   int blocks = g_stream_grid;
   if (a.partial != nullptr && blocks * waves > a.partial_rows) blocks = a.partial_rows / waves;
   if (blocks < 1) return -2;
@@ -451,7 +491,7 @@ int launch_stream(const StreamArgs &a, hipStream_t st) {
 // (plain operand: K, lda multiples of 4 and 16-byte aligned A; gather: C a multiple of 4,
 // C >= 100, ns in {16, 32, 64}).
 extern "C" int s2c_rows_stream_supported(long long M, int N, int K, int gather) {
-  if (!stream_on() || pick_cfg(M, N, K, gather != 0) < 0) return 0;
+  if (!stream_on() || pick_cfg(M, N, K, gather ? SPRO_GATHER : SPRO_BNRELU) < 0) return 0;
   if (gather) return (K - 3) % 4 == 0 && K - 3 >= 100;
   return K % 4 == 0;
 }
@@ -476,6 +516,25 @@ extern "C" int s2c_rows_stream_gemm(long long M, int N, int K, const float *A, i
   a.M = M; a.N = N; a.K = K; a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.Y = Y; a.ldy = ldy;
   a.partial = partial; a.partial_rows = partial_rows;
   return launch_stream<SPRO_NONE>(a, (hipStream_t)stream);
+}
+
+// Y = relu?(A * scale + shift) W^T with the activated operand written to `side` (M x K, may be
+// NULL): one pass over the pre-activation tensor A instead of s2c_bn_relu + s2c_rows_gemm.
+// Streaming kernel only: returns -2 when the shape is not taken (call the two separately).
+extern "C" int s2c_rows_gemm_bn_relu_side(long long M, int N, int K, const float *A, int lda,
+                                          const float *scale, const float *shift, int relu,
+                                          float *side, int ld_side, const float *W, int ldw,
+                                          float *Y, int ldy, float *partial, void *stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || !A || !W || !Y || !scale || !shift || lda < K || ldw < K)
+    return -1;
+  if (!s2c_rows_stream_supported(M, N, K, 0) || (lda & 3) || ((uintptr_t)A & 15) ||
+      (ldy & 3) || ((uintptr_t)Y & 15) || (side && ((ld_side & 3) || ((uintptr_t)side & 15))))
+    return -2;
+  StreamArgs a = {};
+  a.M = M; a.N = N; a.K = K; a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.Y = Y; a.ldy = ldy;
+  a.partial = partial; a.partial_rows = s2c_rows_gemm_blocks(M, N);
+  a.scale = scale; a.shift = shift; a.relu = relu; a.side = side; a.ld_side = ld_side;
+  return launch_stream<SPRO_BNRELU>(a, (hipStream_t)stream);
 }
 
 extern "C" int s2c_sa_gather_stream_gemm(int b, int n, int m, int ns, int C,

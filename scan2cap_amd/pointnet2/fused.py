@@ -37,6 +37,7 @@ _C.register("s2c_bn_relu_max", [_L, _I, _I, _P, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_bn_relu_bwd", [_L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_rows_gemm", [_L, _I, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _P])
 _C.register("s2c_sa_gather_gemm", [_I, _I, _I, _I, _I, _L, _L, _F, _I, _P, _P, _P, _P, _I, _P, _I, _P, _I, _P, _P])
+_C.register("s2c_rows_gemm_bn_relu_side", [_L, _I, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P])
 _C.register("s2c_bn_finalize_partials", [_I, _L, _I, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_weight_grad", [_L, _I, _I, _P, _L, _P, _L, _P, _I, _P, _P, _P])
 _C.register("s2c_bn_relu_max_bwd", [_L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P])
@@ -80,6 +81,9 @@ SCATTER_DW = True
 # Backward of a BN(+ReLU) layer: statistics pass, then ONE kernel that forms dY in the operand
 # load of the input-gradient GEMM dX = dY W (s2c_bn_bwd_gemm) -- no apply pass, no library GEMM
 import os as _os
+# the BN+ReLU pass between two layers folded into the next layer's streaming GEMM (the
+# activated operand leaves as a side output of csrc/s2c_gemm2.hip): S2C_FUSE_BNRELU_GEMM=0 = off
+FUSE_BNRELU_GEMM = _os.environ.get("S2C_FUSE_BNRELU_GEMM", "1") != "0"
 FUSE_BWD_GEMM = _os.environ.get("S2C_FUSE_BWD_GEMM", "1") != "0"
 # input gradients of the remaining layers (pooled / BN-free) through the hand-written GEMM
 # instead of torch.mm (hipBLASLt)
@@ -253,6 +257,28 @@ class LayerSpec(object):
         self.has_bias, self.bn, self.relu = has_bias, bn, relu
 
 
+def _next_takes_prologue(specs, params, pi, li, M, K):
+    """Can layer li+1 (its parameters start at params[pi]) run as the streaming GEMM with the
+    BN+ReLU prologue?  Same conditions as `gemm_stats` of the forward loop + the kernel's."""
+    nsp = specs[li + 1]
+    W = params[pi]
+    bn = nsp.bn
+    if not (USE_MFMA_GEMM and _gemm_split_on() and bn is not None and not nsp.has_bias
+            and (bn.training or bn.running_mean is None) and W.stride(1) == 1
+            and W.dtype == torch.float32 and W.is_cuda):
+        return False
+    return _stream_takes(M, W.shape[0], K)
+
+
+def _stream_takes(M, N, K):
+    lib = _C.load()
+    if not hasattr(lib, "_s2c_stream_sig"):
+        lib.s2c_rows_stream_supported.argtypes = [_L, _I, _I, _I]
+        lib.s2c_rows_stream_supported.restype = _I
+        lib._s2c_stream_sig = True
+    return bool(lib.s2c_rows_stream_supported(M, N, K, 0))
+
+
 class _MLPRows(Function):
     """forward(X, specs, pool_ns, *params) with params = per layer
     [W (Cout,Cin), bias?, gamma?, beta?].  pool_ns > 0: the last layer's
@@ -279,6 +305,7 @@ class _MLPRows(Function):
         nl = len(specs)
         partial = None
         out = None
+        deferred = None     # (Y, scale, shift, relu) of the previous layer: BN+ReLU not applied yet
         for li, sp in enumerate(specs):
             W = params[pi]; pi += 1
             bias = None
@@ -296,7 +323,8 @@ class _MLPRows(Function):
                     "implemented on the rows path; use a float momentum")
             from_gather = gather is not None and li == 0
             gemm_stats = (USE_MFMA_GEMM and train_stats and bias is None
-                          and W.stride(1) == 1 and (from_gather or A.stride(1) == 1))
+                          and W.stride(1) == 1
+                          and (from_gather or deferred is not None or A.stride(1) == 1))
             if from_gather:
                 assert bias is None and W.stride(1) == 1
                 g = gather
@@ -309,6 +337,20 @@ class _MLPRows(Function):
                       Y.data_ptr(), Cout, _ptr(gpart),
                       alg_bytes=4 * (min(g.B * g.N, M) * (3 + g.C) + M + M * Cout),
                       alg_flops=2 * M * (3 + g.C) * Cout)
+            elif deferred is not None:
+                # the previous layer's BN+ReLU happens in THIS layer's operand load; the
+                # activation (needed for the weight gradient) leaves as a side output
+                pY, pscale, pshift, prelu = deferred
+                deferred = None
+                nbg = _gemm_blocks(M, Cout)
+                gpart = torch.empty(nbg * 2 * Cout, device=dev)
+                Y = torch.empty((M, Cout), device=dev)
+                K_in = pY.shape[1]
+                A = torch.empty_like(pY)
+                _call("s2c_rows_gemm_bn_relu_side", Y, M, Cout, K_in, pY.data_ptr(), pY.stride(0),
+                      pscale.data_ptr(), pshift.data_ptr(), int(prelu), A.data_ptr(), K_in,
+                      W.data_ptr(), W.stride(0), Y.data_ptr(), Cout, gpart.data_ptr(),
+                      alg_bytes=4 * (2 * M * K_in + M * Cout), alg_flops=2 * M * K_in * Cout)
             elif gemm_stats:
                 # hand-written f32 MFMA GEMM; BN batch statistics come out of its
                 # epilogue as per-row-block partials (no extra pass over Y)
@@ -366,6 +408,9 @@ class _MLPRows(Function):
                           alg_bytes=4 * (M * Cout + 2 * J * Cout))
                     rec["arg"] = arg
                     rec["ymax"] = ymax
+                elif (FUSE_BNRELU_GEMM and not last and _next_takes_prologue(specs, params, pi, li, M, Cout)):
+                    deferred = (Y, scale, shift, sp.relu)
+                    A = None
                 else:
                     A = torch.empty_like(Y)
                     _call("s2c_bn_relu", Y, M, Cout, Y.data_ptr(), scale.data_ptr(),

@@ -856,3 +856,40 @@ def test_stream_gather_gemm_matches_gathered_rows(B, n, m, ns, C, N, normalize):
     p = part.view(nb, 2, N).double().sum(0)
     assert float((p[0] - ref.sum(0)).abs().max()) <= 1e-4 * float(ref.abs().sum(0).max())
     assert float((p[1] - (ref * ref).sum(0)).abs().max()) <= 1e-5 * float((ref * ref).sum(0).max())
+
+
+@pytest.mark.parametrize("M,N,K,relu", [(131072 + 5, 64, 64, 1), (140000, 128, 64, 1), (131072, 64, 128, 0)])
+def test_stream_gemm_bn_relu_prologue_equals_the_two_passes(M, N, K, relu):
+    """s2c_rows_gemm_bn_relu_side = s2c_bn_relu followed by s2c_rows_gemm: the activation it
+    writes back and its products are bit-identical (same arithmetic, same order)."""
+    import ctypes
+    from scan2cap_amd.pointnet2 import fused
+    _C, lib = _stream_lib()
+    torch.manual_seed(N + K)
+    Yp = torch.randn(M, K, device="cuda")
+    scale = torch.rand(K, device="cuda") + 0.5
+    shift = torch.randn(K, device="cuda") * 0.3
+    W = torch.randn(N, K, device="cuda") * 0.2
+    nb = lib.s2c_rows_gemm_blocks(M, N)
+    A1 = torch.full((M, K), float("nan"), device="cuda")
+    Y1 = torch.full((M, N), float("nan"), device="cuda")
+    p1 = torch.full((nb * 2 * N,), float("nan"), device="cuda")
+    _C.call("s2c_rows_gemm_bn_relu_side", M, N, K, Yp.data_ptr(), K, scale.data_ptr(), shift.data_ptr(),
+            relu, A1.data_ptr(), K, W.data_ptr(), K, Y1.data_ptr(), N, p1.data_ptr(), _C.stream_ptr())
+    A2 = torch.empty_like(Yp)
+    _C.call("s2c_bn_relu", M, K, Yp.data_ptr(), scale.data_ptr(), shift.data_ptr(), A2.data_ptr(), relu,
+            _C.stream_ptr())
+    Y2 = torch.empty((M, N), device="cuda")
+    p2 = torch.empty(nb * 2 * N, device="cuda")
+    _C.call("s2c_rows_gemm", M, N, K, A2.data_ptr(), K, W.data_ptr(), K, None, None,
+            Y2.data_ptr(), N, p2.data_ptr(), _C.stream_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(A1, A2)
+    assert torch.equal(Y1, Y2)
+    assert torch.equal(p1.view(nb, 2, N).sum(0), p2.view(nb, 2, N).sum(0))
+    # no side output requested: same products
+    Y3 = torch.full((M, N), float("nan"), device="cuda")
+    _C.call("s2c_rows_gemm_bn_relu_side", M, N, K, Yp.data_ptr(), K, scale.data_ptr(), shift.data_ptr(),
+            relu, None, 0, W.data_ptr(), K, Y3.data_ptr(), N, None, _C.stream_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(Y3, Y2)
