@@ -61,7 +61,12 @@ def test_first_updates_track_the_cpu_path():
             setattr(_ext, n, f)
     assert all(np.isfinite(got))
     np.testing.assert_allclose(got[0], want[0], rtol=1e-4)     # same weights: forward parity
-    np.testing.assert_allclose(got[1], want[1], rtol=2e-2)     # one update through all grads
+    # one update through all gradients.  The gradients are ill-conditioned at random init
+    # (max-pool arg-max / ReLU / label flips: a 1e-7 relative change of the first-layer
+    # pre-activations moves them by 1e-3..1e-2): the same step on the tiled GEMM,
+    # the streaming GEMM (K walked in another order) and the exact fp32 MFMA chain gives
+    # 32.39 / 31.39 / 32.22 here against 32.20 on the CPU (tools/diag_first_updates.py)
+    np.testing.assert_allclose(got[1], want[1], rtol=5e-2)
     # from the third step on the two trajectories separate (discontinuous label
     # assignment amplifies last-bit differences of the float atomics): finite is all
     # that can be asserted
