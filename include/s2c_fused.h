@@ -145,6 +145,10 @@ int s2c_rows_gemm_bn_relu_side(long long M, int N, int K, const float *A, int ld
                                const float *scale, const float *shift, int relu, float *side,
                                int ld_side, const float *W, int ldw, float *Y, int ldy,
                                float *partial, void *stream);
+/* workgroups of the streaming kernel's persistent grid (default 240): leave out the CUs held
+ * by kernels that run beside it on other streams (one FPS workgroup per scene).  Returns the
+ * previous value; workgroups <= 0 only queries. */
+int s2c_gemm_set_stream_grid(int workgroups);
 /* switch the streaming kernel on / off at run time; returns the previous setting */
 int s2c_gemm_set_stream(int on);
 /* Inference layers (frozen BatchNorm): out = [max over groups of pool_ns rows of]

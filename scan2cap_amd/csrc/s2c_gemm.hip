@@ -808,6 +808,22 @@ extern "C" int s2c_sa_gather_stream_gemm(int b, int n, int m, int ns, int C,
                                          int N, const float *W, int ldw, float *Y, int ldy,
                                          float *partial, int partial_rows, void *stream);
 
+extern "C" int s2c_rows_stream_gemm_bn_eval(long long M, int N, int K, const float *A, int lda,
+                                            const float *W, int ldw, const float *gamma,
+                                            const float *beta, const float *mean, const float *var,
+                                            float eps, int relu, int pool_ns, float *out, int ldo,
+                                            void *stream);
+extern "C" int s2c_sa_gather_stream_gemm_bn_eval(int b, int n, int m, int ns, int C,
+                                                 long long feat_row_stride,
+                                                 long long feat_batch_stride, float radius,
+                                                 int normalize, const float *xyz,
+                                                 const float *new_xyz, const float *feats,
+                                                 const int *idx, int N, const float *W, int ldw,
+                                                 const float *gamma, const float *beta,
+                                                 const float *mean, const float *var, float eps,
+                                                 int relu, int pool_ns, float *out, int ldo,
+                                                 void *stream);
+
 extern "C" int s2c_rows_gemm_blocks(long long M, int N) {
   const int BM = N <= 64 ? 256 : 128;
   return (int)((M + BM - 1) / BM);
@@ -939,6 +955,11 @@ extern "C" int s2c_rows_gemm_bn_eval(long long M, int N, int K, const float *A, 
   }
   GatherArgs ga = {};
   EpiArgs ep = {gamma, beta, mean, var, eps, relu, pool_ns, out, ldo};
+  if (use_split()) {
+    const int rc = s2c_rows_stream_gemm_bn_eval(M, N, K, A, lda, W, ldw, gamma, beta, mean, var,
+                                                eps, relu, pool_ns, out, ldo, stream);
+    if (rc != -2) return rc;
+  }
   if (use_split())
     return launch_x3<PRO_NONE>(M, N, K, A, lda, W, ldw, nullptr, nullptr, ga, out, ldo, nullptr,
                                (hipStream_t)stream, ep);
@@ -969,6 +990,13 @@ extern "C" int s2c_sa_gather_gemm_bn_eval(int b, int n, int m, int ns, int C,
   ga.frs = feat_row_stride; ga.fbs = feat_batch_stride;
   ga.n = n; ga.m = m; ga.ns = ns; ga.radius = radius; ga.normalize = normalize;
   EpiArgs ep = {gamma, beta, mean, var, eps, relu, pool_ns, out, ldo};
+  if (use_split()) {
+    const int rc = s2c_sa_gather_stream_gemm_bn_eval(b, n, m, ns, C, feat_row_stride,
+                                                     feat_batch_stride, radius, normalize, xyz,
+                                                     new_xyz, feats, idx, N, W, ldw, gamma, beta,
+                                                     mean, var, eps, relu, pool_ns, out, ldo, stream);
+    if (rc != -2) return rc;
+  }
   if (use_split())
     return launch_x3<PRO_GATHER>(M, N, K, nullptr, K, W, ldw, nullptr, nullptr, ga, out, ldo,
                                  nullptr, (hipStream_t)stream, ep);

@@ -62,6 +62,10 @@ struct StreamArgs {
   // when side != nullptr -- the activation the backward pass needs leaves with the GEMM that
   // consumes it instead of through a separate pass over the pre-activation tensor
   const float *scale, *shift; int relu; float *side; int ld_side;
+  // inference epilogue (ep_mean != nullptr): out = relu?(acc * sc[c] + sh[c]) with
+  // sc = gamma / sqrt(var + eps), sh = beta - mean * sc (affine_epilogue of s2c_gemm.hip),
+  // optionally max-pooled over groups of pool_ns consecutive rows; written to Y (row stride ldy)
+  const float *ep_gamma, *ep_beta, *ep_mean, *ep_var; float ep_eps; int ep_relu, pool_ns;
   const float *W; int ldw;
   float *Y; int ldy;
   float *partial; int partial_rows;
@@ -182,8 +186,15 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void rows_stream_gemm_kernel
   const long long tiles = (M + 31) >> 5;
   const long long wid = (long long)blockIdx.x * WAVES + wave, nw = (long long)gridDim.x * WAVES;
 
+  // the n-th tile of this wave: tiles of one pooling group (pool_ns = 64: two tiles) stay
+  // with one wave, groups are dealt round-robin over all waves of the grid
+  const int TG = p.pool_ns == 64 ? 2 : 1;
+  auto tile_at = [&](long long n) -> long long {
+    return TG == 1 ? wid + n * nw : (wid + (n >> 1) * nw) * 2 + (n & 1);
+  };
+
   // ---- issue cursor ---------------------------------------------------------------------
-  long long it_tile = wid;
+  long long it_n = 0, it_tile = tile_at(0);
   int it_c = 0, it_slot = 0, it_par = 0;
   const float *rp[4];                            // source rows of this lane's 4 DMA pieces
   const int dma_r0 = lane >> 3;                  // row of piece i: 8 i + dma_r0
@@ -224,7 +235,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void rows_stream_gemm_kernel
         glds4(src + 1, ctr_lds + par * 24 + 8);
         glds4(src + 2, ctr_lds + par * 24 + 16);
       }
-      if (t + nw < tiles) issue_idx(t + nw, par ^ 1);
+      const long long tn = tile_at(it_n + 1);
+      if (tn < tiles) issue_idx(tn, par ^ 1);
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -246,7 +258,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void rows_stream_gemm_kernel
     it_slot = it_slot + 1 == SLOTS ? 0 : it_slot + 1;
     if (++it_c == KC) {
       it_c = 0;
-      it_tile += nw;
+      it_tile = tile_at(++it_n);
       it_par ^= 1;
       if (it_tile < tiles) setup_rows(it_tile, it_par);
     }
@@ -267,10 +279,27 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void rows_stream_gemm_kernel
 #pragma unroll
   for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
 
+  // inference epilogue coefficients of this lane's columns
+  float esc[NT], esh[NT], gmax[NT][2];
+  if (p.ep_mean != nullptr) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = 32 * j + li;
+      esc[j] = esh[j] = 0.f;
+      if (col < N) {
+        const float invstd = 1.0f / sqrtf(p.ep_var[col] + p.ep_eps);
+        esc[j] = (p.ep_gamma ? p.ep_gamma[col] : 1.0f) * invstd;
+        esh[j] = (p.ep_beta ? p.ep_beta[col] : 0.0f) - p.ep_mean[col] * esc[j];
+      }
+      gmax[j][0] = gmax[j][1] = -INFINITY;
+    }
+  }
+
   const int swz = (li >> 1) & 7;
   int slot = 0, par = 0;
 #pragma unroll 1
-  for (long long t = wid; t < tiles; t += nw) {
+  for (long long n = 0; tile_at(n) < tiles; ++n) {
+    const long long t = tile_at(n);
     f32x16 acc[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j)
@@ -358,6 +387,49 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void rows_stream_gemm_kernel
     }
     par ^= 1;
 
+    if (p.ep_mean != nullptr && p.pool_ns > 0) {
+      // ---- inference: BN + ReLU + max over the pool_ns rows of a centre ----------------------
+      // lane (li, lk) holds rows 4 lk + {0..3, 8..11, 16..19, 24..27} of column li: e < 8 are
+      // rows 0..15, e >= 8 rows 16..31
+      const int ns = p.pool_ns;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          float v = acc[j][e] * esc[j] + esh[j];
+          if (p.ep_relu) v = fmaxf(v, 0.f);
+          const int h = ns == 16 ? (e >> 3) : 0;
+          if (h == 0) gmax[j][0] = fmaxf(gmax[j][0], v); else gmax[j][1] = fmaxf(gmax[j][1], v);
+        }
+      }
+      const bool flush = ns != 64 || (n & 1);
+      if (flush) {
+        const long long centres = M / ns;
+        const long long c0 = ns == 64 ? (t >> 1) : (ns == 32 ? t : 2 * t);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int col = 32 * j + li;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            if (h == 1 && ns != 16) continue;
+            const float m = fmaxf(gmax[j][h], __shfl_xor(gmax[j][h], 32, 64));
+            if (lk == 0 && col < N && c0 + h < centres) p.Y[(c0 + h) * p.ldy + col] = m;
+            gmax[j][h] = -INFINITY;
+          }
+        }
+      }
+      continue;
+    }
+    if (p.ep_mean != nullptr) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          float v = acc[j][e] * esc[j] + esh[j];
+          if (p.ep_relu) v = fmaxf(v, 0.f);
+          acc[j][e] = v;
+        }
+    }
     // ---- epilogue: statistics, 4x4 DPP transposes, dwordx4 stores -------------------------
     // C/D layout of 32x32: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
 #pragma unroll
@@ -494,6 +566,61 @@ extern "C" int s2c_rows_stream_supported(long long M, int N, int K, int gather) 
   if (!stream_on() || pick_cfg(M, N, K, gather ? SPRO_GATHER : SPRO_BNRELU) < 0) return 0;
   if (gather) return (K - 3) % 4 == 0 && K - 3 >= 100;
   return K % 4 == 0;
+}
+
+// Workgroups of the persistent grid (default 240 of the 256 CUs; S2C_GEMM_STREAM_GRID).  A
+// persistent workgroup that finds no free CU at launch starts when another one has FINISHED,
+// i.e. doubles the kernel's time -- so the grid must leave out the CUs held by kernels running
+// beside it (the geometry stage on the side stream: one FPS workgroup per scene for
+// milliseconds).  scan2cap_amd.pipeline.GeometrySlots sets 256 - scenes per pass - 8.
+// Returns the previous value.
+extern "C" int s2c_gemm_set_stream_grid(int workgroups) {
+  stream_on();
+  const int old = g_stream_grid;
+  if (workgroups > 0) g_stream_grid = workgroups > 1024 ? 1024 : workgroups;
+  return old;
+}
+
+// Inference variants (BatchNorm + ReLU (+ max-pool) in the epilogue): the contracts of
+// s2c_rows_gemm_bn_eval / s2c_sa_gather_gemm_bn_eval.  -2: shape not taken.
+extern "C" int s2c_rows_stream_gemm_bn_eval(long long M, int N, int K, const float *A, int lda,
+                                            const float *W, int ldw, const float *gamma,
+                                            const float *beta, const float *mean, const float *var,
+                                            float eps, int relu, int pool_ns, float *out, int ldo,
+                                            void *stream) {
+  if (!s2c_rows_stream_supported(M, N, K, 0) || (lda & 3) || ((uintptr_t)A & 15) ||
+      (ldo & 3) || ((uintptr_t)out & 15))
+    return -2;
+  StreamArgs a = {};
+  a.M = M; a.N = N; a.K = K; a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.Y = out; a.ldy = ldo;
+  a.ep_gamma = gamma; a.ep_beta = beta; a.ep_mean = mean; a.ep_var = var; a.ep_eps = eps;
+  a.ep_relu = relu; a.pool_ns = pool_ns;
+  return launch_stream<SPRO_NONE>(a, (hipStream_t)stream);
+}
+
+extern "C" int s2c_sa_gather_stream_gemm_bn_eval(int b, int n, int m, int ns, int C,
+                                                 long long feat_row_stride,
+                                                 long long feat_batch_stride, float radius,
+                                                 int normalize, const float *xyz,
+                                                 const float *new_xyz, const float *feats,
+                                                 const int *idx, int N, const float *W, int ldw,
+                                                 const float *gamma, const float *beta,
+                                                 const float *mean, const float *var, float eps,
+                                                 int relu, int pool_ns, float *out, int ldo,
+                                                 void *stream) {
+  const long long M = (long long)b * m * ns;
+  const int K = 3 + C;
+  if (!s2c_rows_stream_supported(M, N, K, 1) || !(ns == 16 || ns == 32 || ns == 64) ||
+      (ldo & 3) || ((uintptr_t)out & 15) || ((uintptr_t)feats & 3))
+    return -2;
+  StreamArgs a = {};
+  a.M = M; a.N = N; a.K = K; a.W = W; a.ldw = ldw; a.Y = out; a.ldy = ldo;
+  a.xyz = xyz; a.new_xyz = new_xyz; a.feats = feats; a.idx = idx;
+  a.frs = feat_row_stride; a.fbs = feat_batch_stride;
+  a.n = n; a.m = m; a.ns = ns; a.C = C; a.radius = radius; a.normalize = normalize;
+  a.ep_gamma = gamma; a.ep_beta = beta; a.ep_mean = mean; a.ep_var = var; a.ep_eps = eps;
+  a.ep_relu = relu; a.pool_ns = pool_ns;
+  return launch_stream<SPRO_GATHER>(a, (hipStream_t)stream);
 }
 
 // 1: tall eligible shapes run on the streaming kernel (default), 0: everything on the tiled

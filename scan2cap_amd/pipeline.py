@@ -14,6 +14,9 @@ all work of every batch is still executed, none is cached or skipped.
     pipe.attach(data_dict, h)                           # main stream waits on the event
     model(data_dict)
 """
+import ctypes as _ctypes
+import os as _os
+
 import torch
 
 
@@ -169,6 +172,14 @@ class GeometrySlots(object):
             raise ValueError("GeometrySlots: depth must be a multiple of group")
         self.streams = independent_streams(self.depth // self.group if self.group > 1
                                            else self.depth)
+        # the persistent GEMM grid on the main stream must fit beside this stage's FPS
+        # workgroups (one per scene of a pass, resident for milliseconds): measured optimum
+        # 256 - scenes - 8 (cfg3: 240, cfg2 with 3 batches per pass: 224)
+        if point_clouds.is_cuda and not _os.environ.get("S2C_GEMM_STREAM_GRID"):
+            from . import _C
+            lib = _C.load()
+            lib.s2c_gemm_set_stream_grid.argtypes = [_ctypes.c_int]
+            lib.s2c_gemm_set_stream_grid(max(64, 256 - point_clouds.shape[0] * self.group - 8))
         geo0 = backbone.compute_geometry(point_clouds)
         self._slots = []
         for _ in range(self.depth):

@@ -391,6 +391,11 @@ def test_device_prefetcher_delivers_identical_batches():
     (2, 4096, 5, 512, 0.3, 64, [64, 64, 128]),
     (2, 1024, 128, 256, 0.5, 32, [128, 128, 256]),
     (3, 700, 61, 90, 0.6, 16, [128, 128, 100]),
+    # >= 131072 rows: the streaming kernel's epilogue (csrc/s2c_gemm2.hip), pool over 64 rows =
+    # two tiles of one wave, 32 = one tile, 16 = two centres per tile
+    (2, 8192, 132, 2048, 0.3, 64, [64, 64, 128]),
+    (8, 2048, 128, 1024, 0.5, 32, [128, 128, 256]),
+    (16, 1024, 128, 512, 0.6, 16, [64, 64, 128]),
 ])
 def test_sa_inference_epilogue_matches_unfused(B, N, C, npoint, radius, ns, mlp):
     """eval() + no_grad: BN, ReLU and the max-pool leave with the GEMM
