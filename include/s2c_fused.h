@@ -46,6 +46,13 @@ int s2c_sa_scatter_rows(int b, int n, int m, int ns, int C, float radius,
  * dW = [ (Z^T xyz - S^T new_xyz)(/r) | Z^T feats ]  -- no (rows x (3+C)) operand. */
 int s2c_sa_scatter_sum(int b, int n, int m, int ns, int C, const float *dY, const int *idx,
                        float *Z, float *S, void *stream);
+/* the same with dY = BatchNorm(+ReLU) backward of (dA, Y) formed on the fly (coef from
+ * s2c_bn_relu_bwd_stats; the arithmetic of s2c_bn_relu_bwd): the first layer's dY is never
+ * written or re-read */
+int s2c_sa_scatter_sum_bn_bwd(int b, int n, int m, int ns, int C, const float *dA,
+                              const float *Y, const float *scale, const float *shift,
+                              const float *mean, const float *invstd, const float *coef,
+                              int relu, const int *idx, float *Z, float *S, void *stream);
 
 /* Feature propagation on point-major rows (pointnet2_modules.py:398-410):
  * out (b*n, C2+C1) = [ three_interpolate(known (b,m,C2), idx (b,n,3), weight (b,n,3)) |

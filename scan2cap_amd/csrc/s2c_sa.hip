@@ -159,9 +159,19 @@ extern "C" int s2c_sa_scatter_rows(int b, int n, int m, int ns, int C,
 // The two products run over B*N point rows instead of B*m*ns gathered rows, and the
 // (rows x (3+C)) operand (566 MB at SA1) is neither written nor re-read.
 // Block = one centre; wave = every 4th sample row; lane = channel (strided).
+// BNBWD: dY is not read but formed on the fly from the upstream gradient dA and the layer's
+// pre-activation Y (the arithmetic of bn_bwd_apply_kernel, bit for bit): the first layer of a
+// stack has no input gradient to produce, so its dY (268 MB at SA1) is neither written nor
+// re-read -- it only ever feeds these sums.
+struct BnBwdCoefs {
+  const float *Y, *scale, *shift, *mean, *invstd, *coef;   // coef = 3 C (s2c_bn_relu_bwd_stats)
+  int relu;
+};
+
+template <bool BNBWD>
 __global__ __launch_bounds__(256) void sa_scatter_sum_kernel(
     int n, int m, int ns, int C, const float *__restrict__ dY,
-    const int *__restrict__ idx, float *__restrict__ Z, float *__restrict__ S) {
+    const int *__restrict__ idx, float *__restrict__ Z, float *__restrict__ S, BnBwdCoefs bw) {
   __shared__ float s_sum[4][1024];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long bj = blockIdx.x;
@@ -169,11 +179,21 @@ __global__ __launch_bounds__(256) void sa_scatter_sum_kernel(
   for (int c0 = 0; c0 < C; c0 += 64) {
     const int c = c0 + lane;
     float acc = 0.f;
+    float sc = 0.f, sh = 0.f, mu = 0.f, is = 0.f, k0 = 0.f, k1 = 0.f, k2 = 0.f;
+    if (BNBWD && c < C) {
+      sc = bw.scale[c]; sh = bw.shift[c]; mu = bw.mean[c]; is = bw.invstd[c];
+      k0 = bw.coef[c]; k1 = bw.coef[C + c]; k2 = bw.coef[2 * C + c];
+    }
     for (int s = wave; s < ns; s += 4) {
       const long long r = bj * ns + s;
       const int p = idx[r];
       if (c < C) {
-        const float v = dY[r * C + c];
+        float v = dY[r * C + c];
+        if (BNBWD) {
+          const float y = bw.Y[r * C + c];
+          if (bw.relu && !(y * sc + sh > 0.f)) v = 0.f;
+          v = k0 * (v - k1 - ((y - mu) * is) * k2);
+        }
         acc += v;
         atomicAdd(Z + (b * n + p) * (long long)C + c, v);
       }
@@ -192,9 +212,27 @@ extern "C" int s2c_sa_scatter_sum(int b, int n, int m, int ns, int C, const floa
   hipStream_t st = (hipStream_t)stream;
   if (zero_async(Z, sizeof(float) * (size_t)b * n * C, st) != hipSuccess)
     return fail2("memset");
-  hipLaunchKernelGGL(sa_scatter_sum_kernel, dim3((unsigned)(b * m)), dim3(256), 0, st, n, m,
-                     ns, C, dY, idx, Z, S);
+  hipLaunchKernelGGL(sa_scatter_sum_kernel<false>, dim3((unsigned)(b * m)), dim3(256), 0, st, n,
+                     m, ns, C, dY, idx, Z, S, BnBwdCoefs());
   return check2("sa_scatter_sum");
+}
+
+// The same sums of dY = bn_relu_backward(dA, Y) without materialising dY (see BnBwdCoefs).
+extern "C" int s2c_sa_scatter_sum_bn_bwd(int b, int n, int m, int ns, int C, const float *dA,
+                                         const float *Y, const float *scale, const float *shift,
+                                         const float *mean, const float *invstd,
+                                         const float *coef, int relu, const int *idx, float *Z,
+                                         float *S, void *stream) {
+  if (b <= 0 || n <= 0 || m <= 0 || ns <= 0 || C <= 0 || C > 1024 || !dA || !Y || !scale ||
+      !shift || !mean || !invstd || !coef || !idx || !Z || !S)
+    return fail2("sa_scatter_sum_bn_bwd: sizes / null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (zero_async(Z, sizeof(float) * (size_t)b * n * C, st) != hipSuccess)
+    return fail2("memset");
+  BnBwdCoefs bw = {Y, scale, shift, mean, invstd, coef, relu};
+  hipLaunchKernelGGL(sa_scatter_sum_kernel<true>, dim3((unsigned)(b * m)), dim3(256), 0, st, n,
+                     m, ns, C, dA, idx, Z, S, bw);
+  return check2("sa_scatter_sum_bn_bwd");
 }
 
 // Feature propagation on point-major rows (PointnetFPModule.forward,

@@ -14,6 +14,7 @@ Both are torch.autograd.Functions with hand-written backward, so nothing of
 torch's conv / batch-norm / pooling machinery (MIOpen) is on the hot path.
 """
 import ctypes
+import os as _os
 
 import torch
 from torch.autograd import Function
@@ -25,6 +26,7 @@ _I, _L, _P, _F = ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_floa
 _C.register("s2c_sa_gather_rows", [_I, _I, _I, _I, _I, _L, _L, _F, _I, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_sa_scatter_rows", [_I, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_sa_scatter_sum", [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P])
+_C.register("s2c_sa_scatter_sum_bn_bwd", [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P])
 _C.register("s2c_fp_interp_rows", [_I, _I, _I, _I, _I, _P, _P, _P, _P, _L, _L, _P, _P])
 _C.register("s2c_fp_interp_rows_grad", [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P])
 _C.register("s2c_rows_gemm_bn_eval", [_L, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _F, _I, _I, _P, _I, _P])
@@ -76,6 +78,9 @@ USE_MFMA_GEMM = True
 # weight gradient of a gather-fused first layer from point-indexed sums when its
 # inputs need no gradient (no re-materialised operand)
 SCATTER_DW = True
+# the first layer's dY (it has no input gradient to feed) formed inside the point-sum kernel
+# from (dA, Y) instead of written by the BN-backward pass and read back: S2C_FUSE_DY_SCATTER=0 = off
+FUSE_DY_SCATTER = _os.environ.get("S2C_FUSE_DY_SCATTER", "1") != "0"
 
 
 # Backward of a BN(+ReLU) layer: statistics pass, then ONE kernel that forms dY in the operand
@@ -470,8 +475,21 @@ class _MLPRows(Function):
                 has_affine = rec["gamma"] is not None
                 dgamma = torch.empty(Cout, device=dev) if has_affine else None
                 dbeta = torch.empty(Cout, device=dev) if has_affine else None
-                dY = torch.empty_like(Y)
-                if li == nl - 1 and pool_ns > 0:
+                lazy_bn = None
+                dY = None if (lazy_dw and FUSE_DY_SCATTER and not (li == nl - 1 and pool_ns > 0)
+                              and not rec["has_bias"] and dA.stride(1) == 1
+                              and dA.stride(0) == Cout) else torch.empty_like(Y)
+                if dY is None:
+                    # statistics only; dY itself is formed inside GatherSpec.weight_grad
+                    _call("s2c_bn_relu_bwd_stats", Y, M, Cout, dA.data_ptr(), Y.data_ptr(),
+                          rec["scale"].data_ptr(), rec["shift"].data_ptr(),
+                          rec["mean"].data_ptr(), rec["invstd"].data_ptr(),
+                          _ptr(rec["gamma"]), int(rec["relu"]), int(rec["frozen"]),
+                          partial.data_ptr(), coef.data_ptr(), _ptr(dgamma),
+                          _ptr(dbeta), alg_bytes=4 * 2 * M * Cout)
+                    lazy_bn = (dA, Y, rec["scale"], rec["shift"], rec["mean"], rec["invstd"],
+                               coef, int(rec["relu"]))
+                elif li == nl - 1 and pool_ns > 0:
                     J = M // pool_ns
                     _call("s2c_bn_relu_max_bwd", Y, J, pool_ns, Cout, dA.data_ptr(),
                           rec["arg"].data_ptr(), rec["ymax"].data_ptr(), Y.data_ptr(),
@@ -512,7 +530,10 @@ class _MLPRows(Function):
                 dY = dA * (rec["Y"] > 0)
             else:
                 dY = dA
-            dW = gather.weight_grad(dY) if lazy_dw else _weight_grad(dY, A_in, pending)
+            if lazy_dw:
+                dW = gather.weight_grad(dY, bn_bwd=lazy_bn if sp.bn is not None else None)
+            else:
+                dW = _weight_grad(dY, A_in, pending)
             dbias = None
             if rec["has_bias"]:
                 if BATCH_PARTIAL_SUMS and dY.is_cuda and dY.dtype == torch.float32 \
@@ -796,17 +817,30 @@ class GatherSpec(object):
                              + self.rows + self.rows * (3 + self.C)))
         return X
 
-    def weight_grad(self, dY):
+    def weight_grad(self, dY, bn_bwd=None):
         """dW (Cout, 3+C) = dY^T G without building G (csrc/s2c_sa.hip:
-        sa_scatter_sum): the products run over the B*N points."""
-        dev = dY.device
-        Cout = dY.shape[1]
-        dY = dY.contiguous()
+        sa_scatter_sum): the products run over the B*N points.  bn_bwd = (dA, Y, scale,
+        shift, mean, invstd, coef, relu): dY is None and formed on the fly as the
+        BatchNorm(+ReLU) backward of dA (s2c_sa_scatter_sum_bn_bwd)."""
+        ref = dY if dY is not None else bn_bwd[0]
+        dev = ref.device
+        Cout = ref.shape[1]
         Z = torch.empty((self.B, self.N, Cout), device=dev)
         S = torch.empty((self.B, self.m, Cout), device=dev)
-        _call("s2c_sa_scatter_sum", dY, self.B, self.N, self.m, self.ns, Cout,
-              dY.data_ptr(), self.idx.data_ptr(), Z.data_ptr(), S.data_ptr(),
-              alg_bytes=4 * (self.rows * (Cout + 1) + (self.B * self.N + self.B * self.m) * Cout))
+        if bn_bwd is not None and dY is None:
+            dA, Y, scale, shift, mean, invstd, coef, relu = bn_bwd
+            _call("s2c_sa_scatter_sum_bn_bwd", dA, self.B, self.N, self.m, self.ns, Cout,
+                  dA.data_ptr(), Y.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                  mean.data_ptr(), invstd.data_ptr(), coef.data_ptr(), relu,
+                  self.idx.data_ptr(), Z.data_ptr(), S.data_ptr(),
+                  alg_bytes=4 * (self.rows * (2 * Cout + 1)
+                                 + (self.B * self.N + self.B * self.m) * Cout))
+        else:
+            dY = dY.contiguous()
+            _call("s2c_sa_scatter_sum", dY, self.B, self.N, self.m, self.ns, Cout,
+                  dY.data_ptr(), self.idx.data_ptr(), Z.data_ptr(), S.data_ptr(),
+                  alg_bytes=4 * (self.rows * (Cout + 1)
+                                 + (self.B * self.N + self.B * self.m) * Cout))
         Z2 = Z.view(self.B * self.N, Cout)
         dWx = _weight_grad(Z2, self.xyz.view(-1, 3)) - \
             _weight_grad(S.view(-1, Cout), self.new_xyz.view(-1, 3))

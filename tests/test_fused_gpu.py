@@ -898,3 +898,28 @@ def test_stream_gemm_bn_relu_prologue_equals_the_two_passes(M, N, K, relu):
             relu, None, 0, W.data_ptr(), K, Y3.data_ptr(), N, None, _C.stream_ptr())
     torch.cuda.synchronize()
     assert torch.equal(Y3, Y2)
+
+
+def test_first_layer_dY_formed_inside_the_point_sums():
+    """s2c_sa_scatter_sum_bn_bwd (dY = BN+ReLU backward of (dA, Y) formed on the fly) gives the
+    weight gradient of s2c_bn_relu_bwd + s2c_sa_scatter_sum (same values into the same atomics:
+    equal up to the atomics' order)."""
+    from scan2cap_amd.pointnet2 import fused
+    B, n, m, ns, C, Cout = 2, 3000, 256, 32, 61, 64
+    torch.manual_seed(5)
+    pc = torch.randn(B, n, 3 + C, device="cuda")
+    xyz, feats = pc[..., :3].contiguous(), pc[..., 3:]
+    inds = torch.stack([torch.randperm(n, device="cuda")[:m] for _ in range(B)])
+    new_xyz = torch.gather(xyz, 1, inds.unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    idx = torch.randint(0, n, (B, m, ns), device="cuda", dtype=torch.int32)
+    M = B * m * ns
+    dA, Y = torch.randn(M, Cout, device="cuda"), torch.randn(M, Cout, device="cuda")
+    scale, shift = torch.rand(Cout, device="cuda") + 0.5, torch.randn(Cout, device="cuda") * 0.2
+    mean, invstd = torch.randn(Cout, device="cuda") * 0.1, torch.rand(Cout, device="cuda") + 0.5
+    coef = torch.cat([scale, torch.randn(Cout, device="cuda") * 0.01, torch.randn(Cout, device="cuda") * 0.01])
+    g = fused.GatherSpec(xyz, new_xyz, feats, idx, 0.3, True)
+    got = g.weight_grad(None, bn_bwd=(dA, Y, scale, shift, mean, invstd, coef, 1))
+    dz = dA * ((Y * scale + shift) > 0)
+    dY = coef[:Cout] * (dz - coef[Cout:2 * Cout] - ((Y - mean) * invstd) * coef[2 * Cout:])
+    want = g.weight_grad(dY)
+    assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
