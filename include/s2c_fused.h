@@ -152,6 +152,22 @@ int s2c_rows_gemm_bn_relu_side(long long M, int N, int K, const float *A, int ld
                                const float *scale, const float *shift, int relu, float *side,
                                int ld_side, const float *W, int ldw, float *Y, int ldy,
                                float *partial, void *stream);
+/* Pooled last layer of a training stack on the streaming kernel: the products and statistics
+ * partials of s2c_rows_gemm_bn_relu_side (scale == NULL: plain operand), and per centre
+ * (pool_ns = 16 / 32 / 64 consecutive rows) and column the raw maximum / minimum of Y with the
+ * first row index of each (J x N, J = M / pool_ns) -- all that BatchNorm + ReLU + max-pool
+ * (pointnet2_modules.py:255-257) needs once the statistics are known: s2c_pool_select.
+ * Y may be NULL (not written).  -2: shape not taken. */
+int s2c_rows_gemm_pool_raw(long long M, int N, int K, const float *A, int lda, const float *scale,
+                           const float *shift, int relu, float *side, int ld_side,
+                           const float *W, int ldw, int pool_ns, float *raw_max, int *raw_amax,
+                           float *raw_min, int *raw_amin, float *Y, int ldy, float *partial,
+                           void *stream);
+/* out (J x C) = relu(y * scale + shift), arg, ymax (= y) with y = raw_max / raw_min by the
+ * sign of scale: the outputs of s2c_bn_relu_max */
+int s2c_pool_select(long long J, int C, const float *raw_max, const int *raw_amax,
+                    const float *raw_min, const int *raw_amin, const float *scale,
+                    const float *shift, float *out, int *arg, float *ymax, void *stream);
 /* workgroups of the streaming kernel's persistent grid (default 240): leave out the CUs held
  * by kernels that run beside it on other streams (one FPS workgroup per scene).  Returns the
  * previous value; workgroups <= 0 only queries. */

@@ -66,6 +66,12 @@ struct StreamArgs {
   // sc = gamma / sqrt(var + eps), sh = beta - mean * sc (affine_epilogue of s2c_gemm.hip),
   // optionally max-pooled over groups of pool_ns consecutive rows; written to Y (row stride ldy)
   const float *ep_gamma, *ep_beta, *ep_mean, *ep_var; float ep_eps; int ep_relu, pool_ns;
+  // training, pooled last layer (raw_max != nullptr): per (centre, column) the maximum and the
+  // minimum of Y over the pool_ns rows of the centre and the FIRST sample index of each; with
+  // the statistics partials this is all the BatchNorm + ReLU + max-pool that follows needs
+  // (relu(y * scale + shift) is monotone in y: its maximum sits at max y for scale >= 0, at min
+  // y otherwise), so Y itself need not be written (Y == nullptr)
+  float *raw_max, *raw_min; int *raw_amax, *raw_amin;
   const float *W; int ldw;
   float *Y; int ldy;
   float *partial; int partial_rows;
@@ -295,6 +301,15 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void rows_stream_gemm_kernel
     }
   }
 
+  float rmax[NT][2], rmin[NT][2];
+  int ramax[NT][2], ramin[NT][2];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      rmax[j][h] = -INFINITY; rmin[j][h] = INFINITY; ramax[j][h] = ramin[j][h] = 0;
+    }
+
   const int swz = (li >> 1) & 7;
   int slot = 0, par = 0;
 #pragma unroll 1
@@ -430,6 +445,54 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void rows_stream_gemm_kernel
           acc[j][e] = v;
         }
     }
+    if (p.raw_max != nullptr) {
+      // ---- training, pooled layer: running max / min (+ first index) per centre ------------
+      const int ns = p.pool_ns;
+      const int sbase = (ns == 64 && (n & 1)) ? 32 : 0;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {            // ascending rows of this lane: strict compares
+          const int rl = (e & 3) + 8 * (e >> 2) + 4 * lk;   // keep the first extremum
+          const float v = acc[j][e];
+          const int s = ns == 16 ? (rl & 15) : rl + sbase;
+          const int h = ns == 16 ? (e >> 3) : 0;
+          if (r0 + rl < M) {
+            if (h == 0) {
+              if (v > rmax[j][0]) { rmax[j][0] = v; ramax[j][0] = s; }
+              if (v < rmin[j][0]) { rmin[j][0] = v; ramin[j][0] = s; }
+            } else {
+              if (v > rmax[j][1]) { rmax[j][1] = v; ramax[j][1] = s; }
+              if (v < rmin[j][1]) { rmin[j][1] = v; ramin[j][1] = s; }
+            }
+          }
+        }
+      }
+      if (ns != 64 || (n & 1)) {
+        const long long centres = M / ns;
+        const long long c0 = ns == 64 ? (t >> 1) : (ns == 32 ? t : 2 * t);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int col = 32 * j + li;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            if (h == 1 && ns != 16) continue;
+            float v1 = rmax[j][h], v0 = rmin[j][h];
+            int a1 = ramax[j][h], a0 = ramin[j][h];
+            const float o1 = __shfl_xor(v1, 32, 64), o0 = __shfl_xor(v0, 32, 64);
+            const int b1 = __shfl_xor(a1, 32, 64), b0 = __shfl_xor(a0, 32, 64);
+            if (o1 > v1 || (o1 == v1 && b1 < a1)) { v1 = o1; a1 = b1; }
+            if (o0 < v0 || (o0 == v0 && b0 < a0)) { v0 = o0; a0 = b0; }
+            if (lk == 0 && col < N && c0 + h < centres) {
+              const long long o = (c0 + h) * N + col;
+              p.raw_max[o] = v1; p.raw_amax[o] = a1;
+              p.raw_min[o] = v0; p.raw_amin[o] = a0;
+            }
+            rmax[j][h] = -INFINITY; rmin[j][h] = INFINITY; ramax[j][h] = ramin[j][h] = 0;
+          }
+        }
+      }
+    }
     // ---- epilogue: statistics, 4x4 DPP transposes, dwordx4 stores -------------------------
     // C/D layout of 32x32: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
 #pragma unroll
@@ -444,6 +507,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void rows_stream_gemm_kernel
           a4[i] = v;
           if (r0 + 8 * g + 4 * lk + i < M && col < N) { s1[j] += v; s2[j] += v * v; }
         }
+        if (p.Y == nullptr) continue;             // statistics only (pooled training layer)
         quad_transpose(a4, lane);
         const long long row = r0 + 8 * g + 4 * lk + (lane & 3);
         const int c0 = 32 * j + (li & ~3);
@@ -662,6 +726,34 @@ extern "C" int s2c_rows_gemm_bn_relu_side(long long M, int N, int K, const float
   a.partial = partial; a.partial_rows = s2c_rows_gemm_blocks(M, N);
   a.scale = scale; a.shift = shift; a.relu = relu; a.side = side; a.ld_side = ld_side;
   return launch_stream<SPRO_BNRELU>(a, (hipStream_t)stream);
+}
+
+// The pooled LAST layer of a training stack: products as s2c_rows_gemm_bn_relu_side (scale ==
+// NULL: plain operand, no side output), statistics partials as s2c_rows_gemm, and instead of
+// (or, Y != NULL, besides) Y the per-centre raw extrema (StreamArgs::raw_max): the BatchNorm +
+// ReLU + max-pool that follows (s2c_pool_select) reads J x N values, not M x N.  -2: shape not
+// taken by the streaming kernel.
+extern "C" int s2c_rows_gemm_pool_raw(long long M, int N, int K, const float *A, int lda,
+                                      const float *scale, const float *shift, int relu,
+                                      float *side, int ld_side, const float *W, int ldw,
+                                      int pool_ns, float *raw_max, int *raw_amax, float *raw_min,
+                                      int *raw_amin, float *Y, int ldy, float *partial,
+                                      void *stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || !A || !W || !raw_max || !raw_amax || !raw_min || !raw_amin ||
+      lda < K || ldw < K || !(pool_ns == 16 || pool_ns == 32 || pool_ns == 64) || M % pool_ns)
+    return -1;
+  if (!s2c_rows_stream_supported(M, N, K, 0) || (lda & 3) || ((uintptr_t)A & 15) ||
+      (Y && ((ldy & 3) || ((uintptr_t)Y & 15))) ||
+      (side && ((ld_side & 3) || ((uintptr_t)side & 15))))
+    return -2;
+  StreamArgs a = {};
+  a.M = M; a.N = N; a.K = K; a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.Y = Y; a.ldy = ldy;
+  a.partial = partial; a.partial_rows = s2c_rows_gemm_blocks(M, N);
+  a.scale = scale; a.shift = shift; a.relu = relu; a.side = side; a.ld_side = ld_side;
+  a.pool_ns = pool_ns; a.raw_max = raw_max; a.raw_amax = raw_amax; a.raw_min = raw_min;
+  a.raw_amin = raw_amin;
+  if (scale != nullptr) return launch_stream<SPRO_BNRELU>(a, (hipStream_t)stream);
+  return launch_stream<SPRO_NONE>(a, (hipStream_t)stream);
 }
 
 extern "C" int s2c_sa_gather_stream_gemm(int b, int n, int m, int ns, int C,

@@ -615,6 +615,42 @@ extern "C" int s2c_bn_relu_max(long long J, int ns, int C, const float *Y,
   return check2("bn_relu_max");
 }
 
+// 4b. The same outputs from the per-centre raw extrema of Y (s2c_rows_gemm_pool_raw):
+// relu(y * scale + shift) is monotone in y, so its maximum over the rows of a centre is taken
+// at max y when scale >= 0 and at min y otherwise.  out / ymax as bn_relu_max; arg = the first
+// row of that extremum (where bn_relu_max's "first maximum AFTER the ReLU" differs -- every
+// row clamped to 0 -- the routed gradient is masked to zero anyway).
+__global__ __launch_bounds__(256) void pool_select_kernel(
+    const float *__restrict__ raw_max, const int *__restrict__ raw_amax,
+    const float *__restrict__ raw_min, const int *__restrict__ raw_amin,
+    const float *__restrict__ scale, const float *__restrict__ shift, float *__restrict__ out,
+    int *__restrict__ arg, float *__restrict__ ymax, long long total, int C) {
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total;
+       e += (long long)gridDim.x * 256) {
+    const int c = (int)(e % C);
+    const float sc = scale[c], sh = shift[c];
+    const bool up = sc >= 0.f;
+    const float y = up ? raw_max[e] : raw_min[e];
+    out[e] = fmaxf(y * sc + sh, 0.f);
+    arg[e] = up ? raw_amax[e] : raw_amin[e];
+    if (ymax != nullptr) ymax[e] = y;
+  }
+}
+
+extern "C" int s2c_pool_select(long long J, int C, const float *raw_max, const int *raw_amax,
+                               const float *raw_min, const int *raw_amin, const float *scale,
+                               const float *shift, float *out, int *arg, float *ymax,
+                               void *stream) {
+  if (J < 0 || C <= 0 || !raw_max || !raw_amax || !raw_min || !raw_amin || !scale || !shift ||
+      !out || !arg)
+    return fail2("pool_select: sizes / null pointer");
+  if (J == 0) return 0;
+  hipLaunchKernelGGL(pool_select_kernel, dim3(grid1d(J * C, 256)), dim3(256), 0,
+                     (hipStream_t)stream, raw_max, raw_amax, raw_min, raw_amin, scale, shift, out,
+                     arg, ymax, J * C, C);
+  return check2("pool_select");
+}
+
 // ---------------------------------------------------------------------------
 // 5. backward of BN(+ReLU):  dz = dA * [z > 0]   (z = Y*scale + shift)
 //    s1 = sum dz, s2 = sum dz * xhat            (xhat = (Y - mean) * invstd)

@@ -923,3 +923,74 @@ def test_first_layer_dY_formed_inside_the_point_sums():
     dY = coef[:Cout] * (dz - coef[Cout:2 * Cout] - ((Y - mean) * invstd) * coef[2 * Cout:])
     want = g.weight_grad(dY)
     assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
+# ---- pooled last layer without the pre-activation tensor ------------------------------------------
+@pytest.mark.parametrize("M,N,K,ns,pro", [(131072, 128, 64, 64, True), (131072 + 64, 64, 64, 64, False),
+                                          (135168, 128, 128, 32, True), (131072, 100, 64, 16, True)])
+def test_pool_raw_epilogue_and_select_equal_bn_relu_max(M, N, K, ns, pro):
+    """s2c_rows_gemm_pool_raw + s2c_pool_select (per-centre raw extrema of Y out of the GEMM's
+    epilogue, Y never written) vs s2c_rows_gemm + s2c_bn_relu_max on the materialised Y, with
+    scales of both signs."""
+    import ctypes
+    _C, lib = _stream_lib()
+    I, L, P = ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p
+    _C.register("s2c_rows_gemm_pool_raw", [L, I, I, P, I, P, P, I, P, I, P, I, I, P, P, P, P, P, I, P, P])
+    _C.register("s2c_pool_select", [L, I, P, P, P, P, P, P, P, P, P, P])
+    _C.register("s2c_bn_relu_max", [L, I, I, P, P, P, P, P, P, P])
+    _C.register("s2c_bn_relu", [L, I, P, P, P, P, I, P])
+    torch.manual_seed(N + ns)
+    Yp = torch.randn(M, K, device="cuda")
+    psc, psh = torch.rand(K, device="cuda") + 0.5, torch.randn(K, device="cuda") * 0.3
+    W = torch.randn(N, K, device="cuda") * 0.2
+    scale = torch.randn(N, device="cuda")                   # both signs
+    shift = torch.randn(N, device="cuda") * 0.5
+    J = M // ns
+    nb = lib.s2c_rows_gemm_blocks(M, N)
+    # reference: (BN+ReLU pass,) GEMM, pooled BN+ReLU
+    if pro:
+        A = torch.empty_like(Yp)
+        _C.call("s2c_bn_relu", M, K, Yp.data_ptr(), psc.data_ptr(), psh.data_ptr(), A.data_ptr(), 1, _C.stream_ptr())
+    else:
+        A = Yp
+    Y = torch.empty(M, N, device="cuda"); p_ref = torch.empty(nb * 2 * N, device="cuda")
+    _C.call("s2c_rows_gemm", M, N, K, A.data_ptr(), K, W.data_ptr(), K, None, None, Y.data_ptr(), N,
+            p_ref.data_ptr(), _C.stream_ptr())
+    Np = (N + 3) // 4 * 4
+    assert Np == N or True
+    out_r = torch.empty(J, N, device="cuda"); arg_r = torch.empty(J, N, dtype=torch.int32, device="cuda")
+    ym_r = torch.empty(J, N, device="cuda")
+    if N % 4 == 0:
+        _C.call("s2c_bn_relu_max", J, ns, N, Y.data_ptr(), scale.data_ptr(), shift.data_ptr(), out_r.data_ptr(),
+                arg_r.data_ptr(), ym_r.data_ptr(), _C.stream_ptr())
+    else:
+        v = torch.relu(Y.view(J, ns, N) * scale + shift)
+        out_r, a = v.max(1)
+        arg_r = a.to(torch.int32)
+        ym_r = torch.gather(Y.view(J, ns, N), 1, a.unsqueeze(1)).squeeze(1)
+    # streaming: raw extrema, then select
+    rmax = torch.full((J, N), float("nan"), device="cuda"); rmin = torch.full((J, N), float("nan"), device="cuda")
+    amax = torch.full((J, N), -1, dtype=torch.int32, device="cuda"); amin = torch.full((J, N), -1, dtype=torch.int32, device="cuda")
+    side = torch.empty_like(Yp) if pro else None
+    p_new = torch.full((nb * 2 * N,), float("nan"), device="cuda")
+    _C.call("s2c_rows_gemm_pool_raw", M, N, K, Yp.data_ptr(), K, psc.data_ptr() if pro else None,
+            psh.data_ptr() if pro else None, 1, side.data_ptr() if pro else None, K, W.data_ptr(), K, ns,
+            rmax.data_ptr(), amax.data_ptr(), rmin.data_ptr(), amin.data_ptr(), None, 0, p_new.data_ptr(),
+            _C.stream_ptr())
+    out = torch.empty(J, N, device="cuda"); arg = torch.empty(J, N, dtype=torch.int32, device="cuda")
+    ym = torch.empty(J, N, device="cuda")
+    _C.call("s2c_pool_select", J, N, rmax.data_ptr(), amax.data_ptr(), rmin.data_ptr(), amin.data_ptr(),
+            scale.data_ptr(), shift.data_ptr(), out.data_ptr(), arg.data_ptr(), ym.data_ptr(), _C.stream_ptr())
+    torch.cuda.synchronize()
+    Y3 = Y.view(J, ns, N)
+    assert torch.equal(rmax, Y3.max(1)[0]) and torch.equal(rmin, Y3.min(1)[0])
+    assert torch.equal(amax.long(), (Y3 == rmax.unsqueeze(1)).int().argmax(1))       # FIRST maximum
+    assert torch.equal(amin.long(), (Y3 == rmin.unsqueeze(1)).int().argmax(1))
+    if pro:
+        assert torch.equal(side, A)
+    # (pool_ns = 64 deals PAIRS of tiles to the waves: same addends, another order)
+    a, b = p_new.view(nb, 2, N).double().sum(0), p_ref.view(nb, 2, N).double().sum(0)
+    assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max())
+    assert torch.equal(out, out_r)
+    live = out_r > 0
+    assert torch.equal(ym[live], ym_r[live]) and torch.equal(arg[live], arg_r[live])
