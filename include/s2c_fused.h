@@ -168,6 +168,24 @@ int s2c_rows_gemm_pool_raw(long long M, int N, int K, const float *A, int lda, c
 int s2c_pool_select(long long J, int C, const float *raw_max, const int *raw_amax,
                     const float *raw_min, const int *raw_amin, const float *scale,
                     const float *shift, float *out, int *arg, float *ymax, void *stream);
+/* Backward of a max-pooled BatchNorm + ReLU layer WITHOUT its (M x C3) tensors Y3 / dY3
+ * (DESIGN 4.3): with Y3 = A W3^T, dY3 = dkrow - g (.) Y3 + e per channel, hence
+ *   dA  = dkrow W3 - A (W3^T diag(g) W3) + e W3           (s2c_pool_bwd_input_grad)
+ *   dW3 = SP - diag(g) W3 (A^T A) + e (x) colsum(A)        (SP: s2c_pool_bwd_sp)
+ * with dk = k0 * routed gradient (s2c_pool_bwd_dk), coef from s2c_bn_relu_max_bwd_stats. */
+int s2c_bn_relu_max_bwd_stats(long long J, int ns, int C, const float *dOut, const float *ymax,
+                              const float *scale, const float *shift, const float *mean,
+                              const float *invstd, const float *gamma, int frozen,
+                              float *partial, float *coef, float *dgamma, float *dbeta,
+                              void *stream);
+int s2c_pool_bwd_dk(long long J, int C, const float *dOut, const float *ymax, const float *scale,
+                    const float *shift, const float *coef, float *dk, void *stream);
+int s2c_pool_bwd_sp_blocks(long long J);
+int s2c_pool_bwd_sp(long long J, int ns, int C3, int K, const float *A, const int *arg,
+                    const float *dk, float *partial, void *stream);
+int s2c_pool_bwd_input_grad(long long M, int N, int KA, int C3, int ns, const float *A, int lda,
+                            const int *arg, const float *dk, const float *Wcat, int ldw,
+                            const float *cvec, float *dA, int ldd, void *stream);
 /* workgroups of the streaming kernel's persistent grid (default 240): leave out the CUs held
  * by kernels that run beside it on other streams (one FPS workgroup per scene).  Returns the
  * previous value; workgroups <= 0 only queries. */

@@ -51,7 +51,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int CHUNK_BYTES = 4096; // 32 rows x 32 floats
 constexpr int AUX_BYTES = 1088;   // gather: idx[2][32] int, xyz[2][32][3], centres[2][2][3] float
 
-enum { SPRO_NONE = 0, SPRO_BNRELU = 1, SPRO_GATHER = 2 };
+enum { SPRO_NONE = 0, SPRO_BNRELU = 1, SPRO_GATHER = 2, SPRO_POOLBWD = 3 };
+constexpr int PB_AUX_BYTES = 4096;   // pool-backward: arg[2][2][<=128] int, dk[2][2][<=128] float
 
 struct StreamArgs {
   long long M;
@@ -72,6 +73,14 @@ struct StreamArgs {
   // (relu(y * scale + shift) is monotone in y: its maximum sits at max y for scale >= 0, at min
   // y otherwise), so Y itself need not be written (Y == nullptr)
   float *raw_max, *raw_min; int *raw_amax, *raw_amin;
+  // SPRO_POOLBWD: input gradient of a max-pooled BatchNorm layer WITHOUT its (M x C3) tensors.
+  // With Y3 = A W3^T the layer's dY3 = dkrow - g (.) Y3 + e per channel (g = k0 k2 invstd,
+  // e = g mean - k0 k1; dkrow = k0 * routed upstream gradient, one nonzero per centre and
+  // channel), so dA = dY3 W3 = dkrow W3 - A G + cvec with G = W3^T diag(g) W3 (K x K).  The
+  // operand is [A (DMA, KA = pb_ka columns) | dkrow (generated from arg / dk, pb_c3 columns)],
+  // W = [-G^T | W3^T] (N x (KA + C3)), `bias` = cvec.  pb_arg / pb_dk: (J, C3), pb_ns rows per
+  // centre.
+  const int *pb_arg; const float *pb_dk; const float *bias; int pb_ka, pb_c3, pb_ns;
   const float *W; int ldw;
   float *Y; int ldy;
   float *partial; int partial_rows;
@@ -125,14 +134,14 @@ template <int NT, int PRO, int WAVES, int SLOTS>
 __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void rows_stream_gemm_kernel(StreamArgs p) {
   constexpr int NP = 32 * NT;
   constexpr int DEPTH = SLOTS - 1;
-  constexpr int AUXB = PRO == SPRO_GATHER ? AUX_BYTES : 0;
+  constexpr int AUXB = PRO == SPRO_GATHER ? AUX_BYTES : (PRO == SPRO_POOLBWD ? PB_AUX_BYTES : 0);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lk = lane >> 5;
   const long long M = p.M;
   const int N = p.N, K = p.K;
-  const int KA = PRO == SPRO_GATHER ? p.C : K;   // columns that arrive by DMA (multiple of 4)
+  const int KA = PRO == SPRO_GATHER ? p.C : (PRO == SPRO_POOLBWD ? p.pb_ka : K);   // DMA columns
   const int KC = (KA + 31) >> 5;                 // DMA chunks per tile
   const int KS = (K + 15) >> 4;                  // k16 steps per tile
   const int KB = 2 * KS;                         // k-blocks of 8 in the W planes
@@ -147,6 +156,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void rows_stream_gemm_kernel
   unsigned char *ring = mine;
   int *idxbuf = reinterpret_cast<int *>(mine + SLOTS * CHUNK_BYTES);          // [2][32]
   float *xyzbuf = reinterpret_cast<float *>(mine + SLOTS * CHUNK_BYTES + 256); // [2][32][3]
+  int *pb_argbuf = reinterpret_cast<int *>(mine + SLOTS * CHUNK_BYTES);           // [2][2][128]
+  float *pb_dkbuf = reinterpret_cast<float *>(mine + SLOTS * CHUNK_BYTES + 2048);  // [2][2][128]
+  const unsigned pbarg_lds = (unsigned)(size_t)pb_argbuf, pbdk_lds = (unsigned)(size_t)pb_dkbuf;
   const unsigned ring_lds = (unsigned)(size_t)ring;
   float *ctrbuf = reinterpret_cast<float *>(mine + SLOTS * CHUNK_BYTES + 1024);  // [2][2][3]
   const unsigned idx_lds = (unsigned)(size_t)idxbuf, xyz_lds = (unsigned)(size_t)xyzbuf;
@@ -252,6 +264,26 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void rows_stream_gemm_kernel
       }
     }
   };
+  // SPRO_POOLBWD: arg / dk rows of a tile's centre (two centres when pb_ns = 16), 16 B per lane.
+  // Requested at the START of the previous tile of this wave (two buffers by tile parity): the
+  // issue cursor runs up to two tiles ahead of the MFMAs, so tying these to it would overwrite a
+  // buffer whose tile has not reached its generated columns yet.
+  auto issue_pb = [&](long long t, int par) {
+    if (PRO == SPRO_POOLBWD) {
+      const int c3 = p.pb_c3;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (h == 1 && p.pb_ns != 16) continue;
+        long long row = t * 32 + 16 * h;
+        if (row >= M) row = M - 1;
+        const long long ctr = row / p.pb_ns;
+        if (lane * 4 < c3) {
+          glds16(p.pb_arg + ctr * c3 + lane * 4, pbarg_lds + (par * 2 + h) * 512);
+          glds16(p.pb_dk + ctr * c3 + lane * 4, pbdk_lds + (par * 2 + h) * 512);
+        }
+      }
+    }
+  };
   auto issue_next = [&]() -> bool {
     if (it_tile >= tiles) return false;
 #pragma unroll
@@ -277,6 +309,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void rows_stream_gemm_kernel
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     setup_rows(it_tile, 0);
+    issue_pb(it_tile, 0);
   }
 #pragma unroll 1
   for (int d = 0; d < DEPTH; ++d) issue_next();
@@ -301,6 +334,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void rows_stream_gemm_kernel
     }
   }
 
+  float pbias[NT];                               // SPRO_POOLBWD: cvec of this lane's columns
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+    pbias[j] = (PRO == SPRO_POOLBWD && p.bias != nullptr && 32 * j + li < N) ? p.bias[32 * j + li] : 0.f;
   float rmax[NT][2], rmin[NT][2];
   int ramax[NT][2], ramin[NT][2];
 #pragma unroll
@@ -315,6 +352,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void rows_stream_gemm_kernel
 #pragma unroll 1
   for (long long n = 0; tile_at(n) < tiles; ++n) {
     const long long t = tile_at(n);
+    if (PRO == SPRO_POOLBWD && tile_at(n + 1) < tiles) issue_pb(tile_at(n + 1), par ^ 1);
     f32x16 acc[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j)
@@ -380,6 +418,22 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void rows_stream_gemm_kernel
               va = make_float4(0.f, 0.f, 0.f, 0.f); vb = va;
             }
           }
+          if (PRO == SPRO_POOLBWD && ks * 16 >= KA) {
+            // generated columns: dkrow[r][c] = dk[centre][c] where arg[centre][c] is this row
+            const int cb = ks * 16 + lk * 8 - KA;
+            const int h = p.pb_ns == 16 ? (li >> 4) : 0;
+            const int srow = p.pb_ns == 16 ? (li & 15)
+                                           : li + ((p.pb_ns == 64 && (t & 1)) ? 32 : 0);
+            const int *ab = pb_argbuf + (par * 2 + h) * 128 + cb;
+            const float *db = pb_dkbuf + (par * 2 + h) * 128 + cb;
+            const int4 a0 = *reinterpret_cast<const int4 *>(ab), a1 = *reinterpret_cast<const int4 *>(ab + 4);
+            const float4 d0 = *reinterpret_cast<const float4 *>(db), d1 = *reinterpret_cast<const float4 *>(db + 4);
+            const bool in = cb < p.pb_c3;
+            va.x = (in && a0.x == srow) ? d0.x : 0.f; va.y = (in && a0.y == srow) ? d0.y : 0.f;
+            va.z = (in && a0.z == srow) ? d0.z : 0.f; va.w = (in && a0.w == srow) ? d0.w : 0.f;
+            vb.x = (in && a1.x == srow) ? d1.x : 0.f; vb.y = (in && a1.y == srow) ? d1.y : 0.f;
+            vb.z = (in && a1.z == srow) ? d1.z : 0.f; vb.w = (in && a1.w == srow) ? d1.w : 0.f;
+          }
           bf16x8 a[3];
           split8(va, vb, a);
           bf16x8 b[NT][3];
@@ -444,6 +498,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void rows_stream_gemm_kernel
           if (p.ep_relu) v = fmaxf(v, 0.f);
           acc[j][e] = v;
         }
+    }
+    if (PRO == SPRO_POOLBWD) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] += pbias[j];
     }
     if (p.raw_max != nullptr) {
       // ---- training, pooled layer: running max / min (+ first index) per centre ------------
@@ -545,7 +605,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void rows_stream_gemm_kernel
 size_t stream_lds_bytes(int NT, int K, int waves, int slots, int pro) {
   const int KS = (K + 15) / 16;
   return (size_t)3 * 2 * KS * 32 * NT * 16 + (pro == SPRO_BNRELU ? (size_t)2 * 2 * KS * 8 * 4 : 0) +
-         (size_t)waves * (slots * CHUNK_BYTES + (pro == SPRO_GATHER ? AUX_BYTES : 0));
+         (size_t)waves * (slots * CHUNK_BYTES +
+                          (pro == SPRO_GATHER ? AUX_BYTES : (pro == SPRO_POOLBWD ? PB_AUX_BYTES : 0)));
 }
 
 int g_stream_on = -1, g_stream_grid = 0;
@@ -754,6 +815,27 @@ extern "C" int s2c_rows_gemm_pool_raw(long long M, int N, int K, const float *A,
   a.raw_amin = raw_amin;
   if (scale != nullptr) return launch_stream<SPRO_BNRELU>(a, (hipStream_t)stream);
   return launch_stream<SPRO_NONE>(a, (hipStream_t)stream);
+}
+
+// dA (M x N) = [A | dkrow] [-G^T | W3^T]^T + cvec  (see StreamArgs::pb_arg): the input gradient
+// of a max-pooled BatchNorm(+ReLU) layer from the layer's INPUT activation A (M x KA), the
+// routed pooled gradient dk / arg (J x C3) and Wcat (N x (KA + C3)), bias cvec (N).  KA % 16 == 0,
+// C3 % 8 == 0, C3 <= 128, ns in {16, 32, 64}.  -2: shape not taken.
+extern "C" int s2c_pool_bwd_input_grad(long long M, int N, int KA, int C3, int ns, const float *A,
+                                       int lda, const int *arg, const float *dk,
+                                       const float *Wcat, int ldw, const float *cvec, float *dA,
+                                       int ldd, void *stream) {
+  if (M <= 0 || N <= 0 || KA <= 0 || C3 <= 0 || !A || !arg || !dk || !Wcat || !dA ||
+      lda < KA || ldw < KA + C3 || !(ns == 16 || ns == 32 || ns == 64) || M % ns)
+    return -1;
+  if (!stream_on() || (KA & 15) || (C3 & 7) || C3 > 128 || (lda & 3) || ((uintptr_t)A & 15) ||
+      (ldd & 3) || ((uintptr_t)dA & 15) || ((uintptr_t)arg & 15) || ((uintptr_t)dk & 15) ||
+      pick_cfg(M, N, KA + C3, SPRO_POOLBWD) < 0)
+    return -2;
+  StreamArgs a = {};
+  a.M = M; a.N = N; a.K = KA + C3; a.A = A; a.lda = lda; a.W = Wcat; a.ldw = ldw; a.Y = dA; a.ldy = ldd;
+  a.pb_arg = arg; a.pb_dk = dk; a.bias = cvec; a.pb_ka = KA; a.pb_c3 = C3; a.pb_ns = ns;
+  return launch_stream<SPRO_POOLBWD>(a, (hipStream_t)stream);
 }
 
 extern "C" int s2c_sa_gather_stream_gemm(int b, int n, int m, int ns, int C,

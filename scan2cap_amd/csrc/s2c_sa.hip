@@ -871,3 +871,97 @@ extern "C" int s2c_bn_relu_max_bwd(long long J, int ns, int C, const float *dOut
                      C >> 2, C);
   return check2("bn_relu_max_bwd");
 }
+
+// The statistics half of s2c_bn_relu_max_bwd only (pooled data: J x C): dgamma, dbeta, coef.
+extern "C" int s2c_bn_relu_max_bwd_stats(long long J, int ns, int C, const float *dOut,
+                                         const float *ymax, const float *scale,
+                                         const float *shift, const float *mean,
+                                         const float *invstd, const float *gamma, int frozen,
+                                         float *partial, float *coef, float *dgamma,
+                                         float *dbeta, void *stream) {
+  if (J <= 0 || ns <= 0 || C <= 0 || (C & 3) || C > 1024)
+    return fail2("bn_relu_max_bwd_stats: C%4==0");
+  hipStream_t st = (hipStream_t)stream;
+  long long rpb;
+  const int nb = stat_blocks(J, &rpb);
+  hipLaunchKernelGGL(pool_bwd_stats_kernel, dim3(nb), dim3(STAT_BLOCK), 0, st, dOut,
+                     ymax, scale, shift, mean, invstd, J, C, partial, rpb);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(FIN_BLOCK), 0, st,
+                     partial, nb, C, J * ns, frozen, gamma, invstd, dgamma, dbeta, coef);
+  return check2("bn_relu_max_bwd_stats");
+}
+
+// dk[j,c] = k0[c] * (ymax[j,c] * scale[c] + shift[c] > 0 ? dOut[j,c] : 0): the routed pooled
+// gradient times gamma * invstd (the one nonzero of k0 * dz per centre and channel).
+__global__ __launch_bounds__(256) void pool_bwd_dk_kernel(
+    const float *__restrict__ dOut, const float *__restrict__ ymax,
+    const float *__restrict__ scale, const float *__restrict__ shift,
+    const float *__restrict__ coef, float *__restrict__ dk, long long total, int C) {
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total;
+       e += (long long)gridDim.x * 256) {
+    const int c = (int)(e % C);
+    const float g = (ymax[e] * scale[c] + shift[c] > 0.f) ? dOut[e] : 0.f;
+    dk[e] = coef[c] * g;
+  }
+}
+
+// SP[c, k] = sum_j dk[j,c] * A[j * ns + arg[j,c], k]   (C3 x K): the routed part of the pooled
+// layer's weight gradient, read straight from the layer's INPUT activation A (M x K).
+// Thread = (channel c, quarter of the K columns); a workgroup walks its centres and writes one
+// partial (C3 x K) -- summed over workgroups by the caller (kernel boundary reduction).
+constexpr int SP_KQ = 16;      // columns per thread
+__global__ __launch_bounds__(256) void pool_bwd_sp_kernel(
+    long long J, int ns, int C3, int K, const float *__restrict__ A, const int *__restrict__ arg,
+    const float *__restrict__ dk, float *__restrict__ partial) {
+  const int per = K / SP_KQ;                 // threads per channel
+  const int cpb = 256 / per;                 // channels per pass
+  const int kq = threadIdx.x % per, cl = threadIdx.x / per;
+  for (int c0 = 0; c0 < C3; c0 += cpb) {
+    const int c = c0 + cl;
+    float acc[SP_KQ];
+#pragma unroll
+    for (int i = 0; i < SP_KQ; ++i) acc[i] = 0.f;
+    if (c < C3) {
+      for (long long j = blockIdx.x; j < J; j += gridDim.x) {
+        const float d = dk[j * C3 + c];
+        if (d != 0.f) {
+          const float4 *row = reinterpret_cast<const float4 *>(
+              A + (j * ns + arg[j * C3 + c]) * (long long)K + kq * SP_KQ);
+#pragma unroll
+          for (int i = 0; i < SP_KQ / 4; ++i) {
+            const float4 v = row[i];
+            acc[4 * i] += d * v.x; acc[4 * i + 1] += d * v.y;
+            acc[4 * i + 2] += d * v.z; acc[4 * i + 3] += d * v.w;
+          }
+        }
+      }
+      float *dst = partial + ((size_t)blockIdx.x * C3 + c) * K + kq * SP_KQ;
+#pragma unroll
+      for (int i = 0; i < SP_KQ; ++i) dst[i] = acc[i];
+    }
+  }
+}
+
+extern "C" int s2c_pool_bwd_dk(long long J, int C, const float *dOut, const float *ymax,
+                               const float *scale, const float *shift, const float *coef,
+                               float *dk, void *stream) {
+  if (J <= 0 || C <= 0 || !dOut || !ymax || !scale || !shift || !coef || !dk)
+    return fail2("pool_bwd_dk: sizes / null pointer");
+  hipLaunchKernelGGL(pool_bwd_dk_kernel, dim3(grid1d(J * C, 256)), dim3(256), 0,
+                     (hipStream_t)stream, dOut, ymax, scale, shift, coef, dk, J * C, C);
+  return check2("pool_bwd_dk");
+}
+
+extern "C" int s2c_pool_bwd_sp_blocks(long long J) { return J < 512 ? (int)J : 512; }
+
+// partial: s2c_pool_bwd_sp_blocks(J) x C3 x K floats.  K % 16 == 0, K <= 256.
+extern "C" int s2c_pool_bwd_sp(long long J, int ns, int C3, int K, const float *A, const int *arg,
+                               const float *dk, float *partial, void *stream) {
+  if (J <= 0 || ns <= 0 || C3 <= 0 || K <= 0 || (K % SP_KQ) || K > 256 * SP_KQ || 256 % (K / SP_KQ) ||
+      !A || !arg || !dk || !partial)
+    return fail2("pool_bwd_sp: sizes / null pointer");
+  hipLaunchKernelGGL(pool_bwd_sp_kernel, dim3(s2c_pool_bwd_sp_blocks(J)), dim3(256), 0,
+                     (hipStream_t)stream, J, ns, C3, K, A, arg, dk, partial);
+  return check2("pool_bwd_sp");
+}
+

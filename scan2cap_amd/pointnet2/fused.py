@@ -262,6 +262,80 @@ class LayerSpec(object):
         self.has_bias, self.bn, self.relu = has_bias, bn, relu
 
 
+_C.register("s2c_rows_gemm_pool_raw", [_L, _I, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P])
+_C.register("s2c_pool_select", [_L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P])
+_C.register("s2c_bn_relu_max_bwd_stats", [_L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P])
+_C.register("s2c_pool_bwd_dk", [_L, _I, _P, _P, _P, _P, _P, _P, _P])
+_C.register("s2c_pool_bwd_sp", [_L, _I, _I, _I, _P, _P, _P, _P, _P])
+_C.register("s2c_pool_bwd_input_grad", [_L, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _P, _I, _P])
+
+# The pooled LAST layer of a training stack without its (M x C3) pre-activation / gradient
+# tensors (DESIGN 4.3 "pooled layer algebra"): forward = raw extrema out of the GEMM epilogue,
+# backward = input / weight gradients from the layer's INPUT activation.  S2C_POOL_ALGEBRA=0: off.
+POOL_ALGEBRA = _os.environ.get("S2C_POOL_ALGEBRA", "1") != "0"
+
+
+def pool_algebra_takes(M, Cout, K_in, pool_ns):
+    return (POOL_ALGEBRA and pool_ns in (16, 32, 64) and M % pool_ns == 0 and Cout <= 128
+            and Cout % 8 == 0 and K_in % 16 == 0 and _gemm_split_on()
+            and _stream_takes(M, Cout, K_in) and _stream_takes(M, K_in, K_in + Cout))
+
+
+def pooled_layer_backward(dOut, arg, ymax, scale, shift, mean, invstd, gamma, frozen, A, W, ns,
+                          need_dA=True):
+    """Gradients of out = max over ns rows of relu(BN(A W^T)) w.r.t. A (M x K), W (C3 x K),
+    gamma, beta, given dOut (J x C3) -- without Y3 = A W^T or dY3 (M x C3 each):
+        dY3 = dkrow - g (.) Y3 + e   per channel, g = k0 k2 invstd, e = g mean - k0 k1,
+        dA  = dkrow W - A (W^T diag(g) W) + e W,
+        dW  = SP - diag(g) W (A^T A) + e (x) colsum(A),   SP[c] = sum_j dk[j,c] A[row(j,c)].
+    (coef k0 k1 k2 = the statistics of s2c_bn_relu_max_bwd; float64 for the small matrices.)"""
+    dev = dOut.device
+    J, C3 = dOut.shape
+    M, K = A.shape
+    nb = _stat_blocks(J)
+    partial = torch.empty(nb * 2 * max(C3, 256), device=dev)
+    coef = torch.empty(3 * C3, device=dev)
+    has_affine = gamma is not None
+    dgamma = torch.empty(C3, device=dev) if has_affine else None
+    dbeta = torch.empty(C3, device=dev) if has_affine else None
+    dOut = dOut.contiguous()
+    _call("s2c_bn_relu_max_bwd_stats", dOut, J, ns, C3, dOut.data_ptr(), ymax.data_ptr(),
+          scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), _ptr(gamma),
+          int(frozen), partial.data_ptr(), coef.data_ptr(), _ptr(dgamma), _ptr(dbeta),
+          alg_bytes=4 * 2 * J * C3)
+    dk = torch.empty_like(dOut)
+    _call("s2c_pool_bwd_dk", dOut, J, C3, dOut.data_ptr(), ymax.data_ptr(), scale.data_ptr(),
+          shift.data_ptr(), coef.data_ptr(), dk.data_ptr(), alg_bytes=4 * 3 * J * C3)
+    k0, k1, k2 = coef[:C3].double(), coef[C3:2 * C3].double(), coef[2 * C3:].double()
+    g = k0 * k2 * invstd.double()
+    e = g * mean.double() - k0 * k1
+    Wd = W.double()
+    # ---- weight gradient -------------------------------------------------------------------
+    lib = _C.load()
+    lib.s2c_pool_bwd_sp_blocks.argtypes = [_L]
+    lib.s2c_pool_bwd_sp_blocks.restype = _I
+    nblk = lib.s2c_pool_bwd_sp_blocks(J)
+    sp = torch.empty((nblk, C3 * K), device=dev)
+    _call("s2c_pool_bwd_sp", A, J, ns, C3, K, A.data_ptr(), arg.data_ptr(), dk.data_ptr(),
+          sp.data_ptr(), alg_bytes=4 * (M * K + 2 * J * C3 + nblk * C3 * K))
+    SP = sp.sum(0, dtype=torch.float64).view(C3, K)
+    gram = _weight_grad(A, A).double()                      # A^T A  (K x K)
+    colsum = A.sum(0, dtype=torch.float64)
+    dW = (SP - (g.unsqueeze(1) * Wd) @ gram + e.unsqueeze(1) * colsum.unsqueeze(0)).float()
+    # ---- input gradient --------------------------------------------------------------------
+    dA = None
+    if need_dA:
+        G = Wd.t() @ (g.unsqueeze(1) * Wd)                  # K x K
+        cvec = (e @ Wd).float().contiguous()                # K
+        Wcat = torch.cat([(-G.t()).float(), W.t()], 1).contiguous()      # (K, K + C3)
+        dA = torch.empty((M, K), device=dev)
+        _call("s2c_pool_bwd_input_grad", A, M, K, K, C3, ns, A.data_ptr(), A.stride(0),
+              arg.data_ptr(), dk.data_ptr(), Wcat.data_ptr(), Wcat.stride(0), cvec.data_ptr(),
+              dA.data_ptr(), K, alg_bytes=4 * (2 * M * K + 2 * J * C3),
+              alg_flops=2 * M * K * (K + C3))
+    return dA, dW, dgamma, dbeta
+
+
 def _next_takes_prologue(specs, params, pi, li, M, K):
     """Can layer li+1 (its parameters start at params[pi]) run as the streaming GEMM with the
     BN+ReLU prologue?  Same conditions as `gemm_stats` of the forward loop + the kernel's."""

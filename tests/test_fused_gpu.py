@@ -994,3 +994,48 @@ def test_pool_raw_epilogue_and_select_equal_bn_relu_max(M, N, K, ns, pro):
     assert torch.equal(out, out_r)
     live = out_r > 0
     assert torch.equal(ym[live], ym_r[live]) and torch.equal(arg[live], arg_r[live])
+
+
+@pytest.mark.parametrize("J,ns,K,C3", [(2048, 64, 64, 128), (4096, 32, 64, 64), (8192, 16, 64, 128), (4096, 32, 32, 96)])
+def test_pooled_layer_backward_algebra_matches_the_materialised_path(J, ns, K, C3):
+    """fused.pooled_layer_backward (no Y3 / dY3: dA = dkrow W - A G + e W on the streaming kernel,
+    dW = SP - diag(g) W A^T A + e (x) colsum A) against s2c_bn_relu_max_bwd on the materialised
+    Y3 followed by dense products, in float64."""
+    import ctypes
+    from scan2cap_amd.pointnet2 import fused
+    from scan2cap_amd import _C
+    I, L, P = ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p
+    _C.register("s2c_bn_relu_max_bwd", [L, I, I, P, P, P, P, P, P, P, P, P, I, P, P, P, P, P, P])
+    _C.register("s2c_bn_relu_max", [L, I, I, P, P, P, P, P, P, P])
+    torch.manual_seed(J + C3)
+    M = J * ns
+    A = torch.relu(torch.randn(M, K, device="cuda"))
+    W = torch.randn(C3, K, device="cuda") * 0.2
+    Y = A @ W.t()
+    gamma = torch.randn(C3, device="cuda")                  # both signs
+    beta = torch.randn(C3, device="cuda") * 0.3
+    mean, var = Y.mean(0), Y.var(0, unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    scale = gamma * invstd
+    shift = beta - mean * scale
+    out = torch.empty(J, C3, device="cuda"); arg = torch.empty(J, C3, dtype=torch.int32, device="cuda")
+    ymax = torch.empty(J, C3, device="cuda")
+    _C.call("s2c_bn_relu_max", J, ns, C3, Y.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.data_ptr(),
+            arg.data_ptr(), ymax.data_ptr(), _C.stream_ptr())
+    dOut = torch.randn(J, C3, device="cuda")
+    # materialised reference
+    nb = fused._stat_blocks(J)
+    partial = torch.empty(nb * 2 * max(C3, 256), device="cuda"); coef = torch.empty(3 * C3, device="cuda")
+    dg = torch.empty(C3, device="cuda"); db = torch.empty(C3, device="cuda"); dY = torch.empty_like(Y)
+    _C.call("s2c_bn_relu_max_bwd", J, ns, C3, dOut.data_ptr(), arg.data_ptr(), ymax.data_ptr(), Y.data_ptr(),
+            scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), 0,
+            partial.data_ptr(), coef.data_ptr(), dg.data_ptr(), db.data_ptr(), dY.data_ptr(), _C.stream_ptr())
+    dA_ref = dY.double() @ W.double()
+    dW_ref = dY.double().t() @ A.double()
+    assert fused.pool_algebra_takes(M, C3, K, ns)
+    dA, dW, dgamma, dbeta = fused.pooled_layer_backward(dOut, arg, ymax, scale, shift, mean, invstd, gamma,
+                                                        False, A, W, ns)
+    torch.cuda.synchronize()
+    assert torch.equal(dgamma, dg) and torch.equal(dbeta, db)
+    assert float((dA.double() - dA_ref).abs().max()) <= 2e-5 * float(dA_ref.abs().max())
+    assert float((dW.double() - dW_ref).abs().max()) <= 2e-5 * float(dW_ref.abs().max())
