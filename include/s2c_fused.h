@@ -178,13 +178,15 @@ int s2c_bn_relu_max_bwd_stats(long long J, int ns, int C, const float *dOut, con
                               const float *invstd, const float *gamma, int frozen,
                               float *partial, float *coef, float *dgamma, float *dbeta,
                               void *stream);
+/* dk and (arg16 != NULL) the arg-max rows as int16 for s2c_pool_bwd_input_grad */
 int s2c_pool_bwd_dk(long long J, int C, const float *dOut, const float *ymax, const float *scale,
-                    const float *shift, const float *coef, float *dk, void *stream);
+                    const float *shift, const float *coef, const int *arg, float *dk,
+                    short *arg16, void *stream);
 int s2c_pool_bwd_sp_blocks(long long J);
 int s2c_pool_bwd_sp(long long J, int ns, int C3, int K, const float *A, const int *arg,
                     const float *dk, float *partial, void *stream);
 int s2c_pool_bwd_input_grad(long long M, int N, int KA, int C3, int ns, const float *A, int lda,
-                            const int *arg, const float *dk, const float *Wcat, int ldw,
+                            const short *arg16, const float *dk, const float *Wcat, int ldw,
                             const float *cvec, float *dA, int ldd, void *stream);
 /* workgroups of the streaming kernel's persistent grid (default 240): leave out the CUs held
  * by kernels that run beside it on other streams (one FPS workgroup per scene).  Returns the

@@ -52,7 +52,7 @@ constexpr int CHUNK_BYTES = 4096; // 32 rows x 32 floats
 constexpr int AUX_BYTES = 1088;   // gather: idx[2][32] int, xyz[2][32][3], centres[2][2][3] float
 
 enum { SPRO_NONE = 0, SPRO_BNRELU = 1, SPRO_GATHER = 2, SPRO_POOLBWD = 3 };
-constexpr int PB_AUX_BYTES = 4096;   // pool-backward: arg[2][2][<=128] int, dk[2][2][<=128] float
+constexpr int PB_AUX_BYTES = 3072;   // pool-backward: arg[2][2][<=128] int16, dk[2][2][<=128] float
 
 struct StreamArgs {
   long long M;
@@ -80,7 +80,7 @@ struct StreamArgs {
   // operand is [A (DMA, KA = pb_ka columns) | dkrow (generated from arg / dk, pb_c3 columns)],
   // W = [-G^T | W3^T] (N x (KA + C3)), `bias` = cvec.  pb_arg / pb_dk: (J, C3), pb_ns rows per
   // centre.
-  const int *pb_arg; const float *pb_dk; const float *bias; int pb_ka, pb_c3, pb_ns;
+  const short *pb_arg; const float *pb_dk; const float *bias; int pb_ka, pb_c3, pb_ns;
   const float *W; int ldw;
   float *Y; int ldy;
   float *partial; int partial_rows;
@@ -130,8 +130,13 @@ __device__ __forceinline__ void split8(const float4 &va, const float4 &vb, bf16x
 
 // NT: 32-column MFMA tiles per wave (N <= 32 NT); WAVES per workgroup (one workgroup per CU);
 // SLOTS: ring slots per wave, SLOTS - 1 chunks requested ahead of the one being consumed.
-template <int NT, int PRO, int WAVES, int SLOTS>
-__global__ __launch_bounds__(64 * WAVES, WAVES / 4) void rows_stream_gemm_kernel(StreamArgs p) {
+// EPI: 0 = Y + statistics partials (training), 1 = raw per-centre extrema (+ statistics; pooled
+// training layer), 2 = inference epilogue (BatchNorm + ReLU (+ max-pool)).  A template parameter
+// because each keeps its own per-lane state: as run-time branches the three together spilled
+// the NT = 4 kernels to scratch.
+enum { EPI_TRAIN = 0, EPI_RAW = 1, EPI_EVAL = 2 };
+template <int NT, int PRO, int WAVES, int SLOTS, int EPI>
+__global__ __launch_bounds__(64 * WAVES, (NT == 4 && WAVES == 4) ? 1 : 2) void rows_stream_gemm_kernel(StreamArgs p) {
   constexpr int NP = 32 * NT;
   constexpr int DEPTH = SLOTS - 1;
   constexpr int AUXB = PRO == SPRO_GATHER ? AUX_BYTES : (PRO == SPRO_POOLBWD ? PB_AUX_BYTES : 0);
@@ -156,8 +161,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void rows_stream_gemm_kernel
   unsigned char *ring = mine;
   int *idxbuf = reinterpret_cast<int *>(mine + SLOTS * CHUNK_BYTES);          // [2][32]
   float *xyzbuf = reinterpret_cast<float *>(mine + SLOTS * CHUNK_BYTES + 256); // [2][32][3]
-  int *pb_argbuf = reinterpret_cast<int *>(mine + SLOTS * CHUNK_BYTES);           // [2][2][128]
-  float *pb_dkbuf = reinterpret_cast<float *>(mine + SLOTS * CHUNK_BYTES + 2048);  // [2][2][128]
+  short *pb_argbuf = reinterpret_cast<short *>(mine + SLOTS * CHUNK_BYTES);        // [2][2][128]
+  float *pb_dkbuf = reinterpret_cast<float *>(mine + SLOTS * CHUNK_BYTES + 1024);  // [2][2][128]
   const unsigned pbarg_lds = (unsigned)(size_t)pb_argbuf, pbdk_lds = (unsigned)(size_t)pb_dkbuf;
   const unsigned ring_lds = (unsigned)(size_t)ring;
   float *ctrbuf = reinterpret_cast<float *>(mine + SLOTS * CHUNK_BYTES + 1024);  // [2][2][3]
@@ -277,10 +282,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void rows_stream_gemm_kernel
         long long row = t * 32 + 16 * h;
         if (row >= M) row = M - 1;
         const long long ctr = row / p.pb_ns;
-        if (lane * 4 < c3) {
-          glds16(p.pb_arg + ctr * c3 + lane * 4, pbarg_lds + (par * 2 + h) * 512);
-          glds16(p.pb_dk + ctr * c3 + lane * 4, pbdk_lds + (par * 2 + h) * 512);
-        }
+        if (lane * 8 < c3) glds16(p.pb_arg + ctr * c3 + lane * 8, pbarg_lds + (par * 2 + h) * 256);
+        if (lane * 4 < c3) glds16(p.pb_dk + ctr * c3 + lane * 4, pbdk_lds + (par * 2 + h) * 512);
       }
     }
   };
@@ -319,8 +322,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void rows_stream_gemm_kernel
   for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
 
   // inference epilogue coefficients of this lane's columns
-  float esc[NT], esh[NT], gmax[NT][2];
-  if (p.ep_mean != nullptr) {
+  constexpr int NE = EPI == EPI_EVAL ? NT : 1, NR = EPI == EPI_RAW ? NT : 1;
+  float esc[NE], esh[NE], gmax[NE][2];
+  if constexpr (EPI == EPI_EVAL) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int col = 32 * j + li;
@@ -334,14 +338,20 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void rows_stream_gemm_kernel
     }
   }
 
+  // SPRO_POOLBWD per-lane constants (kept in VGPRs: the scalar registers are over-subscribed
+  // and a kernarg re-load inside the k loop stalls a wave that has no sibling on its SIMD)
+  const int pb_srow0 = PRO == SPRO_POOLBWD ? (p.pb_ns == 16 ? (li & 15) : li) + 0 * lane : 0;
+  const int pb_sodd = PRO == SPRO_POOLBWD ? (p.pb_ns == 64 ? 32 : 0) + 0 * lane : 0;
+  const int pb_hoff = PRO == SPRO_POOLBWD ? (p.pb_ns == 16 ? (li >> 4) * 128 : 0) + 0 * lane : 0;
+  const int pb_c3v = PRO == SPRO_POOLBWD ? p.pb_c3 + 0 * lane : 0;
   float pbias[NT];                               // SPRO_POOLBWD: cvec of this lane's columns
 #pragma unroll
   for (int j = 0; j < NT; ++j)
     pbias[j] = (PRO == SPRO_POOLBWD && p.bias != nullptr && 32 * j + li < N) ? p.bias[32 * j + li] : 0.f;
-  float rmax[NT][2], rmin[NT][2];
-  int ramax[NT][2], ramin[NT][2];
+  float rmax[NR][2], rmin[NR][2];
+  int ramax[NR][2], ramin[NR][2];
 #pragma unroll
-  for (int j = 0; j < NT; ++j)
+  for (int j = 0; j < NR; ++j)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       rmax[j][h] = -INFINITY; rmin[j][h] = INFINITY; ramax[j][h] = ramin[j][h] = 0;
@@ -421,18 +431,16 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void rows_stream_gemm_kernel
           if (PRO == SPRO_POOLBWD && ks * 16 >= KA) {
             // generated columns: dkrow[r][c] = dk[centre][c] where arg[centre][c] is this row
             const int cb = ks * 16 + lk * 8 - KA;
-            const int h = p.pb_ns == 16 ? (li >> 4) : 0;
-            const int srow = p.pb_ns == 16 ? (li & 15)
-                                           : li + ((p.pb_ns == 64 && (t & 1)) ? 32 : 0);
-            const int *ab = pb_argbuf + (par * 2 + h) * 128 + cb;
-            const float *db = pb_dkbuf + (par * 2 + h) * 128 + cb;
-            const int4 a0 = *reinterpret_cast<const int4 *>(ab), a1 = *reinterpret_cast<const int4 *>(ab + 4);
+            const int srow = pb_srow0 + ((t & 1) ? pb_sodd : 0);
+            const short *ab = pb_argbuf + par * 256 + pb_hoff + cb;
+            const float *db = pb_dkbuf + par * 256 + pb_hoff + cb;
+            const uint4 aw = *reinterpret_cast<const uint4 *>(ab);              // 8 x int16
             const float4 d0 = *reinterpret_cast<const float4 *>(db), d1 = *reinterpret_cast<const float4 *>(db + 4);
-            const bool in = cb < p.pb_c3;
-            va.x = (in && a0.x == srow) ? d0.x : 0.f; va.y = (in && a0.y == srow) ? d0.y : 0.f;
-            va.z = (in && a0.z == srow) ? d0.z : 0.f; va.w = (in && a0.w == srow) ? d0.w : 0.f;
-            vb.x = (in && a1.x == srow) ? d1.x : 0.f; vb.y = (in && a1.y == srow) ? d1.y : 0.f;
-            vb.z = (in && a1.z == srow) ? d1.z : 0.f; vb.w = (in && a1.w == srow) ? d1.w : 0.f;
+            const unsigned sr = cb < pb_c3v ? (unsigned)srow : 0xffffu;          // 0xffff never matches
+            va.x = (aw.x & 0xffffu) == sr ? d0.x : 0.f; va.y = (aw.x >> 16) == sr ? d0.y : 0.f;
+            va.z = (aw.y & 0xffffu) == sr ? d0.z : 0.f; va.w = (aw.y >> 16) == sr ? d0.w : 0.f;
+            vb.x = (aw.z & 0xffffu) == sr ? d1.x : 0.f; vb.y = (aw.z >> 16) == sr ? d1.y : 0.f;
+            vb.z = (aw.w & 0xffffu) == sr ? d1.z : 0.f; vb.w = (aw.w >> 16) == sr ? d1.w : 0.f;
           }
           bf16x8 a[3];
           split8(va, vb, a);
@@ -456,7 +464,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void rows_stream_gemm_kernel
     }
     par ^= 1;
 
-    if (p.ep_mean != nullptr && p.pool_ns > 0) {
+    if constexpr (EPI == EPI_EVAL) {
+    if (p.pool_ns > 0) {
       // ---- inference: BN + ReLU + max over the pool_ns rows of a centre ----------------------
       // lane (li, lk) holds rows 4 lk + {0..3, 8..11, 16..19, 24..27} of column li: e < 8 are
       // rows 0..15, e >= 8 rows 16..31
@@ -489,7 +498,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void rows_stream_gemm_kernel
       }
       continue;
     }
-    if (p.ep_mean != nullptr) {
+    }
+    if constexpr (EPI == EPI_EVAL) {
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -505,7 +515,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void rows_stream_gemm_kernel
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][e] += pbias[j];
     }
-    if (p.raw_max != nullptr) {
+    if constexpr (EPI == EPI_RAW) {
       // ---- training, pooled layer: running max / min (+ first index) per centre ------------
       const int ns = p.pool_ns;
       const int sbase = (ns == 64 && (n & 1)) ? 32 : 0;
@@ -627,38 +637,58 @@ constexpr size_t LDS_LIMIT = 160 * 1024;
 // Workgroup shapes in order of preference: more waves (latency hiding on the compute side),
 // then more ring slots (bytes in flight).  LDS is what decides.
 struct StreamCfg { int waves, slots; };
-constexpr StreamCfg CFGS[4] = {{8, 3}, {4, 4}, {4, 3}, {4, 2}};   // (8,4) measured slower than (8,3)
+constexpr StreamCfg CFGS[5] = {{8, 3}, {8, 2}, {4, 4}, {4, 3}, {4, 2}};   // (8,4) measured slower than (8,3)
+// (8,2) only for the pool-backward mode: its generated columns are pure MFMA + VALU work, which
+// one wave per SIMD cannot overlap with anything (4 x 4: 337 us)
 
 int pick_cfg(long long M, int N, int K, int pro) {
   if (M < STREAM_MIN_ROWS || N <= 0 || N > 128 || K <= 0) return -1;
   const int NT = N <= 64 ? 2 : 4;
-  for (int c = 0; c < 4; ++c)
+  for (int c = 0; c < 5; ++c) {
+    if (c == 1 && pro != SPRO_POOLBWD) continue;
     if (stream_lds_bytes(NT, K, CFGS[c].waves, CFGS[c].slots, pro) <= LDS_LIMIT) return c;
+  }
   return -1;
 }
 
-template <int NT, int PRO, int WAVES, int SLOTS>
+template <int NT, int PRO, int WAVES, int SLOTS, int EPI>
 int launch_one(const StreamArgs &a, int blocks, size_t lds, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute((const void *)rows_stream_gemm_kernel<NT, PRO, WAVES, SLOTS>,
+    if (hipFuncSetAttribute((const void *)rows_stream_gemm_kernel<NT, PRO, WAVES, SLOTS, EPI>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT) != hipSuccess)
       return -1;
     attr_done = true;
   }
-  hipLaunchKernelGGL((rows_stream_gemm_kernel<NT, PRO, WAVES, SLOTS>), dim3(blocks), dim3(64 * WAVES),
+  hipLaunchKernelGGL((rows_stream_gemm_kernel<NT, PRO, WAVES, SLOTS, EPI>), dim3(blocks), dim3(64 * WAVES),
                      lds, st, a);
   return 0;
 }
 
-template <int NT, int PRO>
+template <int NT, int PRO, int EPI>
 int launch_cfg(const StreamArgs &a, int cfg, int blocks, size_t lds, hipStream_t st) {
   switch (cfg) {
-    case 0: return launch_one<NT, PRO, 8, 3>(a, blocks, lds, st);
-    case 1: return launch_one<NT, PRO, 4, 4>(a, blocks, lds, st);
-    case 2: return launch_one<NT, PRO, 4, 3>(a, blocks, lds, st);
-    default: return launch_one<NT, PRO, 4, 2>(a, blocks, lds, st);
+    case 0: return launch_one<NT, PRO, 8, 3, EPI>(a, blocks, lds, st);
+    case 1:
+      if constexpr (PRO == SPRO_POOLBWD) return launch_one<NT, PRO, 8, 2, EPI>(a, blocks, lds, st);
+      else return -1;
+    case 2: return launch_one<NT, PRO, 4, 4, EPI>(a, blocks, lds, st);
+    case 3: return launch_one<NT, PRO, 4, 3, EPI>(a, blocks, lds, st);
+    default: return launch_one<NT, PRO, 4, 2, EPI>(a, blocks, lds, st);
   }
+}
+
+// the (prologue, epilogue) pairs that exist: plain / BN+ReLU prologue x {train, raw}; plain /
+// gather x eval; gather x train; pool-backward x train
+template <int NT, int PRO>
+int launch_epi(const StreamArgs &a, int cfg, int blocks, size_t lds, hipStream_t st) {
+  const int epi = a.raw_max != nullptr ? EPI_RAW : (a.ep_mean != nullptr ? EPI_EVAL : EPI_TRAIN);
+  if (epi == EPI_TRAIN) return launch_cfg<NT, PRO, EPI_TRAIN>(a, cfg, blocks, lds, st);
+  if constexpr (PRO == SPRO_NONE || PRO == SPRO_BNRELU)
+    if (epi == EPI_RAW) return launch_cfg<NT, PRO, EPI_RAW>(a, cfg, blocks, lds, st);
+  if constexpr (PRO == SPRO_NONE || PRO == SPRO_GATHER)
+    if (epi == EPI_EVAL) return launch_cfg<NT, PRO, EPI_EVAL>(a, cfg, blocks, lds, st);
+  return -1;
 }
 
 template <int PRO>
@@ -671,8 +701,8 @@ int launch_stream(const StreamArgs &a, hipStream_t st) {
   int blocks = g_stream_grid;
   if (a.partial != nullptr && blocks * waves > a.partial_rows) blocks = a.partial_rows / waves;
   if (blocks < 1) return -2;
-  const int rc = NT == 2 ? launch_cfg<2, PRO>(a, cfg, blocks, lds, st)
-                         : launch_cfg<4, PRO>(a, cfg, blocks, lds, st);
+  const int rc = NT == 2 ? launch_epi<2, PRO>(a, cfg, blocks, lds, st)
+                         : launch_epi<4, PRO>(a, cfg, blocks, lds, st);
   if (rc != 0) return rc;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -822,7 +852,7 @@ extern "C" int s2c_rows_gemm_pool_raw(long long M, int N, int K, const float *A,
 // routed pooled gradient dk / arg (J x C3) and Wcat (N x (KA + C3)), bias cvec (N).  KA % 16 == 0,
 // C3 % 8 == 0, C3 <= 128, ns in {16, 32, 64}.  -2: shape not taken.
 extern "C" int s2c_pool_bwd_input_grad(long long M, int N, int KA, int C3, int ns, const float *A,
-                                       int lda, const int *arg, const float *dk,
+                                       int lda, const short *arg, const float *dk,
                                        const float *Wcat, int ldw, const float *cvec, float *dA,
                                        int ldd, void *stream) {
   if (M <= 0 || N <= 0 || KA <= 0 || C3 <= 0 || !A || !arg || !dk || !Wcat || !dA ||

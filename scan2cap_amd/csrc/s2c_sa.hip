@@ -896,12 +896,14 @@ extern "C" int s2c_bn_relu_max_bwd_stats(long long J, int ns, int C, const float
 __global__ __launch_bounds__(256) void pool_bwd_dk_kernel(
     const float *__restrict__ dOut, const float *__restrict__ ymax,
     const float *__restrict__ scale, const float *__restrict__ shift,
-    const float *__restrict__ coef, float *__restrict__ dk, long long total, int C) {
+    const float *__restrict__ coef, const int *__restrict__ arg, float *__restrict__ dk,
+    short *__restrict__ arg16, long long total, int C) {
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total;
        e += (long long)gridDim.x * 256) {
     const int c = (int)(e % C);
     const float g = (ymax[e] * scale[c] + shift[c] > 0.f) ? dOut[e] : 0.f;
     dk[e] = coef[c] * g;
+    if (arg16 != nullptr) arg16[e] = (short)arg[e];
   }
 }
 
@@ -944,15 +946,15 @@ __global__ __launch_bounds__(256) void pool_bwd_sp_kernel(
 
 extern "C" int s2c_pool_bwd_dk(long long J, int C, const float *dOut, const float *ymax,
                                const float *scale, const float *shift, const float *coef,
-                               float *dk, void *stream) {
-  if (J <= 0 || C <= 0 || !dOut || !ymax || !scale || !shift || !coef || !dk)
+                               const int *arg, float *dk, short *arg16, void *stream) {
+  if (J <= 0 || C <= 0 || !dOut || !ymax || !scale || !shift || !coef || !dk || (arg16 && !arg))
     return fail2("pool_bwd_dk: sizes / null pointer");
   hipLaunchKernelGGL(pool_bwd_dk_kernel, dim3(grid1d(J * C, 256)), dim3(256), 0,
-                     (hipStream_t)stream, dOut, ymax, scale, shift, coef, dk, J * C, C);
+                     (hipStream_t)stream, dOut, ymax, scale, shift, coef, arg, dk, arg16, J * C, C);
   return check2("pool_bwd_dk");
 }
 
-extern "C" int s2c_pool_bwd_sp_blocks(long long J) { return J < 512 ? (int)J : 512; }
+extern "C" int s2c_pool_bwd_sp_blocks(long long J) { return J < 256 ? (int)J : 256; }
 
 // partial: s2c_pool_bwd_sp_blocks(J) x C3 x K floats.  K % 16 == 0, K <= 256.
 extern "C" int s2c_pool_bwd_sp(long long J, int ns, int C3, int K, const float *A, const int *arg,

@@ -265,7 +265,7 @@ class LayerSpec(object):
 _C.register("s2c_rows_gemm_pool_raw", [_L, _I, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P])
 _C.register("s2c_pool_select", [_L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_bn_relu_max_bwd_stats", [_L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P])
-_C.register("s2c_pool_bwd_dk", [_L, _I, _P, _P, _P, _P, _P, _P, _P])
+_C.register("s2c_pool_bwd_dk", [_L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_pool_bwd_sp", [_L, _I, _I, _I, _P, _P, _P, _P, _P])
 _C.register("s2c_pool_bwd_input_grad", [_L, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _P, _I, _P])
 
@@ -304,8 +304,10 @@ def pooled_layer_backward(dOut, arg, ymax, scale, shift, mean, invstd, gamma, fr
           int(frozen), partial.data_ptr(), coef.data_ptr(), _ptr(dgamma), _ptr(dbeta),
           alg_bytes=4 * 2 * J * C3)
     dk = torch.empty_like(dOut)
+    arg16 = torch.empty((J, C3), dtype=torch.int16, device=dev)
     _call("s2c_pool_bwd_dk", dOut, J, C3, dOut.data_ptr(), ymax.data_ptr(), scale.data_ptr(),
-          shift.data_ptr(), coef.data_ptr(), dk.data_ptr(), alg_bytes=4 * 3 * J * C3)
+          shift.data_ptr(), coef.data_ptr(), arg.data_ptr(), dk.data_ptr(), arg16.data_ptr(),
+          alg_bytes=4 * 4 * J * C3)
     k0, k1, k2 = coef[:C3].double(), coef[C3:2 * C3].double(), coef[2 * C3:].double()
     g = k0 * k2 * invstd.double()
     e = g * mean.double() - k0 * k1
@@ -318,9 +320,9 @@ def pooled_layer_backward(dOut, arg, ymax, scale, shift, mean, invstd, gamma, fr
     sp = torch.empty((nblk, C3 * K), device=dev)
     _call("s2c_pool_bwd_sp", A, J, ns, C3, K, A.data_ptr(), arg.data_ptr(), dk.data_ptr(),
           sp.data_ptr(), alg_bytes=4 * (M * K + 2 * J * C3 + nblk * C3 * K))
-    SP = sp.sum(0, dtype=torch.float64).view(C3, K)
+    SP = sp.sum(0).double().view(C3, K)
     gram = _weight_grad(A, A).double()                      # A^T A  (K x K)
-    colsum = A.sum(0, dtype=torch.float64)
+    colsum = A.sum(0).double()
     dW = (SP - (g.unsqueeze(1) * Wd) @ gram + e.unsqueeze(1) * colsum.unsqueeze(0)).float()
     # ---- input gradient --------------------------------------------------------------------
     dA = None
@@ -330,7 +332,7 @@ def pooled_layer_backward(dOut, arg, ymax, scale, shift, mean, invstd, gamma, fr
         Wcat = torch.cat([(-G.t()).float(), W.t()], 1).contiguous()      # (K, K + C3)
         dA = torch.empty((M, K), device=dev)
         _call("s2c_pool_bwd_input_grad", A, M, K, K, C3, ns, A.data_ptr(), A.stride(0),
-              arg.data_ptr(), dk.data_ptr(), Wcat.data_ptr(), Wcat.stride(0), cvec.data_ptr(),
+              arg16.data_ptr(), dk.data_ptr(), Wcat.data_ptr(), Wcat.stride(0), cvec.data_ptr(),
               dA.data_ptr(), K, alg_bytes=4 * (2 * M * K + 2 * J * C3),
               alg_flops=2 * M * K * (K + C3))
     return dA, dW, dgamma, dbeta
@@ -385,6 +387,7 @@ class _MLPRows(Function):
         partial = None
         out = None
         deferred = None     # (Y, scale, shift, relu) of the previous layer: BN+ReLU not applied yet
+        pooled_raw = None   # raw per-centre extrema of the last layer (pool algebra path)
         for li, sp in enumerate(specs):
             W = params[pi]; pi += 1
             bias = None
@@ -416,6 +419,33 @@ class _MLPRows(Function):
                       Y.data_ptr(), Cout, _ptr(gpart),
                       alg_bytes=4 * (min(g.B * g.N, M) * (3 + g.C) + M + M * Cout),
                       alg_flops=2 * M * (3 + g.C) * Cout)
+            elif (li == nl - 1 and pool_ns > 0 and gemm_stats and need_grad
+                  and pool_algebra_takes(M, Cout, (deferred[0] if deferred is not None else A).shape[1],
+                                         pool_ns)):
+                # pooled last layer: raw per-centre extrema out of the GEMM's epilogue, the
+                # (M x Cout) pre-activation is never written (pooled_layer_backward needs none)
+                nbg = _gemm_blocks(M, Cout)
+                gpart = torch.empty(nbg * 2 * Cout, device=dev)
+                J = M // pool_ns
+                raws = (torch.empty((J, Cout), device=dev), torch.empty((J, Cout), dtype=torch.int32, device=dev),
+                        torch.empty((J, Cout), device=dev), torch.empty((J, Cout), dtype=torch.int32, device=dev))
+                if deferred is not None:
+                    pY, pscale, pshift, prelu = deferred
+                    deferred = None
+                    A = torch.empty_like(pY)
+                    src, K_in = pY, pY.shape[1]
+                    pro = (pscale.data_ptr(), pshift.data_ptr(), int(prelu), A.data_ptr(), K_in)
+                else:
+                    src, K_in = A, A.shape[1]
+                    pro = (None, None, 0, None, 0)
+                _call("s2c_rows_gemm_pool_raw", src, M, Cout, K_in, src.data_ptr(), src.stride(0),
+                      pro[0], pro[1], pro[2], pro[3], pro[4], W.data_ptr(), W.stride(0), pool_ns,
+                      raws[0].data_ptr(), raws[1].data_ptr(), raws[2].data_ptr(), raws[3].data_ptr(),
+                      None, 0, gpart.data_ptr(),
+                      alg_bytes=4 * (M * K_in * (2 if pro[0] else 1) + 4 * J * Cout),
+                      alg_flops=2 * M * K_in * Cout)
+                Y = None
+                pooled_raw = raws
             elif deferred is not None:
                 # the previous layer's BN+ReLU happens in THIS layer's operand load; the
                 # activation (needed for the weight gradient) leaves as a side output
@@ -453,7 +483,7 @@ class _MLPRows(Function):
                 invstd = torch.empty(Cout, device=dev)
                 if gemm_stats and gpart is not None:
                     mom = bn.momentum if bn.momentum is not None else 0.0
-                    _call("s2c_bn_finalize_partials", Y, nbg, M, Cout, gpart.data_ptr(),
+                    _call("s2c_bn_finalize_partials", gpart, nbg, M, Cout, gpart.data_ptr(),
                           float(bn.eps), float(mom), _ptr(gamma), _ptr(beta),
                           _ptr(bn.running_mean), _ptr(bn.running_var),
                           scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
@@ -476,7 +506,20 @@ class _MLPRows(Function):
                           shift.data_ptr(), mean.data_ptr(), invstd.data_ptr())
                 rec.update(Y=Y, scale=scale, shift=shift, mean=mean, invstd=invstd,
                            gamma=gamma, frozen=not train_stats, relu=sp.relu)
-                if last and pool_ns > 0:
+                if last and pool_ns > 0 and pooled_raw is not None:
+                    J = M // pool_ns
+                    out = torch.empty((J, Cout), device=dev)
+                    arg = torch.empty((J, Cout), dtype=torch.int32, device=dev)
+                    ymax = torch.empty((J, Cout), device=dev)
+                    _call("s2c_pool_select", out, J, Cout, pooled_raw[0].data_ptr(),
+                          pooled_raw[1].data_ptr(), pooled_raw[2].data_ptr(),
+                          pooled_raw[3].data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                          out.data_ptr(), arg.data_ptr(), ymax.data_ptr(),
+                          alg_bytes=4 * 7 * J * Cout)
+                    rec["arg"] = arg
+                    rec["ymax"] = ymax
+                    rec["algebra"] = True
+                elif last and pool_ns > 0:
                     J = M // pool_ns
                     out = torch.empty((J, Cout), device=dev)
                     arg = torch.empty((J, Cout), dtype=torch.int32, device=dev)
@@ -540,6 +583,17 @@ class _MLPRows(Function):
             Cout = W.shape[0]
             M = A_in.shape[0] if A_in is not None else gather.rows
             dgamma = dbeta = None
+            if rec.get("algebra"):
+                # pooled last layer without Y3 / dY3 (pooled_layer_backward)
+                need_dA = li > 0 or ctx.x_needs_grad
+                dA, dW, dgamma, dbeta = pooled_layer_backward(
+                    dA, rec["arg"], rec["ymax"], rec["scale"], rec["shift"], rec["mean"],
+                    rec["invstd"], rec["gamma"], rec["frozen"], A_in, W, pool_ns, need_dA=need_dA)
+                g = [dW]
+                if sp.bn is not None:
+                    g += [dgamma, dbeta]
+                grads.append(g)
+                continue
             if sp.bn is not None:
                 Y = rec["Y"]
                 nb = _stat_blocks(M)
