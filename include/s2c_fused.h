@@ -171,7 +171,8 @@ int s2c_pool_select(long long J, int C, const float *raw_max, const int *raw_ama
 /* Backward of a max-pooled BatchNorm + ReLU layer WITHOUT its (M x C3) tensors Y3 / dY3
  * (DESIGN 4.3): with Y3 = A W3^T, dY3 = dkrow - g (.) Y3 + e per channel, hence
  *   dA  = dkrow W3 - A (W3^T diag(g) W3) + e W3           (s2c_pool_bwd_input_grad)
- *   dW3 = SP - diag(g) W3 (A^T A) + e (x) colsum(A)        (SP: s2c_pool_bwd_sp)
+ *   dW3 = SP - diag(g) W3 (A^T A) + e (x) colsum(A)        (SP, colsum: s2c_pool_bwd_sp, one pass over A;
+ *                                                            partial = blocks x (C3 K + K) floats)
  * with dk = k0 * routed gradient (s2c_pool_bwd_dk), coef from s2c_bn_relu_max_bwd_stats. */
 int s2c_bn_relu_max_bwd_stats(long long J, int ns, int C, const float *dOut, const float *ymax,
                               const float *scale, const float *shift, const float *mean,

@@ -908,40 +908,63 @@ __global__ __launch_bounds__(256) void pool_bwd_dk_kernel(
 }
 
 // SP[c, k] = sum_j dk[j,c] * A[j * ns + arg[j,c], k]   (C3 x K): the routed part of the pooled
-// layer's weight gradient, read straight from the layer's INPUT activation A (M x K).
-// Thread = (channel c, quarter of the K columns); a workgroup walks its centres and writes one
-// partial (C3 x K) -- summed over workgroups by the caller (kernel boundary reduction).
-constexpr int SP_KQ = 16;      // columns per thread
+// layer's weight gradient, and colsum[k] = sum_r A[r, k] -- both from ONE coalesced pass over
+// the layer's INPUT activation A (M x K): a workgroup stages the ns x K rows of a centre in
+// LDS, thread = (column k, group of C3 / G channels) adds dk * T[arg][k] for its channels into
+// registers, group 0 also sums the column.  Partials per workgroup (summed by the caller:
+// kernel-boundary reduction): partial[blk][C3 * K | K].
+constexpr int SP_CG = 32;                    // channels per thread (registers)
+constexpr int SP_MAXQ = 16;                  // float4 per thread of one staged tile (ns K <= 16384)
 __global__ __launch_bounds__(256) void pool_bwd_sp_kernel(
     long long J, int ns, int C3, int K, const float *__restrict__ A, const int *__restrict__ arg,
     const float *__restrict__ dk, float *__restrict__ partial) {
-  const int per = K / SP_KQ;                 // threads per channel
-  const int cpb = 256 / per;                 // channels per pass
-  const int kq = threadIdx.x % per, cl = threadIdx.x / per;
-  for (int c0 = 0; c0 < C3; c0 += cpb) {
-    const int c = c0 + cl;
-    float acc[SP_KQ];
+  extern __shared__ __attribute__((aligned(16))) float s_t[];      // ns x K tile | dk[C3] | arg[C3]
+  const int tid = threadIdx.x;
+  const int k = tid % K, grp = tid / K;                  // 256 / K channel groups
+  float *s_dk = s_t + ns * K;
+  int *s_arg = reinterpret_cast<int *>(s_dk + C3);
+  float acc[SP_CG];
 #pragma unroll
-    for (int i = 0; i < SP_KQ; ++i) acc[i] = 0.f;
-    if (c < C3) {
-      for (long long j = blockIdx.x; j < J; j += gridDim.x) {
-        const float d = dk[j * C3 + c];
-        if (d != 0.f) {
-          const float4 *row = reinterpret_cast<const float4 *>(
-              A + (j * ns + arg[j * C3 + c]) * (long long)K + kq * SP_KQ);
+  for (int i = 0; i < SP_CG; ++i) acc[i] = 0.f;
+  float csum = 0.f;
+  const int tile4 = ns * K / 4;
+  // register prefetch of the next centre's tile (and its dk / arg rows) under the compute
+  float4 r[SP_MAXQ];
+  float rd = 0.f;
+  int ra = 0;
+  auto fetch = [&](long long j) {
+    const float4 *src = reinterpret_cast<const float4 *>(A + j * ns * (long long)K);
 #pragma unroll
-          for (int i = 0; i < SP_KQ / 4; ++i) {
-            const float4 v = row[i];
-            acc[4 * i] += d * v.x; acc[4 * i + 1] += d * v.y;
-            acc[4 * i + 2] += d * v.z; acc[4 * i + 3] += d * v.w;
-          }
-        }
-      }
-      float *dst = partial + ((size_t)blockIdx.x * C3 + c) * K + kq * SP_KQ;
+    for (int q = 0; q < SP_MAXQ; ++q)
+      if (tid + q * 256 < tile4) r[q] = src[tid + q * 256];
+    if (tid < C3) { rd = dk[j * C3 + tid]; ra = arg[j * C3 + tid]; }
+  };
+  long long j = blockIdx.x;
+  if (j < J) fetch(j);
+  for (; j < J; j += gridDim.x) {
+    __syncthreads();                                     // previous tile fully consumed
 #pragma unroll
-      for (int i = 0; i < SP_KQ; ++i) dst[i] = acc[i];
+    for (int q = 0; q < SP_MAXQ; ++q)
+      if (tid + q * 256 < tile4) reinterpret_cast<float4 *>(s_t)[tid + q * 256] = r[q];
+    if (tid < C3) { s_dk[tid] = rd; s_arg[tid] = ra; }
+    __syncthreads();
+    if (j + gridDim.x < J) fetch(j + gridDim.x);
+    if (grp == 0)
+      for (int rr = 0; rr < ns; ++rr) csum += s_t[rr * K + k];
+    const int c0 = grp * SP_CG;
+#pragma unroll
+    for (int i = 0; i < SP_CG; ++i) {
+      const int c = c0 + i;
+      if (c < C3) acc[i] += s_dk[c] * s_t[s_arg[c] * K + k];
     }
   }
+  float *dst = partial + (size_t)blockIdx.x * ((size_t)C3 * K + K);
+#pragma unroll
+  for (int i = 0; i < SP_CG; ++i) {
+    const int c = grp * SP_CG + i;
+    if (c < C3) dst[(size_t)c * K + k] = acc[i];
+  }
+  if (grp == 0) dst[(size_t)C3 * K + k] = csum;
 }
 
 extern "C" int s2c_pool_bwd_dk(long long J, int C, const float *dOut, const float *ymax,
@@ -954,16 +977,18 @@ extern "C" int s2c_pool_bwd_dk(long long J, int C, const float *dOut, const floa
   return check2("pool_bwd_dk");
 }
 
-extern "C" int s2c_pool_bwd_sp_blocks(long long J) { return J < 256 ? (int)J : 256; }
+extern "C" int s2c_pool_bwd_sp_blocks(long long J) { return J < 1024 ? (int)J : 1024; }
 
-// partial: s2c_pool_bwd_sp_blocks(J) x C3 x K floats.  K % 16 == 0, K <= 256.
+// partial: s2c_pool_bwd_sp_blocks(J) x (C3 * K + K) floats (SP | column sums of A).
+// K in {32, 64, 128, 256}, C3 <= (256 / K) * 32, ns * K * 4 bytes of LDS (<= 64 KB).
 extern "C" int s2c_pool_bwd_sp(long long J, int ns, int C3, int K, const float *A, const int *arg,
                                const float *dk, float *partial, void *stream) {
-  if (J <= 0 || ns <= 0 || C3 <= 0 || K <= 0 || (K % SP_KQ) || K > 256 * SP_KQ || 256 % (K / SP_KQ) ||
-      !A || !arg || !dk || !partial)
+  if (J <= 0 || ns <= 0 || C3 <= 0 || !(K == 32 || K == 64 || K == 128 || K == 256) ||
+      C3 > (256 / K) * SP_CG || C3 > 256 || ns * K > 256 * 4 * SP_MAXQ || !A || !arg || !dk || !partial)
     return fail2("pool_bwd_sp: sizes / null pointer");
-  hipLaunchKernelGGL(pool_bwd_sp_kernel, dim3(s2c_pool_bwd_sp_blocks(J)), dim3(256), 0,
-                     (hipStream_t)stream, J, ns, C3, K, A, arg, dk, partial);
+  hipLaunchKernelGGL(pool_bwd_sp_kernel, dim3(s2c_pool_bwd_sp_blocks(J)), dim3(256),
+                     ((size_t)ns * K + 2 * C3) * sizeof(float), (hipStream_t)stream, J, ns, C3, K, A,
+                     arg, dk, partial);
   return check2("pool_bwd_sp");
 }
 

@@ -277,7 +277,8 @@ POOL_ALGEBRA = _os.environ.get("S2C_POOL_ALGEBRA", "1") != "0"
 
 def pool_algebra_takes(M, Cout, K_in, pool_ns):
     return (POOL_ALGEBRA and pool_ns in (16, 32, 64) and M % pool_ns == 0 and Cout <= 128
-            and Cout % 8 == 0 and K_in % 16 == 0 and _gemm_split_on()
+            and Cout % 8 == 0 and K_in in (32, 64, 128) and Cout <= (256 // K_in) * 32
+            and _gemm_split_on()
             and _stream_takes(M, Cout, K_in) and _stream_takes(M, K_in, K_in + Cout))
 
 
@@ -317,12 +318,12 @@ def pooled_layer_backward(dOut, arg, ymax, scale, shift, mean, invstd, gamma, fr
     lib.s2c_pool_bwd_sp_blocks.argtypes = [_L]
     lib.s2c_pool_bwd_sp_blocks.restype = _I
     nblk = lib.s2c_pool_bwd_sp_blocks(J)
-    sp = torch.empty((nblk, C3 * K), device=dev)
+    sp = torch.empty((nblk, C3 * K + K), device=dev)
     _call("s2c_pool_bwd_sp", A, J, ns, C3, K, A.data_ptr(), arg.data_ptr(), dk.data_ptr(),
-          sp.data_ptr(), alg_bytes=4 * (M * K + 2 * J * C3 + nblk * C3 * K))
-    SP = sp.sum(0).double().view(C3, K)
+          sp.data_ptr(), alg_bytes=4 * (M * K + 2 * J * C3 + nblk * (C3 + 1) * K))
+    spsum = sp.sum(0).double()
+    SP, colsum = spsum[:C3 * K].view(C3, K), spsum[C3 * K:]
     gram = _weight_grad(A, A).double()                      # A^T A  (K x K)
-    colsum = A.sum(0).double()
     dW = (SP - (g.unsqueeze(1) * Wd) @ gram + e.unsqueeze(1) * colsum.unsqueeze(0)).float()
     # ---- input gradient --------------------------------------------------------------------
     dA = None
