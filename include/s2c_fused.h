@@ -184,6 +184,14 @@ int s2c_pool_bwd_dk(long long J, int C, const float *dOut, const float *ymax, co
                     const float *shift, const float *coef, const int *arg, float *dk,
                     short *arg16, void *stream);
 int s2c_pool_bwd_sp_blocks(long long J);
+/* the small matrices: Wcat (K x (K+C3)) = [-G^T | W^T], cvec (K), ge (2 C3) = g | e from coef;
+ * dW (C3 x K) from the SP / colsum partials summed over the workgroups (C3 K + K floats) and
+ * Gram = A^T A (K x K) */
+int s2c_pool_bwd_prep(int C3, int K, const float *coef, const float *mean, const float *invstd,
+                      const float *W, float *Wcat, float *cvec, float *ge, void *stream);
+int s2c_pool_bwd_final(int C3, int K, const float *partial_sum, const float *gram,
+                       const float *W, const float *coef, const float *mean, const float *invstd,
+                       float *dW, void *stream);
 int s2c_pool_bwd_sp(long long J, int ns, int C3, int K, const float *A, const int *arg,
                     const float *dk, float *partial, void *stream);
 int s2c_pool_bwd_input_grad(long long M, int N, int KA, int C3, int ns, const float *A, int lda,

@@ -914,41 +914,68 @@ __global__ __launch_bounds__(256) void pool_bwd_dk_kernel(
 // registers, group 0 also sums the column.  Partials per workgroup (summed by the caller:
 // kernel-boundary reduction): partial[blk][C3 * K | K].
 constexpr int SP_CG = 32;                    // channels per thread (registers)
-constexpr int SP_MAXQ = 16;                  // float4 per thread of one staged tile (ns K <= 16384)
+constexpr int SP_RING = 3;                   // tiles in flight per workgroup (LDS-DMA ring)
+
+__device__ __forceinline__ void sp_glds16(const void *gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// Tiles arrive by LDS-DMA into a ring of SP_RING slots (tile | dk row | arg row): with the
+// register prefetch of the first version a workgroup had one 16 KB tile in flight and the
+// pass ran at 1.2-1.7 TB/s; the ring keeps (SP_RING - 1) tiles per workgroup outstanding with
+// no VGPR cost.  Every wave issues the same number of DMA instructions per tile (TI + 1), so
+// one `s_waitcnt vmcnt` immediate serves all of them.
 __global__ __launch_bounds__(256) void pool_bwd_sp_kernel(
     long long J, int ns, int C3, int K, const float *__restrict__ A, const int *__restrict__ arg,
     const float *__restrict__ dk, float *__restrict__ partial) {
-  extern __shared__ __attribute__((aligned(16))) float s_t[];      // ns x K tile | dk[C3] | arg[C3]
-  const int tid = threadIdx.x;
+  extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int k = tid % K, grp = tid / K;                  // 256 / K channel groups
-  float *s_dk = s_t + ns * K;
-  int *s_arg = reinterpret_cast<int *>(s_dk + C3);
+  const int tile_bytes = ns * K * 4;                     // multiple of 4096
+  const int slot_bytes = tile_bytes + 1024;              // + dk[<=128] | arg[<=128]
+  const int TI = tile_bytes / 4096;                      // DMA instructions per wave and tile
+  const unsigned base = (unsigned)(size_t)sp_smem;
   float acc[SP_CG];
 #pragma unroll
   for (int i = 0; i < SP_CG; ++i) acc[i] = 0.f;
   float csum = 0.f;
-  const int tile4 = ns * K / 4;
-  // register prefetch of the next centre's tile (and its dk / arg rows) under the compute
-  float4 r[SP_MAXQ];
-  float rd = 0.f;
-  int ra = 0;
-  auto fetch = [&](long long j) {
-    const float4 *src = reinterpret_cast<const float4 *>(A + j * ns * (long long)K);
-#pragma unroll
-    for (int q = 0; q < SP_MAXQ; ++q)
-      if (tid + q * 256 < tile4) r[q] = src[tid + q * 256];
-    if (tid < C3) { rd = dk[j * C3 + tid]; ra = arg[j * C3 + tid]; }
+  auto issue = [&](long long j, int slot) {
+    const char *src = reinterpret_cast<const char *>(A + j * ns * (long long)K);
+    const unsigned dst = base + slot * slot_bytes;
+    for (int i = 0; i < TI; ++i)
+      sp_glds16(src + (wave * TI + i) * 1024 + lane * 16, dst + (wave * TI + i) * 1024);
+    // lanes 0-31: dk row, lanes 32-63: arg row (every wave issues it: uniform counts; same data)
+    const int l = lane & 31;
+    const char *aux = lane < 32 ? reinterpret_cast<const char *>(dk + j * C3)
+                                : reinterpret_cast<const char *>(arg + j * C3);
+    const int off = l * 16 < C3 * 4 ? l * 16 : 0;        // C3 < 128: re-read the head (ignored)
+    sp_glds16(aux + off, dst + tile_bytes);
   };
-  long long j = blockIdx.x;
-  if (j < J) fetch(j);
-  for (; j < J; j += gridDim.x) {
-    __syncthreads();                                     // previous tile fully consumed
-#pragma unroll
-    for (int q = 0; q < SP_MAXQ; ++q)
-      if (tid + q * 256 < tile4) reinterpret_cast<float4 *>(s_t)[tid + q * 256] = r[q];
-    if (tid < C3) { s_dk[tid] = rd; s_arg[tid] = ra; }
-    __syncthreads();
-    if (j + gridDim.x < J) fetch(j + gridDim.x);
+  const long long stride = gridDim.x;
+  long long jn = blockIdx.x;                             // next tile to request
+  int islot = 0;
+  for (int d = 0; d < SP_RING - 1; ++d)
+    if (jn < J) { issue(jn, islot); jn += stride; islot = islot + 1 == SP_RING ? 0 : islot + 1; }
+  int slot = 0;
+  for (long long j = blockIdx.x; j < J; j += stride) {
+    if (jn < J) {
+      issue(jn, islot); jn += stride; islot = islot + 1 == SP_RING ? 0 : islot + 1;
+      // newer than tile j: SP_RING - 1 tiles of (TI + 1) instructions
+      if (TI == 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      else if (TI == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (TI == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                        // every wave's pieces of tile j landed
+    const float *s_t = reinterpret_cast<const float *>(sp_smem + slot * slot_bytes);
+    const float *s_dk = s_t + ns * K;
+    const int *s_arg = reinterpret_cast<const int *>(s_dk + 128);
     if (grp == 0)
       for (int rr = 0; rr < ns; ++rr) csum += s_t[rr * K + k];
     const int c0 = grp * SP_CG;
@@ -957,6 +984,8 @@ __global__ __launch_bounds__(256) void pool_bwd_sp_kernel(
       const int c = c0 + i;
       if (c < C3) acc[i] += s_dk[c] * s_t[s_arg[c] * K + k];
     }
+    __builtin_amdgcn_s_barrier();                        // slot free for the request after next
+    slot = slot + 1 == SP_RING ? 0 : slot + 1;
   }
   float *dst = partial + (size_t)blockIdx.x * ((size_t)C3 * K + K);
 #pragma unroll
@@ -965,6 +994,93 @@ __global__ __launch_bounds__(256) void pool_bwd_sp_kernel(
     if (c < C3) dst[(size_t)c * K + k] = acc[i];
   }
   if (grp == 0) dst[(size_t)C3 * K + k] = csum;
+}
+
+// The small matrices of the pooled-layer algebra in two launches (they were ~25 tiny torch
+// kernels): with g = k0 k2 invstd, e = g mean - k0 k1 per channel (coef = k0 | k1 | k2)
+//   prep:  Wcat (K x (K + C3)) = [ -G^T | W^T ],  G = W^T diag(g) W;  cvec (K) = e W;  ge = g | e
+//   final: dW (C3 x K) = sum_blk SP_blk - diag(g) W Gram + e (x) sum_blk colsum_blk
+// float64 accumulation, fixed order.
+__global__ __launch_bounds__(256) void pool_bwd_prep_kernel(
+    int C3, int K, const float *__restrict__ coef, const float *__restrict__ mean,
+    const float *__restrict__ invstd, const float *__restrict__ W, float *__restrict__ Wcat,
+    float *__restrict__ cvec, float *__restrict__ ge) {
+  __shared__ double s_g[256], s_e[256];
+  __shared__ double s_part[4][64], s_cv[4][64];
+  const int k = blockIdx.x;                     // row of Wcat
+  const int ld = K + C3;
+  for (int c = threadIdx.x; c < C3; c += 256) {
+    const double g = (double)coef[c] * (double)coef[2 * C3 + c] * (double)invstd[c];
+    s_g[c] = g;
+    s_e[c] = g * (double)mean[c] - (double)coef[c] * (double)coef[C3 + c];
+  }
+  __syncthreads();
+  // thread = (column kp of a 64-wide pass, quarter of the channels); fixed-order combine
+  const int part = threadIdx.x >> 6, kl = threadIdx.x & 63;
+  const int cq = (C3 + 3) / 4;
+  for (int k0 = 0; k0 < K; k0 += 64) {
+    const int kp = k0 + kl;
+    double s = 0.0, cv = 0.0;
+    if (kp < K) {
+      const int c1 = min(C3, (part + 1) * cq);
+#pragma unroll 4
+      for (int c = part * cq; c < c1; ++c) {
+        const double w = (double)W[c * K + kp];
+        s += s_g[c] * w * (double)W[c * K + k];
+        cv += s_e[c] * w;
+      }
+    }
+    s_part[part][kl] = s;
+    s_cv[part][kl] = cv;
+    __syncthreads();
+    if (part == 0 && kp < K) {
+      const double st = (s_part[0][kl] + s_part[1][kl]) + (s_part[2][kl] + s_part[3][kl]);
+      Wcat[(size_t)k * ld + kp] = (float)(-st);           // -G^T[k][kp] = -G[kp][k] (symmetric)
+      if (k == 0) cvec[kp] = (float)((s_cv[0][kl] + s_cv[1][kl]) + (s_cv[2][kl] + s_cv[3][kl]));
+    }
+    __syncthreads();
+  }
+  for (int c = threadIdx.x; c < C3; c += 256) {
+    Wcat[(size_t)k * ld + K + c] = W[c * K + k];
+    if (k == 0) { ge[c] = (float)s_g[c]; ge[C3 + c] = (float)s_e[c]; }
+  }
+}
+
+// partial_sum = the SP / colsum partials already summed over the workgroups (C3 K + K floats)
+__global__ __launch_bounds__(256) void pool_bwd_final_kernel(
+    int C3, int K, const float *__restrict__ partial_sum, const float *__restrict__ gram,
+    const float *__restrict__ W, const float *__restrict__ coef, const float *__restrict__ mean,
+    const float *__restrict__ invstd, float *__restrict__ dW) {
+  const int c = blockIdx.x;
+  const double g = (double)coef[c] * (double)coef[2 * C3 + c] * (double)invstd[c];
+  const double e = g * (double)mean[c] - (double)coef[c] * (double)coef[C3 + c];
+  for (int k = threadIdx.x; k < K; k += 256) {
+    double wg = 0.0;
+#pragma unroll 8
+    for (int kk = 0; kk < K; ++kk) wg += (double)W[c * K + kk] * (double)gram[kk * K + k];
+    dW[(size_t)c * K + k] = (float)((double)partial_sum[(size_t)c * K + k] - g * wg +
+                                    e * (double)partial_sum[(size_t)C3 * K + k]);
+  }
+}
+
+extern "C" int s2c_pool_bwd_prep(int C3, int K, const float *coef, const float *mean,
+                                 const float *invstd, const float *W, float *Wcat, float *cvec,
+                                 float *ge, void *stream) {
+  if (C3 <= 0 || C3 > 256 || K <= 0 || !coef || !mean || !invstd || !W || !Wcat || !cvec || !ge)
+    return fail2("pool_bwd_prep: sizes / null pointer");
+  hipLaunchKernelGGL(pool_bwd_prep_kernel, dim3(K), dim3(256), 0, (hipStream_t)stream, C3, K, coef,
+                     mean, invstd, W, Wcat, cvec, ge);
+  return check2("pool_bwd_prep");
+}
+
+extern "C" int s2c_pool_bwd_final(int C3, int K, const float *partial_sum, const float *gram,
+                                  const float *W, const float *coef, const float *mean,
+                                  const float *invstd, float *dW, void *stream) {
+  if (C3 <= 0 || K <= 0 || !partial_sum || !gram || !W || !coef || !mean || !invstd || !dW)
+    return fail2("pool_bwd_final: sizes / null pointer");
+  hipLaunchKernelGGL(pool_bwd_final_kernel, dim3(C3), dim3(256), 0, (hipStream_t)stream, C3, K,
+                     partial_sum, gram, W, coef, mean, invstd, dW);
+  return check2("pool_bwd_final");
 }
 
 extern "C" int s2c_pool_bwd_dk(long long J, int C, const float *dOut, const float *ymax,
@@ -977,18 +1093,19 @@ extern "C" int s2c_pool_bwd_dk(long long J, int C, const float *dOut, const floa
   return check2("pool_bwd_dk");
 }
 
-extern "C" int s2c_pool_bwd_sp_blocks(long long J) { return J < 1024 ? (int)J : 1024; }
+extern "C" int s2c_pool_bwd_sp_blocks(long long J) { return J < 768 ? (int)J : 768; }
 
 // partial: s2c_pool_bwd_sp_blocks(J) x (C3 * K + K) floats (SP | column sums of A).
 // K in {32, 64, 128, 256}, C3 <= (256 / K) * 32, ns * K * 4 bytes of LDS (<= 64 KB).
 extern "C" int s2c_pool_bwd_sp(long long J, int ns, int C3, int K, const float *A, const int *arg,
                                const float *dk, float *partial, void *stream) {
   if (J <= 0 || ns <= 0 || C3 <= 0 || !(K == 32 || K == 64 || K == 128 || K == 256) ||
-      C3 > (256 / K) * SP_CG || C3 > 256 || ns * K > 256 * 4 * SP_MAXQ || !A || !arg || !dk || !partial)
+      C3 > (256 / K) * SP_CG || C3 > 128 || (C3 & 3) || (ns * K * 4) % 4096 || ns * K * 4 > 16384 ||
+      !A || !arg || !dk || !partial || ((uintptr_t)A & 15) || ((uintptr_t)dk & 15) || ((uintptr_t)arg & 15))
     return fail2("pool_bwd_sp: sizes / null pointer");
-  hipLaunchKernelGGL(pool_bwd_sp_kernel, dim3(s2c_pool_bwd_sp_blocks(J)), dim3(256),
-                     ((size_t)ns * K + 2 * C3) * sizeof(float), (hipStream_t)stream, J, ns, C3, K, A,
-                     arg, dk, partial);
+  const size_t lds = (size_t)SP_RING * ((size_t)ns * K * 4 + 1024);
+  hipLaunchKernelGGL(pool_bwd_sp_kernel, dim3(s2c_pool_bwd_sp_blocks(J)), dim3(256), lds,
+                     (hipStream_t)stream, J, ns, C3, K, A, arg, dk, partial);
   return check2("pool_bwd_sp");
 }
 

@@ -267,6 +267,8 @@ _C.register("s2c_pool_select", [_L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_bn_relu_max_bwd_stats", [_L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P])
 _C.register("s2c_pool_bwd_dk", [_L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_pool_bwd_sp", [_L, _I, _I, _I, _P, _P, _P, _P, _P])
+_C.register("s2c_pool_bwd_prep", [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P])
+_C.register("s2c_pool_bwd_final", [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_pool_bwd_input_grad", [_L, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _P, _I, _P])
 
 # The pooled LAST layer of a training stack without its (M x C3) pre-activation / gradient
@@ -309,10 +311,20 @@ def pooled_layer_backward(dOut, arg, ymax, scale, shift, mean, invstd, gamma, fr
     _call("s2c_pool_bwd_dk", dOut, J, C3, dOut.data_ptr(), ymax.data_ptr(), scale.data_ptr(),
           shift.data_ptr(), coef.data_ptr(), arg.data_ptr(), dk.data_ptr(), arg16.data_ptr(),
           alg_bytes=4 * 4 * J * C3)
-    k0, k1, k2 = coef[:C3].double(), coef[C3:2 * C3].double(), coef[2 * C3:].double()
-    g = k0 * k2 * invstd.double()
-    e = g * mean.double() - k0 * k1
-    Wd = W.double()
+    W = W.contiguous()
+    # ---- input gradient --------------------------------------------------------------------
+    dA = None
+    if need_dA:
+        Wcat = torch.empty((K, K + C3), device=dev)
+        cvec = torch.empty(K, device=dev)
+        ge = torch.empty(2 * C3, device=dev)
+        _call("s2c_pool_bwd_prep", W, C3, K, coef.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+              W.data_ptr(), Wcat.data_ptr(), cvec.data_ptr(), ge.data_ptr())
+        dA = torch.empty((M, K), device=dev)
+        _call("s2c_pool_bwd_input_grad", A, M, K, K, C3, ns, A.data_ptr(), A.stride(0),
+              arg16.data_ptr(), dk.data_ptr(), Wcat.data_ptr(), Wcat.stride(0), cvec.data_ptr(),
+              dA.data_ptr(), K, alg_bytes=4 * (2 * M * K + 2 * J * C3),
+              alg_flops=2 * M * K * (K + C3))
     # ---- weight gradient -------------------------------------------------------------------
     lib = _C.load()
     lib.s2c_pool_bwd_sp_blocks.argtypes = [_L]
@@ -321,21 +333,11 @@ def pooled_layer_backward(dOut, arg, ymax, scale, shift, mean, invstd, gamma, fr
     sp = torch.empty((nblk, C3 * K + K), device=dev)
     _call("s2c_pool_bwd_sp", A, J, ns, C3, K, A.data_ptr(), arg.data_ptr(), dk.data_ptr(),
           sp.data_ptr(), alg_bytes=4 * (M * K + 2 * J * C3 + nblk * (C3 + 1) * K))
-    spsum = sp.sum(0).double()
-    SP, colsum = spsum[:C3 * K].view(C3, K), spsum[C3 * K:]
-    gram = _weight_grad(A, A).double()                      # A^T A  (K x K)
-    dW = (SP - (g.unsqueeze(1) * Wd) @ gram + e.unsqueeze(1) * colsum.unsqueeze(0)).float()
-    # ---- input gradient --------------------------------------------------------------------
-    dA = None
-    if need_dA:
-        G = Wd.t() @ (g.unsqueeze(1) * Wd)                  # K x K
-        cvec = (e @ Wd).float().contiguous()                # K
-        Wcat = torch.cat([(-G.t()).float(), W.t()], 1).contiguous()      # (K, K + C3)
-        dA = torch.empty((M, K), device=dev)
-        _call("s2c_pool_bwd_input_grad", A, M, K, K, C3, ns, A.data_ptr(), A.stride(0),
-              arg16.data_ptr(), dk.data_ptr(), Wcat.data_ptr(), Wcat.stride(0), cvec.data_ptr(),
-              dA.data_ptr(), K, alg_bytes=4 * (2 * M * K + 2 * J * C3),
-              alg_flops=2 * M * K * (K + C3))
+    gram = _weight_grad(A, A).contiguous()                  # A^T A  (K x K)
+    dW = torch.empty((C3, K), device=dev)
+    spsum = sp.sum(0)
+    _call("s2c_pool_bwd_final", dW, C3, K, spsum.data_ptr(), gram.data_ptr(), W.data_ptr(),
+          coef.data_ptr(), mean.data_ptr(), invstd.data_ptr(), dW.data_ptr())
     return dA, dW, dgamma, dbeta
 
 
