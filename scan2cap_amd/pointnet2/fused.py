@@ -333,9 +333,16 @@ def pooled_layer_backward(dOut, arg, ymax, scale, shift, mean, invstd, gamma, fr
     sp = torch.empty((nblk, C3 * K + K), device=dev)
     _call("s2c_pool_bwd_sp", A, J, ns, C3, K, A.data_ptr(), arg.data_ptr(), dk.data_ptr(),
           sp.data_ptr(), alg_bytes=4 * (M * K + 2 * J * C3 + nblk * (C3 + 1) * K))
-    gram = _weight_grad(A, A).contiguous()                  # A^T A  (K x K)
+    # both partial tables are summed by ONE multi_colsum launch (kernel-boundary reduction).
+    # NOT torch.sum: its cross-block reductions reset a semaphore buffer with hipMemsetAsync,
+    # and memset nodes of a captured hipGraph are not ordered against kernels on ROCm 7.2
+    # (DESIGN 5): the second replay of a two-graph step returned a wrong dW here.
+    pending = []
+    gram = _weight_grad(A, A, pending)                      # A^T A  (K x K)
+    spsum = torch.empty(C3 * K + K, device=dev)
+    pending.append((sp.view(nblk, 1, C3 * K + K), spsum))
+    flush_partial_sums(pending)
     dW = torch.empty((C3, K), device=dev)
-    spsum = sp.sum(0)
     _call("s2c_pool_bwd_final", dW, C3, K, spsum.data_ptr(), gram.data_ptr(), W.data_ptr(),
           coef.data_ptr(), mean.data_ptr(), invstd.data_ptr(), dW.data_ptr())
     return dA, dW, dgamma, dbeta

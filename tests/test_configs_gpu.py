@@ -244,6 +244,10 @@ def test_cfg3_graph_replay_matches_eager():
         return torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5,
                                 capturable=True, fused=True)
     state = {k: v.clone() for k, v in model.state_dict().items()}
+    # (the slots first: they size the persistent GEMM grid beside the geometry stage, and the
+    # grid decides the order of the BatchNorm partial sums -- eager and replay must share it
+    # to be "the same kernels")
+    slots = GeometrySlots(model.backbone_net, dd["point_clouds"], 1)
     eager = bench.make_step(model, wl, cfg, new_opt(), None, dev)
     ref = [float(eager(dd).detach()) for _ in range(2)]
     w_ref = {k: v.clone() for k, v in model.state_dict().items()}
@@ -251,7 +255,6 @@ def test_cfg3_graph_replay_matches_eager():
     model.load_state_dict(state)
     opt = new_opt()
     step = bench.make_step(model, wl, cfg, opt, None, dev)
-    slots = GeometrySlots(model.backbone_net, dd["point_clouds"], 1)
 
     def body():
         d = dict(dd)

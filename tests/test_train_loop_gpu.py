@@ -79,6 +79,9 @@ def test_graphed_training_replays_eager_steps():
     from scan2cap_amd.graphs import GraphedCallable
     from scan2cap_amd.pipeline import GeometrySlots
     bench, wl, model, opt, dd, cfg, dev = _setup()
+    # (slots first: they size the persistent GEMM grid, which fixes the order of the BatchNorm
+    # partial sums for the eager steps and the replays alike)
+    slots = GeometrySlots(model.backbone_net, dd["point_clouds"], 1)
     eager = bench.make_step(model, wl, cfg, opt, None, dev)
     state = {k: v.clone() for k, v in model.state_dict().items()}
     ref = [float(eager(dd).detach()) for _ in range(3)]
@@ -86,7 +89,6 @@ def test_graphed_training_replays_eager_steps():
     opt2 = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5, capturable=True,
                             fused=True)
     step = bench.make_step(model, wl, cfg, opt2, None, dev)
-    slots = GeometrySlots(model.backbone_net, dd["point_clouds"], 1)
 
     def body():
         d = dict(dd)
