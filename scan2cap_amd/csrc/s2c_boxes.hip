@@ -301,26 +301,36 @@ extern "C" int s2c_batch_prep(const s2c_prep_args *a, void *stream) {
 // its own framework reduction kernel).  Fixed summation order.
 namespace {
 
+// Workgroup = 64 outputs x 4 phases of the partial index (thread = (e, phase)): phase p adds
+// the partials s = p, p + 4, ... on four independent chains, the four phase sums meet through
+// LDS in a fixed order.  (One thread per output walked all S partials alone: 85 us for the
+// 768 x 8256 table of the pooled-layer algebra.)
 __global__ __launch_bounds__(256) void multi_colsum_kernel(s2c_colsum_args a) {
+  __shared__ float s_ph[4][64];
   long long blk = blockIdx.x;
+  const int el = threadIdx.x & 63, ph = threadIdx.x >> 6;
   for (int j = 0; j < a.n_jobs; ++j) {
-    const long long nb = (a.n[j] + 255) / 256;
+    const long long nb = (a.n[j] + 63) / 64;
     if (blk < nb) {
-      const long long e = blk * 256 + threadIdx.x;
-      if (e >= a.n[j]) return;
-      const float *p = a.part[j] + e;
+      const long long e = blk * 64 + el;
       const long long n = a.n[j];
       const int S = a.S[j];
       float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-      int s = 0;
-      for (; s + 4 <= S; s += 4) {          // four independent chains, fixed order
-        s0 += p[(long long)s * n];
-        s1 += p[(long long)(s + 1) * n];
-        s2 += p[(long long)(s + 2) * n];
-        s3 += p[(long long)(s + 3) * n];
+      if (e < n) {
+        const float *p = a.part[j] + e;
+        int s = ph;
+        for (; s + 12 < S; s += 16) {         // four independent chains, fixed order
+          s0 += p[(long long)s * n];
+          s1 += p[(long long)(s + 4) * n];
+          s2 += p[(long long)(s + 8) * n];
+          s3 += p[(long long)(s + 12) * n];
+        }
+        for (; s < S; s += 4) s0 += p[(long long)s * n];
       }
-      for (; s < S; ++s) s0 += p[(long long)s * n];
-      a.out[j][e] = (s0 + s1) + (s2 + s3);
+      s_ph[ph][el] = (s0 + s1) + (s2 + s3);
+      __syncthreads();
+      if (ph == 0 && e < n)
+        a.out[j][e] = (s_ph[0][el] + s_ph[1][el]) + (s_ph[2][el] + s_ph[3][el]);
       return;
     }
     blk -= nb;
@@ -334,7 +344,7 @@ extern "C" int s2c_multi_colsum(const s2c_colsum_args *a, void *stream) {
   long long blocks = 0;
   for (int j = 0; j < a->n_jobs; ++j) {
     if (!a->part[j] || !a->out[j] || a->S[j] <= 0 || a->n[j] <= 0) return -1;
-    blocks += (a->n[j] + 255) / 256;
+    blocks += (a->n[j] + 63) / 64;
   }
   hipLaunchKernelGGL(multi_colsum_kernel, dim3((unsigned)blocks), dim3(256), 0,
                      (hipStream_t)stream, *a);
