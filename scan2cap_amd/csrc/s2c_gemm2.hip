@@ -518,22 +518,37 @@ __global__ __launch_bounds__(64 * WAVES, (NT == 4 && WAVES == 4) ? 1 : 2) void r
     if constexpr (EPI == EPI_RAW) {
       // ---- training, pooled layer: running max / min (+ first index) per centre ------------
       const int ns = p.pool_ns;
-      const int sbase = (ns == 64 && (n & 1)) ? 32 : 0;
+      const int sl = 4 * lk + ((ns == 64 && (n & 1)) ? 32 : 0);   // sample index of this lane's e = 0
+      const bool full = r0 + 32 <= M;                             // (M % ns == 0: only a last tile is ragged)
+      if (ns != 16) {
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
+        for (int j = 0; j < NT; ++j) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {            // ascending rows of this lane: strict compares
-          const int rl = (e & 3) + 8 * (e >> 2) + 4 * lk;   // keep the first extremum
-          const float v = acc[j][e];
-          const int s = ns == 16 ? (rl & 15) : rl + sbase;
-          const int h = ns == 16 ? (e >> 3) : 0;
-          if (r0 + rl < M) {
-            if (h == 0) {
-              if (v > rmax[j][0]) { rmax[j][0] = v; ramax[j][0] = s; }
-              if (v < rmin[j][0]) { rmin[j][0] = v; ramin[j][0] = s; }
-            } else {
-              if (v > rmax[j][1]) { rmax[j][1] = v; ramax[j][1] = s; }
-              if (v < rmin[j][1]) { rmin[j][1] = v; ramin[j][1] = s; }
+          for (int e = 0; e < 16; ++e) {          // ascending rows of this lane: strict compares
+            const int ro = (e & 3) + 8 * (e >> 2);                // keep the first extremum
+            const float v = acc[j][e];
+            if (full || r0 + ro + 4 * lk < M) {
+              if (v > rmax[j][0]) { rmax[j][0] = v; ramax[j][0] = sl + ro; }
+              if (v < rmin[j][0]) { rmin[j][0] = v; ramin[j][0] = sl + ro; }
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {          // rows 0-15 (e < 8) / 16-31: two centres
+            const int rl = (e & 3) + 8 * (e >> 2) + 4 * lk;
+            const float v = acc[j][e];
+            const int s = rl & 15;
+            if (full || r0 + rl < M) {
+              if (e < 8) {
+                if (v > rmax[j][0]) { rmax[j][0] = v; ramax[j][0] = s; }
+                if (v < rmin[j][0]) { rmin[j][0] = v; ramin[j][0] = s; }
+              } else {
+                if (v > rmax[j][1]) { rmax[j][1] = v; ramax[j][1] = s; }
+                if (v < rmin[j][1]) { rmin[j][1] = v; ramin[j][1] = s; }
+              }
             }
           }
         }
