@@ -194,6 +194,7 @@ int s2c_pool_bwd_final(int C3, int K, const float *partial_sum, const float *gra
                        float *dW, void *stream);
 int s2c_pool_bwd_sp(long long J, int ns, int C3, int K, const float *A, const int *arg,
                     const float *dk, float *partial, void *stream);
+int s2c_pool_bwd_supported(long long M, int N, int KA, int C3);   /* 1: the call below takes it */
 int s2c_pool_bwd_input_grad(long long M, int N, int KA, int C3, int ns, const float *A, int lda,
                             const short *arg16, const float *dk, const float *Wcat, int ldw,
                             const float *cvec, float *dA, int ldd, void *stream);

@@ -862,6 +862,12 @@ extern "C" int s2c_rows_gemm_pool_raw(long long M, int N, int K, const float *A,
   return launch_stream<SPRO_NONE>(a, (hipStream_t)stream);
 }
 
+// 1 when s2c_pool_bwd_input_grad takes (M, N, KA, C3) (the exact test of its dispatch)
+extern "C" int s2c_pool_bwd_supported(long long M, int N, int KA, int C3) {
+  return stream_on() && KA > 0 && C3 > 0 && !(KA & 15) && !(C3 & 7) && C3 <= 128 &&
+         pick_cfg(M, N, KA + C3, SPRO_POOLBWD) >= 0;
+}
+
 // dA (M x N) = [A | dkrow] [-G^T | W3^T]^T + cvec  (see StreamArgs::pb_arg): the input gradient
 // of a max-pooled BatchNorm(+ReLU) layer from the layer's INPUT activation A (M x KA), the
 // routed pooled gradient dk / arg (J x C3) and Wcat (N x (KA + C3)), bias cvec (N).  KA % 16 == 0,

@@ -277,11 +277,21 @@ _C.register("s2c_pool_bwd_input_grad", [_L, _I, _I, _I, _I, _P, _I, _P, _P, _P, 
 POOL_ALGEBRA = _os.environ.get("S2C_POOL_ALGEBRA", "1") != "0"
 
 
+def _pool_bwd_takes(M, N, KA, C3):
+    lib = _C.load()
+    if not hasattr(lib, "_s2c_pool_bwd_sig"):
+        lib.s2c_pool_bwd_supported.argtypes = [_L, _I, _I, _I]
+        lib.s2c_pool_bwd_supported.restype = _I
+        lib._s2c_pool_bwd_sig = True
+    return bool(lib.s2c_pool_bwd_supported(M, N, KA, C3))
+
+
 def pool_algebra_takes(M, Cout, K_in, pool_ns):
     return (POOL_ALGEBRA and pool_ns in (16, 32, 64) and M % pool_ns == 0 and Cout <= 128
             and Cout % 8 == 0 and K_in in (32, 64, 128) and Cout <= (256 // K_in) * 32
+            and pool_ns * K_in * 4 <= 16384 and (pool_ns * K_in * 4) % 4096 == 0   # s2c_pool_bwd_sp tiles
             and _gemm_split_on()
-            and _stream_takes(M, Cout, K_in) and _stream_takes(M, K_in, K_in + Cout))
+            and _stream_takes(M, Cout, K_in) and _pool_bwd_takes(M, K_in, K_in, Cout))
 
 
 def pooled_layer_backward(dOut, arg, ymax, scale, shift, mean, invstd, gamma, frozen, A, W, ns,
