@@ -244,3 +244,36 @@ def test_c_abi_library_exports_every_declared_symbol():
     for sym in sorted(declared):
         assert hasattr(lib, sym), "missing export: " + sym
     assert lib.s2c_abi_version() == 1
+
+
+def test_streaming_gemm_dispatch_table():
+    """Which layer shapes the streaming kernel of csrc/s2c_gemm2.hip takes is host logic (LDS
+    budget: W planes + one LDS-DMA ring per wave): pinned here without a GPU."""
+    import ctypes
+    from scan2cap_amd import _C
+    lib = _C.load()
+    L, I = ctypes.c_longlong, ctypes.c_int
+    lib.s2c_rows_stream_supported.argtypes = [L, I, I, I]
+    lib.s2c_rows_stream_supported.restype = I
+    lib.s2c_pool_bwd_supported.argtypes = [L, I, I, I]
+    lib.s2c_pool_bwd_supported.restype = I
+    lib.s2c_gemm_set_stream.argtypes = [I]
+    lib.s2c_gemm_set_stream_grid.argtypes = [I]
+    M1, M2 = 8 * 2048 * 64, 8 * 1024 * 32
+    take = lambda M, N, K, g=0: lib.s2c_rows_stream_supported(M, N, K, g)
+    # SA1 (1M rows): every layer; SA2: the N = 128 layers, not the N = 256 one
+    assert take(M1, 64, 64) == 1 and take(M1, 128, 64) == 1 and take(M1, 64, 128) == 1
+    assert take(M1, 64, 135, 1) == 1 and take(M2, 128, 131, 1) == 1 and take(M2, 128, 128) == 1
+    assert take(M2, 256, 128) == 0 and take(M2, 128, 256) == 0
+    assert take(M1, 64, 66) == 0                     # K % 4
+    assert take(M1, 64, 134, 1) == 0                 # gather: (K - 3) % 4
+    assert take(65536, 64, 64) == 0                  # too few rows for a persistent grid
+    assert lib.s2c_pool_bwd_supported(M1, 64, 64, 128) == 1
+    assert lib.s2c_pool_bwd_supported(M2, 128, 128, 256) == 0
+    prev = lib.s2c_gemm_set_stream(0)
+    try:
+        assert take(M1, 64, 64) == 0
+    finally:
+        lib.s2c_gemm_set_stream(prev)
+    old = lib.s2c_gemm_set_stream_grid(200)
+    assert lib.s2c_gemm_set_stream_grid(old) == 200 and lib.s2c_gemm_set_stream_grid(0) == old
