@@ -18,15 +18,32 @@ import torch
 import torch.distributed as dist
 
 
+def dist_backend(backend=None):
+    """Collective backend of the N>1 path: RCCL ("nccl" on ROCm) when there is a GPU per
+    rank; `S2C_DIST_BACKEND=gloo` runs the very same launcher / two-graph step with several
+    ranks sharing ONE GPU (RCCL refuses two ranks on one device), which is how the N>1 path
+    is exercised on a single leased MI355X (tests/test_bench_launch_gpu.py)."""
+    if backend is None:
+        backend = os.environ.get("S2C_DIST_BACKEND")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"  # nccl == RCCL on ROCm
+    return backend
+
+
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (as set by
-    `python -m torch.distributed.run`).  Returns (rank, world, local_rank)."""
+    `python -m torch.distributed.run` or bench.py's own launcher).
+    Returns (rank, world, local_rank)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"  # nccl == RCCL on ROCm
+        backend = dist_backend(backend)
+        if backend == "nccl" and torch.cuda.is_available() \
+                and torch.cuda.device_count() < min(world, 8):
+            raise SystemExit("RCCL needs one GPU per rank (%d ranks, %d visible GPUs); set "
+                             "S2C_DIST_BACKEND=gloo to run several ranks on one GPU"
+                             % (world, torch.cuda.device_count()))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

@@ -159,8 +159,13 @@ class GeometrySlots(object):
             slots.refill(p, next_point_clouds)   # ... and starts batch i+depth
     """
 
-    def __init__(self, backbone, point_clouds, depth=1, group=1):
-        """group > 1: the geometry of `group` consecutive batches is computed by ONE
+    def __init__(self, backbone, point_clouds, depth=1, group=1, reserve_cus=8):
+        """reserve_cus: compute units the persistent GEMM grid of the main stream leaves free
+        on top of the FPS workgroups of this stage (one per scene of a pass) -- 8 for the
+        ball-query / 3-NN launches; pass 8 + the RCCL channel count when a collective runs
+        beside the step (bench.py does for N > 1).  The grid is a process-wide setting of
+        libs2c_hip.so: `close()` restores the value found here.
+        group > 1: the geometry of `group` consecutive batches is computed by ONE
         set of launches on the stacked clouds (the FPS kernels run one workgroup per
         scene for ~6 ms whatever the batch: stacking G batches gives G times the
         geometry throughput from a single side stream); `depth` must be a multiple of
@@ -175,11 +180,14 @@ class GeometrySlots(object):
         # the persistent GEMM grid on the main stream must fit beside this stage's FPS
         # workgroups (one per scene of a pass, resident for milliseconds): measured optimum
         # 256 - scenes - 8 (cfg3: 240, cfg2 with 3 batches per pass: 224)
+        self._old_grid = None
         if point_clouds.is_cuda and not _os.environ.get("S2C_GEMM_STREAM_GRID"):
             from . import _C
             lib = _C.load()
             lib.s2c_gemm_set_stream_grid.argtypes = [_ctypes.c_int]
-            lib.s2c_gemm_set_stream_grid(max(64, 256 - point_clouds.shape[0] * self.group - 8))
+            cus = torch.cuda.get_device_properties(point_clouds.device).multi_processor_count
+            self._old_grid = lib.s2c_gemm_set_stream_grid(
+                max(cus // 4, cus - point_clouds.shape[0] * self.group - int(reserve_cus)))
         geo0 = backbone.compute_geometry(point_clouds)
         self._slots = []
         for _ in range(self.depth):
@@ -188,6 +196,13 @@ class GeometrySlots(object):
         self._published = [None] * self.depth
         self._consumed = [None] * self.depth
         torch.cuda.synchronize()
+
+    def close(self):
+        """Give the persistent GEMM grid back the size it had before these slots existed."""
+        if self._old_grid:
+            from . import _C
+            _C.load().s2c_gemm_set_stream_grid(self._old_grid)
+            self._old_grid = None
 
     def geometry(self, p):
         return unflatten_geometry(self._slots[p])
