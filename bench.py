@@ -775,7 +775,10 @@ def main():
         return {"elapsed": elapsed, "overlap": overlap, "depth": depth,
                 "group": slots.group if slots is not None else 1,
                 "fed": feeder is not None, "windows_ms": windows,
-                "pairs": pairs if use_graph else [], "g2": g2 if use_graph else None}
+                "pairs": pairs if use_graph else [], "g2": g2 if use_graph else None,
+                # the captured graphs read these static tensors by address: whoever replays
+                # a graph after this function returns (ddp_evidence) must keep them alive
+                "keepalive": (slots, dd_sets, feeder)}
 
     head = measure(args.feed, args.steps, args.warmup)
     elapsed, overlap, depth = head["elapsed"], head["overlap"], head["depth"]

@@ -78,6 +78,17 @@ int s2c_fps_small_limit(void);
 int s2c_furthest_point_sampling_small(int b, int n, int m, const float *xyz, int *idx,
                                       int threads, s2c_stream_t stream);
 
+/* FPS of a point set that is EXPECTED to be in FPS pick order already (SA2..SA4 sample the
+ * previous stage's centres, backbone_module.py:106-115, so their picks are 0..m-1 unless a
+ * tie or a skipped point breaks the property): the expectation is PROVEN per scene on the
+ * device under the reference's exact rule (n*m parallel pair tests, no serial rounds); scenes
+ * that fail it run the real rounds.  Identical output to s2c_furthest_point_sampling for every
+ * input.  Scratch of s2c_fps_prefix_workspace_bytes(b, m) bytes; after the call its first b
+ * ints hold 1 for the scenes that ran the rounds, 0 for the proven ones. */
+long long s2c_fps_prefix_workspace_bytes(int b, int m);
+int s2c_furthest_point_sampling_prefix(int b, int n, int m, const float *xyz, void *workspace,
+                                       int *idx, int threads, s2c_stream_t stream);
+
 /* replaces gather_points_kernel_wrapper (sampling.cpp:5-7, sampling_gpu.cu:22-30).
  * points (b,c,n), idx (b,npoints) -> out (b,c,npoints) */
 int s2c_gather_points(int b, int c, int n, int npoints, const float *points,

@@ -22,6 +22,7 @@ _SIGNATURES = {
     "s2c_furthest_point_sampling_bucketed": [_INT, _INT, _INT, _PTR, _PTR, _PTR, _PTR],
     "s2c_furthest_point_sampling_small": [_INT, _INT, _INT, _PTR, _PTR, _INT, _PTR],
     "s2c_furthest_point_sampling_cells": [_INT, _INT, _INT, _PTR, _PTR, _PTR, _INT, _PTR],
+    "s2c_furthest_point_sampling_prefix": [_INT, _INT, _INT, _PTR, _PTR, _PTR, _INT, _PTR],
     "s2c_gather_points": [_INT, _INT, _INT, _INT, _PTR, _PTR, _PTR, _PTR],
     "s2c_gather_points_grad": [_INT, _INT, _INT, _INT, _PTR, _PTR, _PTR, _PTR],
     "s2c_ball_query": [_INT, _INT, _INT, _FLT, _INT, _PTR, _PTR, _PTR, _PTR],
@@ -60,6 +61,8 @@ def load():
     lib.s2c_fps_workspace_bytes.argtypes = [_INT, _INT]
     lib.s2c_fps_cells_workspace_bytes.restype = ctypes.c_longlong
     lib.s2c_fps_cells_workspace_bytes.argtypes = [_INT, _INT]
+    lib.s2c_fps_prefix_workspace_bytes.restype = ctypes.c_longlong
+    lib.s2c_fps_prefix_workspace_bytes.argtypes = [_INT, _INT]
     lib.s2c_ball_query_workspace_bytes.restype = ctypes.c_longlong
     lib.s2c_ball_query_workspace_bytes.argtypes = [_INT, _INT]
     lib.s2c_ball_query_grid_max_nsample.restype = _INT
@@ -75,7 +78,7 @@ def declared_symbols():
     return ["s2c_abi_version", "s2c_last_error_string",
             "s2c_fps_resident_limit", "s2c_fps_workspace_bytes",
             "s2c_fps_small_limit", "s2c_ball_query_workspace_bytes", "s2c_fps_cells_workspace_bytes",
-            "s2c_ball_query_grid_max_nsample"] + list(_SIGNATURES)
+            "s2c_fps_prefix_workspace_bytes", "s2c_ball_query_grid_max_nsample"] + list(_SIGNATURES)
 
 
 def register(name, argtypes):

@@ -20,8 +20,9 @@ HIPCC_FLAGS = [
     # hardware float atomics (global_atomic_add_f32) instead of CAS loops in the
     # scatter-add (grad) kernels
     "-munsafe-fp-atomics",
-    "-shared", "-fPIC",
+    "-fPIC",
 ]
+OBJ_DIR = os.path.join(LIB_DIR, "obj")
 
 
 def sources():
@@ -37,16 +38,36 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _headers_mtime():
+    deps = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(
+        os.path.join(_HERE, "..", "include", "*.h"))
+    return max(os.path.getmtime(d) for d in deps)
+
+
 def build(force=False, verbose=False):
-    """Compile every .hip source into lib/libs2c_hip.so.  Returns the path."""
+    """Compile every .hip source (one object per source, in parallel, only the stale ones
+    unless `force`) and link lib/libs2c_hip.so.  Returns the path."""
     if not force and not _stale():
         return LIB_PATH
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "hipcc")
-    os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH] + sources()
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hdr = _headers_mtime()
+    jobs, objs = [], []
+    for src in sources():
+        obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or \
+                os.path.getmtime(obj) < max(os.path.getmtime(src), hdr):
+            jobs.append([hipcc] + HIPCC_FLAGS + ["-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        list(pool.map(run, jobs))
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs)
     return LIB_PATH
 
 

@@ -29,10 +29,13 @@ __device__ __forceinline__ u32 bitrev_n(u32 v, int nbits) {
 
 struct __attribute__((aligned(16))) Slot { u64 key; float x, y, z, pad; };
 
+// `verified` (optional): per-scene flags of the prefix verification below.  0 = the picks of
+// this scene were PROVEN to be 0, 1, ..., m-1 -- they are written and the rounds never run.
 template <int T, int PPT>
 __global__ __launch_bounds__(T) void fps_small_kernel(int n, int m, int bs, int log2bs,
                                                       const float *__restrict__ xyz,
-                                                      int *__restrict__ idx) {
+                                                      int *__restrict__ idx,
+                                                      const int *__restrict__ verified) {
   constexpr int NW = T / 64;
   __shared__ Slot s_slot[2][NW];
   if (m <= 0) return;
@@ -40,6 +43,10 @@ __global__ __launch_bounds__(T) void fps_small_kernel(int n, int m, int bs, int 
   xyz += (size_t)b * n * 3;
   idx += (size_t)b * m;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (verified != nullptr && verified[b] == 0) {
+    for (int j = t; j < m; j += T) idx[j] = j;
+    return;
+  }
 
   float px[PPT], py[PPT], pz[PPT], mind[PPT];
   u32 nrank[PPT];  // ~rank
@@ -119,6 +126,117 @@ __global__ __launch_bounds__(T) void fps_small_kernel(int n, int m, int bs, int 
   }
 }
 
+// ---- "is the answer 0, 1, ..., m-1 ?" ------------------------------------------------------
+// FPS of a point set that is already in FPS pick order returns arange(m):
+// SA2 samples SA1's centres, SA3 SA2's, SA4 SA3's (backbone_module.py:106-115), so three of
+// the reference's five FPS calls are strictly serial round chains (sampling_gpu.cu:69-173)
+// whose result is known -- unless a tie or a skipped point breaks the property.  Instead of
+// trusting it, PROVE it per scene, in parallel, under the reference's exact rule:
+//   picks == arange(m)  <=>  for every round j = 1..m-1 the arg-max over ALL points k of
+//   key(k, D_j(k)),  D_j(k) = min_{i<j} d(p_k, p_i),  is point j (and its key is not 0),
+// with d the reference's float expression, the |p|^2 <= 1e-3 skip and the 64-bit key whose
+// low word carries the reference's thread-layout tie rule (same key as fps_small_kernel).
+// Kernel 1: star[j] = key(j, D_j(j)) (thread per j, j pair tests).  Kernel 2: thread per k
+// walks the rounds with its running minimum and raises the scene's flag if its key ever
+// beats star[j].  n*m pair tests, no per-round synchronisation; the real FPS kernel then
+// starts with "flag clear -> write arange, return" (no host round trip).
+struct __attribute__((aligned(16))) Pivot { float x, y, z; u32 star_hi; };
+
+__device__ __forceinline__ float fps_d2(float px, float py, float pz, float cx, float cy,
+                                        float cz) {
+  return (px - cx) * (px - cx) + (py - cy) * (py - cy) + (pz - cz) * (pz - cz);
+}
+
+constexpr int PFX_T = 256;      // threads per workgroup
+constexpr int PFX_CHUNK = 512;  // pivots staged in LDS at a time
+
+__global__ __launch_bounds__(PFX_T) void fps_prefix_star_kernel(
+    int n, int m, int bs, int log2bs, const float *__restrict__ xyz, u64 *__restrict__ star,
+    int *__restrict__ flag) {
+  __shared__ float4 s_p[PFX_CHUNK];
+  const int b = blockIdx.y;
+  xyz += (size_t)b * n * 3;
+  star += (size_t)b * m;
+  const int t = threadIdx.x;
+  const int j = blockIdx.x * PFX_T + t;
+  if (blockIdx.x == 0 && t == 0) flag[b] = 0;     // (kernel 2 runs after this kernel)
+  const int jj = j < m ? j : m - 1;
+  const float x = xyz[jj * 3 + 0], y = xyz[jj * 3 + 1], z = xyz[jj * 3 + 2];
+  const float mag = (x * x) + (y * y) + (z * z);
+  const bool skip = (double)mag <= 1e-3;
+  float D = 1e10f;
+  const int jmax = min(m, (int)(blockIdx.x + 1) * PFX_T);   // pivots this workgroup needs
+  for (int c0 = 0; c0 < jmax; c0 += PFX_CHUNK) {
+    __syncthreads();
+    for (int i = t; i < PFX_CHUNK && c0 + i < jmax; i += PFX_T) {
+      const float *q = xyz + (size_t)(c0 + i) * 3;
+      s_p[i] = make_float4(q[0], q[1], q[2], 0.f);
+    }
+    __syncthreads();
+    const int hi = min(jj - c0, PFX_CHUNK);      // pivots i < j of this chunk
+    for (int i = 0; i < hi; ++i) {
+      const float4 c = s_p[i];
+      D = fminf(fps_d2(x, y, z, c.x, c.y, c.z), D);
+    }
+  }
+  if (j < m) {
+    const u32 rank = (bitrev_n((u32)j & (u32)(bs - 1), log2bs) << 22) | ((u32)j >> log2bs);
+    star[j] = skip ? 0ull
+                   : ((u64)(__float_as_uint(D) + 1u) << 32) | (u64)(0xFFFFFFFFu - rank);
+  }
+}
+
+__global__ __launch_bounds__(PFX_T) void fps_prefix_check_kernel(
+    int n, int m, int bs, int log2bs, const float *__restrict__ xyz,
+    const u64 *__restrict__ star, int *__restrict__ flag) {
+  __shared__ Pivot s_p[PFX_CHUNK];     // pivot i together with the high word of star[i + 1]
+  __shared__ u32 s_lo[PFX_CHUNK];      // low word of star[i + 1]
+  const int b = blockIdx.y;
+  xyz += (size_t)b * n * 3;
+  star += (size_t)b * m;
+  const int t = threadIdx.x;
+  const int k = blockIdx.x * PFX_T + t;
+  const int kk = k < n ? k : n - 1;
+  const float x = xyz[kk * 3 + 0], y = xyz[kk * 3 + 1], z = xyz[kk * 3 + 2];
+  const float mag = (x * x) + (y * y) + (z * z);
+  // a skipped point's key is 0 in every round: it can never beat star[j] (which must be > 0)
+  const bool live = k < n && !((double)mag <= 1e-3);
+  const u32 rank = (bitrev_n((u32)kk & (u32)(bs - 1), log2bs) << 22) | ((u32)kk >> log2bs);
+  const u32 nrank = 0xFFFFFFFFu - rank;
+  float D = 1e10f;
+  bool bad = false;
+  // round j = i + 1 uses pivot i; rounds 1 .. m-1  <=>  i = 0 .. m-2
+  for (int c0 = 0; c0 < m - 1; c0 += PFX_CHUNK) {
+    __syncthreads();
+    for (int i = t; i < PFX_CHUNK && c0 + i < m - 1; i += PFX_T) {
+      const float *q = xyz + (size_t)(c0 + i) * 3;
+      const u64 st = star[c0 + i + 1];
+      Pivot pv; pv.x = q[0]; pv.y = q[1]; pv.z = q[2]; pv.star_hi = (u32)(st >> 32);
+      s_p[i] = pv;
+      s_lo[i] = (u32)st;
+      if (st == 0ull) bad = true;                  // point j itself is not selectable
+    }
+    __syncthreads();
+    if (live) {
+      const int hi = min(m - 1 - c0, PFX_CHUNK);
+      for (int i = 0; i < hi; ++i) {
+        const Pivot c = s_p[i];
+        D = fminf(fps_d2(x, y, z, c.x, c.y, c.z), D);
+        const u32 khi = __float_as_uint(D) + 1u;
+        if (khi >= c.star_hi) {                    // rare: at least once per thread (k == j)
+          // keys are unique (the rank is), so equality of the whole key means k == j
+          if (khi > c.star_hi || nrank > s_lo[i]) bad = true;
+        }
+      }
+    }
+  }
+  if (__ballot(bad) != 0ull && (t & 63) == 0) atomicOr(flag + b, 1);
+}
+
+__global__ void fps_prefix_set_kernel(int *flag, int b, int v) {
+  for (int i = threadIdx.x; i < b; i += blockDim.x) flag[i] = v;
+}
+
 int ref_opt_n_threads(int work_size) {
   const int pow_2 = (int)(log((double)work_size) / log(2.0));  // cuda_utils.h:13-19
   int t = 1 << pow_2;
@@ -131,18 +249,59 @@ int ref_opt_n_threads(int work_size) {
 
 #define FPS_SMALL(T_, P_)                                                         \
   hipLaunchKernelGGL((fps_small_kernel<T_, P_>), dim3(b), dim3(T_), 0, st, n, m, bs, \
-                     log2bs, xyz, idx)
+                     log2bs, xyz, idx, verified)
 
 extern "C" int s2c_fps_small_limit(void) { return 8192; }
 
 // threads = 0: heuristic.  Otherwise one of 64/128/256/512/1024 (ceil(n/threads)
 // must be <= 8).
+static int fps_small_launch(int b, int n, int m, const float *xyz, int *idx, int threads,
+                            const int *verified, hipStream_t st);
+
 extern "C" int s2c_furthest_point_sampling_small(int b, int n, int m, const float *xyz,
                                                  int *idx, int threads,
                                                  s2c_stream_t stream) {
   if (b < 0 || n <= 0 || m < 0 || n > 8192 || !xyz || !idx) return S2C_EINVAL;
   if (b == 0 || m == 0) return 0;
+  return fps_small_launch(b, n, m, xyz, idx, threads, nullptr, (hipStream_t)stream);
+}
+
+// workspace layout: int flag[b] (padded to 16 bytes) | u64 star[b][m]
+static size_t pfx_flag_bytes(int b) { return (((size_t)b * 4) + 15) & ~(size_t)15; }
+
+extern "C" long long s2c_fps_prefix_workspace_bytes(int b, int m) {
+  if (b < 0 || m < 0) return S2C_EINVAL;
+  return (long long)(pfx_flag_bytes(b) + (size_t)b * m * 8);
+}
+
+// FPS for inputs that are EXPECTED to be in FPS pick order already (the centres of the
+// previous set-abstraction stage): the result is identical to s2c_furthest_point_sampling for
+// EVERY input -- the expectation is verified on the device per scene, scenes that fail it run
+// the real rounds.  After the call workspace[0..b) (int) holds 1 for the scenes that fell back.
+extern "C" int s2c_furthest_point_sampling_prefix(int b, int n, int m, const float *xyz,
+                                                  void *workspace, int *idx, int threads,
+                                                  s2c_stream_t stream) {
+  if (b < 0 || n <= 0 || m < 0 || n > 8192 || !xyz || !idx || !workspace) return S2C_EINVAL;
+  if (b == 0 || m == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
+  int *flag = (int *)workspace;
+  if (m > n) {   // cannot be a prefix: every scene runs the rounds (flags say so)
+    hipLaunchKernelGGL(fps_prefix_set_kernel, dim3(1), dim3(64), 0, st, flag, b, 1);
+    return fps_small_launch(b, n, m, xyz, idx, threads, flag, st);
+  }
+  u64 *star = (u64 *)((char *)workspace + pfx_flag_bytes(b));
+  const int bs = ref_opt_n_threads(n);
+  int log2bs = 0;
+  while ((1 << log2bs) < bs) ++log2bs;
+  hipLaunchKernelGGL(fps_prefix_star_kernel, dim3((m + PFX_T - 1) / PFX_T, b), dim3(PFX_T), 0,
+                     st, n, m, bs, log2bs, xyz, star, flag);
+  hipLaunchKernelGGL(fps_prefix_check_kernel, dim3((n + PFX_T - 1) / PFX_T, b), dim3(PFX_T), 0,
+                     st, n, m, bs, log2bs, xyz, (const u64 *)star, flag);
+  return fps_small_launch(b, n, m, xyz, idx, threads, flag, st);
+}
+
+static int fps_small_launch(int b, int n, int m, const float *xyz, int *idx, int threads,
+                            const int *verified, hipStream_t st) {
   const int bs = ref_opt_n_threads(n);
   int log2bs = 0;
   while ((1 << log2bs) < bs) ++log2bs;

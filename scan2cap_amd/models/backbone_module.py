@@ -25,6 +25,10 @@ class Pointnet2Backbone(nn.Module):
                 npoint=npoint, radius=radius, nsample=nsample,
                 mlp=[cin] + list(tail), use_xyz=True, normalize_xyz=True))
             cin = tail[-1]
+            # sa2..sa4 sample the centres of the stage before them, which are in FPS pick
+            # order: their FPS result is 0..npoint-1 and is proven instead of iterated
+            # (csrc/s2c_fps_small.hip; backbone_module.py:106,111,115 note the same fact)
+            getattr(self, "sa%d" % i).fps_input_in_pick_order = i >= 2
         self.fp1 = PointnetFPModule(mlp=[256 + 256, 256, 256])
         self.fp2 = PointnetFPModule(mlp=[256 + 256, 256, 256])
 

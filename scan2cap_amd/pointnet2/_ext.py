@@ -8,6 +8,8 @@ is enqueued on the current HIP stream, nothing synchronises.  CPU tensors are
 rejected exactly like the reference ("CPU not supported",
 ball_query.cpp:27-29) -- there is no fallback.
 """
+import os
+
 import torch
 
 from .. import _C
@@ -69,12 +71,28 @@ def gather_points_grad(grad_out, idx, n):
 FPS_BUCKET_MIN_N = 8192
 
 
-def furthest_point_sampling(points, nsamples):
-    """sampling.cpp:66-87.  (B,N,3) f32 -> (B,nsamples) i32"""
+def furthest_point_sampling(points, nsamples, prefix_hint=False, return_fallback=False):
+    """sampling.cpp:66-87.  (B,N,3) f32 -> (B,nsamples) i32
+    prefix_hint: the caller expects `points` to be in FPS pick order already (the centres of a
+    previous FPS): the picks 0..nsamples-1 are then PROVEN per scene by a parallel kernel pair
+    and the serial rounds run only for scenes where the proof fails -- same result for every
+    input (csrc/s2c_fps_small.hip).  return_fallback: also return the (B,) int32 flags
+    (1 = the scene ran the rounds)."""
     _chk_f(points, "points")
     b, n, _ = points.shape
     out = torch.empty((b, nsamples), dtype=torch.int32, device=points.device)
     ab = 4 * (3 * b * n + b * nsamples)
+    if prefix_hint and n <= _C.load().s2c_fps_small_limit() and FPS_PREFIX_VERIFY:
+        ws = torch.empty(_C.load().s2c_fps_prefix_workspace_bytes(b, int(nsamples)),
+                         dtype=torch.uint8, device=points.device)
+        _run("s2c_furthest_point_sampling_prefix", points, b, n, int(nsamples),
+             points.data_ptr(), ws.data_ptr(), out.data_ptr(), int(FPS_SMALL_THREADS),
+             alg_bytes=ab)
+        if return_fallback:
+            return out, ws[:4 * b].view(torch.int32)
+        return out
+    if return_fallback:
+        raise ValueError("return_fallback needs prefix_hint and n <= s2c_fps_small_limit()")
     if n >= FPS_BUCKET_MIN_N and FPS_LARGE_IMPL == "cells":
         # wave-owned grid cells, one barrier per round (csrc/s2c_fps_cells.hip)
         ws = torch.empty(_C.load().s2c_fps_cells_workspace_bytes(b, n), dtype=torch.uint8,
@@ -95,6 +113,7 @@ def furthest_point_sampling(points, nsamples):
 
 
 FPS_SMALL_THREADS = 0   # 0 = library heuristic (tests sweep 64..1024)
+FPS_PREFIX_VERIFY = os.environ.get("S2C_FPS_PREFIX", "1") != "0"   # honour prefix_hint
 FPS_LARGE_IMPL = "cells"   # "cells" (s2c_fps_cells.hip) | "bucket" (s2c_fps_bucket.hip)
 FPS_CELLS_WAVES = 0        # rounds-kernel workgroup in waves: 4 / 8 / 16, 0 = library default
 

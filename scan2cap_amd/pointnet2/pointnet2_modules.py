@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _ext
 from . import fused
 from . import pointnet2_utils
 from . import pytorch_utils as pt_utils
@@ -57,7 +58,13 @@ class PointnetSAModuleVotes(nn.Module):
         not depend on features or weights, so a pipeline can compute it ahead of
         time on another stream (scan2cap_amd/pipeline.py)."""
         if inds is None:
-            inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
+            if getattr(self, "fps_input_in_pick_order", False) and xyz.is_cuda:
+                # the input is the previous stage's centres: picks 0..npoint-1, proven on the
+                # device instead of npoint-1 serial rounds (same result for any input)
+                inds = _ext.furthest_point_sampling(xyz.contiguous(), self.npoint,
+                                                    prefix_hint=True)
+            else:
+                inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
         new_xyz = torch.gather(xyz, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3))
         idx = pointnet2_utils.ball_query(self.radius, self.nsample, xyz, new_xyz)
         return inds, new_xyz, idx

@@ -120,6 +120,74 @@ def test_fps_degenerate(ext, oracle):
     np.testing.assert_array_equal(got, oracle.furthest_point_sampling(xyz, 200))
 
 
+def _fps_ordered(oracle, xyz, m_keep):
+    """The cloud re-ordered so that its first m_keep points are its own FPS picks, in pick
+    order (what SA2..SA4 receive from the stage before them)."""
+    picks = oracle.furthest_point_sampling(xyz, m_keep).astype(np.int64)
+    return np.take_along_axis(xyz, picks[..., None], 1)
+
+
+@pytest.mark.parametrize("threads", [0, 64, 256, 1024])
+@pytest.mark.parametrize("B,N,n,m,mode", [
+    (8, 40000, 2048, 1024, "volume"),    # SA2: SA1's centres -> 1024
+    (3, 40000, 1024, 512, "surface"),    # SA3
+    (2, 8192, 512, 256, "volume"),       # SA4 (single-wave FPS kernel behind the proof)
+    (2, 4096, 700, 333, "surface"),      # ragged sizes: partial workgroups, partial LDS chunks
+    (1, 9000, 8192, 1500, "volume"),     # the size limit of the register-resident kernel
+])
+def test_fps_prefix_proof_on_pick_ordered_input(ext, oracle, monkeypatch, threads, B, N, n, m, mode):
+    """FPS of a pick-ordered set is 0..m-1: proven on the device (no scene runs the rounds),
+    and the result is the oracle's FPS of the same points -- adversarial clouds included
+    (duplicates, skipped points near the origin, all-zero rows)."""
+    monkeypatch.setattr(ext, "FPS_SMALL_THREADS", threads)
+    if threads and (n + threads - 1) // threads > 8:
+        pytest.skip("geometry not available for this n")
+    xyz = _fps_ordered(oracle, scene_xyz(B, N, seed=3 + n, mode=mode, adversarial=True), n)
+    want = oracle.furthest_point_sampling(xyz, m)
+    got, fell_back = ext.furthest_point_sampling(dev(xyz), m, prefix_hint=True,
+                                                 return_fallback=True)
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    np.testing.assert_array_equal(want, np.broadcast_to(np.arange(m, dtype=np.int32), (B, m)))
+    assert fell_back.cpu().numpy().tolist() == [0] * B
+
+
+def test_fps_prefix_proof_fails_where_it_must(ext, oracle):
+    """Inputs for which 0..m-1 is NOT the answer -- un-ordered clouds, a swapped pair, a
+    duplicated early pick, a skipped point inside the prefix, ties broken by the thread-layout
+    rule (lattice), everything skipped -- mixed in ONE batch with a pick-ordered scene: the
+    flags single out exactly the scenes that need the rounds, and every scene equals the
+    oracle."""
+    n, m = 2048, 1024
+    base = _fps_ordered(oracle, scene_xyz(8, 20000, seed=11, mode="volume"), n)
+    xyz = base.copy()
+    xyz[1] = scene_xyz(1, n, seed=5, mode="surface")[0]           # un-ordered cloud
+    xyz[2, [700, 701]] = xyz[2, [701, 700]]                        # one swapped pair
+    xyz[3, 900] = xyz[3, 3]                                        # duplicate of an early pick
+    xyz[4, 500] = (0.01, 0.01, 0.01)                               # skipped point in the prefix
+    g = np.stack(np.meshgrid(np.arange(16), np.arange(16), np.arange(8), indexing="ij"), -1)
+    xyz[5] = g.reshape(-1, 3).astype(np.float32) * 0.25 + 1.0      # lattice: ties everywhere
+    xyz[6] = 0.0                                                   # everything skipped
+    xyz[7, 1500] = xyz[7, 1400]                    # duplicate BEHIND the prefix: still arange
+    want = oracle.furthest_point_sampling(xyz, m)
+    got, fell_back = ext.furthest_point_sampling(dev(xyz), m, prefix_hint=True,
+                                                 return_fallback=True)
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    is_arange = (want == np.arange(m, dtype=np.int32)).all(1)
+    # the proof may only succeed where the answer IS 0..m-1, and must succeed there
+    np.testing.assert_array_equal(fell_back.cpu().numpy() == 0, is_arange)
+    assert is_arange.tolist() == [True, False, False, False, False, False, False, True]
+    # the plain entry point gives the same picks
+    np.testing.assert_array_equal(ext.furthest_point_sampling(dev(xyz), m).cpu().numpy(), want)
+
+
+def test_fps_prefix_m_exceeds_n_and_tiny(ext, oracle):
+    xyz = _fps_ordered(oracle, scene_xyz(2, 300, seed=2, mode="volume"), 40)
+    for m in (1, 2, 40):
+        got, fb = ext.furthest_point_sampling(dev(xyz), m, prefix_hint=True, return_fallback=True)
+        np.testing.assert_array_equal(got.cpu().numpy(), oracle.furthest_point_sampling(xyz, m))
+        assert fb.cpu().numpy().tolist() == [0, 0]
+
+
 BQ_CASES = [
     # (B, N, m, radius, nsample, mode)
     (2, 4096, 512, 0.2, 64, "volume"),
