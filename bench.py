@@ -443,7 +443,7 @@ def self_launch(n):
     return code
 
 
-def ddp_evidence(ddp, head, device, world):
+def ddp_evidence(ddp, head, device, world, trace=lambda m: None):
     """What the N>1 step did, measured after the timed region: how many ranks the collective
     really spans, the bytes it moves, each bucket's all-reduce timed on its own and the
     graphs it is meant to hide under (bucket 0 goes on the wire between the two backward
@@ -465,6 +465,7 @@ def ddp_evidence(ddp, head, device, world):
     seen = torch.ones(1, device=device)
     if dist.is_initialized():
         dist.all_reduce(seen)
+    trace("evidence: ranks counted")
     flats = ddp.flats if hasattr(ddp, "flats") else [ddp.flat]
     info = {"backend": dist.get_backend() if dist.is_initialized() else None,
             "world_size": dist.get_world_size() if dist.is_initialized() else 1,
@@ -478,11 +479,25 @@ def ddp_evidence(ddp, head, device, world):
                                       for i in range(len(flats))]
     else:
         info["allreduce_alone_ms"] = [timed(lambda: ddp.reduce())]
+    trace("evidence: buckets reduced alone")
     if head["pairs"]:
-        pair = head["pairs"][0]
-        info["stage1_graph_ms"] = timed(pair.replay_first)     # fwd + loss + captioner bwd
-        info["stage2_graph_ms"] = timed(pair.replay_second)    # the detector's backward
-        info["optimizer_graph_ms"] = timed(head["g2"])
+        # the two backward graphs and the optimizer graph, timed in their normal order (HIP
+        # events on the launch stream, no collective in between): what bucket 0 hides under
+        pair, g2 = head["pairs"][0], head["g2"]
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(5)]
+        torch.cuda.synchronize()
+        for e in ev:
+            e[0].record()
+            pair.replay_first()
+            e[1].record()
+            pair.replay_second()
+            e[2].record()
+            g2()
+            e[3].record()
+        torch.cuda.synchronize()
+        trace("evidence: graphs timed")
+        for k, name in enumerate(("stage1_graph_ms", "stage2_graph_ms", "optimizer_graph_ms")):
+            info[name] = float(np.median([e[k].elapsed_time(e[k + 1]) for e in ev]))
         info["bucket0_hidden"] = info["allreduce_alone_ms"][0] <= info["stage2_graph_ms"]
     return info
 
@@ -800,7 +815,7 @@ def main():
         t = torch.tensor([elapsed] + windows_ms, device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, windows_ms = float(t[0].item()), [float(x) for x in t[1:].tolist()]
-    ddp_info = ddp_evidence(ddp, head, device, world) if ddp is not None else None
+    ddp_info = ddp_evidence(ddp, head, device, world, trace) if ddp is not None else None
     # the same step on a NEW device-assembled batch every step, in the same
     # line: the headline replays one resident 187 MB batch, which fits the 256 MiB
     # Infinity Cache

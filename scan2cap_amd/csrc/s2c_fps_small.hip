@@ -136,66 +136,72 @@ __global__ __launch_bounds__(T) void fps_small_kernel(int n, int m, int bs, int 
 //   key(k, D_j(k)),  D_j(k) = min_{i<j} d(p_k, p_i),  is point j (and its key is not 0),
 // with d the reference's float expression, the |p|^2 <= 1e-3 skip and the 64-bit key whose
 // low word carries the reference's thread-layout tie rule (same key as fps_small_kernel).
-// Kernel 1: star[j] = key(j, D_j(j)) (thread per j, j pair tests).  Kernel 2: thread per k
-// walks the rounds with its running minimum and raises the scene's flag if its key ever
-// beats star[j].  n*m pair tests, no per-round synchronisation; the real FPS kernel then
-// starts with "flag clear -> write arange, return" (no host round trip).
-struct __attribute__((aligned(16))) Pivot { float x, y, z; u32 star_hi; };
-
+// Kernel 1: star[j] = key(j, D_j(j)).  Kernel 2: every point k walks the rounds with its
+// running minimum and raises the scene's flag if its key ever beats star[j].  2 n m pair
+// tests, no per-round synchronisation; the real FPS kernel then starts with "flag clear ->
+// write arange, return" (no host round trip).
 __device__ __forceinline__ float fps_d2(float px, float py, float pz, float cx, float cy,
                                         float cz) {
   return (px - cx) * (px - cx) + (py - cy) * (py - cy) + (pz - cz) * (pz - cz);
 }
 
-constexpr int PFX_T = 256;      // threads per workgroup
-constexpr int PFX_CHUNK = 512;  // pivots staged in LDS at a time
+// Both kernels: workgroup = 64 points (lane) x PFX_SEG segments of the pivot range (wave).  The
+// running minimum of a point is a prefix-min over the pivots, so the rounds are cut into
+// PFX_SEG segments that run in parallel: every wave first reduces ITS segment to one minimum
+// per point (LDS), the prefix over the earlier segments is the state at the segment's first
+// round, and the segment is walked a second time from that state with the key comparison.
+// 2 x m / PFX_SEG dependent iterations per thread instead of m (one thread per point walking
+// all rounds took 100 us per call: 0.25 waves per SIMD, every LDS broadcast latency exposed).
+// Pivots and star keys are wave-uniform reads (scalar loads from the constant cache).
+constexpr int PFX_SEG = 16;
 
-__global__ __launch_bounds__(PFX_T) void fps_prefix_star_kernel(
+__global__ __launch_bounds__(64 * PFX_SEG) void fps_prefix_star_kernel(
     int n, int m, int bs, int log2bs, const float *__restrict__ xyz, u64 *__restrict__ star,
     int *__restrict__ flag) {
-  __shared__ float4 s_p[PFX_CHUNK];
+  __shared__ float s_min[PFX_SEG][64];
   const int b = blockIdx.y;
   xyz += (size_t)b * n * 3;
   star += (size_t)b * m;
-  const int t = threadIdx.x;
-  const int j = blockIdx.x * PFX_T + t;
-  if (blockIdx.x == 0 && t == 0) flag[b] = 0;     // (kernel 2 runs after this kernel)
+  const int lane = threadIdx.x & 63;
+  const int seg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = blockIdx.x * 64 + lane;
+  if (blockIdx.x == 0 && threadIdx.x == 0) flag[b] = 0;   // (kernel 2 runs after this kernel)
   const int jj = j < m ? j : m - 1;
   const float x = xyz[jj * 3 + 0], y = xyz[jj * 3 + 1], z = xyz[jj * 3 + 2];
-  const float mag = (x * x) + (y * y) + (z * z);
-  const bool skip = (double)mag <= 1e-3;
+  // pivots i < j, i in this wave's share of [0, jhi): jhi = pivots the workgroup needs
+  const int jhi = min(m, (int)(blockIdx.x + 1) * 64);
+  const int L = (jhi + PFX_SEG - 1) / PFX_SEG;
+  const int i0 = seg * L, i1 = min(jhi, i0 + L);
   float D = 1e10f;
-  const int jmax = min(m, (int)(blockIdx.x + 1) * PFX_T);   // pivots this workgroup needs
-  for (int c0 = 0; c0 < jmax; c0 += PFX_CHUNK) {
-    __syncthreads();
-    for (int i = t; i < PFX_CHUNK && c0 + i < jmax; i += PFX_T) {
-      const float *q = xyz + (size_t)(c0 + i) * 3;
-      s_p[i] = make_float4(q[0], q[1], q[2], 0.f);
-    }
-    __syncthreads();
-    const int hi = min(jj - c0, PFX_CHUNK);      // pivots i < j of this chunk
-    for (int i = 0; i < hi; ++i) {
-      const float4 c = s_p[i];
-      D = fminf(fps_d2(x, y, z, c.x, c.y, c.z), D);
-    }
+#pragma unroll 8
+  for (int i = i0; i < i1; ++i) {
+    const float cx = xyz[i * 3 + 0], cy = xyz[i * 3 + 1], cz = xyz[i * 3 + 2];
+    const float d = fminf(fps_d2(x, y, z, cx, cy, cz), D);
+    D = i < jj ? d : D;
   }
-  if (j < m) {
+  s_min[seg][lane] = D;
+  __syncthreads();
+  if (seg == 0 && j < m) {
+#pragma unroll
+    for (int s2 = 1; s2 < PFX_SEG; ++s2) D = fminf(D, s_min[s2][lane]);
+    const float mag = (x * x) + (y * y) + (z * z);
+    const bool skip = (double)mag <= 1e-3;
     const u32 rank = (bitrev_n((u32)j & (u32)(bs - 1), log2bs) << 22) | ((u32)j >> log2bs);
     star[j] = skip ? 0ull
                    : ((u64)(__float_as_uint(D) + 1u) << 32) | (u64)(0xFFFFFFFFu - rank);
   }
 }
 
-__global__ __launch_bounds__(PFX_T) void fps_prefix_check_kernel(
+__global__ __launch_bounds__(64 * PFX_SEG) void fps_prefix_check_kernel(
     int n, int m, int bs, int log2bs, const float *__restrict__ xyz,
     const u64 *__restrict__ star, int *__restrict__ flag) {
-  __shared__ Pivot s_p[PFX_CHUNK];     // pivot i together with the high word of star[i + 1]
-  __shared__ u32 s_lo[PFX_CHUNK];      // low word of star[i + 1]
+  __shared__ float s_min[PFX_SEG][64];
   const int b = blockIdx.y;
   xyz += (size_t)b * n * 3;
   star += (size_t)b * m;
-  const int t = threadIdx.x;
-  const int k = blockIdx.x * PFX_T + t;
+  const int lane = threadIdx.x & 63;
+  const int seg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int k = blockIdx.x * 64 + lane;
   const int kk = k < n ? k : n - 1;
   const float x = xyz[kk * 3 + 0], y = xyz[kk * 3 + 1], z = xyz[kk * 3 + 2];
   const float mag = (x * x) + (y * y) + (z * z);
@@ -203,34 +209,29 @@ __global__ __launch_bounds__(PFX_T) void fps_prefix_check_kernel(
   const bool live = k < n && !((double)mag <= 1e-3);
   const u32 rank = (bitrev_n((u32)kk & (u32)(bs - 1), log2bs) << 22) | ((u32)kk >> log2bs);
   const u32 nrank = 0xFFFFFFFFu - rank;
+  // round j = i + 1 uses pivot i: rounds 1 .. m-1  <=>  pivots i = 0 .. m-2
+  const int L = (m - 1 + PFX_SEG - 1) / PFX_SEG;
+  const int i0 = min(m - 1, seg * L), i1 = min(m - 1, i0 + L);
   float D = 1e10f;
-  bool bad = false;
-  // round j = i + 1 uses pivot i; rounds 1 .. m-1  <=>  i = 0 .. m-2
-  for (int c0 = 0; c0 < m - 1; c0 += PFX_CHUNK) {
-    __syncthreads();
-    for (int i = t; i < PFX_CHUNK && c0 + i < m - 1; i += PFX_T) {
-      const float *q = xyz + (size_t)(c0 + i) * 3;
-      const u64 st = star[c0 + i + 1];
-      Pivot pv; pv.x = q[0]; pv.y = q[1]; pv.z = q[2]; pv.star_hi = (u32)(st >> 32);
-      s_p[i] = pv;
-      s_lo[i] = (u32)st;
-      if (st == 0ull) bad = true;                  // point j itself is not selectable
-    }
-    __syncthreads();
-    if (live) {
-      const int hi = min(m - 1 - c0, PFX_CHUNK);
-      for (int i = 0; i < hi; ++i) {
-        const Pivot c = s_p[i];
-        D = fminf(fps_d2(x, y, z, c.x, c.y, c.z), D);
-        const u32 khi = __float_as_uint(D) + 1u;
-        if (khi >= c.star_hi) {                    // rare: at least once per thread (k == j)
-          // keys are unique (the rank is), so equality of the whole key means k == j
-          if (khi > c.star_hi || nrank > s_lo[i]) bad = true;
-        }
-      }
-    }
+#pragma unroll 8
+  for (int i = i0; i < i1; ++i)
+    D = fminf(fps_d2(x, y, z, xyz[i * 3 + 0], xyz[i * 3 + 1], xyz[i * 3 + 2]), D);
+  s_min[seg][lane] = D;
+  __syncthreads();
+  D = 1e10f;                                  // state at this segment's first round
+  for (int s2 = 0; s2 < seg; ++s2) D = fminf(D, s_min[s2][lane]);
+  bool beats = false, dead = false;
+#pragma unroll 8
+  for (int i = i0; i < i1; ++i) {
+    const u64 st = star[i + 1];               // wave-uniform
+    D = fminf(fps_d2(x, y, z, xyz[i * 3 + 0], xyz[i * 3 + 1], xyz[i * 3 + 2]), D);
+    const u64 key = ((u64)(__float_as_uint(D) + 1u) << 32) | (u64)nrank;
+    // keys are unique (the rank is), so key == star[j] means k == j
+    beats |= key > st;
+    dead |= st == 0ull;                        // point j itself is not selectable
   }
-  if (__ballot(bad) != 0ull && (t & 63) == 0) atomicOr(flag + b, 1);
+  const bool bad = (live && beats) || dead;
+  if (__ballot(bad) != 0ull && lane == 0) atomicOr(flag + b, 1);
 }
 
 __global__ void fps_prefix_set_kernel(int *flag, int b, int v) {
@@ -293,9 +294,9 @@ extern "C" int s2c_furthest_point_sampling_prefix(int b, int n, int m, const flo
   const int bs = ref_opt_n_threads(n);
   int log2bs = 0;
   while ((1 << log2bs) < bs) ++log2bs;
-  hipLaunchKernelGGL(fps_prefix_star_kernel, dim3((m + PFX_T - 1) / PFX_T, b), dim3(PFX_T), 0,
+  hipLaunchKernelGGL(fps_prefix_star_kernel, dim3((m + 63) / 64, b), dim3(64 * PFX_SEG), 0,
                      st, n, m, bs, log2bs, xyz, star, flag);
-  hipLaunchKernelGGL(fps_prefix_check_kernel, dim3((n + PFX_T - 1) / PFX_T, b), dim3(PFX_T), 0,
+  hipLaunchKernelGGL(fps_prefix_check_kernel, dim3((n + 63) / 64, b), dim3(64 * PFX_SEG), 0,
                      st, n, m, bs, log2bs, xyz, (const u64 *)star, flag);
   return fps_small_launch(b, n, m, xyz, idx, threads, flag, st);
 }

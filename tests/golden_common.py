@@ -154,12 +154,37 @@ def forced_vote_sampling(model, inds):
         del sa.forward
 
 
+def aim_reference_boxes_at_proposals(model, dd):
+    """At random init no proposal overlaps the synthetic ground-truth box of a scene by
+    IoU >= 0.25, so `good_bbox_masks` is all False, the caption loss is exactly 0
+    (lib/loss_helper.py:189-230 masks it) and every gradient of the captioner and the relation
+    graph is exactly 0 -- a comparison of zeros.  Point each scene's described box
+    (`ref_box_corner_label`) at the box the model itself predicts for proposal 0: IoU = 1,
+    the caption loss and its backward through decoder, attention and EdgeConv are live.
+    Returns the updated batch dict (the model's weights / BN statistics are left untouched)."""
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    was_training = model.training
+    with torch.no_grad():
+        out = model(dict(dd), use_tf=True, is_eval=False)
+    model.load_state_dict(state)
+    model.train(was_training)
+    dd = dict(dd)
+    dd["ref_box_corner_label"] = out["bbox_corner"][:, 0].detach().to(
+        dd["ref_box_corner_label"].dtype).clone()
+    return dd
+
+
 ULP_NOISE = 1.0e-7      # relative, rms: about one float32 rounding error per value
 # A K-term fp32 dot product summed in another order (another GEMM tiling, another
 # reduction tree) differs by up to ~sqrt(K)/2 roundings, K = 64..512 on this path, and a
 # BatchNorm statistic over 1e3..1e6 rows likewise: the allowance over the response to ONE
-# rounding per value.
-SENS_FACTOR = 8.0
+# rounding per value.  Round 3: measured err / sens is 0.95..1.05 on every cfg3 gradient key
+# (gpurun_out reports: configs_report_cfg3_grads.json) and <= 1.6 on the small fixtures, so the
+# factor is 3, not 8.  Where 3 x sens still exceeds a few per cent of a tensor's scale (backbone
+# weight gradients at cfg3: sens 0.1-0.2) the bound says little by itself -- those kernels are
+# pinned at the same shapes, at 2e-5, by tests/test_modules_cfg3_gpu.py (float64, decisions
+# forced) and end to end by tests/test_directional_gpu.py.
+SENS_FACTOR = 3.0
 
 
 @contextlib.contextmanager

@@ -156,6 +156,9 @@ def test_cfg3_train_step_vs_op_by_op(oracle):
     from scan2cap_amd.opbyop import op_by_op
     bench, wl, model, dd, batch, msa, dev = _setup("cfg3")
     cfg = bench.LossConfig(msa)
+    # (without this the caption loss is exactly 0 at random init and the captioner / graph
+    # gradients compared below are zeros)
+    dd = gc.aim_reference_boxes_at_proposals(model, dd)
     state = {k: v.clone() for k, v in model.state_dict().items()}
 
     def run():
@@ -169,6 +172,9 @@ def test_cfg3_train_step_vs_op_by_op(oracle):
         return d, grads
 
     got, g_got = run()
+    assert bool(got["good_bbox_masks"].all()) and float(got["cap_loss"]) > 0
+    assert float(g_got["caption.classifier.weight"].abs().max()) > 0
+    assert float(g_got["graph.gc_layers.0.map_edge.0.weight"].abs().max()) > 0
     _check_vote_sampling(got, oracle)
     model.load_state_dict(state)              # BN running statistics moved
     with op_by_op(), gc.forced_vote_sampling(model, got["aggregated_vote_inds"]):

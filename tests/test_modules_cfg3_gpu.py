@@ -19,10 +19,18 @@ evaluate the module three ways from those identical inputs --
       proposal_module.py:46-54) over the nine `_ext` ops,
   (c) a float64 torch evaluation of (b),
 
-and require (a) to be as close to (c) as fp32 can be: within max(1e-5, 4 x the largest error
-(b) itself shows against (c) on that module) of each tensor's scale.  Measured: 3e-7..3e-6
-everywhere except SA3/SA4 (few rows per BatchNorm channel: 2e-4..9e-4 for BOTH fp32 paths).
-A missing or wrong term shows up at 1e-2..1.
+with ONE refinement: a module holds ~1e6..1e8 ReLU thresholds and max-pool arg-maxes, and a
+float64 evaluation decides a handful of them differently from ANY float32 evaluation (values
+within one rounding of the threshold).  One flipped ReLU mask moves a bias gradient by that
+element's upstream gradient: 3e-4 of scale on fp2, 2e-2 on sa2 (tools/diag_fp2.py: 1 flip in
+2 097 152, the kernel equals the sum over ITS mask to 1e-7).  So the float64 evaluation (c)
+takes the discrete decisions -- every layer's ReLU mask and the pooled layer's arg-max --
+from the fused run (they are saved for its backward), and everything continuous (products,
+BatchNorm statistics and their backward, the gather / scatter, interpolation) is evaluated
+in float64.  Against that the fused path must hold 2e-05 of every tensor's scale, forward
+and every gradient; the same comparison with the decisions NOT forced is reported beside
+it (op-by-op fp32 and fused both at 1e-6..2e-2 depending on how many thresholds flipped).
+A missing or wrong term in a kernel shows up at 1e-2..1 whatever the decisions.
 """
 import contextlib
 import copy
@@ -40,8 +48,7 @@ sys.path.insert(0, ROOT)
 
 pytestmark = pytest.mark.gpu
 
-FLOOR = 1e-5          # fp32 evaluation of a well-conditioned module vs float64
-FACTOR = 4.0          # x the op-by-op fp32 path's own worst error on the same module
+TOL = 2e-5            # fused fp32 path vs float64 with the same discrete decisions
 
 
 def _e(a, t):
@@ -125,21 +132,77 @@ def captured():
 
 
 def _judge(name, rows):
-    """rows: key -> (err of the op-by-op fp32 path, err of the fused path), both vs float64."""
-    worst_ref = max(v[0] for v in rows.values())
-    bound = max(FLOOR, FACTOR * worst_ref)
+    """rows: key -> (op-by-op fp32 vs free float64, fused vs free float64,
+    fused vs decision-forced float64); only the last one is asserted."""
     out = os.environ.get("S2C_GOLDEN_REPORT")
     if out:
         os.makedirs(out, exist_ok=True)
         with open(os.path.join(out, "module_fp64_%s.json" % name), "w") as f:
-            json.dump({"bound": bound, "keys": {k: {"opbyop": v[0], "fused": v[1]}
-                                                for k, v in rows.items()}}, f, indent=1)
-    bad = {k: v for k, v in rows.items() if not v[1] <= bound}
-    assert not bad, "%s: fused path beyond %.1e of scale vs float64 (op-by-op, fused): %s" % (
-        name, bound, bad)
-    # and the comparison itself must be meaningful: the fp32 reference formulation agrees
-    # with float64 far below the model-level tolerances this file replaces
-    assert worst_ref < 2e-3, (name, worst_ref)
+            json.dump({"tol": TOL, "keys": {k: {"opbyop_vs_free": v[0], "fused_vs_free": v[1],
+                                                "fused_vs_forced": v[2]}
+                                            for k, v in rows.items()}}, f, indent=1)
+    bad = {k: v[2] for k, v in rows.items() if not v[2] <= TOL}
+    assert not bad, "%s: fused path beyond %.0e of scale vs float64 (same ReLU masks / " \
+                    "arg-maxes): %s" % (name, TOL, bad)
+
+
+def _find_ctx(fn, depth=0):
+    """The _MLPRows autograd node behind an output (its ctx.saved = per-layer records)."""
+    if fn is None or depth > 16:
+        return None
+    if isinstance(getattr(fn, "saved", None), list):
+        return fn
+    for nf, _ in fn.next_functions:
+        r = _find_ctx(nf, depth + 1)
+        if r is not None:
+            return r
+    return None
+
+
+def _decisions(y):
+    """Per layer of the fused run behind `y`: (ReLU mask (M,C) bool or None, arg (J,C) or None,
+    pooled mask (J,C) or None) -- the discrete decisions its backward will use."""
+    ctx = _find_ctx(y.grad_fn)
+    assert ctx is not None, "no fused layer stack behind this output"
+    out = []
+    for r in ctx.saved:
+        mask = arg = pmask = None
+        if torch.is_tensor(r.get("arg")):
+            arg = r["arg"].long().clone()
+            pmask = (r["ymax"] * r["scale"] + r["shift"]) > 0
+        elif torch.is_tensor(r.get("scale")) and r.get("relu"):
+            mask = (r["Y"] * r["scale"] + r["shift"]) > 0
+        elif r.get("relu"):
+            mask = r["Y"] > 0
+        out.append((mask, arg, pmask))
+    return out
+
+
+def _forced_stack64(X, layers, decisions, pool_ns=0):
+    """float64 rows MLP: X (M,Cin) -> per layer Y = X W^T (+ b); train-mode BatchNorm (biased
+    variance, pytorch_utils.py:100-120 -> nn.BatchNorm2d); ReLU as multiplication with the
+    GIVEN mask; last layer with pool_ns: the GIVEN arg-max row of every (centre, channel)."""
+    A = X
+    for (W, bias, bn), (mask, arg, pmask) in zip(layers, decisions):
+        Y = A @ W.view(W.shape[0], -1).t()
+        if bias is not None:
+            Y = Y + bias
+        if bn is not None:
+            mu, var = Y.mean(0), Y.var(0, unbiased=False)
+            Y = (Y - mu) / torch.sqrt(var + bn.eps) * bn.weight + bn.bias
+        if arg is not None:
+            J = Y.shape[0] // pool_ns
+            A = Y.view(J, pool_ns, -1).gather(1, arg.unsqueeze(1)).squeeze(1) * pmask
+        elif mask is not None:
+            A = Y * mask
+        else:
+            A = Y
+    return A
+
+
+def _mlp_layers64(mlp64):
+    return [(layer.conv.weight, layer.conv.bias, layer.bn.bn if hasattr(layer, "bn") else None)
+            for layer in mlp64.children()]
 
 
 def _sa_three_ways(rec, sa, pc=None):
@@ -161,34 +224,51 @@ def _sa_three_ways(rec, sa, pc=None):
         with ctx:
             nx, nf, ni = mod(x, f, inds=inds)
         assert torch.equal(ni, inds)
+        dec = _decisions(nf) if fused_run else None
         (nf * dOut).sum().backward()
         g = {n: p.grad for n, p in mod.named_parameters()}
-        return g, (f.grad if needs else None), (x.grad if needs else None), nf.detach()
+        return g, (f.grad if needs else None), (x.grad if needs else None), nf.detach(), dec
 
+    fused_run = True
     fused_out = run(contextlib.nullcontext())
+    fused_run = False
     ref_out = run(op_by_op())
     # float64: QueryAndGroup -> 3 x (1x1 conv, BatchNorm2d, ReLU) -> max over nsample
     new_xyz = torch.gather(xyz, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3))
     idx = _ext.ball_query(new_xyz.contiguous(), xyz.contiguous(), sa.radius, sa.nsample).long()
     B, m, ns = idx.shape
-    x64 = xyz.double().requires_grad_(needs)
-    f64 = rec["feat"].double().contiguous().requires_grad_(needs)
-    mod64 = copy.deepcopy(sa).double().train()
 
     def grp(t):                                   # (B,C,N) -> (B,C,m,ns)
         return torch.gather(t, 2, idx.view(B, 1, m * ns).expand(-1, t.shape[1], -1)).view(
             B, t.shape[1], m, ns)
-    centre = torch.gather(x64, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3))
-    gx = (grp(x64.transpose(1, 2)) - centre.transpose(1, 2).unsqueeze(-1)) / sa.radius
-    h = mod64.mlp_module(torch.cat([gx, grp(f64)], 1))
-    y64 = F.max_pool2d(h, kernel_size=[1, ns]).squeeze(-1)
-    (y64 * dOut.double()).sum().backward()
-    rows = {"forward": (_e(ref_out[3], y64), _e(fused_out[3], y64))}
+
+    def eval64(decisions):
+        x64 = xyz.double().requires_grad_(needs)
+        f64 = rec["feat"].double().contiguous().requires_grad_(needs)
+        mod64 = copy.deepcopy(sa).double().train()
+        centre = torch.gather(x64, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3))
+        gx = (grp(x64.transpose(1, 2)) - centre.transpose(1, 2).unsqueeze(-1)) / sa.radius
+        h = torch.cat([gx, grp(f64)], 1)                           # pointnet2_utils.py:348-359
+        if decisions is None:
+            y64 = F.max_pool2d(mod64.mlp_module(h), kernel_size=[1, ns]).squeeze(-1)
+        else:        # rows (b, centre, sample) x channels, the fused run's masks and arg-maxes
+            X = h.permute(0, 2, 3, 1).reshape(B * m * ns, -1)
+            y64 = _forced_stack64(X, _mlp_layers64(mod64.mlp_module), decisions, ns)
+            y64 = y64.view(B, m, -1).transpose(1, 2)
+        (y64 * dOut.double()).sum().backward()
+        return ({n: p.grad for n, p in mod64.named_parameters()},
+                f64.grad if needs else None, x64.grad if needs else None, y64.detach())
+    free, forced = eval64(None), eval64(fused_out[4])
+    rows = {"forward": (_e(ref_out[3], free[3]), _e(fused_out[3], free[3]),
+                        _e(fused_out[3], forced[3]))}
     if needs:
-        rows["d features"] = (_e(ref_out[1], f64.grad), _e(fused_out[1], f64.grad))
-        rows["d xyz"] = (_e(ref_out[2], x64.grad), _e(fused_out[2], x64.grad))
-    for n, p in mod64.named_parameters():
-        rows[n] = (_e(ref_out[0][n], p.grad), _e(fused_out[0][n], p.grad))
+        rows["d features"] = (_e(ref_out[1], free[1]), _e(fused_out[1], free[1]),
+                              _e(fused_out[1], forced[1]))
+        rows["d xyz"] = (_e(ref_out[2], free[2]), _e(fused_out[2], free[2]),
+                         _e(fused_out[2], forced[2]))
+    for n in free[0]:
+        rows[n] = (_e(ref_out[0][n], free[0][n]), _e(fused_out[0][n], free[0][n]),
+                   _e(fused_out[0][n], forced[0][n]))
     return rows
 
 
@@ -220,25 +300,41 @@ def test_feature_propagation_vs_float64(captured, name):
         kf = rec["kf"].clone().requires_grad_(True)
         with ctx:
             y = mod(rec["unknown"], rec["known"], uf, kf, geom=geom)
+        dec = _decisions(y) if fused_run else None
         (y * dOut).sum().backward()
-        return {n: p.grad for n, p in mod.named_parameters()}, uf.grad, kf.grad, y.detach()
+        return ({n: p.grad for n, p in mod.named_parameters()}, uf.grad, kf.grad, y.detach(),
+                dec)
+    fused_run = True
     fo = run(contextlib.nullcontext())
+    fused_run = False
     ro = run(op_by_op())
     idx, w = geom[0].long(), geom[1].double()
-    uf = rec["uf"].double().requires_grad_(True)
-    kf = rec["kf"].double().requires_grad_(True)
-    mod64 = copy.deepcopy(fp).double().train()
     B, n, _ = idx.shape
-    g = torch.gather(kf, 2, idx.view(B, 1, n * 3).expand(-1, kf.shape[1], -1)).view(
-        B, kf.shape[1], n, 3)
-    interp = (g * w.unsqueeze(1)).sum(-1)                     # interpolate_gpu.cu:87-99
-    y64 = mod64.mlp(torch.cat([interp, uf], 1).unsqueeze(-1)).squeeze(-1)
-    (y64 * dOut.double()).sum().backward()
-    rows = {"forward": (_e(ro[3], y64), _e(fo[3], y64)),
-            "d unknown feats": (_e(ro[1], uf.grad), _e(fo[1], uf.grad)),
-            "d known feats": (_e(ro[2], kf.grad), _e(fo[2], kf.grad))}
-    for nme, p in mod64.named_parameters():
-        rows[nme] = (_e(ro[0][nme], p.grad), _e(fo[0][nme], p.grad))
+
+    def eval64(decisions):
+        uf = rec["uf"].double().requires_grad_(True)
+        kf = rec["kf"].double().requires_grad_(True)
+        mod64 = copy.deepcopy(fp).double().train()
+        g = torch.gather(kf, 2, idx.view(B, 1, n * 3).expand(-1, kf.shape[1], -1)).view(
+            B, kf.shape[1], n, 3)
+        interp = (g * w.unsqueeze(1)).sum(-1)                     # interpolate_gpu.cu:87-99
+        h = torch.cat([interp, uf], 1)                            # pointnet2_modules.py:408
+        if decisions is None:
+            y64 = mod64.mlp(h.unsqueeze(-1)).squeeze(-1)
+        else:
+            X = h.transpose(1, 2).reshape(B * n, -1)
+            y64 = _forced_stack64(X, _mlp_layers64(mod64.mlp), decisions).view(
+                B, n, -1).transpose(1, 2)
+        (y64 * dOut.double()).sum().backward()
+        return ({nme: p.grad for nme, p in mod64.named_parameters()}, uf.grad, kf.grad,
+                y64.detach())
+    free, forced = eval64(None), eval64(fo[4])
+    rows = {"forward": (_e(ro[3], free[3]), _e(fo[3], free[3]), _e(fo[3], forced[3])),
+            "d unknown feats": (_e(ro[1], free[1]), _e(fo[1], free[1]), _e(fo[1], forced[1])),
+            "d known feats": (_e(ro[2], free[2]), _e(fo[2], free[2]), _e(fo[2], forced[2]))}
+    for nme in free[0]:
+        rows[nme] = (_e(ro[0][nme], free[0][nme]), _e(fo[0][nme], free[0][nme]),
+                     _e(fo[0][nme], forced[0][nme]))
     _judge(name, rows)
 
 
@@ -263,14 +359,16 @@ def test_voting_module_vs_float64(captured):
     ro = run(op_by_op())
     with op_by_op():
         t = run(contextlib.nullcontext(), torch.float64)
-    rows = {"vote_features": (_e(ro[3], t[3]), _e(fo[3], t[3])),
-            "vote_xyz": (_e(ro[4], t[4]), _e(fo[4], t[4])),
-            "d seed_features": (_e(ro[1], t[1]), _e(fo[1], t[1]))}
+    # (the vote head's masks are not exposed: 8192 x 256 thresholds per layer, compared
+    # against the free float64 evaluation -- measured 1e-6, no flip on this batch)
+    rows = {"vote_features": (_e(ro[3], t[3]),) + (_e(fo[3], t[3]),) * 2,
+            "vote_xyz": (_e(ro[4], t[4]),) + (_e(fo[4], t[4]),) * 2,
+            "d seed_features": (_e(ro[1], t[1]),) + (_e(fo[1], t[1]),) * 2}
     for n, g in t[0].items():
         if float(g.abs().max()) < 1e-9:     # conv biases in front of a BatchNorm: exactly 0
             assert float(fo[0][n].abs().max()) < 1e-5, n
             continue
-        rows[n] = (_e(ro[0][n], g), _e(fo[0][n], g))
+        rows[n] = (_e(ro[0][n], g),) + (_e(fo[0][n], g),) * 2
     _judge("vgen", rows)
 
 
@@ -298,10 +396,22 @@ def test_proposal_head_vs_float64(captured):
                   seq[6].weight.view(seq[6].out_channels, -1), seq[6].bias]
         x = X.clone().requires_grad_(True)
         y = fused.mlp_rows(x, specs, params)
+        dec = _decisions(y)
         y.backward(dOut)
+        return {n: q.grad for n, q in seq.named_parameters()}, x.grad, y.detach(), dec
+
+    def run_forced(decisions):
+        seq = copy.deepcopy(p).double().train()
+        x = X.double().requires_grad_(True)
+        layers = [(seq[0].weight, None, seq[1]), (seq[3].weight, None, seq[4]),
+                  (seq[6].weight, seq[6].bias, None)]
+        y = _forced_stack64(x, layers, decisions)
+        y.backward(dOut.double())
         return {n: q.grad for n, q in seq.named_parameters()}, x.grad, y.detach()
     t, ro, fo = run_torch(torch.float64), run_torch(torch.float32), run_fused()
-    rows = {"forward": (_e(ro[2], t[2]), _e(fo[2], t[2])), "d X": (_e(ro[1], t[1]), _e(fo[1], t[1]))}
+    fr = run_forced(fo[3])
+    rows = {"forward": (_e(ro[2], t[2]), _e(fo[2], t[2]), _e(fo[2], fr[2])),
+            "d X": (_e(ro[1], t[1]), _e(fo[1], t[1]), _e(fo[1], fr[1]))}
     for n, g in t[0].items():
-        rows[n] = (_e(ro[0][n], g), _e(fo[0][n], g))
+        rows[n] = (_e(ro[0][n], g), _e(fo[0][n], g), _e(fo[0][n], fr[0][n]))
     _judge("head", rows)
