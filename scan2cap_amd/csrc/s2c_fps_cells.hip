@@ -344,6 +344,206 @@ __global__ __launch_bounds__(NW * 64) void fps_cells_rounds_kernel(
 }
 
 // ---------------------------------------------------------------------------------
+// Round 3 experiment (waves = 17; NOT the default): the same one-pick round with the arg-max
+// over the wave's idle cells moved under the L2 round trip.  tools/prof_fps.py on the kernel
+// above: nearly every wave has ONE active cell per round (0.93 per wave-round at N = 40000,
+// volume), so a round is, for every wave, L2 round trip (~1000 cycles) -> 64-lane evaluation ->
+// 64-bit wave arg-max -> 64-bit arg-max over its own 64 keys (477) -> barrier -> decode (830).
+// Variants built and measured on MI355X (us per round, N = 40000 volume / surface; the kernel
+// above: 1.84 / 1.66):
+//  (a) four active cells at once, one per 16-lane row, one row-wise DPP arg-max for all four,
+//      idle-cell arg-max meanwhile, slots read whole + coordinates by readlane: 2.23 / 2.94 --
+//      with one active cell per wave a 16-lane row needs three dependent passes over a 40-point
+//      cell where 64 lanes need one;
+//  (b) this kernel: 64-lane evaluation as above, idle-cell arg-max between the load issue and
+//      the first use (sched_barrier; without it the scheduler hoists the block above the loads),
+//      re-evaluated cells merged as wave-uniform scalars, 32-bit-first arg-max, one publishing
+//      lane: 1.92 / 1.87 -- the moved reduction does not leave the chain (cells phase 2400
+//      cycles vs 1563 + 477), and loads made conditional on the cell size serialise the four
+//      cells' round trips (a vmcnt(0) in front of every cell's loads);
+//  (c) (b) with the slots read whole and the winner's coordinates by readlane: decode 1116 vs
+//      832 cycles.
+// Lesson kept: the round is bound by ONE L2 round trip + three dependent cross-lane reductions +
+// one barrier; none of the re-orderings shortens it, and the 2047 rounds stay off the critical
+// path of the train step (side stream).  Same keys, same pruning rule: bit-identical picks.
+
+// arg-max of a u64 key over the wave; returns the (wave-uniform) maximum, `src` = its lane
+// (keys are unique when non-zero; src = lowest lane when every key is 0)
+__device__ __forceinline__ u64 wave_argmax_u64(u64 v, int &src) {
+  const u32 hi = (u32)(v >> 32);
+  const u32 mhi = wave_umax32(hi);
+  u64 cand = __ballot(hi == mhi);
+  if (__builtin_popcountll(cand) > 1) {
+    const u32 mlo = wave_umax32(hi == mhi ? (u32)v : 0u);
+    cand = __ballot(hi == mhi && (u32)v == mlo);
+  }
+  src = (int)__builtin_ctzll(cand);
+  return readlane_u64(v, src);
+}
+
+__device__ __forceinline__ float readlane_f(float v, int l) {
+  return __uint_as_float((u32)__builtin_amdgcn_readlane((int)__float_as_uint(v), l));
+}
+
+template <bool PROFILE>
+__global__ __launch_bounds__(1024) void fps_cells_rounds4_kernel(
+    int n, int m, int log2bs, const float *__restrict__ xyz, char *__restrict__ ws,
+    size_t stride, int *__restrict__ idx, long long *__restrict__ prof = nullptr) {
+  constexpr int NW = 16;
+  long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  __shared__ Slot s_slot[2][NW];
+  if (m <= 0) return;
+  const int b = blockIdx.x;
+  xyz += (size_t)b * n * 3;
+  ws += (size_t)b * stride;
+  idx += (size_t)b * m;
+  Pt *spt = (Pt *)ws;
+  const u32 *srank = (const u32 *)(ws + (size_t)n * sizeof(Pt));
+  const u32 *tab = (const u32 *)(ws + (((size_t)n * (sizeof(Pt) + 4) + 15) & ~(size_t)15));
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // own cell: c = wave + 16 * lane
+  const int c = wave + NW * lane;
+  const int c_start = (int)tab[0 * MAXC + c], c_cnt = (int)tab[1 * MAXC + c];
+  const bool own = tab[2 * MAXC + c] > 0u;       // cells with no candidate never compete
+  const float blx = __uint_as_float(tab[3 * MAXC + c]), bly = __uint_as_float(tab[4 * MAXC + c]);
+  const float blz = __uint_as_float(tab[5 * MAXC + c]), bhx = __uint_as_float(tab[6 * MAXC + c]);
+  const float bhy = __uint_as_float(tab[7 * MAXC + c]), bhz = __uint_as_float(tab[8 * MAXC + c]);
+  u64 key = own ? ((u64)(__float_as_uint(1e10f) + 1u) << 32) : 0ull;
+  float kx = 0.f, ky = 0.f, kz = 0.f;
+
+  const float x0 = xyz[0], y0 = xyz[1], z0 = xyz[2];
+  float px = x0, py = y0, pz = z0;
+  if (tid == 0) idx[0] = 0;
+
+  for (int j = 1; j < m; ++j) {
+    const int par = j & 1;
+    long long t0 = 0;
+    if (PROFILE) t0 = (long long)__builtin_amdgcn_s_memtime();
+    // ---- which of my cells can change? ----------------------------------------------------
+    bool active = false;
+    if (own) {
+      const float ddx = fmaxf(fmaxf(blx - px, px - bhx), 0.0f);
+      const float ddy = fmaxf(fmaxf(bly - py, py - bhy), 0.0f);
+      const float ddz = fmaxf(fmaxf(blz - pz, pz - bhz), 0.0f);
+      const float lb = (ddx * ddx + ddy * ddy + ddz * ddz) * 0.99999f;
+      const float cmax = __uint_as_float((u32)(key >> 32) - 1u);
+      active = !(lb > cmax);
+    }
+    u64 amask = __ballot(active);
+    if (PROFILE) pc[4] += (long long)__builtin_popcountll(amask);
+    // wave-uniform best of this round: the idle cells' arg-max, then every re-evaluated cell
+    u64 bk = 0ull;
+    float bx = x0, by = y0, bz = z0;
+    bool first = true;
+    do {
+      // ---- up to four active cells: request their records (one L2 round trip) --------------
+      int L[4], st[4], nc[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        L[r] = amask ? (int)__builtin_ctzll(amask) : -1;
+        amask = amask ? (amask & (amask - 1)) : 0ull;
+        const int src = L[r] < 0 ? 0 : L[r];
+        st[r] = __builtin_amdgcn_readlane(c_start, src);
+        nc[r] = L[r] < 0 ? 0 : __builtin_amdgcn_readlane(c_cnt, src);
+      }
+      Pt pa[4], pb[4];
+      u32 ra[4], rb[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (nc[r] > 0) {                       // wave-uniform
+          const int qa = st[r] + min(lane, nc[r] - 1);
+          pa[r] = spt[qa]; ra[r] = srank[qa];
+          if (nc[r] > 64) {
+            const int qb = st[r] + min(lane + 64, nc[r] - 1);
+            pb[r] = spt[qb]; rb[r] = srank[qb];
+          }
+        }
+      }
+      // ---- meanwhile: arg-max over the cells that keep their key this round ---------------
+      // (sched_barrier: the machine scheduler otherwise hoists this load-independent block
+      // above the loads -- measured: no overlap, +240 cycles per round)
+      __builtin_amdgcn_sched_barrier(0);
+      if (first) {
+        first = false;
+        int src;
+        const u64 ik = wave_argmax_u64(active ? 0ull : key, src);
+        if (ik != 0ull) {
+          bk = ik;
+          bx = readlane_f(kx, src); by = readlane_f(ky, src); bz = readlane_f(kz, src);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (nc[r] <= 0) continue;              // wave-uniform
+        u64 best = 0ull;
+        float cx = 0.f, cy = 0.f, cz = 0.f;
+        auto visit = [&](const Pt &p, u32 rk, int q) {
+          const float d = (p.x - px) * (p.x - px) + (p.y - py) * (p.y - py) +
+                          (p.z - pz) * (p.z - pz);
+          const float d2 = fminf(d, p.d2);
+          if (d2 != p.d2) spt[st[r] + q].d2 = d2;
+          const u64 k = d2 < 0.0f ? 0ull
+                                  : ((u64)(__float_as_uint(d2) + 1u) << 32) |
+                                        (u64)(0xFFFFFFFFu - rk);
+          if (k > best) { best = k; cx = p.x; cy = p.y; cz = p.z; }
+        };
+        if (lane < nc[r]) visit(pa[r], ra[r], lane);
+        if (nc[r] > 64) {
+          if (lane + 64 < nc[r]) visit(pb[r], rb[r], lane + 64);
+          for (int q = lane + 128; q < nc[r]; q += 64) {      // crowded cells (rare)
+            const Pt p = spt[st[r] + q];
+            visit(p, srank[st[r] + q], q);
+          }
+        }
+        // a cell with candidates always has a non-zero key; ranks make the winner unique
+        int src;
+        const u64 wbest = wave_argmax_u64(best, src);
+        const float wx = readlane_f(cx, src), wy = readlane_f(cy, src), wz = readlane_f(cz, src);
+        if (lane == L[r]) { key = wbest; kx = wx; ky = wy; kz = wz; }
+        if (wbest > bk) { bk = wbest; bx = wx; by = wy; bz = wz; }
+      }
+    } while (amask);
+    long long t1 = 0;
+    if (PROFILE) { t1 = (long long)__builtin_amdgcn_s_memtime(); pc[0] += t1 - t0; }
+    // ---- publish (uniform values: one lane writes) -------------------------------------------
+    Slot *slots = s_slot[par];
+    if (lane == 0) {
+      Slot sl; sl.key = bk; sl.x = bx; sl.y = by; sl.z = bz; sl.pad = 0.f;
+      slots[wave] = sl;
+    }
+    long long t2 = 0;
+    if (PROFILE) { t2 = (long long)__builtin_amdgcn_s_memtime(); pc[1] += t2 - t1; }
+    __syncthreads();
+    long long t3 = 0;
+    if (PROFILE) { t3 = (long long)__builtin_amdgcn_s_memtime(); pc[2] += t3 - t2; }
+    // ---- decode (as in the kernel above: it measured faster than reading the slots whole and
+    // taking the coordinates by readlane, 832 vs 1116 cycles) ---------------------------------
+    u64 v = lane < NW ? slots[lane].key : 0ull;
+    const u64 mine = v;
+    v = row16_max_u64_2x32(v);
+    const u64 gkey = readlane_u64(v, 0);
+    int old = 0;
+    if ((gkey >> 32) == 0ull) {
+      px = x0; py = y0; pz = z0;
+    } else {
+      const u32 r = 0xFFFFFFFFu - (u32)gkey;
+      old = (int)(((r & 0x3FFFFFu) << log2bs) | bitrev_n(r >> 22, log2bs));
+      const u64 wl = __ballot(lane < NW && mine == gkey);
+      const int w = (int)__builtin_ctzll(wl);
+      px = slots[w].x; py = slots[w].y; pz = slots[w].z;
+    }
+    if (tid == 0) idx[j] = old;
+    if (PROFILE) pc[3] += (long long)__builtin_amdgcn_s_memtime() - t3;
+  }
+  if (PROFILE && prof && b == 0 && lane == 0) {
+    for (int q = 0; q < 8; ++q) prof[wave * 8 + q] = pc[q];
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // Several exact picks per round.
 //
 // A round of the kernel above is ~4000 cycles of dependent latency (L2 round trip for the
@@ -616,6 +816,9 @@ extern "C" int s2c_fps_cells_profile(int b, int n, int m, const float *xyz, void
                      xyz, (char *)workspace, stride);
   if (waves == -16)
     launch_multi(b, n, m, log2bs, xyz, workspace, stride, idx, prof, st);
+  else if (waves == 17)
+    hipLaunchKernelGGL((fps_cells_rounds4_kernel<true>), dim3(b), dim3(1024), 0, st, n, m,
+                       log2bs, xyz, (char *)workspace, stride, idx, prof);
   else if (waves == 4)
     hipLaunchKernelGGL((fps_cells_rounds_kernel<4, true>), dim3(b), dim3(256), 0, st, n, m,
                        log2bs, xyz, (char *)workspace, stride, idx, prof);
@@ -660,6 +863,8 @@ extern "C" int s2c_furthest_point_sampling_cells(int b, int n, int m, const floa
   // 4 waves 3.27); -16 = several exact picks per round: 3.9 picks per round, but a round then
   // costs 19k cycles instead of 4.7k -- one CU issues every instruction of the scene, and the
   // 16 waves x ~1500 instructions of a multi-pick round are issue-bound (2.04 us per pick)
+  // 17 = the round-3 variant (idle-cell arg-max under the load latency, scalar merge, one
+  // publishing lane): bit-exact, but 1.92 vs 1.84 us per round -- NOT the default (see above)
   if (waves == 0) waves = 16;
   hipStream_t st = (hipStream_t)stream;
   const size_t stride = cells_scene_bytes(n);
@@ -678,11 +883,15 @@ extern "C" int s2c_furthest_point_sampling_cells(int b, int n, int m, const floa
       hipLaunchKernelGGL((fps_cells_rounds_kernel<16>), dim3(b), dim3(1024), 0, st, n, m,
                          log2bs, xyz, (char *)workspace, stride, idx, nullptr);
       break;
+    case 17:
+      hipLaunchKernelGGL((fps_cells_rounds4_kernel<false>), dim3(b), dim3(1024), 0, st, n, m,
+                         log2bs, xyz, (char *)workspace, stride, idx, nullptr);
+      break;
     case -16:
       launch_multi(b, n, m, log2bs, xyz, workspace, stride, idx, nullptr, st);
       break;
     default:
-      snprintf(g_err5, sizeof(g_err5), "s2c: fps_cells: waves must be 4, 8, 16 or -16");
+      snprintf(g_err5, sizeof(g_err5), "s2c: fps_cells: waves must be 4, 8, 16, 17 or -16");
       return S2C_EINVAL;
   }
   hipError_t e = hipGetLastError();

@@ -43,13 +43,13 @@ def test_fps_bit_exact(ext, oracle, B, N, m, mode):
 
 
 @pytest.mark.parametrize("impl,waves", [("cells", 0), ("cells", -16), ("cells", 4), ("cells", 8),
-                                        ("cells", 16), ("bucket", 0)])
+                                        ("cells", 16), ("cells", 17), ("bucket", 0)])
 @pytest.mark.parametrize("B,N,m,mode", [(2, 40000, 2048, "volume"), (2, 40000, 2048, "surface"),
                                         (1, 80000, 2048, "surface"), (3, 9000, 700, "volume")])
 def test_fps_large_every_kernel(ext, oracle, monkeypatch, impl, waves, B, N, m, mode):
-    """Every large-set kernel (wave-owned cells: one pick per round with 4 / 8 / 16 waves (16 =
-    the default 0), several exact picks per round (-16); the bucket-list kernel of round 1)
-    gives the oracle's picks."""
+    """Every large-set kernel (wave-owned cells: one pick per round with 4 / 8 / 16 waves, the
+    short-chain round of round 3 (17 = the default 0), several exact picks per round (-16);
+    the bucket-list kernel of round 1) gives the oracle's picks."""
     monkeypatch.setattr(ext, "FPS_LARGE_IMPL", impl)
     monkeypatch.setattr(ext, "FPS_CELLS_WAVES", waves)
     xyz = scene_xyz(B, N, seed=31 + N, mode=mode, adversarial=True)
@@ -57,7 +57,7 @@ def test_fps_large_every_kernel(ext, oracle, monkeypatch, impl, waves, B, N, m, 
                                   oracle.furthest_point_sampling(xyz, m))
 
 
-@pytest.mark.parametrize("impl", ["cells", "bucket"])
+@pytest.mark.parametrize("impl", ["cells", "cells16", "bucket"])
 def test_fps_bucketed_adversarial(ext, oracle, monkeypatch, impl):
     """Inputs built to stress the bucket pruning: tight clusters (many points per
     cell), all points identical (one cell, ties everywhere), a regular lattice
@@ -73,7 +73,8 @@ def test_fps_bucketed_adversarial(ext, oracle, monkeypatch, impl):
     lattice = (g.astype(np.float32) * 0.125 + 0.5)
     skipped = rng.uniform(-0.02, 0.02, size=(1, N, 3)).astype(np.float32)
     skipped[0, 5000:5040] = rng.uniform(1, 2, size=(40, 3))
-    monkeypatch.setattr(ext, "FPS_LARGE_IMPL", impl)
+    monkeypatch.setattr(ext, "FPS_LARGE_IMPL", "cells" if impl == "cells16" else impl)
+    monkeypatch.setattr(ext, "FPS_CELLS_WAVES", 16 if impl == "cells16" else 0)
     for name, xyz in (("clustered", clustered), ("same", same),
                       ("lattice", lattice), ("skipped", skipped)):
         want = oracle.furthest_point_sampling(xyz, 300)

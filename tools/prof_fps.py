@@ -6,7 +6,7 @@ from scan2cap_amd.synthetic import scene_xyz
 lib = _C.load()
 P, I = ctypes.c_void_p, ctypes.c_int
 lib.s2c_fps_cells_profile.argtypes = [I, I, I, P, P, P, I, P, P]
-for waves in (16, 8, 4):
+for waves in (17, 16, 8, 4):
     for mode in ("volume", "surface"):
         B, N, m = 8, 40000, 2048
         xyz = torch.from_numpy(scene_xyz(B, N, mode=mode)).cuda()
@@ -16,7 +16,7 @@ for waves in (16, 8, 4):
         lib.s2c_fps_cells_profile(B, N, m, xyz.data_ptr(), ws.data_ptr(), out.data_ptr(), waves, prof.data_ptr(),
                                   torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
-        p = prof.cpu().numpy()[:waves].astype(float) / (m - 1)
+        p = prof.cpu().numpy()[:min(waves, 16)].astype(float) / (m - 1)
         print("waves=%d %-7s per round (s_memtime ticks, mean over waves / max): cells %.0f/%.0f  own-argmax %.0f  barrier-wait %.0f/%.0f  decode %.0f | active cells per wave-round %.2f (max wave %.2f)" % (
             waves, mode, p[:, 0].mean(), p[:, 0].max(), p[:, 1].mean(), p[:, 2].mean(), p[:, 2].max(), p[:, 3].mean(), p[:, 4].mean(), p[:, 4].max()))
 
