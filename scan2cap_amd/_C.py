@@ -145,7 +145,10 @@ class KernelTimer(object):
 TIMER = KernelTimer()
 
 
-def call(name, *args):
+def call(name, *args, allow=()):
+    """Call an entry point; a non-zero return code raises S2CError unless it is listed in
+    `allow` (e.g. S2C_ENOSUP = -2 where the caller has another kernel to fall back to), in
+    which case it is returned."""
     lib = load()
     if TIMER.enabled:
         import torch
@@ -159,9 +162,10 @@ def call(name, *args):
         TIMER.alg_flops = 0
     else:
         rc = getattr(lib, name)(*args)
-    if rc != 0:
+    if rc != 0 and rc not in allow:
         raise S2CError("%s failed (rc=%d): %s" %
                        (name, rc, lib.s2c_last_error_string().decode()))
+    return rc
 
 
 def stream_ptr():

@@ -36,6 +36,7 @@ namespace {
 constexpr int BT = 1024;          // build: threads per scene
 constexpr int BNW = BT / 64;
 constexpr int MAXC = 32768;       // cells per scene (LDS histogram of the build)
+constexpr int MAXAXIS = 256;      // cells per axis (keeps the cell-index rounding inside the margin)
 constexpr int QW = 4;             // query: waves (centres) per workgroup
 constexpr int CAP = 1024;         // query: hit list entries per wave
 constexpr int HDR_BYTES = 64;
@@ -133,21 +134,28 @@ __global__ __launch_bounds__(BT) void bq_grid_build_kernel(
         ext[a] = fmaxf(ord_inv(h) - flo[a], 0.0f);
       }
       // edge >= r (1 + 1e-4): two points closer than r along an axis are at most one
-      // cell apart whatever the rounding of (v - lo) * inv (relative error ~1e-7 x the
-      // cell index); grown until the grid fits the LDS histogram
+      // cell apart whatever the rounding of (v - lo) * inv (relative error ~1.2e-7 x the
+      // cell index: the 1e-4 margin covers indices up to MAXAXIS = 256 with a factor 3 to
+      // spare, so no axis gets more cells than that -- a corridor-like cloud, extent / r in
+      // the hundreds, gets coarser cells instead of a missed neighbour); grown until the
+      // grid fits the LDS histogram
       float e = fmaxf(radius * 1.0001f, 1e-12f);
       int g[3];
       for (int it = 0; it < 200; ++it) {
         long long prod = 1;
+        int gmax = 0;
         for (int a = 0; a < 3; ++a) {
           const float q = ext[a] / e;
           g[a] = q < 4.0e6f ? (int)q + 1 : 4000001;
           prod *= g[a];
+          gmax = max(gmax, g[a]);
         }
-        if (prod <= MAXC) break;
+        if (prod <= MAXC && gmax <= MAXAXIS) break;
         e *= 1.1f;
       }
-      if ((long long)g[0] * g[1] * g[2] > MAXC) { g[0] = g[1] = g[2] = 1; }
+      if ((long long)g[0] * g[1] * g[2] > MAXC || max(g[0], max(g[1], g[2])) > MAXAXIS) {
+        g[0] = g[1] = g[2] = 1;
+      }
       for (int a = 0; a < 3; ++a) {
         s_hdr.lo[a] = flo[a];
         s_hdr.inv[a] = 1.0f / e;
@@ -397,11 +405,23 @@ extern "C" int s2c_ball_query_grid(int b, int n, int m, float radius, int nsampl
   }
   hipStream_t st = (hipStream_t)stream;
   const size_t stride = (scene_bytes(n) + 15) & ~(size_t)15;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)bq_grid_build_kernel,
-                        hipFuncAttributeMaxDynamicSharedMemorySize, HIST_WORDS * 4);
-    attr_set = true;
+  // the build kernel's LDS histogram needs the opt-in dynamic LDS size: set (and checked) once
+  // per DEVICE; a device / context that refuses it gets S2C_ENOSUP and the caller falls back
+  // to the brute-force kernel (s2c_ball_query)
+  {
+    static int attr_state[64];                 // 0 unknown, 1 ok, -1 refused
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (attr_state[dev] == 0)
+      attr_state[dev] = hipFuncSetAttribute((const void *)bq_grid_build_kernel,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            HIST_WORDS * 4) == hipSuccess ? 1 : -1;
+    if (attr_state[dev] < 0) {
+      (void)hipGetLastError();
+      snprintf(g_err4, sizeof(g_err4), "s2c: ball_query_grid: %d bytes of LDS not available",
+               HIST_WORDS * 4);
+      return S2C_ENOSUP;
+    }
   }
   hipLaunchKernelGGL(bq_grid_build_kernel, dim3(b), dim3(BT), HIST_WORDS * 4, st, n, radius, xyz,
                      (char *)workspace, stride);

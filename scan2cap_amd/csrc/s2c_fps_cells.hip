@@ -105,15 +105,29 @@ __global__ __launch_bounds__(PT) void fps_cells_prep_kernel(
         flo[a] = ord_inv(l); fhi[a] = ord_inv(h);
         ext[a] = fmaxf(fhi[a] - flo[a], 1e-6f);
       }
-      const float vol = ext[0] * ext[1] * ext[2];
-      float e = cbrtf(vol / (float)target_cells);
-      int g[3];
-      for (int it = 0; it < 64; ++it) {
-        for (int a = 0; a < 3; ++a) g[a] = max(1, min(1024, (int)(ext[a] / e) + 1));
-        if ((long long)g[0] * g[1] * g[2] <= MAXC) break;
-        e *= 1.05f;
+      // cells of equal edge over the axes the cloud really extends along: a planar or linear
+      // cloud (one extent ~0) would otherwise drive the edge towards 0 and end in the 1x1x1
+      // fallback -- a single cell = a single wave re-evaluating all n points every round
+      const float emax = fmaxf(ext[0], fmaxf(ext[1], ext[2]));
+      bool live[3];
+      int nlive = 0;
+      float vol = 1.0f;
+      for (int a = 0; a < 3; ++a) {
+        live[a] = ext[a] > 1e-3f * emax;
+        if (live[a]) { ++nlive; vol *= ext[a]; }
       }
-      if ((long long)g[0] * g[1] * g[2] > MAXC) { g[0] = g[1] = g[2] = 1; }
+      int g[3] = {1, 1, 1};
+      if (nlive > 0) {
+        float e = nlive == 3 ? cbrtf(vol / (float)target_cells)
+                             : powf(vol / (float)target_cells, 1.0f / (float)nlive);
+        for (int it = 0; it < 400; ++it) {
+          for (int a = 0; a < 3; ++a)
+            g[a] = live[a] ? max(1, min(1024, (int)(ext[a] / e) + 1)) : 1;
+          if ((long long)g[0] * g[1] * g[2] <= MAXC) break;
+          e *= 1.05f;
+        }
+        if ((long long)g[0] * g[1] * g[2] > MAXC) { g[0] = g[1] = g[2] = 1; }
+      }
       for (int a = 0; a < 3; ++a) {
         s_grid[a] = flo[a];
         s_grid[3 + a] = (float)g[a] / ext[a];

@@ -668,12 +668,19 @@ int pick_cfg(long long M, int N, int K, int pro) {
 
 template <int NT, int PRO, int WAVES, int SLOTS, int EPI>
 int launch_one(const StreamArgs &a, int blocks, size_t lds, hipStream_t st) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void *)rows_stream_gemm_kernel<NT, PRO, WAVES, SLOTS, EPI>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT) != hipSuccess)
-      return -1;
-    attr_done = true;
+  // opt-in dynamic LDS size: set (and checked) once per DEVICE and kernel instance; a device
+  // that refuses it makes the shape "not taken" (-2): the dispatch falls back to the tiled kernel
+  static int attr_state[64];                   // 0 unknown, 1 ok, -1 refused
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (attr_state[dev] == 0)
+    attr_state[dev] =
+        hipFuncSetAttribute((const void *)rows_stream_gemm_kernel<NT, PRO, WAVES, SLOTS, EPI>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT) == hipSuccess
+            ? 1 : -1;
+  if (attr_state[dev] < 0) {
+    (void)hipGetLastError();
+    return -2;
   }
   hipLaunchKernelGGL((rows_stream_gemm_kernel<NT, PRO, WAVES, SLOTS, EPI>), dim3(blocks), dim3(64 * WAVES),
                      lds, st, a);

@@ -32,14 +32,14 @@ def _chk_i(x, name):
     _check(x.is_cuda, "%s must be a CUDA tensor" % name)
 
 
-def _run(name, ref, *args, alg_bytes=0):
+def _run(name, ref, *args, alg_bytes=0, allow=()):
     """alg_bytes: algorithmic HBM bytes of this call under the op contract
     (compulsory reads + writes), recorded only while bench.py's
-    kernel timer is on."""
+    kernel timer is on.  allow: return codes handed back instead of raised."""
     if _C.TIMER.enabled:
         _C.TIMER.alg_bytes = int(alg_bytes)
     with torch.cuda.device(ref.device):
-        _C.call(name, *args, _C.stream_ptr())
+        return _C.call(name, *args, _C.stream_ptr(), allow=allow)
 
 
 def gather_points(points, idx):
@@ -201,9 +201,12 @@ def ball_query(new_xyz, xyz, radius, nsample):
         # large clouds: uniform grid, a centre visits <= 27 cells (csrc/s2c_bq_grid.hip)
         ws = torch.empty(_C.load().s2c_ball_query_workspace_bytes(b, n), dtype=torch.uint8,
                          device=new_xyz.device)
-        _run("s2c_ball_query_grid", new_xyz, b, n, m, float(radius), int(nsample),
-             new_xyz.data_ptr(), xyz.data_ptr(), ws.data_ptr(), idx.data_ptr(), alg_bytes=ab)
-        return idx
+        rc = _run("s2c_ball_query_grid", new_xyz, b, n, m, float(radius), int(nsample),
+                  new_xyz.data_ptr(), xyz.data_ptr(), ws.data_ptr(), idx.data_ptr(),
+                  alg_bytes=ab, allow=(-2,))
+        if rc == 0:
+            return idx
+        # S2C_ENOSUP: this device refused the build kernel's LDS size -> brute-force kernel
     _run("s2c_ball_query", new_xyz, b, n, m, float(radius), int(nsample),
          new_xyz.data_ptr(), xyz.data_ptr(), idx.data_ptr(),
          alg_bytes=4 * (3 * b * n + 3 * b * m + b * m * nsample))

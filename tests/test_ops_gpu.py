@@ -249,6 +249,62 @@ def test_ball_query_grid_bit_exact(ext, oracle, B, N, m, radius, ns, mode, centr
         np.testing.assert_array_equal(got, oracle.ball_query(new_xyz, xyz, radius, ns))
 
 
+def test_ball_query_grid_corridor(ext, oracle):
+    """A corridor-like cloud: extent / radius = 1500 along one axis.  With cells of edge
+    r (1 + 1e-4) that axis would get 1500 cells, and the float rounding of the cell index
+    (~1.2e-7 x index) could put two points closer than r two cells apart -- a missed
+    neighbour.  The build caps the cells per axis (coarser cells instead): rows identical to
+    the oracle, points placed on both sides of every cell boundary."""
+    rng = np.random.default_rng(9)
+    N, m, r = 16384, 1024, 0.2
+    xyz = np.empty((2, N, 3), np.float32)
+    xyz[..., 0] = rng.uniform(0, 300.0, (2, N))
+    xyz[..., 1] = rng.uniform(0, 1.0, (2, N))
+    xyz[..., 2] = rng.uniform(0, 0.5, (2, N))
+    # pairs straddling multiples of the nominal cell edge, far out along the corridor
+    edge = np.float32(r) * np.float32(1.0001)
+    ks = rng.integers(700, 1499, 2048)
+    xyz[0, :2048, 0] = (ks * edge - 1e-4).astype(np.float32)
+    xyz[0, 2048:4096, 0] = (ks * edge + 1e-4).astype(np.float32)
+    xyz[0, 2048:4096, 1:] = xyz[0, :2048, 1:]
+    sel = np.stack([rng.choice(4096, m, replace=False) for _ in range(2)])
+    new_xyz = np.take_along_axis(xyz, sel[..., None], 1)
+    got = ext.ball_query(dev(new_xyz), dev(xyz), r, 16).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.ball_query(new_xyz, xyz, r, 16))
+    np.testing.assert_array_equal(
+        got, ext.ball_query_bruteforce(dev(new_xyz), dev(xyz), r, 16).cpu().numpy())
+
+
+def test_fps_cells_degenerate_geometry(ext, oracle):
+    """Planar and linear clouds (one / two extents exactly 0): the grid is laid over the axes
+    the cloud extends along (it used to collapse to ONE cell = one wave sweeping all points
+    every round).  Exact picks; and the planar case must not be an order of magnitude slower
+    than a volume of the same size."""
+    import time
+    rng = np.random.default_rng(4)
+    N, m = 12000, 400
+    plane = rng.uniform(-3, 3, (1, N, 3)).astype(np.float32)
+    plane[..., 2] = 1.5
+    line = np.zeros((1, N, 3), np.float32)
+    line[..., 0] = rng.uniform(1, 9, (1, N))
+    line[..., 1] = 2.0
+    vol = rng.uniform(-3, 3, (1, N, 3)).astype(np.float32)
+    times = {}
+    for name, xyz in (("volume", vol), ("plane", plane), ("line", line)):
+        x = dev(xyz)
+        got = ext.furthest_point_sampling(x, m)
+        np.testing.assert_array_equal(got.cpu().numpy(), oracle.furthest_point_sampling(xyz, m),
+                                      err_msg=name)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            ext.furthest_point_sampling(x, m)
+        torch.cuda.synchronize()
+        times[name] = (time.perf_counter() - t0) / 3
+    assert times["plane"] < 4 * times["volume"], times
+    assert times["line"] < 4 * times["volume"], times
+
+
 def test_ball_query_no_hit_rows_are_zero(ext, oracle):
     xyz = scene_xyz(1, 512, seed=3)
     new_xyz = np.full((1, 9, 3), 50.0, np.float32)  # far away: no hit
