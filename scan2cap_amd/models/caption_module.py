@@ -14,6 +14,8 @@ MI355X-first re-design of the control flow (values are unchanged):
   * no host synchronisation inside the step loop.
 """
 import numpy as np
+import os as _os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -35,6 +37,11 @@ FUSE_EVAL_STEP = True
 SPLIT_EVAL_GEMMS = True
 SPLIT_EVAL_MIN_ROWS = 4096     # measured: +5 % at 8192 rows (cfg5), -9 % at 2048 (cfg3e)
 _split_ok = None
+
+
+# teacher-forced decoder with num_locals = L: attention over the L gathered objects instead of
+# all K with K - L of them masked (S2C_LOCAL_TRAIN_ATTN=0: the dense formulation)
+LOCAL_TRAIN_ATTENTION = _os.environ.get("S2C_LOCAL_TRAIN_ATTN", "1") != "0"
 
 
 def _split_gemm_available():
@@ -296,8 +303,14 @@ class TopDownSceneCaptionModule(nn.Module):
             target_ids, target_ious = select_target(data_dict)
         target_feats = torch.gather(
             obj_feats, 1, target_ids.view(B, 1, 1).expand(B, 1, self.feat_size)).squeeze(1)
-        valid_masks = object_masks if self.num_locals == -1 else \
-            self._query_locals(data_dict, target_ids, object_masks)
+        local_ids = None
+        if self.num_locals == -1:
+            valid_masks = object_masks
+        else:
+            valid_masks, local_ids = query_locals(
+                data_dict["bbox_corner"], object_masks, target_ids.view(B, 1),
+                self.num_locals, self.query_mode, True, CONF.TRAIN.OVERLAID_THRESHOLD)
+            valid_masks, local_ids = valid_masks.squeeze(1), local_ids.squeeze(1)   # (B,K), (B,L)
         if self.use_relation:
             obj_feats = self._add_relation_feat(
                 data_dict, obj_feats, target_ids.view(B, 1)).squeeze(1)
@@ -305,8 +318,25 @@ class TopDownSceneCaptionModule(nn.Module):
         if obj_feats.is_cuda and decoder_fused.supported(
                 self.emb_size, self.hidden_size, self.feat_size, self.num_proposals):
             # hand-written recurrent kernels + hoisted GEMMs (decoder_fused.py)
-            lang_cap, attn = decoder_fused.decode(
-                self, word_embs, target_feats, obj_feats, valid_masks, steps)
+            if local_ids is not None and LOCAL_TRAIN_ATTENTION:
+                # num_locals = L: the mask is a scatter of exactly L ids (query_locals), every
+                # other score is -1e30 and its softmax weight underflows to exactly 0 -- in
+                # the forward pass AND in every gradient.  So the teacher-forced decoder
+                # attends to the L gathered objects only ((B,L,.) instead of (B,K,.): map_feat,
+                # scores, softmax, their backward), as the greedy decoder above already does;
+                # autograd scatters the local gradient back into the (B,K,F) features.
+                L = local_ids.shape[1]
+                local = torch.gather(obj_feats, 1,
+                                     local_ids.unsqueeze(-1).expand(B, L, self.feat_size))
+                ones = torch.ones(B, L, device=obj_feats.device)
+                lang_cap, attn_l = decoder_fused.decode(
+                    self, word_embs, target_feats, local, ones, steps)
+                attn = torch.zeros(B, self.num_proposals, attn_l.shape[2],
+                                   device=obj_feats.device)
+                attn.scatter_(1, local_ids.unsqueeze(-1).expand(B, L, attn_l.shape[2]), attn_l)
+            else:
+                lang_cap, attn = decoder_fused.decode(
+                    self, word_embs, target_feats, obj_feats, valid_masks, steps)
             good, mean_iou = _good_bbox_stats(target_ious, min_iou)
             data_dict["lang_cap"] = lang_cap
             data_dict["pred_ious"] = mean_iou
