@@ -82,6 +82,14 @@ def _lin_pair(R, d1, d2=None, gates=None):
 
 
 ENABLED = True      # scan2cap_amd/opbyop.py: False = the plain `_step` loop
+# One-pass attention (attn_local_kernel, one wave per row) for K <= this many keys.  0 = off:
+# measured at cfg3 (R = 8 rows, K = 10 gathered objects) the single launch is SLOWER than the
+# scores + softmax pair (10.49 vs 10.40 ms per step): one wave per row leaves 8 waves on the
+# chip for 10 x 512 tanh each, the pair spreads them over 80 + 32 workgroups.  (The greedy
+# decoder's thousands of rows are where the one-pass kernel pays.)  Limit of the kernel: 32.
+LOCAL_ATTN_MAX_K = 0
+_C.register("s2c_attn_local_fwd", [_I, _I, _I, _I, _P, _P, _I, _P, ctypes.c_float, _P, _P, _P,
+                                   _P, _I, _P])
 
 
 def supported(emb, hid, feat, K):
@@ -159,9 +167,16 @@ class TopDownDecode(Function):
                       _p(S1[0][t]), _p(S1[1][t]), _p(S1[2][t]), _p(S1[3][t]),
                       alg_bytes=4 * (3 * H * (E + H) + R * (E + 6 * H)))
                 _lin(R, H + E, H, Wqh, H, H1[t + 1], H, QL[t], H + E)
-                _call("s2c_attn_fwd", R, K, H, F, _p(M), _p(QL[t]), H + E, _p(wa),
-                      _p(mask), _p(O), _p(SC), _p(ALPHA[t]), _p(ATT[t]), F,
-                      alg_bytes=4 * (R * K * (H + F) + R * (H + 2 * K + F)))
+                if K <= LOCAL_ATTN_MAX_K:
+                    # few keys (the num_locals gather): scores, mask, softmax and the weighted
+                    # sum in ONE pass, one wave per row (attn_local_kernel)
+                    _call("s2c_attn_local_fwd", R, K, H, F, _p(M), _p(QL[t]), H + E, _p(wa),
+                          0.0, _p(mask), _p(O), _p(ALPHA[t]), _p(ATT[t]), F,
+                          alg_bytes=4 * (R * K * (H + F) + R * (H + 2 * K + F)))
+                else:
+                    _call("s2c_attn_fwd", R, K, H, F, _p(M), _p(QL[t]), H + E, _p(wa),
+                          _p(mask), _p(O), _p(SC), _p(ALPHA[t]), _p(ATT[t]), F,
+                          alg_bytes=4 * (R * K * (H + F) + R * (H + 2 * K + F)))
                 _lin(R, E, F, W_lang, ldlang, ATT[t], F, X2[t], E, bias=b_lang,
                      add1=QL[t][:, H:], ld1=H + E, epi=1)
                 _call("s2c_gru_fwd", R, H, E, _p(W_ih2), _p(W_hh2), _p(b_ih2),

@@ -129,14 +129,30 @@ def test_geometry_slots_grouped_refill_matches_inline():
             assert torch.equal(a, b)
 
 
-def test_fused_decoder_matches_torch_loop():
+@pytest.mark.parametrize("K", [64, 10])
+def test_fused_decoder_matches_torch_loop(K):
     """decoder_fused.TopDownDecode (hand-written step kernels + hoisted GEMMs) vs
     the plain PyTorch step loop of the same module: logits, attention, and every
-    gradient (BPTT) within 1e-4 of scale."""
+    gradient (BPTT) within 1e-4 of scale.  K = 10: the gathered num_locals objects (one-pass
+    attention kernel); K = 64: scores + softmax kernels."""
+    from scan2cap_amd.models import decoder_fused
+    from scan2cap_amd.models.caption_module import TopDownSceneCaptionModule
+    if K == 10:      # exercise the one-pass kernel too (off by default: see decoder_fused.py)
+        import pytest as _pt
+        mp = _pt.MonkeyPatch()
+        mp.setattr(decoder_fused, "LOCAL_ATTN_MAX_K", 32)
+        try:
+            return _decoder_vs_torch_loop(K)
+        finally:
+            mp.undo()
+    return _decoder_vs_torch_loop(K)
+
+
+def _decoder_vs_torch_loop(K):
     from scan2cap_amd.models import decoder_fused
     from scan2cap_amd.models.caption_module import TopDownSceneCaptionModule
     torch.manual_seed(3)
-    V, R, K, T = 50, 8, 64, 9
+    V, R, T = 50, 8, 9
     words = ["w%d" % i for i in range(V)]
     vocab = {"word2idx": {w: i for i, w in enumerate(words)},
              "idx2word": {str(i): w for i, w in enumerate(words)}}
