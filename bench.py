@@ -138,6 +138,35 @@ def pmc_traffic(entry):
     return total / max(calls, 1)
 
 
+def pmc_mfma_busy(name_parts):
+    """MFMA-busy fraction (SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024 SIMDs)) of the kernels
+    whose names contain one of `name_parts`, time-weighted, from the committed SQ-counter summary
+    (profiles/rNN_pmc_sq_bench.json, newest round; its own rocprofv3 pass: tools/make_profiles.sh).
+    None when not available."""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_sq_bench.json")))
+    if not found:
+        return None
+    try:
+        table = json.load(open(found[-1]))
+    except Exception:
+        return None
+    num = den = 0.0
+    per = {}
+    for kname, e in table.items():
+        if not any(p in kname for p in name_parts) or "mfma_util" not in e:
+            continue
+        cyc = e["mean"].get("GRBM_GUI_ACTIVE", 0.0) / 8.0 * e["dispatches"]
+        num += e["mfma_util"] * cyc
+        den += cyc
+        import re
+        m = re.search(r"(\w+_kernel(?:<[^>]*>)?)", kname)
+        per[m.group(1) if m else kname[:60]] = round(e["mfma_util"], 4)
+    if den <= 0:
+        return None
+    return {"busy": num / den, "source": os.path.basename(found[-1]), "per_kernel": per}
+
+
 def make_vocab(V, seed=0):
     rng = np.random.Generator(np.random.PCG64(seed))
     words = ["pad_", "unk", "sos", "eos"] + ["w%d" % i for i in range(V - 4)]
@@ -399,6 +428,10 @@ def family_roofline(table_k, ms_per_step):
             "launches_per_step": sum(k["calls_per_step"] for k in parts),
             "other_roof": {"bound": "mfma", "achieved": tflops, "peak": MFMA_GEMM_PEAK_TF,
                            "unit": "TFLOP/s", "frac": tflops / MFMA_GEMM_PEAK_TF},
+            # hardware view of the same kernels: matrix-pipe busy cycles (PMC, bf16 pipe:
+            # 6 plane products per fp32 product)
+            "mfma_busy": pmc_mfma_busy(("rows_stream_gemm_kernel", "rows_gemm_x3_kernel",
+                                        "rows_gemm_kernel")),
             "parts": {k["kernel"]: {"ms_per_step": k["ms_per_step"], "alg_GBps": k["alg_GBps"],
                                     "avg_launch_us": k["avg_us"]} for k in parts}}
 

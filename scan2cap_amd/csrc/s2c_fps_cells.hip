@@ -575,10 +575,11 @@ __global__ __launch_bounds__(1024) void fps_cells_rounds4_kernel(
 // NOT the default (see the launcher): bit-exact, 3.9x fewer rounds, but each round is 4x as
 // expensive -- the scene's single CU is instruction-issue bound once 16 waves each run the
 // 8-pick update and the candidate selection (tools/prof_fps.py).
-constexpr int MAXP = 8;           // picks per round
 struct __attribute__((aligned(16))) MSlot { u64 key; float x, y, z; int pad; u64 bound; u64 pad2; };
 
-template <bool LDSD2>
+// MAXP: most picks accepted per round (8: 3.9 per round on average but ~57 active cells to update;
+// 2-3: fewer picks, a round close to the one-pick round's cost)
+template <bool LDSD2, int MAXP>
 __global__ __launch_bounds__(1024) void fps_cells_multi_kernel(
     int n, int m, int log2bs, const float *__restrict__ xyz, char *__restrict__ ws,
     size_t stride, int *__restrict__ idx, long long *__restrict__ prof = nullptr) {
@@ -793,21 +794,34 @@ __global__ __launch_bounds__(1024) void fps_cells_multi_kernel(
 }
 
 // n * 4 bytes of min-distances + the static slots must fit the 160 KB of one CU
-void launch_multi(int b, int n, int m, int log2bs, const float *xyz, void *workspace,
-                  size_t stride, int *idx, long long *prof, hipStream_t st) {
+template <int MAXP>
+void launch_multi_p(int b, int n, int m, int log2bs, const float *xyz, void *workspace,
+                    size_t stride, int *idx, long long *prof, hipStream_t st) {
   const size_t lds = (size_t)n * 4;
   if (lds + 4096 <= 160 * 1024) {
     static bool attr = false;
     if (!attr) {
-      (void)hipFuncSetAttribute((const void *)fps_cells_multi_kernel<true>,
+      (void)hipFuncSetAttribute((const void *)fps_cells_multi_kernel<true, MAXP>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
       attr = true;
     }
-    hipLaunchKernelGGL((fps_cells_multi_kernel<true>), dim3(b), dim3(1024), lds, st, n, m,
+    hipLaunchKernelGGL((fps_cells_multi_kernel<true, MAXP>), dim3(b), dim3(1024), lds, st, n, m,
                        log2bs, xyz, (char *)workspace, stride, idx, prof);
   } else {
-    hipLaunchKernelGGL((fps_cells_multi_kernel<false>), dim3(b), dim3(1024), 0, st, n, m,
+    hipLaunchKernelGGL((fps_cells_multi_kernel<false, MAXP>), dim3(b), dim3(1024), 0, st, n, m,
                        log2bs, xyz, (char *)workspace, stride, idx, prof);
+  }
+}
+
+// n * 4 bytes of min-distances + the static slots must fit the 160 KB of one CU.
+// waves = -16: up to 8 picks per round; -2 / -3 / -4: up to 2 / 3 / 4
+void launch_multi(int b, int n, int m, int log2bs, const float *xyz, void *workspace,
+                  size_t stride, int *idx, long long *prof, hipStream_t st, int waves = -16) {
+  switch (waves) {
+    case -2: launch_multi_p<2>(b, n, m, log2bs, xyz, workspace, stride, idx, prof, st); break;
+    case -3: launch_multi_p<3>(b, n, m, log2bs, xyz, workspace, stride, idx, prof, st); break;
+    case -4: launch_multi_p<4>(b, n, m, log2bs, xyz, workspace, stride, idx, prof, st); break;
+    default: launch_multi_p<8>(b, n, m, log2bs, xyz, workspace, stride, idx, prof, st); break;
   }
 }
 
@@ -828,8 +842,8 @@ extern "C" int s2c_fps_cells_profile(int b, int n, int m, const float *xyz, void
   const size_t stride = cells_scene_bytes(n);
   hipLaunchKernelGGL(fps_cells_prep_kernel, dim3(b), dim3(PT), 0, st, n, bs, log2bs, target,
                      xyz, (char *)workspace, stride);
-  if (waves == -16)
-    launch_multi(b, n, m, log2bs, xyz, workspace, stride, idx, prof, st);
+  if (waves == -16 || (waves <= -2 && waves >= -4))
+    launch_multi(b, n, m, log2bs, xyz, workspace, stride, idx, prof, st, waves);
   else if (waves == 17)
     hipLaunchKernelGGL((fps_cells_rounds4_kernel<true>), dim3(b), dim3(1024), 0, st, n, m,
                        log2bs, xyz, (char *)workspace, stride, idx, prof);
@@ -901,8 +915,8 @@ extern "C" int s2c_furthest_point_sampling_cells(int b, int n, int m, const floa
       hipLaunchKernelGGL((fps_cells_rounds4_kernel<false>), dim3(b), dim3(1024), 0, st, n, m,
                          log2bs, xyz, (char *)workspace, stride, idx, nullptr);
       break;
-    case -16:
-      launch_multi(b, n, m, log2bs, xyz, workspace, stride, idx, nullptr, st);
+    case -16: case -2: case -3: case -4:
+      launch_multi(b, n, m, log2bs, xyz, workspace, stride, idx, nullptr, st, waves);
       break;
     default:
       snprintf(g_err5, sizeof(g_err5), "s2c: fps_cells: waves must be 4, 8, 16, 17 or -16");

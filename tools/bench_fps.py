@@ -11,7 +11,7 @@ for (B, N, m) in ((8, 40000, 2048), (16, 80000, 2048)):
         xyz = torch.from_numpy(scene_xyz(B, N, mode=mode)).cuda()
         res = []
         ref = None
-        for impl, waves in (("bucket", 0), ("cells", 16), ("cells", 17), ("cells", -16)):
+        for impl, waves in (("cells", 16), ("cells", -2), ("cells", -3), ("cells", -4), ("cells", -16)):
             _ext.FPS_LARGE_IMPL, _ext.FPS_CELLS_WAVES = impl, waves
             out = _ext.furthest_point_sampling(xyz, m)
             if ref is None:

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates the judged profile set of a round on the GPU box (run through gpurun from the
 # repo root): tools/make_profiles.sh r02   -> gpurun_out/<round>/...  (copy into profiles/)
-R=${1:-r02}
+R=${1:-r03}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$R
 mkdir -p $OUT
@@ -15,6 +15,12 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/p_$c && rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/p_$c -o s -- python $ROOT/bench.py --no-graph --steps 2 --warmup 1 --no-cpu-baseline --no-fed > $OUT/pmc_$c.log 2>&1
 done
 python $ROOT/tools/pmc_summary.py $OUT/${R}_pmc_bench.json FETCH_SIZE=$(ls /tmp/p_FETCH_SIZE/*counter_collection.csv | head -1) WRITE_SIZE=$(ls /tmp/p_WRITE_SIZE/*counter_collection.csv | head -1) > $OUT/pmc_summary.log 2>&1
+# MFMA utilisation and the wave-cycle split of every kernel (round 3: streaming GEMM, pooled-layer
+# kernels, s2c_bn_bwd_gemm, dw_x3): SQ counters in their own pass, --kernel-trace only
+rm -rf /tmp/p_sq && rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d /tmp/p_sq -o s -- python $ROOT/bench.py --no-graph --steps 2 --warmup 1 --no-cpu-baseline --no-fed > $OUT/pmc_sq.log 2>&1
+python $ROOT/tools/pmc_sq_summary.py $(ls /tmp/p_sq/*counter_collection.csv | head -1) $OUT/${R}_pmc_sq_bench.json > $OUT/pmc_sq_summary.log 2>&1
+# the N > 1 path on this one GPU: two ranks over gloo (RCCL refuses two ranks per device)
+S2C_DIST_BACKEND=gloo python $ROOT/bench.py --gpus 2 --no-cpu-baseline > $OUT/${R}_bench_2ranks_gloo_1gpu.json 2> $OUT/bench_2ranks.err
 for w in cfg2 cfg5 cfg3e; do
   python $ROOT/bench.py --workload $w --no-cpu-baseline --no-fed > $OUT/${R}_bench_$w.json 2> $OUT/bench_$w.err
 done
