@@ -460,6 +460,11 @@ int s2c_proposal_decode(int B, int K, int nout, int num_heading_bin, int num_siz
 int s2c_select_target(int B, int K, const double *bbox_corner, const double *ref_box_corner,
                       long long *target_ids, float *target_ious, void *stream);
 
+/* good[b] (bool) = target_ious[b] > min_iou; *mean = mean IoU of the good samples (0 if none):
+ * `good_bbox_masks` / `pred_ious` of caption_module.py:494-498 in one launch. */
+int s2c_good_bbox_stats(int B, const float *target_ious, float min_iou, unsigned char *good,
+                        float *mean, void *stream);
+
 /* Caption loss (lib/loss_helper.py:189-230): masked cross-entropy (ignore_index 0, rows of
  * samples with good[b] == 0 excluded) and word accuracy of the teacher-forced logits pred
  * (B,T,V) f32 contiguous against target (B,T) i64 (row stride target_stride elements).
@@ -499,14 +504,15 @@ typedef struct s2c_prep_args {
 } s2c_prep_args;
 int s2c_batch_prep(const s2c_prep_args *a, void *stream);
 
-/* Up to 8 partial-sum jobs in one launch: out[j] (n[j]) = sum over the S[j] slabs of
- * part[j] (S[j] x n[j], dense), fixed order. */
+/* Up to S2C_COLSUM_MAX_JOBS partial-sum jobs in one launch: out[j] (n[j]) = sum over the S[j]
+ * slabs of part[j] (S[j] x n[j], dense), fixed order. */
+#define S2C_COLSUM_MAX_JOBS 32
 typedef struct s2c_colsum_args {
   int n_jobs;
-  int S[8];
-  long long n[8];
-  const float *part[8];
-  float *out[8];
+  int S[S2C_COLSUM_MAX_JOBS];
+  long long n[S2C_COLSUM_MAX_JOBS];
+  const float *part[S2C_COLSUM_MAX_JOBS];
+  float *out[S2C_COLSUM_MAX_JOBS];
 } s2c_colsum_args;
 int s2c_multi_colsum(const s2c_colsum_args *a, void *stream);
 

@@ -116,6 +116,29 @@ __global__ __launch_bounds__(1024) void select_target_kernel(
   }
 }
 
+// good[b] = ious[b] > min_iou; mean = mean IoU over the good samples, 0 when there is none
+// (caption_module.py:30-36 / :494-498: `pred_ious`, `good_bbox_masks`).  One wave; the sum
+// runs in ascending sample order like the framework's reduction of <= 64 values.
+__global__ __launch_bounds__(64) void good_bbox_stats_kernel(int B, const float *__restrict__ ious,
+                                                             float min_iou, bool *__restrict__ good,
+                                                             float *__restrict__ mean) {
+  float sum = 0.f;
+  int n = 0;
+  for (int b0 = 0; b0 < B; b0 += 64) {
+    const int b = b0 + (int)threadIdx.x;
+    const float v = b < B ? ious[b] : 0.f;
+    const bool g = b < B && v > min_iou;
+    if (b < B) good[b] = g;
+    const unsigned long long m = __ballot(g);
+    n += (int)__builtin_popcountll(m);
+    for (int l = 0; l < 64; ++l) {                 // fixed (ascending) order
+      const float x = __shfl(v, l, 64);
+      if ((m >> l) & 1ull) sum += x;
+    }
+  }
+  if (threadIdx.x == 0) *mean = n > 0 ? sum / (float)n : 0.f;
+}
+
 int chk7(const char *k) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -153,6 +176,14 @@ extern "C" int s2c_select_target(int B, int K, const double *bbox_corner,
   hipLaunchKernelGGL(select_target_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, K,
                      bbox_corner, ref_box_corner, target_ids, target_ious);
   return chk7("select_target");
+}
+
+extern "C" int s2c_good_bbox_stats(int B, const float *ious, float min_iou, unsigned char *good,
+                                   float *mean, void *stream) {
+  if (B <= 0 || !ious || !good || !mean) return -1;
+  hipLaunchKernelGGL(good_bbox_stats_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, B, ious,
+                     min_iou, (bool *)good, mean);
+  return chk7("good_bbox_stats");
 }
 
 // ---------------------------------------------------------------------------------------
@@ -296,7 +327,7 @@ extern "C" int s2c_batch_prep(const s2c_prep_args *a, void *stream) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Batched partial-sum: up to 8 jobs out[j][e] = sum_{s < S[j]} part[j][s * n[j] + e] in ONE
+// Batched partial-sum: up to S2C_COLSUM_MAX_JOBS jobs out[j][e] = sum_{s < S[j]} part[j][s * n[j] + e] in ONE
 // launch (the split-K partial products of the weight gradients of one layer stack; each was
 // its own framework reduction kernel).  Fixed summation order.
 namespace {
@@ -340,7 +371,7 @@ __global__ __launch_bounds__(256) void multi_colsum_kernel(s2c_colsum_args a) {
 }  // namespace
 
 extern "C" int s2c_multi_colsum(const s2c_colsum_args *a, void *stream) {
-  if (!a || a->n_jobs <= 0 || a->n_jobs > 8) return -1;
+  if (!a || a->n_jobs <= 0 || a->n_jobs > S2C_COLSUM_MAX_JOBS) return -1;
   long long blocks = 0;
   for (int j = 0; j < a->n_jobs; ++j) {
     if (!a->part[j] || !a->out[j] || a->S[j] <= 0 || a->n[j] <= 0) return -1;

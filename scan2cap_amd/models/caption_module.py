@@ -124,7 +124,19 @@ def _embedding_table(vocabulary, embeddings, emb_size):
     return torch.from_numpy(table)
 
 
+_C.register("s2c_good_bbox_stats", [_I, _P, _F32, _P, _P, _P])
+
+
 def _good_bbox_stats(target_ious, min_iou):
+    if USE_SELECT_TARGET_KERNEL and target_ious.is_cuda and target_ious.dtype == torch.float32 \
+            and target_ious.dim() == 1 and not target_ious.requires_grad:
+        t = target_ious.contiguous()
+        good = torch.empty(t.shape[0], dtype=torch.bool, device=t.device)
+        mean = torch.empty((), dtype=torch.float32, device=t.device)
+        with torch.cuda.device(t.device):
+            _C.call("s2c_good_bbox_stats", t.shape[0], t.data_ptr(), float(min_iou),
+                    good.data_ptr(), mean.data_ptr(), _C.stream_ptr())
+        return good, mean
     good = target_ious > min_iou
     n = good.sum()
     mean = (target_ious * good).sum() / n.clamp(min=1)

@@ -262,17 +262,19 @@ class TopDownDecode(Function):
             dtf = torch.mm(DA1s, W_td[:, E + H:])                             # (R,F)
             dO = torch.bmm(ALPHA.permute(1, 2, 0), DV[:, :, :F].permute(1, 0, 2))
             # ---- every weight gradient: one stacked GEMM each ------------------
+            # (column blocks written in place by the GEMMs: `out=` on a row-strided view is a
+            # plain ldc for the library -- no temporaries, no copy kernels)
             dW_td = torch.empty_like(W_td)
-            dW_td[:, :E] = torch.mm(da1.t(), words.permute(1, 0, 2).reshape(TR, E))
-            dW_td[:, E:E + H] = torch.mm(da1.t(), H2[:-1].reshape(TR, H))
-            dW_td[:, E + H:] = torch.mm(DA1s.t(), tf)
+            torch.mm(da1.t(), words.permute(1, 0, 2).reshape(TR, E), out=dW_td[:, :E])
+            torch.mm(da1.t(), H2[:-1].reshape(TR, H), out=dW_td[:, E:E + H])
+            torch.mm(DA1s.t(), tf, out=dW_td[:, E + H:])
             dW_ih1 = torch.mm(gi1.t(), X1.view(TR, E))
             dW_hh1 = torch.mm(gh1.t(), H1[:-1].reshape(TR, H))
             h1n = H1[1:].reshape(TR, H)
             dW_h = torch.mm(DQ.view(TR, H).t(), h1n)
             dW_lang = torch.empty_like(W_lang)
-            dW_lang[:, :F] = torch.mm(da2.t(), ATT.view(TR, F))
-            dW_lang[:, F:] = torch.mm(da2.t(), h1n)
+            torch.mm(da2.t(), ATT.view(TR, F), out=dW_lang[:, :F])
+            torch.mm(da2.t(), h1n, out=dW_lang[:, F:])
             dW_ih2 = torch.mm(gi2.t(), X2.view(TR, E))
             dW_hh2 = torch.mm(gh2.t(), H2[:-1].reshape(TR, H))
             dMf = dM.view(R * K, H)

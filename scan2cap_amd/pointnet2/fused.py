@@ -113,6 +113,20 @@ def _fused_bwd_pays(M, C, N):
     return HAND_EVERYWHERE or (M >= 32768 and N % 4 == 0)
 
 
+def _hand_dw_pays(M, C, N):
+    """dW = dY^T A (M rows, C x N output): the slab kernel of csrc/s2c_dw.hip + the partial-sum
+    launch against the split-K library bmm + the same launch, measured on MI355X
+    (tools/bench_dw_mid.py, us hand vs library): (16384,64,3) 23 vs 38 | (20480,128,128) 24 vs 38 |
+    (20480,128,256) 25 vs 40 | (32768,128,128) 24 vs 39 | (32768,256,128) 32 vs 39 |
+    (65536,128,128) 34 vs 37 | (32768,128,259) 52 vs 47 | (65536,256,128) 52 vs 47 |
+    (262144,128,128) 101 vs 81 | (1M,64,64) 146 vs 120."""
+    if M <= 16384:
+        return True
+    if N % 4 != 0:
+        return False
+    return M <= 32768 or (M <= 65536 and C * N <= 16384)
+
+
 def _hand_da_pays(M, C, N):
     return HAND_EVERYWHERE or (M >= 262144 and N <= 64)
 
@@ -837,21 +851,32 @@ def _weight_grad_partials(dY, A, pending):
     return dW
 
 
+COLSUM_MAX_JOBS = 32      # S2C_COLSUM_MAX_JOBS (include/s2c_fused.h)
+
+
 class _ColsumArgs(ctypes.Structure):
     """s2c_colsum_args (include/s2c_fused.h)."""
-    _fields_ = [("n_jobs", ctypes.c_int), ("S", ctypes.c_int * 8),
-                ("n", ctypes.c_longlong * 8), ("part", ctypes.c_void_p * 8),
-                ("out", ctypes.c_void_p * 8)]
+    _fields_ = [("n_jobs", ctypes.c_int), ("S", ctypes.c_int * COLSUM_MAX_JOBS),
+                ("n", ctypes.c_longlong * COLSUM_MAX_JOBS),
+                ("part", ctypes.c_void_p * COLSUM_MAX_JOBS),
+                ("out", ctypes.c_void_p * COLSUM_MAX_JOBS)]
 
 
 _C.register("s2c_multi_colsum", [_P, _P])
 BATCH_PARTIAL_SUMS = True
 
 
+# (Collecting the partial sums of ALL layer stacks of a backward pass into one launch from an
+# end-of-backward callback of the autograd engine was built in round 3 and withdrawn: a weight
+# gradient handed to AccumulateGrad before it is filled is WRONG whenever the engine clones it
+# (another reference alive) or accumulates into an existing .grad (gradient accumulation over
+# micro-batches) -- both happen before the callback runs.  ~0.06 ms is not worth that hazard.)
+
+
 def flush_partial_sums(pending):
-    """[(part (S,Cout,Cin), dW (Cout,Cin))...] -> every dW filled, 8 jobs per launch."""
-    for i in range(0, len(pending), 8):
-        chunk = pending[i:i + 8]
+    """[(part (S,Cout,Cin), dW (Cout,Cin))...] -> every dW filled, COLSUM_MAX_JOBS per launch."""
+    for i in range(0, len(pending), COLSUM_MAX_JOBS):
+        chunk = pending[i:i + COLSUM_MAX_JOBS]
         a = _ColsumArgs()
         a.n_jobs = len(chunk)
         for j, (part, dW) in enumerate(chunk):
@@ -917,7 +942,7 @@ def _weight_grad(dY, A, pending=None):
         return weight_grad_kernel(dY, A)
     if (HAND_DW_GEMM and dY.is_cuda and dY.dtype == torch.float32 and A.dtype == torch.float32
             and dY.stride(1) == 1 and A.stride(1) == 1 and pending is not None
-            and BATCH_PARTIAL_SUMS and (HAND_EVERYWHERE or M <= 16384)):
+            and BATCH_PARTIAL_SUMS and (HAND_EVERYWHERE or _hand_dw_pays(M, dY.shape[1], A.shape[1]))):
         return _weight_grad_partials(dY, A, pending)
     # slabs of >= 1024 rows (>= 2048 from 256k rows on), at most 256 of them: measured best
     # trade between the batched GEMM and the partial sum (tools/bench_dw_split.py)
