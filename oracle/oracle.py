@@ -44,7 +44,17 @@ def lib():
     if _lib is None:
         build()
         _lib = ctypes.CDLL(_SO)
+        # the same switch as the kernels' build-time -DS2C_NVCC_CONTRACT (csrc/s2c_common.h)
+        _lib.s2c_oracle_set_contract(int(os.environ.get("S2C_NVCC_CONTRACT", "0") or 0))
     return _lib
+
+
+def set_contract(mode):
+    """0: canonical arithmetic; 1 | 2: a*a + b*b + c*c of the index-producing ops with the fused
+    multiply-adds of an nvcc build (oracle/s2c_oracle.c: sq3).  Returns the previous mode."""
+    old = int(lib().s2c_oracle_get_contract())
+    lib().s2c_oracle_set_contract(int(mode))
+    return old
 
 
 _F = ctypes.POINTER(ctypes.c_float)

@@ -20,6 +20,10 @@
  * Arithmetic convention (DESIGN.md "canonical arithmetic"): IEEE-754 binary32,
  * operations in the order the reference source writes them, NO fused
  * multiply-add contraction.  Build with -ffp-contract=off (oracle/Makefile).
+ * s2c_oracle_set_contract(1 | 2) switches the three-term sums of squares of the
+ * index-producing ops to the two fused-multiply-add contractions an nvcc build of
+ * the reference (--fmad=true, its default) may use -- the same switch as
+ * -DS2C_NVCC_CONTRACT in scan2cap_amd/csrc/s2c_common.h; 0 restores the canonical form.
  *
  * Each function cites the reference file:line it follows.
  */
@@ -29,6 +33,17 @@
 #include <string.h>
 
 #define S2C_TOTAL_THREADS 512 /* cuda_utils.h:11 */
+
+/* a*a + b*b + c*c (sampling_gpu.cu:100-104, ball_query_gpu.cu:31-32,
+ * interpolate_gpu.cu:36-37): canonical, or one of the two nvcc-style contractions. */
+static int g_contract = 0;
+void s2c_oracle_set_contract(int mode) { g_contract = (mode == 1 || mode == 2) ? mode : 0; }
+int s2c_oracle_get_contract(void) { return g_contract; }
+static inline float sq3(float a, float b, float c) {
+  if (g_contract == 1) return fmaf(c, c, fmaf(a, a, b * b));
+  if (g_contract == 2) return fmaf(c, c, fmaf(b, b, a * a));
+  return (a * a + b * b) + c * c;
+}
 
 /* cuda_utils.h:13-19 -- block size chosen by the reference host code.
  * Restated with the same double-precision log expression so the
@@ -75,12 +90,11 @@ void s2c_oracle_furthest_point_sampling(int b, int n, int m, const float *xyz,
         const float x2 = ds[k * 3 + 0];
         const float y2 = ds[k * 3 + 1];
         const float z2 = ds[k * 3 + 2];
-        const float mag = (x2 * x2) + (y2 * y2) + (z2 * z2);
+        const float mag = sq3(x2, y2, z2);
         /* sampling_gpu.cu:101 compares the float against the double literal
          * 1e-3: the comparison is done in double. */
         if ((double)mag <= 1e-3) continue;
-        const float d = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) +
-                        (z2 - z1) * (z2 - z1);
+        const float d = sq3(x2 - x1, y2 - y1, z2 - z1);
         const float d2 = d < tp[k] ? d : tp[k]; /* min(d, temp[k]) :106 */
         tp[k] = d2;
         if (d2 > dists[t]) { /* strict, :108-109 */
@@ -151,9 +165,7 @@ void s2c_oracle_ball_query(int b, int n, int m, float radius, int nsample,
         const float x = p[k * 3 + 0];
         const float y = p[k * 3 + 1];
         const float z = p[k * 3 + 2];
-        const float d2 = (new_x - x) * (new_x - x) +
-                         (new_y - y) * (new_y - y) +
-                         (new_z - z) * (new_z - z);
+        const float d2 = sq3(new_x - x, new_y - y, new_z - z);
         if (d2 < radius2) { /* strict, :33 */
           if (cnt == 0)
             for (int l = 0; l < nsample; ++l) o[j * nsample + l] = k; /* :34-38 */
@@ -225,8 +237,7 @@ void s2c_oracle_three_nn(int b, int n, int m, const float *unknown,
         const float x = kn[k * 3 + 0];
         const float y = kn[k * 3 + 1];
         const float z = kn[k * 3 + 2];
-        const float d =
-            (ux - x) * (ux - x) + (uy - y) * (uy - y) + (uz - z) * (uz - z);
+        const float d = sq3(ux - x, uy - y, uz - z);
         if (d < best1) {
           best3 = best2; besti3 = besti2;
           best2 = best1; besti2 = besti1;

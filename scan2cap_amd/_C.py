@@ -40,7 +40,7 @@ class S2CError(RuntimeError):
 
 
 def lib_path():
-    return _build.LIB_PATH
+    return _build.lib_path()
 
 
 def load():
@@ -48,7 +48,7 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIB_PATH
+    path = _build.lib_path()      # S2C_NVCC_CONTRACT=1|2: the nvcc-contraction variant
     if not os.path.exists(path):
         raise S2CError(
             "libs2c_hip.so not found at %s -- run `python -m scan2cap_amd.build` "

@@ -307,8 +307,7 @@ __global__ __launch_bounds__(QW * 64) void ball_query_grid_kernel(
     for (int q = 1; q < 9; ++q) r += (cand >= pre[q]) ? 1 : 0;
     const int pos = act ? s_rstart[wave][r] + (cand - s_rpre[wave][r]) : 0;
     const Rec p = rec[pos];
-    const float d2 = (cx - p.x) * (cx - p.x) + (cy - p.y) * (cy - p.y) +
-                     (cz - p.z) * (cz - p.z);
+    const float d2 = sq3(cx - p.x, cy - p.y, cz - p.z);
     const bool hit = act && (d2 < radius2);
     const u64 mask = __ballot(hit);
     if (mask) {
@@ -326,7 +325,7 @@ __global__ __launch_bounds__(QW * 64) void ball_query_grid_kernel(
       const int p = p0 + lane;
       const int pc = p < n ? p : n - 1;
       const float x = xyz[pc * 3], y = xyz[pc * 3 + 1], z = xyz[pc * 3 + 2];
-      const float d2 = (cx - x) * (cx - x) + (cy - y) * (cy - y) + (cz - z) * (cz - z);
+      const float d2 = sq3(cx - x, cy - y, cz - z);
       const bool hit = (p < n) && (d2 < radius2);
       const u64 mask = __ballot(hit);
       if (mask) {

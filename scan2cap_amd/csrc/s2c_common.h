@@ -15,6 +15,32 @@ typedef u32 u32x3 __attribute__((ext_vector_type(3)));
 
 constexpr int kWave = 64;
 
+// a*a + b*b + c*c of the index-producing ops (FPS distance and |p|^2 skip test, ball query,
+// three_nn: sampling_gpu.cu:100-104, ball_query_gpu.cu:31-32, interpolate_gpu.cu:36-37).
+// Default (0) = the canonical arithmetic of DESIGN.md section 2: source order, every product and
+// sum rounded separately.  The reference's own build is nvcc, whose default --fmad=true
+// contracts a product feeding an add into one fused multiply-add; which of the three products
+// stays a plain multiply is the CUDA compiler's choice and cannot be observed here (no CUDA
+// device, no nvcc), so both LLVM-style contractions are provided for a holder of real CUDA
+// outputs to check the <= 1-ulp near-tie class against:
+//   1:  fma(c, c, fma(a, a, b*b))     (the left product fused first, then the outer add)
+//   2:  fma(c, c, fma(b, b, a*a))
+// Selected at BUILD time (-DS2C_NVCC_CONTRACT=1|2 -> libs2c_hip_nvcc<k>.so,
+// `S2C_NVCC_CONTRACT=k python -m scan2cap_amd.build`); the oracle has the same switch at run
+// time (s2c_oracle_set_contract).  Features (floats) are unaffected: only xyz enters these.
+#ifndef S2C_NVCC_CONTRACT
+#define S2C_NVCC_CONTRACT 0
+#endif
+__device__ __forceinline__ float sq3(float a, float b, float c) {
+#if S2C_NVCC_CONTRACT == 1
+  return __builtin_fmaf(c, c, __builtin_fmaf(a, a, b * b));
+#elif S2C_NVCC_CONTRACT == 2
+  return __builtin_fmaf(c, c, __builtin_fmaf(b, b, a * a));
+#else
+  return (a * a + b * b) + c * c;
+#endif
+}
+
 // DPP controls (gfx9 encoding)
 constexpr int DPP_QUAD_1032 = 0xB1;        // quad_perm:[1,0,3,2]
 constexpr int DPP_QUAD_2301 = 0x4E;        // quad_perm:[2,3,0,1]

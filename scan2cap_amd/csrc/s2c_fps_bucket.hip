@@ -159,7 +159,7 @@ __global__ __launch_bounds__(T) void fps_bucket_kernel(
     const float x = xyz[k * 3], y = xyz[k * 3 + 1], z = xyz[k * 3 + 2];
     const int c = cell_of(x, y, z);
     const int pos = atomicAdd(&s_cursor[c], 1);
-    const float mag = (x * x) + (y * y) + (z * z);
+    const float mag = sq3(x, y, z);
     const bool skip = (double)mag <= 1e-3;  // sampling_gpu.cu:100-101
     Pt p; p.x = x; p.y = y; p.z = z; p.d2 = skip ? -1.0f : 1e10f;
     spt[pos] = p;
@@ -227,8 +227,7 @@ __global__ __launch_bounds__(T) void fps_bucket_kernel(
         for (int q = lane; q < nc; q += 64) {
           const Pt p = spt[st + q];
           const u32 rk = srank[st + q];
-          const float d = (p.x - px) * (p.x - px) + (p.y - py) * (p.y - py) +
-                          (p.z - pz) * (p.z - pz);
+          const float d = sq3(p.x - px, p.y - py, p.z - pz);
           const float d2 = fminf(d, p.d2);
           if (d2 != p.d2) spt[st + q].d2 = d2;
           const u64 key = d2 < 0.0f ? 0ull
@@ -251,8 +250,7 @@ __global__ __launch_bounds__(T) void fps_bucket_kernel(
         for (int q = rl; q < nc; q += 16) {
           const Pt p = spt[st + q];
           const u32 rk = srank[st + q];
-          const float d = (p.x - px) * (p.x - px) + (p.y - py) * (p.y - py) +
-                          (p.z - pz) * (p.z - pz);
+          const float d = sq3(p.x - px, p.y - py, p.z - pz);
           const float d2 = fminf(d, p.d2);
           if (d2 != p.d2) spt[st + q].d2 = d2;
           const u64 key = d2 < 0.0f ? 0ull

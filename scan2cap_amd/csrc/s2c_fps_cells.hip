@@ -171,7 +171,7 @@ __global__ __launch_bounds__(PT) void fps_cells_prep_kernel(
     const float x = xyz[k * 3], y = xyz[k * 3 + 1], z = xyz[k * 3 + 2];
     const int c = cell_of(x, y, z);
     const int pos = atomicAdd(&s_cursor[c], 1);
-    const float mag = (x * x) + (y * y) + (z * z);
+    const float mag = sq3(x, y, z);
     const bool skip = (double)mag <= 1e-3;  // sampling_gpu.cu:100-101
     Pt p; p.x = x; p.y = y; p.z = z; p.d2 = skip ? -1.0f : 1e10f;
     spt[pos] = p;
@@ -286,8 +286,7 @@ __global__ __launch_bounds__(NW * 64) void fps_cells_rounds_kernel(
           u64 best = 0ull;
           float bx = 0.f, by = 0.f, bz = 0.f;
           auto visit = [&](const Pt &p, u32 rk, int q) {
-            const float d = (p.x - px) * (p.x - px) + (p.y - py) * (p.y - py) +
-                            (p.z - pz) * (p.z - pz);
+            const float d = sq3(p.x - px, p.y - py, p.z - pz);
             const float d2 = fminf(d, p.d2);
             if (d2 != p.d2) spt[st[r] + q].d2 = d2;
             const u64 k = d2 < 0.0f ? 0ull
@@ -495,8 +494,7 @@ __global__ __launch_bounds__(1024) void fps_cells_rounds4_kernel(
         u64 best = 0ull;
         float cx = 0.f, cy = 0.f, cz = 0.f;
         auto visit = [&](const Pt &p, u32 rk, int q) {
-          const float d = (p.x - px) * (p.x - px) + (p.y - py) * (p.y - py) +
-                          (p.z - pz) * (p.z - pz);
+          const float d = sq3(p.x - px, p.y - py, p.z - pz);
           const float d2 = fminf(d, p.d2);
           if (d2 != p.d2) spt[st[r] + q].d2 = d2;
           const u64 k = d2 < 0.0f ? 0ull
@@ -675,8 +673,7 @@ __global__ __launch_bounds__(1024) void fps_cells_multi_kernel(
           const float px = __uint_as_float((u32)__builtin_amdgcn_readlane((int)__float_as_uint(ax), s));
           const float py = __uint_as_float((u32)__builtin_amdgcn_readlane((int)__float_as_uint(ay), s));
           const float pz = __uint_as_float((u32)__builtin_amdgcn_readlane((int)__float_as_uint(az), s));
-          const float d = (p.x - px) * (p.x - px) + (p.y - py) * (p.y - py) +
-                          (p.z - pz) * (p.z - pz);
+          const float d = sq3(p.x - px, p.y - py, p.z - pz);
           d2 = fminf(d, d2);
         }
         if (d2 != p.d2) {
@@ -759,7 +756,7 @@ __global__ __launch_bounds__(1024) void fps_cells_multi_kernel(
       const float pz = __uint_as_float((u32)__builtin_amdgcn_readlane((int)__float_as_uint(cz), src));
       const float d2t = __uint_as_float((u32)(kt >> 32) - 1u);
       // would an earlier pick of this round lower its min-distance?  (x2 = candidate, x1 = pick)
-      const float d = (px - ax) * (px - ax) + (py - ay) * (py - ay) + (pz - az) * (pz - az);
+      const float d = sq3(px - ax, py - ay, pz - az);
       if (__ballot(lane < P && d < d2t) != 0ull) break;
       if (lane == P) { ax = px; ay = py; az = pz; akey = kt; }
       ++P;

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(T) void fps_small_kernel(int n, int m, int bs, int 
     const int k = t + i * T;
     const int kk = k < n ? k : n - 1;
     const float x = xyz[kk * 3 + 0], y = xyz[kk * 3 + 1], z = xyz[kk * 3 + 2];
-    const float mag = (x * x) + (y * y) + (z * z);
+    const float mag = sq3(x, y, z);
     const bool skip = ((double)mag <= 1e-3) || (k >= n);   // sampling_gpu.cu:100-101
     mind[i] = skip ? -1.0f : 1e10f;
     px[i] = x; py[i] = y; pz[i] = z;
@@ -72,8 +72,7 @@ __global__ __launch_bounds__(T) void fps_small_kernel(int n, int m, int bs, int 
     float bx = x0, by = y0, bz = z0;
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
-      const float d = (px[i] - cx) * (px[i] - cx) + (py[i] - cy) * (py[i] - cy) +
-                      (pz[i] - cz) * (pz[i] - cz);
+      const float d = sq3(px[i] - cx, py[i] - cy, pz[i] - cz);
       const float d2 = fminf(d, mind[i]);
       mind[i] = d2;
       const u64 key = d2 < 0.0f ? 0ull
@@ -142,7 +141,7 @@ __global__ __launch_bounds__(T) void fps_small_kernel(int n, int m, int bs, int 
 // write arange, return" (no host round trip).
 __device__ __forceinline__ float fps_d2(float px, float py, float pz, float cx, float cy,
                                         float cz) {
-  return (px - cx) * (px - cx) + (py - cy) * (py - cy) + (pz - cz) * (pz - cz);
+  return sq3(px - cx, py - cy, pz - cz);
 }
 
 // Both kernels: workgroup = 64 points (lane) x PFX_SEG segments of the pivot range (wave).  The
@@ -184,7 +183,7 @@ __global__ __launch_bounds__(64 * PFX_SEG) void fps_prefix_star_kernel(
   if (seg == 0 && j < m) {
 #pragma unroll
     for (int s2 = 1; s2 < PFX_SEG; ++s2) D = fminf(D, s_min[s2][lane]);
-    const float mag = (x * x) + (y * y) + (z * z);
+    const float mag = sq3(x, y, z);
     const bool skip = (double)mag <= 1e-3;
     const u32 rank = (bitrev_n((u32)j & (u32)(bs - 1), log2bs) << 22) | ((u32)j >> log2bs);
     star[j] = skip ? 0ull
@@ -204,7 +203,7 @@ __global__ __launch_bounds__(64 * PFX_SEG) void fps_prefix_check_kernel(
   const int k = blockIdx.x * 64 + lane;
   const int kk = k < n ? k : n - 1;
   const float x = xyz[kk * 3 + 0], y = xyz[kk * 3 + 1], z = xyz[kk * 3 + 2];
-  const float mag = (x * x) + (y * y) + (z * z);
+  const float mag = sq3(x, y, z);
   // a skipped point's key is 0 in every round: it can never beat star[j] (which must be > 0)
   const bool live = k < n && !((double)mag <= 1e-3);
   const u32 rank = (bitrev_n((u32)kk & (u32)(bs - 1), log2bs) << 22) | ((u32)kk >> log2bs);

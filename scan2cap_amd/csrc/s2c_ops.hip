@@ -94,7 +94,7 @@ __global__ __launch_bounds__(T) void fps_kernel(int n, int m, int bs,
     const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rsrc, t * 12, i * T * 12, 0);
     const float x = __uint_as_float(v.x), y = __uint_as_float(v.y),
                 z = __uint_as_float(v.z);
-    const float mag = (x * x) + (y * y) + (z * z);
+    const float mag = sq3(x, y, z);
     const bool skip = ((double)mag <= 1e-3) || (k >= n);
     mind[i] = skip ? -1.0f : 1e10f;
     if (XYZ_IN_REGS) { px[i] = x; py[i] = y; pz[i] = z; }
@@ -114,8 +114,7 @@ __global__ __launch_bounds__(T) void fps_kernel(int n, int m, int bs,
 #pragma unroll
       for (int i = 0; i < PPT; ++i) {
         const float x2 = px[i], y2 = py[i], z2 = pz[i];
-        const float d = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) +
-                        (z2 - z1) * (z2 - z1);
+        const float d = sq3(x2 - x1, y2 - y1, z2 - z1);
         const float d2 = fminf(d, mind[i]);
         mind[i] = d2;
         // T is a multiple of bs, so within a thread rank(k) grows with i and
@@ -146,9 +145,7 @@ __global__ __launch_bounds__(T) void fps_kernel(int n, int m, int bs,
         }
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
-          const float d = (x2[u] - x1) * (x2[u] - x1) +
-                          (y2[u] - y1) * (y2[u] - y1) +
-                          (z2[u] - z1) * (z2[u] - z1);
+          const float d = sq3(x2[u] - x1, y2[u] - y1, z2[u] - z1);
           const float d2 = fminf(d, mind[c0 + u]);
           mind[c0 + u] = d2;
           const bool gt = d2 > best;
@@ -199,7 +196,7 @@ __global__ __launch_bounds__(T) void fps_kernel_spill(
   const int lane = t & 63, wave = t >> 6;
   for (int k = t; k < n; k += T) {
     const float x = xyz[k * 3 + 0], y = xyz[k * 3 + 1], z = xyz[k * 3 + 2];
-    const float mag = (x * x) + (y * y) + (z * z);
+    const float mag = sq3(x, y, z);
     temp[k] = ((double)mag <= 1e-3) ? -1.0f : 1e10f;
   }
   int old = 0;
@@ -213,8 +210,7 @@ __global__ __launch_bounds__(T) void fps_kernel_spill(
     for (int k = t; k < n; k += T) {
       const float x2 = xyz[k * 3 + 0], y2 = xyz[k * 3 + 1],
                   z2 = xyz[k * 3 + 2];
-      const float d = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) +
-                      (z2 - z1) * (z2 - z1);
+      const float d = sq3(x2 - x1, y2 - y1, z2 - z1);
       const float d2 = fminf(d, temp[k]);
       temp[k] = d2;
       const bool gt = d2 > best;
@@ -416,8 +412,7 @@ __global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_kernel(
         const int p = p0 + lane;
         const int pc = p < tn ? p : tn - 1;
         const float x = s_xyz[0][pc], y = s_xyz[1][pc], z = s_xyz[2][pc];
-        const float d2 = (cx - x) * (cx - x) + (cy - y) * (cy - y) +
-                         (cz - z) * (cz - z);
+        const float d2 = sq3(cx - x, cy - y, cz - z);
         const bool hit = (p < tn) && (d2 < radius2);
         const u64 mask = __ballot(hit);
         if (mask) {
@@ -601,7 +596,7 @@ __global__ __launch_bounds__(256) void three_nn_kernel(
     for (int p = 0; p < tn; ++p) {
       const float x = s_k[0][p], y = s_k[1][p], z = s_k[2][p];
       const float d =
-          (ux - x) * (ux - x) + (uy - y) * (uy - y) + (uz - z) * (uz - z);
+          sq3(ux - x, uy - y, uz - z);
       const int k = base + p;
       if (d < best1) {
         best3 = best2; besti3 = besti2;

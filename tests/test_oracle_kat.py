@@ -231,6 +231,45 @@ def test_opt_n_threads(oracle):
         assert oracle.opt_n_threads(n) == py_opt_n_threads(n)
 
 
+def test_nvcc_contraction_switch(oracle):
+    """The reference's CUDA build contracts a*a + b*b + c*c into fused multiply-adds (nvcc
+    --fmad=true); which product stays a plain multiply cannot be observed here.  The oracle (and,
+    at build time, the kernels: -DS2C_NVCC_CONTRACT) offers both LLVM-style contractions next
+    to the canonical un-contracted form, so that a holder of real CUDA outputs can check the
+    <= 1-ulp near-tie class.  Here: the switch is live (squared distances differ in ~20 % of
+    the entries, by at most one rounding), it follows an independent numpy emulation of the
+    fused form, and neighbour ORDER on a generic cloud does not depend on it."""
+    rng = np.random.default_rng(0)
+    unk = rng.uniform(-3, 3, (1, 4096, 3)).astype(np.float32)
+    kn = rng.uniform(-3, 3, (1, 2048, 3)).astype(np.float32)
+    assert oracle.set_contract(0) == 0
+    try:
+        d0, i0 = oracle.three_nn(unk, kn)
+        for mode in (1, 2):
+            oracle.set_contract(mode)
+            d, i = oracle.three_nn(unk, kn)
+            frac = float((d != d0).mean())
+            assert 0.05 < frac < 0.5, frac
+            assert float(np.abs(d - d0).max() / d0.max()) < 1.2e-7
+            # emulation: fused multiply-add = one rounding of the exact a*b + c (float64 holds
+            # the product of two float32 exactly; the double rounding can differ in <= a few
+            # entries of 12288)
+            diff = unk[0][:, None, :] - kn[0][i[0]]                    # (n, 3 neighbours, xyz)
+            a, b, c = (diff[..., 0].astype(np.float64), diff[..., 1].astype(np.float64),
+                       diff[..., 2].astype(np.float64))
+            if mode == 1:
+                inner = (a * a + (b * b).astype(np.float32).astype(np.float64)).astype(np.float32)
+            else:
+                inner = (b * b + (a * a).astype(np.float32).astype(np.float64)).astype(np.float32)
+            emu = (c * c + inner.astype(np.float64)).astype(np.float32)
+            assert int((emu != d[0]).sum()) <= 3
+            np.testing.assert_array_equal(i, i0)
+    finally:
+        oracle.set_contract(0)
+    # and the canonical mode is what every other test of this suite (and the fixtures) uses
+    assert oracle.lib().s2c_oracle_get_contract() == 0
+
+
 def test_c_abi_library_exports_every_declared_symbol():
     """libs2c_hip.so loads without a GPU and exports everything include/*.h declares."""
     from scan2cap_amd import _C, build
