@@ -49,6 +49,8 @@ def gather_points(points, idx):
     b, c, n = points.shape
     m = idx.shape[1]
     out = torch.empty((b, c, m), dtype=torch.float32, device=points.device)
+    if out.numel() == 0:
+        return out
     _run("s2c_gather_points", points, b, c, n, m, points.data_ptr(),
          idx.data_ptr(), out.data_ptr(), alg_bytes=4 * (2 * b * c * m + b * m))
     return out
@@ -60,6 +62,8 @@ def gather_points_grad(grad_out, idx, n):
     _chk_i(idx, "idx")
     b, c, m = grad_out.shape
     out = torch.empty((b, c, n), dtype=torch.float32, device=grad_out.device)
+    if out.numel() == 0 or m == 0:
+        return out.zero_()
     _run("s2c_gather_points_grad", grad_out, b, c, int(n), m,
          grad_out.data_ptr(), idx.data_ptr(), out.data_ptr(),
          alg_bytes=4 * (b * c * m + b * m + b * c * n))
@@ -81,6 +85,11 @@ def furthest_point_sampling(points, nsamples, prefix_hint=False, return_fallback
     _chk_f(points, "points")
     b, n, _ = points.shape
     out = torch.empty((b, nsamples), dtype=torch.int32, device=points.device)
+    if out.numel() == 0:               # empty batch / no samples asked for: nothing to launch
+        if return_fallback:
+            return out, torch.zeros(b, dtype=torch.int32, device=points.device)
+        return out
+    _check(n > 0, "furthest_point_sampling: no points to sample from")
     ab = 4 * (3 * b * n + b * nsamples)
     if prefix_hint and n <= _C.load().s2c_fps_small_limit() and FPS_PREFIX_VERIFY:
         ws = torch.empty(_C.load().s2c_fps_prefix_workspace_bytes(b, int(nsamples)),
@@ -138,6 +147,8 @@ def three_nn(unknowns, knows):
     m = knows.shape[1]
     dist2 = torch.empty((b, n, 3), dtype=torch.float32, device=unknowns.device)
     idx = torch.empty((b, n, 3), dtype=torch.int32, device=unknowns.device)
+    if idx.numel() == 0:
+        return [dist2, idx]
     _run("s2c_three_nn", unknowns, b, n, m, unknowns.data_ptr(),
          knows.data_ptr(), dist2.data_ptr(), idx.data_ptr(),
          alg_bytes=4 * (3 * b * n + 3 * b * m + 6 * b * n))
@@ -152,6 +163,8 @@ def three_interpolate(points, idx, weight):
     b, c, m = points.shape
     n = idx.shape[1]
     out = torch.empty((b, c, n), dtype=torch.float32, device=points.device)
+    if out.numel() == 0:
+        return out
     _run("s2c_three_interpolate", points, b, c, m, n, points.data_ptr(),
          idx.data_ptr(), weight.data_ptr(), out.data_ptr(),
          alg_bytes=4 * (min(b * c * m, 3 * b * c * n) + 6 * b * n + b * c * n))
@@ -165,6 +178,8 @@ def three_interpolate_grad(grad_out, idx, weight, m):
     _chk_f(weight, "weight")
     b, c, n = grad_out.shape
     out = torch.empty((b, c, m), dtype=torch.float32, device=grad_out.device)
+    if out.numel() == 0 or n == 0:
+        return out.zero_()
     _run("s2c_three_interpolate_grad", grad_out, b, c, n, int(m),
          grad_out.data_ptr(), idx.data_ptr(), weight.data_ptr(),
          out.data_ptr(), alg_bytes=4 * (b * c * n + 6 * b * n + b * c * m))
@@ -196,6 +211,8 @@ def ball_query(new_xyz, xyz, radius, nsample):
     b, m, _ = new_xyz.shape
     n = xyz.shape[1]
     idx = torch.empty((b, m, nsample), dtype=torch.int32, device=new_xyz.device)
+    if idx.numel() == 0 or n == 0:     # nothing to find: rows stay 0 (ball_query.cpp:19-21)
+        return idx.zero_()
     ab = 4 * (3 * b * n + 3 * b * m + b * m * nsample)
     if n >= BQ_GRID_MIN_N and 0 < nsample <= 64 and radius > 0 and b > 0 and m > 0:
         # large clouds: uniform grid, a centre visits <= 27 cells (csrc/s2c_bq_grid.hip)
@@ -220,6 +237,8 @@ def group_points(points, idx):
     b, c, n = points.shape
     _, m, ns = idx.shape
     out = torch.empty((b, c, m, ns), dtype=torch.float32, device=points.device)
+    if out.numel() == 0:
+        return out
     _run("s2c_group_points", points, b, c, n, m, ns, points.data_ptr(),
          idx.data_ptr(), out.data_ptr(),
          alg_bytes=4 * (min(b * c * n, b * c * m * ns) + b * m * ns + b * c * m * ns))
@@ -232,6 +251,8 @@ def group_points_grad(grad_out, idx, n):
     _chk_i(idx, "idx")
     b, c, m, ns = grad_out.shape
     out = torch.empty((b, c, n), dtype=torch.float32, device=grad_out.device)
+    if out.numel() == 0 or m * ns == 0:
+        return out.zero_()
     _run("s2c_group_points_grad", grad_out, b, c, int(n), m, ns,
          grad_out.data_ptr(), idx.data_ptr(), out.data_ptr(),
          alg_bytes=4 * (b * c * m * ns + b * m * ns + b * c * n))

@@ -427,3 +427,34 @@ def test_extreme_shapes(ext, oracle):
     np.testing.assert_array_equal(
         ext.ball_query(dev(one), dev(one), 0.1, 4).cpu().numpy(),
         oracle.ball_query(one, one, 0.1, 4))
+
+
+def test_empty_and_zero_size_inputs(ext):
+    """Zero scenes, zero centres, zero samples, zero neighbours: every op returns a tensor of the
+    right shape (gradients: zeros) without launching anything.  (The reference launches a
+    grid of B blocks and dies in its error check for B = 0, cuda_utils.h:30-39; an empty result
+    is the one sensible reading.)"""
+    dv = torch.device("cuda")
+    f = lambda *s: torch.zeros(*s, device=dv)
+    i = lambda *s: torch.zeros(*s, dtype=torch.int32, device=dv)
+    assert ext.furthest_point_sampling(f(0, 100, 3), 16).shape == (0, 16)
+    assert ext.furthest_point_sampling(f(2, 100, 3), 0).shape == (2, 0)
+    out, fb = ext.furthest_point_sampling(f(0, 64, 3), 8, prefix_hint=True, return_fallback=True)
+    assert out.shape == (0, 8) and fb.shape == (0,)
+    assert ext.gather_points(f(2, 3, 50), i(2, 0)).shape == (2, 3, 0)
+    g = ext.gather_points_grad(f(2, 3, 0), i(2, 0), 50)
+    assert g.shape == (2, 3, 50) and float(g.abs().sum()) == 0.0
+    assert ext.ball_query(f(2, 0, 3), f(2, 100, 3), 0.2, 8).shape == (2, 0, 8)
+    assert ext.ball_query(f(2, 5, 3), f(2, 100, 3), 0.2, 0).shape == (2, 5, 0)
+    bq = ext.ball_query(f(2, 5, 3), f(2, 0, 3), 0.2, 4)
+    assert bq.shape == (2, 5, 4) and int(bq.abs().sum()) == 0
+    assert ext.ball_query(f(0, 5, 3), f(0, 5000, 3), 0.2, 4).shape == (0, 5, 4)
+    assert ext.group_points(f(2, 4, 30), i(2, 0, 8)).shape == (2, 4, 0, 8)
+    gg = ext.group_points_grad(f(2, 4, 0, 8), i(2, 0, 8), 30)
+    assert gg.shape == (2, 4, 30) and float(gg.abs().sum()) == 0.0
+    d, k = ext.three_nn(f(2, 0, 3), f(2, 10, 3))
+    assert d.shape == (2, 0, 3) and k.shape == (2, 0, 3)
+    assert ext.three_interpolate(f(2, 4, 10), i(2, 0, 3), f(2, 0, 3)).shape == (2, 4, 0)
+    tg = ext.three_interpolate_grad(f(2, 4, 0), i(2, 0, 3), f(2, 0, 3), 10)
+    assert tg.shape == (2, 4, 10) and float(tg.abs().sum()) == 0.0
+    torch.cuda.synchronize()
