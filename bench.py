@@ -90,6 +90,7 @@ KERNELS_OF = {
     "s2c_bn_train_stats": ("col_stats_kernel",),
     "s2c_rows_gemm": _GEMM_PLAIN,
     "s2c_sa_gather_gemm": _GEMM_GATHER,
+    "s2c_sa_fused_eval": ("sa_fused_eval_kernel",),
     "s2c_sa_gather_rows": ("sa_gather_rows_kernel",),
     "s2c_sa_scatter_rows": ("sa_scatter_rows_kernel",),
     "s2c_sa_scatter_sum": ("sa_scatter_sum_kernel",),
@@ -392,7 +393,9 @@ def named_roofline(table_k):
     pair is  s2c_ball_query (+ its grid variant for SA1) + s2c_sa_gather_gemm  with the op-contract algorithmic bytes
     of both (xyz + centres + idx;  unique source rows + idx + Y)."""
     parts = [k for k in table_k if k["kernel"] in ("s2c_ball_query", "s2c_ball_query_grid",
-                                                   "s2c_sa_gather_gemm")]
+                                                   "s2c_sa_gather_gemm",
+                                                   "s2c_sa_gather_gemm_bn_eval",
+                                                   "s2c_sa_fused_eval")]
     if not parts:
         return None
     ms = sum(k["ms_per_step"] for k in parts)
@@ -406,7 +409,8 @@ def named_roofline(table_k):
 
 
 GEMM_FAMILY = ("s2c_rows_gemm", "s2c_rows_gemm_bn_relu_side", "s2c_sa_gather_gemm",
-               "s2c_bn_bwd_gemm", "s2c_rows_gemm_bn_eval", "s2c_sa_gather_gemm_bn_eval")
+               "s2c_bn_bwd_gemm", "s2c_rows_gemm_bn_eval", "s2c_sa_gather_gemm_bn_eval",
+               "s2c_sa_fused_eval")
 _DECODER_CHAIN = ("s2c_small_linear", "s2c_small_linear_pair", "s2c_gru_fwd", "s2c_attn_fwd",
                   "s2c_attn_bwd", "s2c_gru_gates_bwd")
 

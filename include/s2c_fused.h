@@ -221,6 +221,25 @@ int s2c_sa_gather_gemm_bn_eval(int b, int n, int m, int ns, int C, long long fea
                                const float *var, float eps, int relu, int pool_ns, float *out,
                                int ldo, void *stream);
 
+/* A WHOLE set-abstraction stage of the inference path in one launch (csrc/s2c_sa_fused.hip):
+ * ball-query rows -> gather -> 3 x [1x1 conv, frozen BatchNorm, ReLU] -> max over the ns rows
+ * of a centre (pointnet2_modules.py:226-257); out (b*m x layers[2].N), row stride ldo.  Nothing
+ * between the cloud and the pooled features is written.  Applies when the three weight
+ * matrices fit LDS as bf16x3 planes: C <= 13 feature channels, widths <= 64 / 64 / 128, ns in
+ * {16, 32, 64}, m*ns % 32 == 0 (s2c_sa_fused_eval_supported); returns -2 otherwise (caller
+ * runs the per-layer entry points above). */
+typedef struct s2c_eval_layer {
+  const float *W;           /* (N x K) row-major, row stride ldw */
+  const float *gamma, *beta, *mean, *var;   /* gamma / beta may be NULL */
+  int N, ldw;
+  float eps;
+} s2c_eval_layer;
+int s2c_sa_fused_eval_supported(int ns, int C, int N1, int N2, int N3);
+int s2c_sa_fused_eval(int b, int n, int m, int ns, int C, long long feat_row_stride,
+                      long long feat_batch_stride, float radius, int normalize,
+                      const float *xyz, const float *new_xyz, const float *feats, const int *idx,
+                      const s2c_eval_layer *layers, float *out, int ldo, void *stream);
+
 /* products of s2c_rows_gemm / s2c_sa_gather_gemm: 1 = bf16x3 split on the bf16 matrix
  * pipe (fp32-accurate, ~1e-7 relative; default), 0 = exact fp32 MFMA chain.  Returns
  * the previous setting. */

@@ -755,9 +755,64 @@ def _eval_fusable(specs, params, pool_ns):
     return True
 
 
+class _EvalLayer(ctypes.Structure):
+    """s2c_eval_layer (include/s2c_fused.h)."""
+    _fields_ = [("W", ctypes.c_void_p), ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p),
+                ("mean", ctypes.c_void_p), ("var", ctypes.c_void_p), ("N", ctypes.c_int),
+                ("ldw", ctypes.c_int), ("eps", ctypes.c_float)]
+
+
+_C.register("s2c_sa_fused_eval", [_I, _I, _I, _I, _I, _L, _L, ctypes.c_float, _I, _P, _P, _P, _P, _P,
+                                  _P, _I, _P])
+# the whole inference stage (gather -> 3 layers -> max) in ONE kernel where its weights fit LDS
+# (csrc/s2c_sa_fused.hip: SA1 with few input channels); S2C_FUSE_EVAL_STAGE=0: per-layer kernels
+FUSE_EVAL_STAGE = _os.environ.get("S2C_FUSE_EVAL_STAGE", "1") != "0"
+
+
+def _eval_stage_fused(gather, M, dev, specs, pool_ns, params):
+    """-> pooled (M / pool_ns, N3) tensor, or None when the fused kernel does not take the stage."""
+    g = gather
+    if not (FUSE_EVAL_STAGE and g is not None and len(specs) == 3 and pool_ns == g.ns
+            and all(sp.relu for sp in specs) and (g.m * g.ns) % 32 == 0):
+        return None
+    Ws = [params[3 * l] for l in range(3)]
+    if [W.shape[1] for W in Ws] != [3 + g.C, Ws[0].shape[0], Ws[1].shape[0]]:
+        return None
+    lib = _C.load()
+    if not getattr(lib, "_fused_eval_sig", False):
+        lib.s2c_sa_fused_eval_supported.argtypes = [_I] * 5
+        lib.s2c_sa_fused_eval_supported.restype = _I
+        lib._fused_eval_sig = True
+    if not lib.s2c_sa_fused_eval_supported(g.ns, g.C, *[W.shape[0] for W in Ws]):
+        return None
+    layers = (_EvalLayer * 3)()
+    for l, sp in enumerate(specs):
+        W, gamma, beta = params[3 * l], params[3 * l + 1], params[3 * l + 2]
+        bn = sp.bn
+        layers[l] = _EvalLayer(W.data_ptr(), _ptr(gamma), _ptr(beta), bn.running_mean.data_ptr(),
+                               bn.running_var.data_ptr(), W.shape[0], W.stride(0), float(bn.eps))
+    N3 = Ws[2].shape[0]
+    out = torch.empty((M // pool_ns, N3), device=dev)
+    flops = 2 * M * ((3 + g.C) * Ws[0].shape[0] + Ws[0].shape[0] * Ws[1].shape[0]
+                     + Ws[1].shape[0] * N3)
+    if _C.TIMER.enabled:
+        # fused contract (SURVEY 8d): unique source rows + ball-query rows + pooled output
+        _C.TIMER.alg_bytes = 4 * (min(g.B * g.N, M) * (3 + g.C) + M + out.numel())
+        _C.TIMER.alg_flops = flops
+    with torch.cuda.device(dev):
+        rc = _C.call("s2c_sa_fused_eval", g.B, g.N, g.m, g.ns, g.C, g.frs, g.fbs, g.radius,
+                     g.normalize, g.xyz.data_ptr(), g.new_xyz.data_ptr(), _ptr(g.feats),
+                     g.idx.data_ptr(), ctypes.addressof(layers), out.data_ptr(), N3,
+                     _C.stream_ptr(), allow=(-2,))
+    return out if rc == 0 else None
+
+
 def _eval_stack(X, gather, M, dev, specs, pool_ns, params):
     """Frozen-BN layer stack: one launch per layer, no pre-activation tensor, the last
-    layer leaves max-pooled."""
+    layer leaves max-pooled (or the whole stage in one launch: _eval_stage_fused)."""
+    fused_out = _eval_stage_fused(gather, M, dev, specs, pool_ns, params)
+    if fused_out is not None:
+        return fused_out
     A, pi, nl = X, 0, len(specs)
     for li, sp in enumerate(specs):
         W, gamma, beta = params[pi], params[pi + 1], params[pi + 2]

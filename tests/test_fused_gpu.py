@@ -447,6 +447,61 @@ def test_sa_inference_epilogue_matches_unfused(B, N, C, npoint, radius, ns, mlp)
     assert _rel(nf, nf2) < 1e-6          # same GEMM, same affine arithmetic
 
 
+@pytest.mark.parametrize("normalize", [True, False])
+@pytest.mark.parametrize("B,N,C,npoint,radius,ns,mlp", [
+    (8, 40000, 4, 2048, 0.2, 64, [64, 64, 128]),     # SA1 of BASELINE configs[1] (cfg2), full size
+    (2, 4096, 1, 512, 0.3, 32, [64, 64, 128]),       # XYZ + height (configs[0])
+    (3, 2048, 13, 256, 0.4, 16, [48, 64, 100]),      # widest operand (k = 16), ragged widths
+    (1, 1500, 0, 96, 0.5, 64, [32, 40, 128]),        # xyz only
+])
+def test_sa_inference_stage_in_one_kernel(B, N, C, npoint, radius, ns, mlp, normalize):
+    """csrc/s2c_sa_fused.hip: gather -> 3 x (conv, frozen BN, ReLU) -> max in ONE launch, nothing
+    written in between -- against the op-by-op torch path (1e-4) and against the per-layer
+    kernels it replaces (same bf16x3 products; layer 1 walks k in the same order as the
+    streaming gather GEMM, the tiled one in another: 2e-6)."""
+    from scan2cap_amd.pointnet2.pointnet2_modules import PointnetSAModuleVotes
+    from scan2cap_amd.pointnet2 import fused
+    torch.manual_seed(5)
+    sa = PointnetSAModuleVotes(npoint=npoint, radius=radius, nsample=ns,
+                               mlp=[C] + mlp, use_xyz=True, normalize_xyz=normalize).cuda()
+    for m in sa.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.uniform_(-0.3, 0.3)
+            m.running_mean.uniform_(-0.2, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+    sa.eval()
+    ref = copy.deepcopy(sa)
+    ref._fused_ok = lambda xyz: False
+    xyz = torch.from_numpy(scene_xyz(B, N, seed=4)).cuda()
+    pc = torch.cat([xyz, torch.randn(B, N, C, device="cuda")], -1)     # (B,N,3+C) rows read in place
+    feats = pc[..., 3:].transpose(1, 2) if C > 0 else None
+    calls = []
+    orig = fused._C.call
+
+    def spy(name, *a, **k):
+        calls.append(name)
+        return orig(name, *a, **k)
+    with torch.no_grad():
+        assert fused.FUSE_EVAL_STAGE
+        fused._C.call = spy
+        try:
+            nx, nf, ni = sa(xyz, feats)
+        finally:
+            fused._C.call = orig
+        assert "s2c_sa_fused_eval" in calls and "s2c_rows_gemm_bn_eval" not in calls, calls
+        rx, rf, ri = ref(xyz, feats.contiguous() if C > 0 else None)
+        fused.FUSE_EVAL_STAGE = False
+        try:
+            _, nf2, _ = sa(xyz, feats)
+        finally:
+            fused.FUSE_EVAL_STAGE = True
+    assert torch.equal(ni, ri) and torch.equal(nx, rx)
+    assert nf.shape == rf.shape == (B, mlp[-1], npoint)
+    assert _rel(nf, rf) < 1e-4
+    assert _rel(nf, nf2) < 2e-6
+
+
 def test_gemm_split_products_match_exact_fp32_chain():
     """bf16x3 split products (6 bf16 MFMAs per product) vs the exact fp32 MFMA chain on a
     whole set-abstraction stack, train mode: both within 2e-6 of scale of each other,
