@@ -316,3 +316,28 @@ def test_streaming_gemm_dispatch_table():
         lib.s2c_gemm_set_stream(prev)
     old = lib.s2c_gemm_set_stream_grid(200)
     assert lib.s2c_gemm_set_stream_grid(old) == 200 and lib.s2c_gemm_set_stream_grid(0) == old
+
+
+def test_fused_inference_stage_and_hand_dw_dispatch():
+    """Host logic of two round-3 dispatch decisions, pinned without a GPU: which inference SA
+    stages run as ONE kernel (all three weight matrices resident in LDS: csrc/s2c_sa_fused.hip)
+    and which weight gradients take the hand-written slab kernel (measured crossover,
+    tools/bench_dw_mid.py)."""
+    import ctypes
+    from scan2cap_amd import _C
+    from scan2cap_amd.pointnet2 import fused
+    lib = _C.load()
+    lib.s2c_sa_fused_eval_supported.argtypes = [ctypes.c_int] * 5
+    lib.s2c_sa_fused_eval_supported.restype = ctypes.c_int
+    ok = lib.s2c_sa_fused_eval_supported
+    assert ok(64, 4, 64, 64, 128) == 1            # SA1 of BASELINE configs[1]
+    assert ok(64, 1, 64, 64, 128) == 1            # configs[0]
+    assert ok(16, 13, 48, 64, 100) == 1
+    assert ok(64, 132, 64, 64, 128) == 0          # multiview: W1 does not fit beside the rest
+    assert ok(32, 4, 128, 128, 256) == 0          # SA2-wide layers
+    assert ok(48, 4, 64, 64, 128) == 0            # rows per centre must be 16 / 32 / 64
+    pays = fused._hand_dw_pays
+    assert pays(8192, 256, 256) and pays(16384, 64, 3)
+    assert pays(20480, 128, 256) and pays(32768, 128, 128) and pays(65536, 128, 128)
+    assert not pays(32768, 128, 259) and not pays(65536, 256, 128)
+    assert not pays(262144, 128, 128) and not pays(1048576, 64, 64)
