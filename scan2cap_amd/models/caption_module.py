@@ -458,7 +458,10 @@ class TopDownSceneCaptionModule(nn.Module):
                       "ih1": _split6(c1.weight_ih, _ORDER_W), "hh1": _split6(c1.weight_hh, _ORDER_W),
                       "q": _split6(self.map_hidd.weight, _ORDER_W),
                       "l": _split6(W_lang[:, F_:], _ORDER_W),
-                      "ih2": _split6(c2.weight_ih, _ORDER_W), "hh2": _split6(c2.weight_hh, _ORDER_W)}
+                      "ih2": _split6(c2.weight_ih, _ORDER_W), "hh2": _split6(c2.weight_hh, _ORDER_W),
+                      # the classifier (R x 512 -> V): the largest GEMM of a step, 276 us in fp32
+                      # at 8192 rows against 220 on the planes, bias included (tools/probe_mm_out.py)
+                      "cls": _split6(self.classifier.weight, _ORDER_W)}
                 gru = torch.ops.aten._thnn_fused_gru_cell
                 h1_6 = _split6(hidden_1, _ORDER_A)
                 h2_6 = _split6(hidden_2, _ORDER_A)
@@ -500,8 +503,12 @@ class TopDownSceneCaptionModule(nn.Module):
                 hidden_1, hidden_2, m = self._step(
                     step_input, target_feats, local, hidden_1, hidden_2, ones, mapped)
                 m = m.squeeze(-1)
-            logits = torch.addmm(self.classifier.bias, hidden_2, self.classifier.weight.t(),
-                                 out=cap_buf[t])                         # (R,V)
+            if fused_step and split:
+                logits = torch.addmm(self.classifier.bias, h2_6, w6["cls"].t(),
+                                     out_dtype=torch.float32, out=cap_buf[t])   # (R,V)
+            else:
+                logits = torch.addmm(self.classifier.bias, hidden_2, self.classifier.weight.t(),
+                                     out=cap_buf[t])                     # (R,V)
             attn[:, :, t].scatter_(1, ids, m)
             step_input = self._emb_table[logits.argmax(dim=-1)]          # greedy
         data_dict["lang_cap"] = cap_buf.view(T, B, K, -1).permute(1, 2, 0, 3)  # (B,K,T,V)
