@@ -41,7 +41,7 @@ def init_from_env(backend=None):
         backend = dist_backend(backend)
         if backend == "nccl" and torch.cuda.is_available() \
                 and torch.cuda.device_count() < min(world, 8):
-            raise SystemExit("RCCL needs one GPU per rank (%d ranks, %d visible GPUs); set "
+            raise RuntimeError("RCCL needs one GPU per rank (%d ranks, %d visible GPUs); set "
                              "S2C_DIST_BACKEND=gloo to run several ranks on one GPU"
                              % (world, torch.cuda.device_count()))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
