@@ -660,8 +660,11 @@ def main():
             # N > 1: RCCL's kernels (one workgroup per channel) run under the detector's
             # backward; a persistent GEMM workgroup without a free CU doubles a launch
             rccl_cus = int(os.environ.get("S2C_RCCL_CUS", "16")) if ddp is not None else 0
+            # beside the FPS workgroups (one per scene of a geometry pass): measured optimum of the
+            # persistent GEMM grid = 248 of 256 for the train step (8 scenes; 240: +0.05 ms, 256:
+            # +0.4 ms) and 216-224 for cfg2's 24 scenes per pass (232: +0.05 ms)
             slots = GeometrySlots(model.backbone_net, dd["point_clouds"], depth, group,
-                                  reserve_cus=8 + rccl_cus)
+                                  reserve_cus=(0 if wl["train"] else 8) + rccl_cus)
 
         feeder = None
         dd_sets = [dd] * max(depth, 1)
