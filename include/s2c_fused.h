@@ -313,6 +313,14 @@ int s2c_attn_fwd(int R, int K, int H, int F, const float *M, const float *q, int
                  const float *wa, const float *mask, const float *O, float *scores,
                  float *alpha, float *att, int lda, void *stream);
 
+/* Few keys (K <= 32: the num_locals gather): the attention above AND the layer that consumes it
+ * in one launch: x2 (R x E) = relu(Wl[:, 0:F] att + bias + add), Wl (E x ldw) row-major; alpha and
+ * att are stored for the backward pass.  (caption_module.py:274-287) */
+int s2c_attn_x2_fwd(int R, int K, int H, int F, int E, const float *M, const float *q, int ldq,
+                    const float *wa, const float *mask, const float *O, const float *Wl, int ldw,
+                    const float *bias, const float *add, int ld_add, float *alpha, float *att,
+                    int lda, float *x2, int ldx2, void *stream);
+
 /* its backward from datt (R x F) and the saved forward output att (R x F):
  * dM (R x K x H) and dwa_rows (R x H; dwa = its sum over rows) ACCUMULATE (caller
  * zeroes them once); dq (R x H) is overwritten.  No atomics: deterministic.

@@ -404,6 +404,114 @@ __global__ __launch_bounds__(256) void attn_softmax_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------
+// Few keys (the num_locals gather, K <= AX_MAXK): the whole attention AND the layer that
+// consumes it in one launch -- scores, mask, softmax, weighted sum, then
+//   x2[r, o] = relu( sum_f Wl[o, f] att[r, f] + bias[o] + add[r, o] )     (caption_module.py:284-287:
+//   map_lang on [att | h1]; the h1 block arrives in `add`)
+// Block = (row, 32 outputs): every block of a row redoes the row's scores (K x H tanh: 20 per
+// thread at K = 10, H = 512) and its softmax / weighted sum (K x F multiply-adds) -- cheaper
+// than the two launch boundaries it replaces (7 -> 5 dependent launches per decoder step).
+// Blocks of output chunk 0 store alpha and att for the backward pass.
+// ---------------------------------------------------------------------------
+constexpr int AX_MAXK = 32, AX_OC = 32, AX_MAXF = 256;
+__global__ __launch_bounds__(256) void attn_x2_kernel(
+    int K, int H, int F, int E, const float *__restrict__ M, const float *__restrict__ q, int ldq,
+    const float *__restrict__ wa, const float *__restrict__ mask, const float *__restrict__ O,
+    const float *__restrict__ Wl, int ldw, const float *__restrict__ bias,
+    const float *__restrict__ add, int ld_add, float *__restrict__ alpha, float *__restrict__ att,
+    int lda, float *__restrict__ x2, int ldx2) {
+  __shared__ float s_sc[AX_MAXK], s_e[AX_MAXK];
+  __shared__ __attribute__((aligned(16))) float s_att[AX_MAXF];
+  const int row = blockIdx.y, oc = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // (1) scores: wave w takes keys w, w + 4, ...; 64 lanes over the H/4 float4s.  Every load of
+  // a pass is issued before the first is used (these launches are pure latency: one L2 round
+  // trip per pass instead of one per key)
+  const float *qq = q + (size_t)row * ldq;
+  constexpr int KW = AX_MAXK / 4;
+  float sc[KW];
+#pragma unroll
+  for (int kk = 0; kk < KW; ++kk) sc[kk] = 0.0f;
+  for (int h4 = lane; h4 < (H >> 2); h4 += 64) {
+    const float4 b = reinterpret_cast<const float4 *>(qq)[h4];
+    const float4 w = reinterpret_cast<const float4 *>(wa)[h4];
+    float4 a[KW];
+#pragma unroll
+    for (int kk = 0; kk < KW; ++kk) {
+      const int k = wave + 4 * kk;
+      a[kk] = k < K ? reinterpret_cast<const float4 *>(M + ((size_t)row * K + k) * H)[h4]
+                    : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int kk = 0; kk < KW; ++kk)
+      if (wave + 4 * kk < K)
+        sc[kk] += w.x * fast_tanh(a[kk].x + b.x) + w.y * fast_tanh(a[kk].y + b.y) +
+                  w.z * fast_tanh(a[kk].z + b.z) + w.w * fast_tanh(a[kk].w + b.w);
+  }
+#pragma unroll
+  for (int kk = 0; kk < KW; ++kk) {
+    const int k = wave + 4 * kk;
+    if (k < K) {                                     // wave-uniform
+      float acc = sc[kk];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+      if (lane == 0) s_sc[k] = mask[(size_t)row * K + k] == 0.0f ? -1e30f : acc;
+    }
+  }
+  __syncthreads();
+  // (2) softmax over the K <= 32 scores: one exponential per key, shared through LDS
+  if (tid < K) {
+    float mx = -INFINITY;
+    for (int k = 0; k < K; ++k) mx = fmaxf(mx, s_sc[k]);
+    s_e[tid] = expf(s_sc[tid] - mx);
+  }
+  __syncthreads();
+  float sum = 0.0f;
+  for (int k = 0; k < K; ++k) sum += s_e[k];
+  const float inv = 1.0f / sum;
+  if (oc == 0 && tid < K) alpha[(size_t)row * K + tid] = s_e[tid] * inv;
+  // (3) att[f] = sum_k alpha_k O[row, k, f]
+  for (int f = tid; f < F; f += 256) {
+    const float *o = O + (size_t)row * K * F + f;
+    float a = 0.0f;
+    for (int k0 = 0; k0 < K; k0 += 8) {              // 8 loads in flight, summed in key order
+      float ov[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) ov[u] = k0 + u < K ? o[(size_t)(k0 + u) * F] : 0.0f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (k0 + u < K) a += (s_e[k0 + u] * inv) * ov[u];
+    }
+    s_att[f] = a;
+    if (oc == 0) att[(size_t)row * lda + f] = a;
+  }
+  __syncthreads();
+  // (4) 32 outputs of the consuming layer: thread = (output, 8 column slices)
+  const int ol = tid >> 3, part = tid & 7;
+  const int o = oc * AX_OC + ol;
+  float acc = 0.0f;
+  if (o < E) {
+    const float4 *w4 = reinterpret_cast<const float4 *>(Wl + (size_t)o * ldw);
+    const float4 *a4 = reinterpret_cast<const float4 *>(s_att);
+    for (int j0 = part; j0 < (F >> 2); j0 += 32) {   // 4 weight loads in flight
+      float4 wv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        wv[u] = j0 + 8 * u < (F >> 2) ? w4[j0 + 8 * u] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (j0 + 8 * u < (F >> 2)) acc += dot4(wv[u], a4[j0 + 8 * u]);
+    }
+  }
+  acc += __shfl_xor(acc, 1, 64);
+  acc += __shfl_xor(acc, 2, 64);
+  acc += __shfl_xor(acc, 4, 64);
+  if (part == 0 && o < E) {
+    float v = acc + (bias ? bias[o] : 0.0f) + (add ? add[(size_t)row * ld_add + o] : 0.0f);
+    x2[(size_t)row * ldx2 + o] = fmaxf(v, 0.0f);
+  }
+}
+
 // Attention backward for one step.  Block = (chunk of ATT_HC hidden units, row);
 // it owns dq[row, chunk] and dwa_rows[row, chunk] outright: no atomics (device-scope
 // float atomics on a few hundred shared addresses serialise at the memory side and
@@ -738,6 +846,21 @@ extern "C" int s2c_attn_fwd(int R, int K, int H, int F, const float *M,
   hipLaunchKernelGGL(attn_softmax_kernel, dim3((F + ATT_FC - 1) / ATT_FC, R), dim3(256),
                      0, st, K, F, scores, O, alpha, att, lda);
   return chk("attn_fwd");
+}
+
+extern "C" int s2c_attn_x2_fwd(int R, int K, int H, int F, int E, const float *M, const float *q,
+                               int ldq, const float *wa, const float *mask, const float *O,
+                               const float *Wl, int ldw, const float *bias, const float *add,
+                               int ld_add, float *alpha, float *att, int lda, float *x2, int ldx2,
+                               void *stream) {
+  if (R <= 0 || K <= 0 || K > AX_MAXK || (H & 3) || (ldq & 3) || F <= 0 || F > AX_MAXF || (F & 3) ||
+      (ldw & 3) || E <= 0 || !M || !q || !wa || !mask || !O || !Wl || !alpha || !att || !x2 ||
+      (((uintptr_t)Wl | (uintptr_t)M | (uintptr_t)q | (uintptr_t)wa) & 15))
+    return -1;
+  hipLaunchKernelGGL(attn_x2_kernel, dim3((E + AX_OC - 1) / AX_OC, R), dim3(256), 0,
+                     (hipStream_t)stream, K, H, F, E, M, q, ldq, wa, mask, O, Wl, ldw, bias, add,
+                     ld_add, alpha, att, lda, x2, ldx2);
+  return chk("attn_x2_fwd");
 }
 
 // dM (R x K x H) and dwa_rows (R x H) ACCUMULATE (the caller zeroes them once and

@@ -90,6 +90,13 @@ ENABLED = True      # scan2cap_amd/opbyop.py: False = the plain `_step` loop
 LOCAL_ATTN_MAX_K = 0
 _C.register("s2c_attn_local_fwd", [_I, _I, _I, _I, _P, _P, _I, _P, ctypes.c_float, _P, _P, _P,
                                    _P, _I, _P])
+# few keys: scores + softmax + weighted sum + the map_lang layer in ONE launch (attn_x2_kernel:
+# 7 -> 5 dependent launches per forward step); S2C_FUSE_ATTN_X2=0: the three launches
+import os as _os
+FUSE_ATTN_X2 = _os.environ.get("S2C_FUSE_ATTN_X2", "1") != "0"
+ATTN_X2_MAX_K = 32
+_C.register("s2c_attn_x2_fwd", [_I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P,
+                                _P, _I, _P, _I, _P])
 
 
 def supported(emb, hid, feat, K):
@@ -167,6 +174,17 @@ class TopDownDecode(Function):
                       _p(S1[0][t]), _p(S1[1][t]), _p(S1[2][t]), _p(S1[3][t]),
                       alg_bytes=4 * (3 * H * (E + H) + R * (E + 6 * H)))
                 _lin(R, H + E, H, Wqh, H, H1[t + 1], H, QL[t], H + E)
+                if FUSE_ATTN_X2 and K <= ATTN_X2_MAX_K and F % 4 == 0 and F <= 256 \
+                        and ldlang % 4 == 0:
+                    _call("s2c_attn_x2_fwd", R, K, H, F, E, _p(M), _p(QL[t]), H + E, _p(wa),
+                          _p(mask), _p(O), _p(W_lang), ldlang, _p(b_lang), _p(QL[t][:, H:]),
+                          H + E, _p(ALPHA[t]), _p(ATT[t]), F, _p(X2[t]), E,
+                          alg_bytes=4 * (R * K * (H + F) + E * F + R * (H + 2 * K + F + 2 * E)))
+                    _call("s2c_gru_fwd", R, H, E, _p(W_ih2), _p(W_hh2), _p(b_ih2),
+                          _p(b_hh2), _p(X2[t]), E, _p(H2[t]), _p(H2[t + 1]),
+                          _p(S2[0][t]), _p(S2[1][t]), _p(S2[2][t]), _p(S2[3][t]),
+                          alg_bytes=4 * (3 * H * (E + H) + R * (E + 6 * H)))
+                    continue
                 if K <= LOCAL_ATTN_MAX_K:
                     # few keys (the num_locals gather): scores, mask, softmax and the weighted
                     # sum in ONE pass, one wave per row (attn_local_kernel)
