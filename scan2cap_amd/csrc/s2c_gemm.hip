@@ -718,6 +718,275 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_x3_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Mid-size problems (2k .. 64k rows: feature-propagation modules, vote / proposal heads,
+// SA3 / SA4): a few MB of operands, so a launch is one memory round trip plus the latency of
+// its own dependent steps -- the kernel above walks K in slices of 32 behind two workgroup
+// barriers each, two slices of loads in flight (3.5 us per slice with one workgroup per CU:
+// 20 us at K = 128, 50 us at K = 512, against 3-5 us of HBM / MFMA time).  Here K is walked
+// in chunks of 128:
+//  * workgroup = 128 rows x 128 columns, 8 waves, wave (rg, cw) = rows 64 rg .. + 63 x columns
+//    32 cw .. + 31; the whole 128 x 128 chunk of BOTH operands sits in LDS as fp32 (2 x 66 KB,
+//    rows padded to 132 floats: fragment reads are conflict-free) -- at K <= 128 every load of
+//    the launch is issued in the first microsecond and there is ONE barrier before the MFMAs;
+//    with more chunks the next one is in flight (registers) while this one is multiplied;
+//  * loads are coalesced (512 contiguous bytes per half-wave).  (Two earlier versions of this
+//    kernel: MFMA lanes fed straight from global memory -- lane (i, half) = 32 bytes of row i,
+//    no LDS -- is bound by the vector L1's 64 tag look-ups per instruction, 8600 cycles to
+//    ISSUE a workgroup's 128 KB; split-K over the waves with wave-private LDS transposers
+//    needs no barrier but re-reads the operands per 64-column block and sums four partial
+//    tiles through LDS: 6.2 us per workgroup against 3 here.)
+//  * fragments are split into bf16 hi / mid / lo planes in registers after the LDS read (the
+//    6 plane products of the kernels above, same accuracy); each wave stores its own 64 x 32
+//    piece, column statistics meet in LDS: one [sum | sumsq] partial row per 128 rows, the
+//    granularity of the 2x2 tiling above (s2c_rows_gemm_blocks is unchanged).
+// The A tile is fetched once per 128-column block (from L2 the second time).
+// S2C_GEMM_MID_ROWS (default 32768; 0 = off) bounds the row count this kernel takes.  Measured
+// on MI355X (tools/bench_mid_gemm.py, us, tiled kernel -> this one | hipBLASLt fp32):
+//   (2048,128,128) 17 -> 11 | 5    (4096,256,256) 29 -> 19 | 10   (4096,256,512) 48 -> 32 | 13
+//   (8192,256,256) 29 -> 20 | 13   (8192,256,512) 51 -> 34 | 21   (8192,259,256) 29 -> 20 | 18
+//   (20480,128,128) 19 -> 14 | 11  (20480,128,256) 31 -> 22 | 26  (32768,128,128) 20 -> 15 | 16
+//   (32768,256,128) 31 -> 29 | 25  (65536,128,128) 31 -> 29 | 27  (65536,256,128) 55 -> 57 | 46
+// (the library computes no column statistics: its numbers lack the pass over Y that the
+// epilogue here replaces).  One workgroup's timeline at (32768,128,128), 256 workgroups = one
+// per CU: loads issued 1.2 us, landed + staged + barrier 1.6 us, 96 MFMAs per wave 3.7 us
+// (two waves share a SIMD: 2.6 us is the bf16x3 MFMA floor of the tile), stores 2.0 us --
+// serial within a workgroup, which is what a one-round problem costs.
+struct MidPlanes { bf16x8 p[3]; };
+
+__device__ __forceinline__ MidPlanes mid_split8(float4 lo4, float4 hi4) {
+  unsigned h[4], m[4], l[4];
+  const f32x2 x0 = {lo4.x, lo4.y}, x1 = {lo4.z, lo4.w}, x2 = {hi4.x, hi4.y}, x3 = {hi4.z, hi4.w};
+  x3_split2(x0, h[0], m[0], l[0]);
+  x3_split2(x1, h[1], m[1], l[1]);
+  x3_split2(x2, h[2], m[2], l[2]);
+  x3_split2(x3, h[3], m[3], l[3]);
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 hv = {h[0], h[1], h[2], h[3]}, mv = {m[0], m[1], m[2], m[3]},
+              lv = {l[0], l[1], l[2], l[3]};
+  MidPlanes o;
+  o.p[0] = __builtin_bit_cast(bf16x8, hv);
+  o.p[1] = __builtin_bit_cast(bf16x8, mv);
+  o.p[2] = __builtin_bit_cast(bf16x8, lv);
+  return o;
+}
+
+// 4 consecutive floats of a row from column k on, zero from column K on (rows need not be
+// 16-byte aligned: lda = 259)
+__device__ __forceinline__ float4 mid_load4(const float *__restrict__ row, int k, int K) {
+  if (k + 4 <= K) {
+    const F4U a = *reinterpret_cast<const F4U *>(row + k);
+    return make_float4(a.x, a.y, a.z, a.w);
+  }
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (k < K) v.x = row[k];
+  if (k + 1 < K) v.y = row[k + 1];
+  if (k + 2 < K) v.z = row[k + 2];
+  return v;
+}
+
+constexpr int MID_LD = 132;                   // floats per staged row: 128 k + 4 pad
+constexpr size_t MID_LDS_BYTES = 2 * 128 * MID_LD * sizeof(float);   // 135168
+
+template <int PRO>
+__global__ __launch_bounds__(512) void rows_mid_gemm_kernel(
+    long long M, int N, int K, const float *__restrict__ A, int lda,
+    const float *__restrict__ W, int ldw, const float *__restrict__ pscale,
+    const float *__restrict__ pshift, float *__restrict__ Y, int ldy,
+    float *__restrict__ partial, BwdArgs bw) {
+  extern __shared__ __attribute__((aligned(16))) float mid_smem[];
+  __shared__ float s_stat[2][2][128];              // [sum | sumsq][row group][column]
+  float *As = mid_smem, *Ws = mid_smem + 128 * MID_LD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rg = wave >> 2, cw = wave & 3;
+  const int li = lane & 31, lk = lane >> 5;
+  const long long m0 = (long long)blockIdx.x * 128;
+  const int n0 = blockIdx.y * 128;
+  const int nchunks = (K + 127) >> 7;
+  // a wave whose 32 columns lie beyond N stages and waits with the others but multiplies nothing
+  const bool live = n0 + 32 * cw < N;
+  long long *pr = g_prof;
+  const bool prof_on = pr != nullptr && (int)blockIdx.x == g_prof_block && blockIdx.y == 0 && tid == 0;
+  int nstamp = 0;
+  X3_STAMP();                  // [0] start
+
+  // load map: pass i = rows 16 i .. 16 i + 15 of the tile, thread -> (row 16 i + tid / 32,
+  // k-quad tid % 32): 512 contiguous bytes per half-wave
+  const int lr = tid >> 5, kq = tid & 31;
+  float4 ra[8], rw[8], ry[PRO == PRO_BNBWD ? 8 : 1];
+  auto issue = [&](int c) {
+    const int k = 128 * c + 4 * kq;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const long long row = m0 + 16 * i + lr;
+      const long long rc = row < M ? row : M - 1;     // clamped: loads stay inside the matrix
+      ra[i] = mid_load4(A + rc * lda, k, K);
+      if (PRO == PRO_BNBWD) ry[PRO == PRO_BNBWD ? i : 0] = mid_load4(bw.Y + rc * (long long)K, k, K);
+      const int n = n0 + 16 * i + lr;
+      rw[i] = mid_load4(W + (long long)(n < N ? n : N - 1) * ldw, k, K);
+    }
+  };
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+  issue(0);
+  X3_STAMP();                  // [1] loads issued
+  for (int c = 0; c < nchunks; ++c) {
+    const int k = 128 * c + 4 * kq;
+    if (PRO == PRO_BNRELU) {
+      const float4 sc = mid_load4(pscale, k, K), sh = mid_load4(pshift, k, K);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float4 v = ra[i];
+        v.x = k < K ? fmaxf(v.x * sc.x + sh.x, 0.f) : 0.f;
+        v.y = k + 1 < K ? fmaxf(v.y * sc.y + sh.y, 0.f) : 0.f;
+        v.z = k + 2 < K ? fmaxf(v.z * sc.z + sh.z, 0.f) : 0.f;
+        v.w = k + 3 < K ? fmaxf(v.w * sc.w + sh.w, 0.f) : 0.f;
+        ra[i] = v;
+      }
+    }
+    if (PRO == PRO_BNBWD) {                          // K % 4 == 0: a quad is inside or outside
+      if (k < K) {
+        const float4 sc = *reinterpret_cast<const float4 *>(bw.scale + k);
+        const float4 sh = *reinterpret_cast<const float4 *>(bw.shift + k);
+        const float4 mu = *reinterpret_cast<const float4 *>(bw.mean + k);
+        const float4 is = *reinterpret_cast<const float4 *>(bw.invstd + k);
+        const float4 k0 = *reinterpret_cast<const float4 *>(bw.coef + k);
+        const float4 k1 = *reinterpret_cast<const float4 *>(bw.coef + K + k);
+        const float4 k2 = *reinterpret_cast<const float4 *>(bw.coef + 2 * K + k);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float4 g = ra[i];
+          const float4 y = ry[PRO == PRO_BNBWD ? i : 0];
+          if (bw.relu) {
+            if (!(y.x * sc.x + sh.x > 0.f)) g.x = 0.f;
+            if (!(y.y * sc.y + sh.y > 0.f)) g.y = 0.f;
+            if (!(y.z * sc.z + sh.z > 0.f)) g.z = 0.f;
+            if (!(y.w * sc.w + sh.w > 0.f)) g.w = 0.f;
+          }
+          float4 v;
+          v.x = k0.x * (g.x - k1.x - ((y.x - mu.x) * is.x) * k2.x);
+          v.y = k0.y * (g.y - k1.y - ((y.y - mu.y) * is.y) * k2.y);
+          v.z = k0.z * (g.z - k1.z - ((y.z - mu.z) * is.z) * k2.z);
+          v.w = k0.w * (g.w - k1.w - ((y.w - mu.w) * is.w) * k2.w);
+          ra[i] = v;
+          const long long row = m0 + 16 * i + lr;
+          if (bw.dY != nullptr && blockIdx.y == 0 && row < M)
+            *reinterpret_cast<float4 *>(bw.dY + row * (long long)K + k) = v;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      *reinterpret_cast<float4 *>(As + (16 * i + lr) * MID_LD + 4 * kq) = ra[i];
+      *reinterpret_cast<float4 *>(Ws + (16 * i + lr) * MID_LD + 4 * kq) = rw[i];
+    }
+    if (c + 1 < nchunks) issue(c + 1);               // flies while this chunk is multiplied
+    __syncthreads();
+    X3_STAMP();                // per chunk: operands landed, staged, barrier
+    if (live) {
+      const int kleft = K - 128 * c;
+      const int nsteps = kleft >= 128 ? 8 : (kleft + 15) >> 4;
+      const float *fa0 = As + (64 * rg + li) * MID_LD + 8 * lk;
+      const float *fw0 = Ws + (32 * cw + li) * MID_LD + 8 * lk;
+      for (int s = 0; s < nsteps; ++s) {
+        const float *fa = fa0 + 16 * s, *fw = fw0 + 16 * s;
+        const MidPlanes pb = mid_split8(*reinterpret_cast<const float4 *>(fw),
+                                        *reinterpret_cast<const float4 *>(fw + 4));
+        MidPlanes pa[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          pa[t] = mid_split8(*reinterpret_cast<const float4 *>(fa + 32 * t * MID_LD),
+                             *reinterpret_cast<const float4 *>(fa + 32 * t * MID_LD + 4));
+        constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[t].p[TA[q]], pb.p[TB[q]], acc[t],
+                                                             0, 0, 0);
+      }
+    }
+    X3_STAMP();                //            MFMAs issued
+    if (c + 1 < nchunks) __syncthreads();            // the tiles are overwritten next
+  }
+
+  // C/D layout of 32x32: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+  const int col = n0 + 32 * cw + li;
+  float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const long long row = m0 + 64 * rg + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * lk;
+      if (row < M && col < N) {
+        Y[row * ldy + col] = acc[t][e];
+        t1 += acc[t][e];
+        t2 += acc[t][e] * acc[t][e];
+      }
+    }
+  X3_STAMP();                  // stores issued
+  if (prof_on) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    X3_STAMP();                // ... and acknowledged
+    pr[63] = nstamp;
+  }
+  if (partial != nullptr) {
+    t1 += __shfl_xor(t1, 32, 64);
+    t2 += __shfl_xor(t2, 32, 64);
+    if (lk == 0) {
+      s_stat[0][rg][32 * cw + li] = t1;
+      s_stat[1][rg][32 * cw + li] = t2;
+    }
+    __syncthreads();
+    if (tid < 128 && n0 + tid < N) {
+      float *p = partial + (long long)blockIdx.x * 2 * N;
+      p[n0 + tid] = s_stat[0][0][tid] + s_stat[0][1][tid];
+      p[N + n0 + tid] = s_stat[1][0][tid] + s_stat[1][1][tid];
+    }
+  }
+}
+
+template <int PRO>
+int launch_mid(long long M, int N, int K, const float *A, int lda, const float *W, int ldw,
+               const float *pscale, const float *pshift, float *Y, int ldy, float *partial,
+               hipStream_t st, const BwdArgs &bw) {
+  static int attr_state[64];                   // per device: 0 unknown, 1 ok, -1 refused
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (attr_state[dev] == 0)
+    attr_state[dev] = hipFuncSetAttribute((const void *)rows_mid_gemm_kernel<PRO>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)MID_LDS_BYTES) == hipSuccess ? 1 : -1;
+  if (attr_state[dev] < 0) {
+    (void)hipGetLastError();
+    return -2;                                 // not taken: the tiled kernel runs instead
+  }
+  dim3 grid((unsigned)((M + 127) / 128), (unsigned)((N + 127) / 128));
+  hipLaunchKernelGGL((rows_mid_gemm_kernel<PRO>), grid, dim3(512), MID_LDS_BYTES, st, M, N, K, A,
+                     lda, W, ldw, pscale, pshift, Y, ldy, partial, bw);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    fprintf(stderr, "s2c_rows_gemm(mid) launch failed: %s\n", hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
+// rows up to which launch_x3 hands N > 64 problems to rows_mid_gemm_kernel (0 = never)
+static int g_mid_rows = -1;
+static int mid_rows() {
+  if (g_mid_rows < 0) {
+    const char *e = getenv("S2C_GEMM_MID_ROWS");
+    g_mid_rows = e ? atoi(e) : 32768;
+  }
+  return g_mid_rows;
+}
+
 template <int PRO>
 int launch(long long M, int N, int K, const float *A, int lda, const float *W, int ldw,
            const float *pscale, const float *pshift, const GatherArgs &ga, float *Y,
@@ -752,6 +1021,12 @@ int launch_x3(long long M, int N, int K, const float *A, int lda, const float *W
               const float *pscale, const float *pshift, const GatherArgs &ga, float *Y,
               int ldy, float *partial, hipStream_t st, const EpiArgs &ep = EpiArgs(),
               const BwdArgs &bw = BwdArgs()) {
+  if constexpr (PRO != PRO_GATHER) {
+    if (ep.mean == nullptr && N > 64 && M <= mid_rows()) {
+      const int rc = launch_mid<PRO>(M, N, K, A, lda, W, ldw, pscale, pshift, Y, ldy, partial, st, bw);
+      if (rc != -2) return rc;
+    }
+  }
   const int avec = A && ((lda & 3) == 0) && (((uintptr_t)A & 15) == 0);
   const int wvec = ((ldw & 3) == 0) && (((uintptr_t)W & 15) == 0);
   static bool attr_done = false;
@@ -850,9 +1125,11 @@ extern "C" int s2c_rows_gemm(long long M, int N, int K, const float *A, int lda,
                               partial, (hipStream_t)stream);
   }
   if (use_split()) {
-    const int rc = s2c_rows_stream_gemm(M, N, K, A, lda, W, ldw, Y, ldy, partial,
-                                        s2c_rows_gemm_blocks(M, N), stream);
-    if (rc != -2) return rc;
+    if (!(N > 64 && M <= mid_rows())) {      // mid-size problems: rows_mid_gemm_kernel
+      const int rc = s2c_rows_stream_gemm(M, N, K, A, lda, W, ldw, Y, ldy, partial,
+                                          s2c_rows_gemm_blocks(M, N), stream);
+      if (rc != -2) return rc;
+    }
     return launch_x3<PRO_NONE>(M, N, K, A, lda, W, ldw, nullptr, nullptr, ga, Y, ldy, partial,
                                (hipStream_t)stream);
   }
@@ -925,6 +1202,14 @@ extern "C" int s2c_gemm_set_profile(long long *prof, int block) {
   if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), &prof, sizeof(prof)) != hipSuccess) return -1;
   if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof_block), &block, sizeof(block)) != hipSuccess) return -1;
   return 0;
+}
+
+/* Largest row count the split-K register-fed kernel takes (N > 64; 0 = off; environment
+ * S2C_GEMM_MID_ROWS, default 32768).  Returns the previous value. */
+extern "C" int s2c_gemm_set_mid_rows(int rows) {
+  const int old = mid_rows();
+  if (rows >= 0) g_mid_rows = rows;
+  return old;
 }
 
 /* 1: bf16x3 split products (default), 0: exact fp32 MFMA chain.  Returns the previous

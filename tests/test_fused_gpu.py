@@ -897,6 +897,47 @@ def test_stream_gemm_matches_fp64_and_the_tiled_kernel(M, N, K, lda):
     assert torch.equal(outs[0][0], outs[1][0])        # same products, same order
 
 
+@pytest.mark.parametrize("M,N,K,lda,pro", [(2048, 128, 128, 128, 0), (5000, 259, 131, 131, 0),
+                                           (8192, 256, 512, 512, 1), (32768, 128, 128, 128, 1),
+                                           (1000, 97, 128, 132, 0), (4099, 131, 259, 259, 1),
+                                           (20480, 256, 128, 128, 0), (129, 65, 16, 16, 0)])
+def test_mid_gemm_matches_fp64_and_the_tiled_kernel(M, N, K, lda, pro):
+    """Mid-size problems (rows_mid_gemm_kernel: K in chunks of 128 resident in LDS) against a
+    float64 product and the tiled kernel (s2c_gemm_set_mid_rows(0)): ragged last row tile, N and
+    K that are no multiples of 4 (unaligned rows), padded rows, a column block with idle waves,
+    with and without the BN+ReLU prologue.  Same bf16x3 products in the same k order: the tiled
+    kernel's values are expected bit for bit."""
+    from scan2cap_amd.pointnet2 import fused
+    _C, lib = _stream_lib()
+    torch.manual_seed(M % 1000 + N + K)
+    A = torch.randn(M, lda, device="cuda")[:, :K]
+    W = torch.randn(N, K, device="cuda") * 0.2
+    sc = (torch.rand(K + 3, device="cuda") + 0.5)[:K].contiguous() if pro else None
+    sh = (torch.randn(K + 3, device="cuda") * 0.3)[:K].contiguous() if pro else None
+    nb = lib.s2c_rows_gemm_blocks(M, N)
+    outs = []
+    for mid in (1 << 20, 0):
+        Y = torch.full((M, N), float("nan"), device="cuda")
+        part = torch.full((nb * 2 * N,), float("nan"), device="cuda")
+        prev = fused.set_gemm_mid_rows(mid)
+        try:
+            _C.call("s2c_rows_gemm", M, N, K, A.data_ptr(), lda, W.data_ptr(), K,
+                    sc.data_ptr() if pro else None, sh.data_ptr() if pro else None,
+                    Y.data_ptr(), N, part.data_ptr(), _C.stream_ptr())
+        finally:
+            fused.set_gemm_mid_rows(prev)
+        torch.cuda.synchronize()
+        outs.append((Y, part.view(nb, 2, N).double().sum(0)))
+    Ain = torch.relu(A * sc + sh) if pro else A
+    ref = Ain.double() @ W.double().t()
+    for Y, p in outs:
+        assert torch.isfinite(Y).all()
+        assert float((Y.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+        assert float((p[0] - ref.sum(0)).abs().max()) <= 1e-4 * float(ref.abs().sum(0).max())
+        assert float((p[1] - (ref * ref).sum(0)).abs().max()) <= 1e-5 * float((ref * ref).sum(0).max())
+    assert torch.equal(outs[0][0], outs[1][0])
+
+
 @pytest.mark.parametrize("B,n,m,ns,C,N,normalize", [(2, 20000, 1024, 64, 132, 64, 1),
                                                    (8, 2048, 1024, 32, 128, 128, 1),
                                                    (3, 5000, 1400, 32, 100, 64, 0),
