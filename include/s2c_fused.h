@@ -245,11 +245,11 @@ int s2c_sa_fused_eval(int b, int n, int m, int ns, int C, long long feat_row_str
  * the previous setting. */
 int s2c_gemm_set_split(int on);
 
-/* Mid-size problems (N > 64, at most `rows` rows; default 32768, environment S2C_GEMM_MID_ROWS,
- * 0 = off) of every entry point above except the gather / inference-epilogue ones run on
- * rows_mid_gemm_kernel (K in chunks of 128 resident in LDS, one barrier per chunk) instead of
- * the 32-k slices of the tiled kernel.  Returns the previous value; rows < 0 only queries. */
-int s2c_gemm_set_mid_rows(int rows);
+/* problems with N > 64 that the streaming kernel does not take: 1 (default, environment
+ * S2C_GEMM_C64) = rows_gemm_c64_kernel (K in 64-chunks of fp32 in LDS, next chunk in flight, two
+ * workgroups per CU), 0 = the 32-k-slice kernel (which keeps the BatchNorm-backward prologue of
+ * s2c_bn_bwd_gemm either way).  Identical results.  Returns the previous setting. */
+int s2c_gemm_set_c64(int on);
 int s2c_rows_gemm(long long M, int N, int K, const float *A, int lda, const float *W,
                   int ldw, const float *pscale, const float *pshift, float *Y,
                   int ldy, float *partial, void *stream);

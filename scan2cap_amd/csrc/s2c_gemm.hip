@@ -719,39 +719,7 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_x3_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
-// Mid-size problems (2k .. 64k rows: feature-propagation modules, vote / proposal heads,
-// SA3 / SA4): a few MB of operands, so a launch is one memory round trip plus the latency of
-// its own dependent steps -- the kernel above walks K in slices of 32 behind two workgroup
-// barriers each, two slices of loads in flight (3.5 us per slice with one workgroup per CU:
-// 20 us at K = 128, 50 us at K = 512, against 3-5 us of HBM / MFMA time).  Here K is walked
-// in chunks of 128:
-//  * workgroup = 128 rows x 128 columns, 8 waves, wave (rg, cw) = rows 64 rg .. + 63 x columns
-//    32 cw .. + 31; the whole 128 x 128 chunk of BOTH operands sits in LDS as fp32 (2 x 66 KB,
-//    rows padded to 132 floats: fragment reads are conflict-free) -- at K <= 128 every load of
-//    the launch is issued in the first microsecond and there is ONE barrier before the MFMAs;
-//    with more chunks the next one is in flight (registers) while this one is multiplied;
-//  * loads are coalesced (512 contiguous bytes per half-wave).  (Two earlier versions of this
-//    kernel: MFMA lanes fed straight from global memory -- lane (i, half) = 32 bytes of row i,
-//    no LDS -- is bound by the vector L1's 64 tag look-ups per instruction, 8600 cycles to
-//    ISSUE a workgroup's 128 KB; split-K over the waves with wave-private LDS transposers
-//    needs no barrier but re-reads the operands per 64-column block and sums four partial
-//    tiles through LDS: 6.2 us per workgroup against 3 here.)
-//  * fragments are split into bf16 hi / mid / lo planes in registers after the LDS read (the
-//    6 plane products of the kernels above, same accuracy); each wave stores its own 64 x 32
-//    piece, column statistics meet in LDS: one [sum | sumsq] partial row per 128 rows, the
-//    granularity of the 2x2 tiling above (s2c_rows_gemm_blocks is unchanged).
-// The A tile is fetched once per 128-column block (from L2 the second time).
-// S2C_GEMM_MID_ROWS (default 32768; 0 = off) bounds the row count this kernel takes.  Measured
-// on MI355X (tools/bench_mid_gemm.py, us, tiled kernel -> this one | hipBLASLt fp32):
-//   (2048,128,128) 17 -> 11 | 5    (4096,256,256) 29 -> 19 | 10   (4096,256,512) 48 -> 32 | 13
-//   (8192,256,256) 29 -> 20 | 13   (8192,256,512) 51 -> 34 | 21   (8192,259,256) 29 -> 20 | 18
-//   (20480,128,128) 19 -> 14 | 11  (20480,128,256) 31 -> 22 | 26  (32768,128,128) 20 -> 15 | 16
-//   (32768,256,128) 31 -> 29 | 25  (65536,128,128) 31 -> 29 | 27  (65536,256,128) 55 -> 57 | 46
-// (the library computes no column statistics: its numbers lack the pass over Y that the
-// epilogue here replaces).  One workgroup's timeline at (32768,128,128), 256 workgroups = one
-// per CU: loads issued 1.2 us, landed + staged + barrier 1.6 us, 96 MFMAs per wave 3.7 us
-// (two waves share a SIMD: 2.6 us is the bf16x3 MFMA floor of the tile), stores 2.0 us --
-// serial within a workgroup, which is what a one-round problem costs.
+// helpers of rows_gemm_c64_kernel below
 struct MidPlanes { bf16x8 p[3]; };
 
 __device__ __forceinline__ MidPlanes mid_split8(float4 lo4, float4 hi4) {
@@ -785,58 +753,122 @@ __device__ __forceinline__ float4 mid_load4(const float *__restrict__ row, int k
   return v;
 }
 
-constexpr int MID_LD = 132;                   // floats per staged row: 128 k + 4 pad
-constexpr size_t MID_LDS_BYTES = 2 * 128 * MID_LD * sizeof(float);   // 135168
+// ---------------------------------------------------------------------------------------
+// Tall problems with N > 64 that the streaming kernel (s2c_gemm2.hip) does not take (K or
+// N = 256: its resident W planes do not fit): the 2x2 tiling of rows_gemm_x3_kernel with the
+// whole 64-k chunks of both operands staged as fp32 --
+//  * workgroup = 4 waves on a 128 x 128 tile (wave = 64 x 64, the accumulator layout and the
+//    epilogues of the kernel above), K in chunks of 64 kept in LDS as fp32 (2 x 34 KB, rows
+//    padded to 68 floats: conflict-free 16-byte fragment reads), split into bf16 planes in
+//    registers after the fragment read;
+//  * (tried first: feeding the MFMA lanes straight from global memory -- lane (i, half) = 32
+//    bytes of row i, no LDS -- is bound by the vector L1's 64 tag look-ups per instruction;
+//    split-K over 8 waves with wave-private LDS transposers needs no barrier but sums four
+//    partial tiles through LDS; 128-k chunks with one workgroup per CU serialise load, MFMA and
+//    store phases: all measured slower than this, tools/bench_mid_gemm.py)
+//  * one chunk = 16 coalesced 16-byte loads per thread (256 contiguous bytes per 16 lanes), the
+//    NEXT chunk in flight while this one is multiplied: half the barriers of the 32-k slices
+//    and twice the bytes in flight per workgroup, two workgroups per CU (70 KB of LDS, <= 256
+//    VGPRs) so that one's loads and stores run under the other's MFMAs.
+// The timeline of the 32-k-slice kernel at (262144, 256, 128) (tools/prof_gemm.py) showed what
+// this replaces: 19-27 us per 128 x 128 x 128 tile, of which 3-8 us to issue the first two
+// slices, 1.6 us to issue each later one and 4 us of epilogue -- against 2.6 us of MFMA time.
+// Same products in the same k order as the kernel above: bit-identical results.
+constexpr int C64_LD = 68;
+constexpr size_t C64_LDS_BYTES = 2 * 128 * C64_LD * sizeof(float);     // 69632
 
 template <int PRO>
-__global__ __launch_bounds__(512) void rows_mid_gemm_kernel(
+__global__ __launch_bounds__(256, 2) void rows_gemm_c64_kernel(
     long long M, int N, int K, const float *__restrict__ A, int lda,
     const float *__restrict__ W, int ldw, const float *__restrict__ pscale,
-    const float *__restrict__ pshift, float *__restrict__ Y, int ldy,
-    float *__restrict__ partial, BwdArgs bw) {
-  extern __shared__ __attribute__((aligned(16))) float mid_smem[];
-  __shared__ float s_stat[2][2][128];              // [sum | sumsq][row group][column]
-  float *As = mid_smem, *Ws = mid_smem + 128 * MID_LD;
+    const float *__restrict__ pshift, GatherArgs ga, float *__restrict__ Y, int ldy,
+    float *__restrict__ partial, EpiArgs ep) {
+  constexpr int WM = 2, WN = 2, BN = 128;
+  extern __shared__ __attribute__((aligned(16))) float c64_smem[];
+  __shared__ float s_stat[2][WM][BN];
+  float *As = c64_smem, *Ws = c64_smem + 128 * C64_LD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int rg = wave >> 2, cw = wave & 3;
+  const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 31, lk = lane >> 5;
-  const long long m0 = (long long)blockIdx.x * 128;
-  const int n0 = blockIdx.y * 128;
-  const int nchunks = (K + 127) >> 7;
-  // a wave whose 32 columns lie beyond N stages and waits with the others but multiplies nothing
-  const bool live = n0 + 32 * cw < N;
+  // 1-D grid, XCD-aware: workgroup ids that differ by 8 share an XCD (its L2) and start one
+  // after the other -- the column blocks of ONE row tile, so that the A tile comes from HBM once
+  const int nby = (N + 127) >> 7;
+  const int by = (int)((blockIdx.x >> 3) % nby);
+  const long long bx = 8ll * ((blockIdx.x >> 3) / nby) + (blockIdx.x & 7);
+  if (bx * 128 >= M) return;
+  const long long m0 = bx * 128;
+  const int n0 = by * 128;
+  const int nchunks = (K + 63) >> 6;
+  const bool live = n0 + 64 * wn < N;               // a wave beyond N multiplies nothing
   long long *pr = g_prof;
-  const bool prof_on = pr != nullptr && (int)blockIdx.x == g_prof_block && blockIdx.y == 0 && tid == 0;
+  const bool prof_on = pr != nullptr && (int)bx == g_prof_block && by == 0 && tid == 0;
   int nstamp = 0;
   X3_STAMP();                  // [0] start
 
-  // load map: pass i = rows 16 i .. 16 i + 15 of the tile, thread -> (row 16 i + tid / 32,
-  // k-quad tid % 32): 512 contiguous bytes per half-wave
-  const int lr = tid >> 5, kq = tid & 31;
-  float4 ra[8], rw[8], ry[PRO == PRO_BNBWD ? 8 : 1];
-  auto issue = [&](int c) {
-    const int k = 128 * c + 4 * kq;
+  // load map: pass i = rows 16 i .. 16 i + 15 of the tile, thread -> (row 16 i + tid / 16,
+  // k-quad tid % 16): 256 contiguous bytes per 16 lanes
+  const int lr = tid >> 4, kq = tid & 15;
+  // gather: per staged row the source offsets (32-bit element offsets: the cloud is below
+  // 2^31 floats); the other prologues recompute their row offsets at every issue (registers)
+  unsigned goff[PRO == PRO_GATHER ? 8 : 1];
+  int g_pt[PRO == PRO_GATHER ? 8 : 1], g_ctr[PRO == PRO_GATHER ? 8 : 1];
+  if (PRO == PRO_GATHER) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const long long row = m0 + 16 * i + lr;
-      const long long rc = row < M ? row : M - 1;     // clamped: loads stay inside the matrix
-      ra[i] = mid_load4(A + rc * lda, k, K);
-      if (PRO == PRO_BNBWD) ry[PRO == PRO_BNBWD ? i : 0] = mid_load4(bw.Y + rc * (long long)K, k, K);
+      const long long rc = row < M ? row : M - 1;
+      const long long bj = rc / ga.ns;
+      const long long b = bj / ga.m;
+      const int p = ga.idx[rc];
+      goff[i] = (unsigned)(b * ga.fbs + (long long)p * ga.frs);
+      g_pt[i] = (int)((b * ga.n + p) * 3);
+      g_ctr[i] = (int)(bj * 3);
+    }
+  }
+
+  float4 ra[8], rw[8];
+  auto issue = [&](int c) {
+    const int k = 64 * c + 4 * kq;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (PRO == PRO_GATHER) {
+        const float *src = ga.feats + goff[PRO == PRO_GATHER ? i : 0];
+        if (k >= 3) {                                 // column k = feature k - 3
+          ra[i] = mid_load4(src - 3, k, K);
+        } else {                                      // k == 0: dx, dy, dz, first feature
+          float e[4];
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            float x = ga.xyz[g_pt[PRO == PRO_GATHER ? i : 0] + q] -
+                      ga.new_xyz[g_ctr[PRO == PRO_GATHER ? i : 0] + q];
+            if (ga.normalize) x = x / ga.radius;
+            e[q] = x;
+          }
+          e[3] = K > 3 ? src[0] : 0.f;
+          ra[i] = make_float4(e[0], e[1], e[2], e[3]);
+        }
+      } else {
+        const long long row = m0 + 16 * i + lr;
+        const long long rc = row < M ? row : M - 1;   // clamped: loads stay inside the matrix
+        ra[i] = mid_load4(A + rc * lda, k, K);
+      }
       const int n = n0 + 16 * i + lr;
       rw[i] = mid_load4(W + (long long)(n < N ? n : N - 1) * ldw, k, K);
     }
   };
 
-  f32x16 acc[2];
+  f32x16 acc[2][2];
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   issue(0);
   X3_STAMP();                  // [1] loads issued
   for (int c = 0; c < nchunks; ++c) {
-    const int k = 128 * c + 4 * kq;
+    const int k = 64 * c + 4 * kq;
     if (PRO == PRO_BNRELU) {
       const float4 sc = mid_load4(pscale, k, K), sh = mid_load4(pshift, k, K);
 #pragma unroll
@@ -849,142 +881,135 @@ __global__ __launch_bounds__(512) void rows_mid_gemm_kernel(
         ra[i] = v;
       }
     }
-    if (PRO == PRO_BNBWD) {                          // K % 4 == 0: a quad is inside or outside
-      if (k < K) {
-        const float4 sc = *reinterpret_cast<const float4 *>(bw.scale + k);
-        const float4 sh = *reinterpret_cast<const float4 *>(bw.shift + k);
-        const float4 mu = *reinterpret_cast<const float4 *>(bw.mean + k);
-        const float4 is = *reinterpret_cast<const float4 *>(bw.invstd + k);
-        const float4 k0 = *reinterpret_cast<const float4 *>(bw.coef + k);
-        const float4 k1 = *reinterpret_cast<const float4 *>(bw.coef + K + k);
-        const float4 k2 = *reinterpret_cast<const float4 *>(bw.coef + 2 * K + k);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          float4 g = ra[i];
-          const float4 y = ry[PRO == PRO_BNBWD ? i : 0];
-          if (bw.relu) {
-            if (!(y.x * sc.x + sh.x > 0.f)) g.x = 0.f;
-            if (!(y.y * sc.y + sh.y > 0.f)) g.y = 0.f;
-            if (!(y.z * sc.z + sh.z > 0.f)) g.z = 0.f;
-            if (!(y.w * sc.w + sh.w > 0.f)) g.w = 0.f;
-          }
-          float4 v;
-          v.x = k0.x * (g.x - k1.x - ((y.x - mu.x) * is.x) * k2.x);
-          v.y = k0.y * (g.y - k1.y - ((y.y - mu.y) * is.y) * k2.y);
-          v.z = k0.z * (g.z - k1.z - ((y.z - mu.z) * is.z) * k2.z);
-          v.w = k0.w * (g.w - k1.w - ((y.w - mu.w) * is.w) * k2.w);
-          ra[i] = v;
-          const long long row = m0 + 16 * i + lr;
-          if (bw.dY != nullptr && blockIdx.y == 0 && row < M)
-            *reinterpret_cast<float4 *>(bw.dY + row * (long long)K + k) = v;
-        }
-      }
-    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      *reinterpret_cast<float4 *>(As + (16 * i + lr) * MID_LD + 4 * kq) = ra[i];
-      *reinterpret_cast<float4 *>(Ws + (16 * i + lr) * MID_LD + 4 * kq) = rw[i];
+      *reinterpret_cast<float4 *>(As + (16 * i + lr) * C64_LD + 4 * kq) = ra[i];
+      *reinterpret_cast<float4 *>(Ws + (16 * i + lr) * C64_LD + 4 * kq) = rw[i];
     }
     if (c + 1 < nchunks) issue(c + 1);               // flies while this chunk is multiplied
     __syncthreads();
     X3_STAMP();                // per chunk: operands landed, staged, barrier
     if (live) {
-      const int kleft = K - 128 * c;
-      const int nsteps = kleft >= 128 ? 8 : (kleft + 15) >> 4;
-      const float *fa0 = As + (64 * rg + li) * MID_LD + 8 * lk;
-      const float *fw0 = Ws + (32 * cw + li) * MID_LD + 8 * lk;
+      const int kleft = K - 64 * c;
+      const int nsteps = kleft >= 64 ? 4 : (kleft + 15) >> 4;
+      const float *fa0 = As + (64 * wm + li) * C64_LD + 8 * lk;
+      const float *fw0 = Ws + (64 * wn + li) * C64_LD + 8 * lk;
       for (int s = 0; s < nsteps; ++s) {
-        const float *fa = fa0 + 16 * s, *fw = fw0 + 16 * s;
-        const MidPlanes pb = mid_split8(*reinterpret_cast<const float4 *>(fw),
-                                        *reinterpret_cast<const float4 *>(fw + 4));
+        // (one W fragment at a time: 20 registers less than holding both; every accumulator
+        // still receives its six products in the same order)
         MidPlanes pa[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-          pa[t] = mid_split8(*reinterpret_cast<const float4 *>(fa + 32 * t * MID_LD),
-                             *reinterpret_cast<const float4 *>(fa + 32 * t * MID_LD + 4));
+        for (int t = 0; t < 2; ++t) {
+          const float *fa = fa0 + 32 * t * C64_LD + 16 * s;
+          pa[t] = mid_split8(*reinterpret_cast<const float4 *>(fa),
+                             *reinterpret_cast<const float4 *>(fa + 4));
+        }
         constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-        for (int q = 0; q < 6; ++q)
+        for (int j = 0; j < 2; ++j) {
+          const float *fw = fw0 + 32 * j * C64_LD + 16 * s;
+          const MidPlanes pb = mid_split8(*reinterpret_cast<const float4 *>(fw),
+                                          *reinterpret_cast<const float4 *>(fw + 4));
 #pragma unroll
-          for (int t = 0; t < 2; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[t].p[TA[q]], pb.p[TB[q]], acc[t],
-                                                             0, 0, 0);
+          for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i].p[TA[q]], pb.p[TB[q]],
+                                                                  acc[i][j], 0, 0, 0);
+        }
       }
     }
     X3_STAMP();                //            MFMAs issued
     if (c + 1 < nchunks) __syncthreads();            // the tiles are overwritten next
   }
 
+  if (ep.mean != nullptr) {    // inference: BN + ReLU (+ max-pool) leave with the GEMM
+    affine_epilogue(acc, ep, M, N, m0 + wm * 64, n0 + wn * 64, li, lk);
+    return;
+  }
   // C/D layout of 32x32: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
-  const int col = n0 + 32 * cw + li;
-  float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wn * 64 + j * 32 + li;
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const long long row = m0 + 64 * rg + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * lk;
-      if (row < M && col < N) {
-        Y[row * ldy + col] = acc[t][e];
-        t1 += acc[t][e];
-        t2 += acc[t][e] * acc[t][e];
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const long long row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+        const float v = acc[i][j][e];
+        if (row < M && col < N) {
+          Y[row * ldy + col] = v;
+          s1 += v;
+          s2 += v * v;
+        }
       }
     }
-  X3_STAMP();                  // stores issued
+    if (partial != nullptr) {
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (lk == 0) {
+        s_stat[0][wm][wn * 64 + j * 32 + li] = s1;
+        s_stat[1][wm][wn * 64 + j * 32 + li] = s2;
+      }
+    }
+  }
+  X3_STAMP();                  // epilogue stores issued
   if (prof_on) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     X3_STAMP();                // ... and acknowledged
     pr[63] = nstamp;
   }
   if (partial != nullptr) {
-    t1 += __shfl_xor(t1, 32, 64);
-    t2 += __shfl_xor(t2, 32, 64);
-    if (lk == 0) {
-      s_stat[0][rg][32 * cw + li] = t1;
-      s_stat[1][rg][32 * cw + li] = t2;
-    }
     __syncthreads();
-    if (tid < 128 && n0 + tid < N) {
-      float *p = partial + (long long)blockIdx.x * 2 * N;
-      p[n0 + tid] = s_stat[0][0][tid] + s_stat[0][1][tid];
-      p[N + n0 + tid] = s_stat[1][0][tid] + s_stat[1][1][tid];
+    for (int c = tid; c < BN; c += 256) {
+      if (n0 + c < N) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) { s1 += s_stat[0][w][c]; s2 += s_stat[1][w][c]; }
+        float *p = partial + bx * 2 * N;
+        p[n0 + c] = s1;
+        p[N + n0 + c] = s2;
+      }
     }
   }
 }
 
+// S2C_GEMM_C64=0: the N > 64 problems stay on the 32-k-slice kernel
+static int g_c64 = -1;
+static bool c64_on() {
+  if (g_c64 < 0) {
+    const char *e = getenv("S2C_GEMM_C64");
+    g_c64 = e ? atoi(e) : 1;
+  }
+  return g_c64 != 0;
+}
+
 template <int PRO>
-int launch_mid(long long M, int N, int K, const float *A, int lda, const float *W, int ldw,
-               const float *pscale, const float *pshift, float *Y, int ldy, float *partial,
-               hipStream_t st, const BwdArgs &bw) {
+int launch_c64(long long M, int N, int K, const float *A, int lda, const float *W, int ldw,
+               const float *pscale, const float *pshift, const GatherArgs &ga, float *Y, int ldy,
+               float *partial, hipStream_t st, const EpiArgs &ep) {
   static int attr_state[64];                   // per device: 0 unknown, 1 ok, -1 refused
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
   if (attr_state[dev] == 0)
-    attr_state[dev] = hipFuncSetAttribute((const void *)rows_mid_gemm_kernel<PRO>,
+    attr_state[dev] = hipFuncSetAttribute((const void *)rows_gemm_c64_kernel<PRO>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)MID_LDS_BYTES) == hipSuccess ? 1 : -1;
+                                          (int)C64_LDS_BYTES) == hipSuccess ? 1 : -1;
   if (attr_state[dev] < 0) {
     (void)hipGetLastError();
-    return -2;                                 // not taken: the tiled kernel runs instead
+    return -2;                                 // not taken: the 32-k-slice kernel runs instead
   }
-  dim3 grid((unsigned)((M + 127) / 128), (unsigned)((N + 127) / 128));
-  hipLaunchKernelGGL((rows_mid_gemm_kernel<PRO>), grid, dim3(512), MID_LDS_BYTES, st, M, N, K, A,
-                     lda, W, ldw, pscale, pshift, Y, ldy, partial, bw);
+  const long long nbx = (M + 127) / 128, nby = (N + 127) / 128;
+  dim3 grid((unsigned)(8 * ((nbx + 7) / 8) * nby));
+  hipLaunchKernelGGL((rows_gemm_c64_kernel<PRO>), grid, dim3(256), C64_LDS_BYTES, st, M, N, K, A,
+                     lda, W, ldw, pscale, pshift, ga, Y, ldy, partial, ep);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
-    fprintf(stderr, "s2c_rows_gemm(mid) launch failed: %s\n", hipGetErrorString(e));
+    fprintf(stderr, "s2c_rows_gemm(c64) launch failed: %s\n", hipGetErrorString(e));
     return (int)e;
   }
   return 0;
-}
-
-// rows up to which launch_x3 hands N > 64 problems to rows_mid_gemm_kernel (0 = never)
-static int g_mid_rows = -1;
-static int mid_rows() {
-  if (g_mid_rows < 0) {
-    const char *e = getenv("S2C_GEMM_MID_ROWS");
-    g_mid_rows = e ? atoi(e) : 32768;
-  }
-  return g_mid_rows;
 }
 
 template <int PRO>
@@ -1021,9 +1046,12 @@ int launch_x3(long long M, int N, int K, const float *A, int lda, const float *W
               const float *pscale, const float *pshift, const GatherArgs &ga, float *Y,
               int ldy, float *partial, hipStream_t st, const EpiArgs &ep = EpiArgs(),
               const BwdArgs &bw = BwdArgs()) {
-  if constexpr (PRO != PRO_GATHER) {
-    if (ep.mean == nullptr && N > 64 && M <= mid_rows()) {
-      const int rc = launch_mid<PRO>(M, N, K, A, lda, W, ldw, pscale, pshift, Y, ldy, partial, st, bw);
+  // (the BatchNorm-backward prologue keeps a third operand in flight: 27 registers over the
+  // budget of two workgroups per CU in the 64-k-chunk kernel, 168 vs 152 us at (262144,128,128))
+  if constexpr (PRO != PRO_BNBWD) {
+    if (N > 64 && c64_on()) {
+      const int rc = launch_c64<PRO>(M, N, K, A, lda, W, ldw, pscale, pshift, ga, Y, ldy, partial,
+                                     st, ep);
       if (rc != -2) return rc;
     }
   }
@@ -1125,11 +1153,9 @@ extern "C" int s2c_rows_gemm(long long M, int N, int K, const float *A, int lda,
                               partial, (hipStream_t)stream);
   }
   if (use_split()) {
-    if (!(N > 64 && M <= mid_rows())) {      // mid-size problems: rows_mid_gemm_kernel
-      const int rc = s2c_rows_stream_gemm(M, N, K, A, lda, W, ldw, Y, ldy, partial,
-                                          s2c_rows_gemm_blocks(M, N), stream);
-      if (rc != -2) return rc;
-    }
+    const int rc = s2c_rows_stream_gemm(M, N, K, A, lda, W, ldw, Y, ldy, partial,
+                                        s2c_rows_gemm_blocks(M, N), stream);
+    if (rc != -2) return rc;
     return launch_x3<PRO_NONE>(M, N, K, A, lda, W, ldw, nullptr, nullptr, ga, Y, ldy, partial,
                                (hipStream_t)stream);
   }
@@ -1204,11 +1230,11 @@ extern "C" int s2c_gemm_set_profile(long long *prof, int block) {
   return 0;
 }
 
-/* Largest row count the split-K register-fed kernel takes (N > 64; 0 = off; environment
- * S2C_GEMM_MID_ROWS, default 32768).  Returns the previous value. */
-extern "C" int s2c_gemm_set_mid_rows(int rows) {
-  const int old = mid_rows();
-  if (rows >= 0) g_mid_rows = rows;
+/* 1 (default; environment S2C_GEMM_C64): problems with N > 64 on rows_gemm_c64_kernel (K in
+ * 64-chunks of fp32 in LDS), 0: on the 32-k-slice kernel.  Returns the previous setting. */
+extern "C" int s2c_gemm_set_c64(int on) {
+  const int old = c64_on() ? 1 : 0;
+  g_c64 = on ? 1 : 0;
   return old;
 }
 

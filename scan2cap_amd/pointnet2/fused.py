@@ -59,13 +59,13 @@ def _call(name, ref, *args, alg_bytes=0, alg_flops=0):
         _C.call(name, *args, _C.stream_ptr())
 
 
-def set_gemm_mid_rows(rows):
-    """Largest row count handed to rows_mid_gemm_kernel (csrc/s2c_gemm.hip; N > 64); 0 = off.
-    Returns the previous value (S2C_GEMM_MID_ROWS, default 32768)."""
+def set_gemm_c64(on):
+    """N > 64 problems on rows_gemm_c64_kernel (True, default) or the 32-k-slice kernel
+    (csrc/s2c_gemm.hip); returns the previous setting."""
     lib = _C.load()
-    lib.s2c_gemm_set_mid_rows.argtypes = [_I]
-    lib.s2c_gemm_set_mid_rows.restype = _I
-    return lib.s2c_gemm_set_mid_rows(int(rows))
+    lib.s2c_gemm_set_c64.argtypes = [_I]
+    lib.s2c_gemm_set_c64.restype = _I
+    return bool(lib.s2c_gemm_set_c64(int(bool(on))))
 
 
 def _stat_blocks(M):

@@ -900,13 +900,14 @@ def test_stream_gemm_matches_fp64_and_the_tiled_kernel(M, N, K, lda):
 @pytest.mark.parametrize("M,N,K,lda,pro", [(2048, 128, 128, 128, 0), (5000, 259, 131, 131, 0),
                                            (8192, 256, 512, 512, 1), (32768, 128, 128, 128, 1),
                                            (1000, 97, 128, 132, 0), (4099, 131, 259, 259, 1),
-                                           (20480, 256, 128, 128, 0), (129, 65, 16, 16, 0)])
-def test_mid_gemm_matches_fp64_and_the_tiled_kernel(M, N, K, lda, pro):
-    """Mid-size problems (rows_mid_gemm_kernel: K in chunks of 128 resident in LDS) against a
-    float64 product and the tiled kernel (s2c_gemm_set_mid_rows(0)): ragged last row tile, N and
-    K that are no multiples of 4 (unaligned rows), padded rows, a column block with idle waves,
-    with and without the BN+ReLU prologue.  Same bf16x3 products in the same k order: the tiled
-    kernel's values are expected bit for bit."""
+                                           (20480, 256, 128, 128, 0), (129, 65, 16, 16, 0),
+                                           (70001, 300, 200, 200, 1)])
+def test_chunk64_gemm_matches_fp64_and_the_slice_kernel(M, N, K, lda, pro):
+    """N > 64 problems on rows_gemm_c64_kernel (K in 64-chunks of fp32 in LDS, XCD-aware 1-D
+    grid) against a float64 product and the 32-k-slice kernel (s2c_gemm_set_c64(0)): ragged last
+    row tile, N and K that are no multiples of 4 (unaligned rows), padded rows, column blocks with
+    idle waves, with and without the BN+ReLU prologue.  Same bf16x3 products in the same k
+    order: the slice kernel's values are expected bit for bit."""
     from scan2cap_amd.pointnet2 import fused
     _C, lib = _stream_lib()
     torch.manual_seed(M % 1000 + N + K)
@@ -916,16 +917,16 @@ def test_mid_gemm_matches_fp64_and_the_tiled_kernel(M, N, K, lda, pro):
     sh = (torch.randn(K + 3, device="cuda") * 0.3)[:K].contiguous() if pro else None
     nb = lib.s2c_rows_gemm_blocks(M, N)
     outs = []
-    for mid in (1 << 20, 0):
+    for c64 in (True, False):
         Y = torch.full((M, N), float("nan"), device="cuda")
         part = torch.full((nb * 2 * N,), float("nan"), device="cuda")
-        prev = fused.set_gemm_mid_rows(mid)
+        prev = fused.set_gemm_c64(c64)
         try:
             _C.call("s2c_rows_gemm", M, N, K, A.data_ptr(), lda, W.data_ptr(), K,
                     sc.data_ptr() if pro else None, sh.data_ptr() if pro else None,
                     Y.data_ptr(), N, part.data_ptr(), _C.stream_ptr())
         finally:
-            fused.set_gemm_mid_rows(prev)
+            fused.set_gemm_c64(prev)
         torch.cuda.synchronize()
         outs.append((Y, part.view(nb, 2, N).double().sum(0)))
     Ain = torch.relu(A * sc + sh) if pro else A
