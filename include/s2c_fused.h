@@ -154,20 +154,19 @@ int s2c_rows_gemm_bn_relu_side(long long M, int N, int K, const float *A, int ld
                                float *partial, void *stream);
 /* Pooled last layer of a training stack on the streaming kernel: the products and statistics
  * partials of s2c_rows_gemm_bn_relu_side (scale == NULL: plain operand), and per centre
- * (pool_ns = 16 / 32 / 64 consecutive rows) and column the raw maximum / minimum of Y with the
- * first row index of each (J x N, J = M / pool_ns) -- all that BatchNorm + ReLU + max-pool
- * (pointnet2_modules.py:255-257) needs once the statistics are known: s2c_pool_select.
- * Y may be NULL (not written).  -2: shape not taken. */
+ * (pool_ns = 16 / 32 / 64 consecutive rows) and column the extremum of Y that BatchNorm + ReLU +
+ * max-pool (pointnet2_modules.py:255-257) will select -- the maximum where gamma[col] >= 0 (or
+ * gamma == NULL), the minimum otherwise: relu(y * gamma * invstd + shift) is monotone in y -- with
+ * its first row index (ext, aext: J x N, J = M / pool_ns): all the pooled layer needs once the
+ * statistics are known (s2c_pool_select).  Y may be NULL (not written).  -2: shape not taken. */
 int s2c_rows_gemm_pool_raw(long long M, int N, int K, const float *A, int lda, const float *scale,
                            const float *shift, int relu, float *side, int ld_side,
-                           const float *W, int ldw, int pool_ns, float *raw_max, int *raw_amax,
-                           float *raw_min, int *raw_amin, float *Y, int ldy, float *partial,
-                           void *stream);
-/* out (J x C) = relu(y * scale + shift), arg, ymax (= y) with y = raw_max / raw_min by the
- * sign of scale: the outputs of s2c_bn_relu_max */
-int s2c_pool_select(long long J, int C, const float *raw_max, const int *raw_amax,
-                    const float *raw_min, const int *raw_amin, const float *scale,
-                    const float *shift, float *out, int *arg, float *ymax, void *stream);
+                           const float *W, int ldw, int pool_ns, const float *gamma, float *ext,
+                           int *aext, float *Y, int ldy, float *partial, void *stream);
+/* out (J x C) = relu(ext * scale + shift): with ext (= ymax) and aext (= arg) of the call above
+ * the three outputs of s2c_bn_relu_max */
+int s2c_pool_select(long long J, int C, const float *ext, const float *scale, const float *shift,
+                    float *out, void *stream);
 /* Backward of a max-pooled BatchNorm + ReLU layer WITHOUT its (M x C3) tensors Y3 / dY3
  * (DESIGN 4.3): with Y3 = A W3^T, dY3 = dkrow - g (.) Y3 + e per channel, hence
  *   dA  = dkrow W3 - A (W3^T diag(g) W3) + e W3           (s2c_pool_bwd_input_grad)

@@ -67,12 +67,18 @@ struct StreamArgs {
   // sc = gamma / sqrt(var + eps), sh = beta - mean * sc (affine_epilogue of s2c_gemm.hip),
   // optionally max-pooled over groups of pool_ns consecutive rows; written to Y (row stride ldy)
   const float *ep_gamma, *ep_beta, *ep_mean, *ep_var; float ep_eps; int ep_relu, pool_ns;
-  // training, pooled last layer (raw_max != nullptr): per (centre, column) the maximum and the
-  // minimum of Y over the pool_ns rows of the centre and the FIRST sample index of each; with
-  // the statistics partials this is all the BatchNorm + ReLU + max-pool that follows needs
-  // (relu(y * scale + shift) is monotone in y: its maximum sits at max y for scale >= 0, at min
-  // y otherwise), so Y itself need not be written (Y == nullptr)
-  float *raw_max, *raw_min; int *raw_amax, *raw_amin;
+  // training, pooled last layer (ext != nullptr): per (centre, column) the extremum of Y over
+  // the pool_ns rows of the centre that the BatchNorm + ReLU + max-pool behind it will pick, and
+  // its FIRST sample index: relu(y * scale + shift) is monotone in y, its maximum sits at max y
+  // for scale >= 0 and at min y otherwise, and the sign of scale = gamma * invstd is the sign of
+  // gamma, known BEFORE the statistics.  The sign is folded into the staged W planes (row n of
+  // W times -1 where ext_sign[n] < 0: planes, products and sums negate exactly), so the
+  // epilogue tracks ONE running maximum per column; ext = sign * max, the statistics partials
+  // get their sign back when they are written.  Y itself need not be written (Y == nullptr).
+  // (A first version tracked max AND min with their indices: the 32 x 128 tile's epilogue was
+  // ~1100 VALU instructions against 156 in its four k-steps -- 45 % issue-active waves, two per
+  // SIMD: the kernel was bound by the vector ALU, not by memory or the matrix cores.)
+  float *ext; int *aext; const float *ext_sign;
   // SPRO_POOLBWD: input gradient of a max-pooled BatchNorm layer WITHOUT its (M x C3) tensors.
   // With Y3 = A W3^T the layer's dY3 = dkrow - g (.) Y3 + e per channel (g = k0 k2 invstd,
   // e = g mean - k0 k1; dkrow = k0 * routed upstream gradient, one nonzero per centre and
@@ -135,6 +141,14 @@ __device__ __forceinline__ void split8(const float4 &va, const float4 &vb, bf16x
 // because each keeps its own per-lane state: as run-time branches the three together spilled
 // the NT = 4 kernels to scratch.
 enum { EPI_TRAIN = 0, EPI_RAW = 1, EPI_EVAL = 2 };
+
+// Diagnostics (tools/prof_stream.py): wave 0 of workgroup g_sprof_block adds up the shader-clock
+// cycles it spends per tile waiting for its ring chunks / in the k-steps / in the epilogue:
+// g_sprof[0..3] = {waits, k-steps, epilogue, tiles}, [4] = whole life.
+__device__ long long *g_sprof = nullptr;
+__device__ int g_sprof_block = 0;
+#define SP_NOW() ([&]() { __builtin_amdgcn_sched_barrier(0); long long t_ = (long long)__builtin_amdgcn_s_memtime(); \
+                          __builtin_amdgcn_sched_barrier(0); return t_; }())
 template <int NT, int PRO, int WAVES, int SLOTS, int EPI>
 __global__ __launch_bounds__(64 * WAVES, (NT == 4 && WAVES == 4) ? 1 : 2) void rows_stream_gemm_kernel(StreamArgs p) {
   constexpr int NP = 32 * NT;
@@ -185,6 +199,9 @@ __global__ __launch_bounds__(64 * WAVES, (NT == 4 && WAVES == 4) ? 1 : 2) void r
           src = k;
         }
         w[c] = (n < N && src >= 0) ? p.W[(long long)n * p.ldw + src] : 0.f;
+      }
+      if (EPI == EPI_RAW && p.ext_sign != nullptr && n < N && p.ext_sign[n] < 0.f) {
+        w[0] = -w[0]; w[1] = -w[1]; w[2] = -w[2]; w[3] = -w[3];
       }
       unsigned h0, m0, l0, h1, m1, l1;
       split2((f32x2){w[0], w[1]}, h0, m0, l0);
@@ -348,20 +365,26 @@ __global__ __launch_bounds__(64 * WAVES, (NT == 4 && WAVES == 4) ? 1 : 2) void r
 #pragma unroll
   for (int j = 0; j < NT; ++j)
     pbias[j] = (PRO == SPRO_POOLBWD && p.bias != nullptr && 32 * j + li < N) ? p.bias[32 * j + li] : 0.f;
-  float rmax[NR][2], rmin[NR][2];
-  int ramax[NR][2], ramin[NR][2];
+  float rmax[NR][2], esgn[NR];                   // EPI_RAW: running maximum of sign * y
+  int ramax[NR][2];                              // its row inside the centre, less 4 lk
 #pragma unroll
-  for (int j = 0; j < NR; ++j)
+  for (int j = 0; j < NR; ++j) {
+    esgn[j] = (EPI == EPI_RAW && p.ext_sign != nullptr && 32 * j + li < N &&
+               p.ext_sign[32 * j + li] < 0.f) ? -1.f : 1.f;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      rmax[j][h] = -INFINITY; rmin[j][h] = INFINITY; ramax[j][h] = ramin[j][h] = 0;
-    }
+    for (int h = 0; h < 2; ++h) { rmax[j][h] = -INFINITY; ramax[j][h] = 0; }
+  }
 
   const int swz = (li >> 1) & 7;
   int slot = 0, par = 0;
+  long long *sprof = g_sprof;
+  const bool sp_on = sprof != nullptr && (int)blockIdx.x == g_sprof_block && wave == 0;
+  long long sp_wait = 0, sp_k = 0, sp_epi = 0, sp_tiles = 0, sp_t0 = 0, sp_life0 = 0;
+  if (sp_on) sp_life0 = SP_NOW();
 #pragma unroll 1
   for (long long n = 0; tile_at(n) < tiles; ++n) {
     const long long t = tile_at(n);
+    if (sp_on) sp_t0 = SP_NOW();
     if (PRO == SPRO_POOLBWD && tile_at(n + 1) < tiles) issue_pb(tile_at(n + 1), par ^ 1);
     f32x16 acc[NT];
 #pragma unroll
@@ -374,8 +397,11 @@ __global__ __launch_bounds__(64 * WAVES, (NT == 4 && WAVES == 4) ? 1 : 2) void r
     for (int c = 0; c < KCT; ++c) {
       const unsigned char *sl = ring + slot * CHUNK_BYTES;
       if (c < KC) {
+        long long sp_a = 0;
+        if (sp_on) sp_a = SP_NOW();
         if (issue_next()) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * DEPTH) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (sp_on) sp_wait += SP_NOW() - sp_a;
         if (PRO == SPRO_BNRELU) {
           // BatchNorm + ReLU applied in place on the landed chunk, every lane on the four
           // 16-byte pieces it requested (row-coalesced for the side store), before any
@@ -463,6 +489,8 @@ __global__ __launch_bounds__(64 * WAVES, (NT == 4 && WAVES == 4) ? 1 : 2) void r
       if (c < KC) slot = slot + 1 == SLOTS ? 0 : slot + 1;
     }
     par ^= 1;
+    long long sp_t1 = 0;
+    if (sp_on) { sp_t1 = SP_NOW(); sp_k += sp_t1 - sp_t0; }
 
     if constexpr (EPI == EPI_EVAL) {
     if (p.pool_ns > 0) {
@@ -516,42 +544,42 @@ __global__ __launch_bounds__(64 * WAVES, (NT == 4 && WAVES == 4) ? 1 : 2) void r
         for (int e = 0; e < 16; ++e) acc[j][e] += pbias[j];
     }
     if constexpr (EPI == EPI_RAW) {
-      // ---- training, pooled layer: running max / min (+ first index) per centre ------------
+      // ---- training, pooled layer: running maximum of sign * y (+ first index) per centre --
       const int ns = p.pool_ns;
-      const int sl = 4 * lk + ((ns == 64 && (n & 1)) ? 32 : 0);   // sample index of this lane's e = 0
+      const int tb = (ns == 64 && (n & 1)) ? 32 : 0;              // wave-uniform row base of the tile
       const bool full = r0 + 32 <= M;                             // (M % ns == 0: only a last tile is ragged)
+      // ascending rows of this lane, strict compares: the first extremum is kept.  The index is
+      // tracked without the lane's own 4 lk (a wave-uniform operand: no add per element)
       if (ns != 16) {
+        if (full) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
+          for (int j = 0; j < NT; ++j)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) {          // ascending rows of this lane: strict compares
-            const int ro = (e & 3) + 8 * (e >> 2);                // keep the first extremum
-            const float v = acc[j][e];
-            if (full || r0 + ro + 4 * lk < M) {
-              if (v > rmax[j][0]) { rmax[j][0] = v; ramax[j][0] = sl + ro; }
-              if (v < rmin[j][0]) { rmin[j][0] = v; ramin[j][0] = sl + ro; }
+            for (int e = 0; e < 16; ++e) {
+              const float v = acc[j][e];
+              if (v > rmax[j][0]) { rmax[j][0] = v; ramax[j][0] = tb + (e & 3) + 8 * (e >> 2); }
             }
-          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int ro = (e & 3) + 8 * (e >> 2);
+              const float v = acc[j][e];
+              if (r0 + ro + 4 * lk < M && v > rmax[j][0]) { rmax[j][0] = v; ramax[j][0] = tb + ro; }
+            }
         }
       } else {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
           for (int e = 0; e < 16; ++e) {          // rows 0-15 (e < 8) / 16-31: two centres
-            const int rl = (e & 3) + 8 * (e >> 2) + 4 * lk;
+            const int ro = (e & 3) + 8 * (e >> 2);
             const float v = acc[j][e];
-            const int s = rl & 15;
-            if (full || r0 + rl < M) {
-              if (e < 8) {
-                if (v > rmax[j][0]) { rmax[j][0] = v; ramax[j][0] = s; }
-                if (v < rmin[j][0]) { rmin[j][0] = v; ramin[j][0] = s; }
-              } else {
-                if (v > rmax[j][1]) { rmax[j][1] = v; ramax[j][1] = s; }
-                if (v < rmin[j][1]) { rmin[j][1] = v; ramin[j][1] = s; }
-              }
+            if ((full || r0 + ro + 4 * lk < M) && v > rmax[j][e >> 3]) {
+              rmax[j][e >> 3] = v; ramax[j][e >> 3] = ro & 15;
             }
           }
-        }
       }
       if (ns != 64 || (n & 1)) {
         const long long centres = M / ns;
@@ -562,18 +590,16 @@ __global__ __launch_bounds__(64 * WAVES, (NT == 4 && WAVES == 4) ? 1 : 2) void r
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             if (h == 1 && ns != 16) continue;
-            float v1 = rmax[j][h], v0 = rmin[j][h];
-            int a1 = ramax[j][h], a0 = ramin[j][h];
-            const float o1 = __shfl_xor(v1, 32, 64), o0 = __shfl_xor(v0, 32, 64);
-            const int b1 = __shfl_xor(a1, 32, 64), b0 = __shfl_xor(a0, 32, 64);
+            float v1 = rmax[j][h];
+            int a1 = ramax[j][h] + 4 * lk;
+            const float o1 = __shfl_xor(v1, 32, 64);
+            const int b1 = __shfl_xor(a1, 32, 64);
             if (o1 > v1 || (o1 == v1 && b1 < a1)) { v1 = o1; a1 = b1; }
-            if (o0 < v0 || (o0 == v0 && b0 < a0)) { v0 = o0; a0 = b0; }
             if (lk == 0 && col < N && c0 + h < centres) {
               const long long o = (c0 + h) * N + col;
-              p.raw_max[o] = v1; p.raw_amax[o] = a1;
-              p.raw_min[o] = v0; p.raw_amin[o] = a0;
+              p.ext[o] = v1 * esgn[j]; p.aext[o] = a1;
             }
-            rmax[j][h] = -INFINITY; rmin[j][h] = INFINITY; ramax[j][h] = ramin[j][h] = 0;
+            rmax[j][h] = -INFINITY; ramax[j][h] = 0;
           }
         }
       }
@@ -585,14 +611,30 @@ __global__ __launch_bounds__(64 * WAVES, (NT == 4 && WAVES == 4) ? 1 : 2) void r
       const int col = 32 * j + li;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
+        // (columns >= N meet zero weight planes: they add exact zeros, no predicate; rows are
+        // checked in a ragged last tile only -- per element the 64-bit compare and the select
+        // tripled the vector-ALU work of this loop)
         float a4[4];
+        if (r0 + 32 <= M) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float v = acc[j][4 * g + i];
-          a4[i] = v;
-          if (r0 + 8 * g + 4 * lk + i < M && col < N) { s1[j] += v; s2[j] += v * v; }
+          for (int i = 0; i < 4; ++i) {
+            const float v = acc[j][4 * g + i];
+            a4[i] = v;
+            s1[j] += v; s2[j] += v * v;
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float v = acc[j][4 * g + i];
+            a4[i] = v;
+            if (r0 + 8 * g + 4 * lk + i < M) { s1[j] += v; s2[j] += v * v; }
+          }
         }
         if (p.Y == nullptr) continue;             // statistics only (pooled training layer)
+        if constexpr (EPI == EPI_RAW) {           // the products carry the folded sign
+#pragma unroll
+          for (int i = 0; i < 4; ++i) a4[i] *= esgn[j];
+        }
         quad_transpose(a4, lane);
         const long long row = r0 + 8 * g + 4 * lk + (lane & 3);
         const int c0 = 32 * j + (li & ~3);
@@ -608,12 +650,17 @@ __global__ __launch_bounds__(64 * WAVES, (NT == 4 && WAVES == 4) ? 1 : 2) void r
         }
       }
     }
+    if (sp_on) { sp_epi += SP_NOW() - sp_t1; ++sp_tiles; }
   }
 
+  if (sp_on && lane == 0) {
+    sprof[0] = sp_wait; sprof[1] = sp_k - sp_wait; sprof[2] = sp_epi; sprof[3] = sp_tiles;
+    sprof[4] = SP_NOW() - sp_life0;
+  }
   if (p.partial != nullptr) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const float t1 = s1[j] + __shfl_xor(s1[j], 32, 64);
+      const float t1 = (s1[j] + __shfl_xor(s1[j], 32, 64)) * (EPI == EPI_RAW ? esgn[EPI == EPI_RAW ? j : 0] : 1.f);
       const float t2 = s2[j] + __shfl_xor(s2[j], 32, 64);
       const int col = 32 * j + li;
       if (lk == 0 && col < N && wid < p.partial_rows) {
@@ -704,7 +751,7 @@ int launch_cfg(const StreamArgs &a, int cfg, int blocks, size_t lds, hipStream_t
 // gather x eval; gather x train; pool-backward x train
 template <int NT, int PRO>
 int launch_epi(const StreamArgs &a, int cfg, int blocks, size_t lds, hipStream_t st) {
-  const int epi = a.raw_max != nullptr ? EPI_RAW : (a.ep_mean != nullptr ? EPI_EVAL : EPI_TRAIN);
+  const int epi = a.ext != nullptr ? EPI_RAW : (a.ep_mean != nullptr ? EPI_EVAL : EPI_TRAIN);
   if (epi == EPI_TRAIN) return launch_cfg<NT, PRO, EPI_TRAIN>(a, cfg, blocks, lds, st);
   if constexpr (PRO == SPRO_NONE || PRO == SPRO_BNRELU)
     if (epi == EPI_RAW) return launch_cfg<NT, PRO, EPI_RAW>(a, cfg, blocks, lds, st);
@@ -743,6 +790,13 @@ extern "C" int s2c_rows_stream_supported(long long M, int N, int K, int gather) 
   if (!stream_on() || pick_cfg(M, N, K, gather ? SPRO_GATHER : SPRO_BNRELU) < 0) return 0;
   if (gather) return (K - 3) % 4 == 0 && K - 3 >= 100;
   return K % 4 == 0;
+}
+
+// Diagnostics: see g_sprof.  prof == NULL switches it off.
+extern "C" int s2c_gemm_stream_set_profile(long long *prof, int block) {
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_sprof), &prof, sizeof(prof)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_sprof_block), &block, sizeof(block)) != hipSuccess) return -1;
+  return 0;
 }
 
 // Workgroups of the persistent grid (default 240 of the 256 CUs; S2C_GEMM_STREAM_GRID).  A
@@ -843,16 +897,15 @@ extern "C" int s2c_rows_gemm_bn_relu_side(long long M, int N, int K, const float
 
 // The pooled LAST layer of a training stack: products as s2c_rows_gemm_bn_relu_side (scale ==
 // NULL: plain operand, no side output), statistics partials as s2c_rows_gemm, and instead of
-// (or, Y != NULL, besides) Y the per-centre raw extrema (StreamArgs::raw_max): the BatchNorm +
-// ReLU + max-pool that follows (s2c_pool_select) reads J x N values, not M x N.  -2: shape not
-// taken by the streaming kernel.
+// (or, Y != NULL, besides) Y the per-centre extremum the pooled BatchNorm + ReLU will select
+// (StreamArgs::ext; `gamma` = the BatchNorm weight of THIS layer, NULL = all positive):
+// s2c_pool_select reads J x N values, not M x N.  -2: shape not taken by the streaming kernel.
 extern "C" int s2c_rows_gemm_pool_raw(long long M, int N, int K, const float *A, int lda,
                                       const float *scale, const float *shift, int relu,
                                       float *side, int ld_side, const float *W, int ldw,
-                                      int pool_ns, float *raw_max, int *raw_amax, float *raw_min,
-                                      int *raw_amin, float *Y, int ldy, float *partial,
-                                      void *stream) {
-  if (M <= 0 || N <= 0 || K <= 0 || !A || !W || !raw_max || !raw_amax || !raw_min || !raw_amin ||
+                                      int pool_ns, const float *gamma, float *ext, int *aext,
+                                      float *Y, int ldy, float *partial, void *stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || !A || !W || !ext || !aext ||
       lda < K || ldw < K || !(pool_ns == 16 || pool_ns == 32 || pool_ns == 64) || M % pool_ns)
     return -1;
   if (!s2c_rows_stream_supported(M, N, K, 0) || (lda & 3) || ((uintptr_t)A & 15) ||
@@ -863,8 +916,7 @@ extern "C" int s2c_rows_gemm_pool_raw(long long M, int N, int K, const float *A,
   a.M = M; a.N = N; a.K = K; a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.Y = Y; a.ldy = ldy;
   a.partial = partial; a.partial_rows = s2c_rows_gemm_blocks(M, N);
   a.scale = scale; a.shift = shift; a.relu = relu; a.side = side; a.ld_side = ld_side;
-  a.pool_ns = pool_ns; a.raw_max = raw_max; a.raw_amax = raw_amax; a.raw_min = raw_min;
-  a.raw_amin = raw_amin;
+  a.pool_ns = pool_ns; a.ext = ext; a.aext = aext; a.ext_sign = gamma;
   if (scale != nullptr) return launch_stream<SPRO_BNRELU>(a, (hipStream_t)stream);
   return launch_stream<SPRO_NONE>(a, (hipStream_t)stream);
 }

@@ -615,39 +615,28 @@ extern "C" int s2c_bn_relu_max(long long J, int ns, int C, const float *Y,
   return check2("bn_relu_max");
 }
 
-// 4b. The same outputs from the per-centre raw extrema of Y (s2c_rows_gemm_pool_raw):
-// relu(y * scale + shift) is monotone in y, so its maximum over the rows of a centre is taken
-// at max y when scale >= 0 and at min y otherwise.  out / ymax as bn_relu_max; arg = the first
-// row of that extremum (where bn_relu_max's "first maximum AFTER the ReLU" differs -- every
-// row clamped to 0 -- the routed gradient is masked to zero anyway).
+// 4b. The same outputs from the per-centre extremum of Y that s2c_rows_gemm_pool_raw leaves
+// (relu(y * scale + shift) is monotone in y: max y for scale >= 0, min y otherwise; the GEMM
+// already chose by the sign of gamma): out = relu(ext * scale + shift); `ext` IS bn_relu_max's
+// ymax and `aext` its arg (the first row of the extremum; where "first maximum AFTER the ReLU"
+// differs -- every row clamped to 0 -- the routed gradient is masked to zero anyway).
 __global__ __launch_bounds__(256) void pool_select_kernel(
-    const float *__restrict__ raw_max, const int *__restrict__ raw_amax,
-    const float *__restrict__ raw_min, const int *__restrict__ raw_amin,
-    const float *__restrict__ scale, const float *__restrict__ shift, float *__restrict__ out,
-    int *__restrict__ arg, float *__restrict__ ymax, long long total, int C) {
+    const float *__restrict__ ext, const float *__restrict__ scale,
+    const float *__restrict__ shift, float *__restrict__ out, long long total, int C) {
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total;
        e += (long long)gridDim.x * 256) {
     const int c = (int)(e % C);
-    const float sc = scale[c], sh = shift[c];
-    const bool up = sc >= 0.f;
-    const float y = up ? raw_max[e] : raw_min[e];
-    out[e] = fmaxf(y * sc + sh, 0.f);
-    arg[e] = up ? raw_amax[e] : raw_amin[e];
-    if (ymax != nullptr) ymax[e] = y;
+    out[e] = fmaxf(ext[e] * scale[c] + shift[c], 0.f);
   }
 }
 
-extern "C" int s2c_pool_select(long long J, int C, const float *raw_max, const int *raw_amax,
-                               const float *raw_min, const int *raw_amin, const float *scale,
-                               const float *shift, float *out, int *arg, float *ymax,
-                               void *stream) {
-  if (J < 0 || C <= 0 || !raw_max || !raw_amax || !raw_min || !raw_amin || !scale || !shift ||
-      !out || !arg)
+extern "C" int s2c_pool_select(long long J, int C, const float *ext, const float *scale,
+                               const float *shift, float *out, void *stream) {
+  if (J < 0 || C <= 0 || !ext || !scale || !shift || !out)
     return fail2("pool_select: sizes / null pointer");
   if (J == 0) return 0;
   hipLaunchKernelGGL(pool_select_kernel, dim3(grid1d(J * C, 256)), dim3(256), 0,
-                     (hipStream_t)stream, raw_max, raw_amax, raw_min, raw_amin, scale, shift, out,
-                     arg, ymax, J * C, C);
+                     (hipStream_t)stream, ext, scale, shift, out, J * C, C);
   return check2("pool_select");
 }
 

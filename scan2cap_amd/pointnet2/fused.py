@@ -137,7 +137,12 @@ def _hand_dw_pays(M, C, N):
 
 
 def _hand_da_pays(M, C, N):
-    return HAND_EVERYWHERE or (M >= 262144 and N <= 64)
+    """dX (M x N) = dY (M x C) W: the streaming kernel for tall narrow layers, the 64-k-chunk
+    kernel for N > 64 from 32768 rows on (tools/bench_da_mid.py, us library vs hand incl. the
+    W^T copy: (32768,128,128) 21 vs 19 | (32768,128,259) 38 vs 33 | (65536,128,259) 65 vs 55 |
+    (65536,256,128) 43 vs 40 | (262144,256,128) 149 vs 140 | (262144,128,131) 124 vs 127; below
+    32768 rows hipBLASLt is ahead inside a replayed graph: (8192,256,256) 13 vs 20)."""
+    return HAND_EVERYWHERE or (M >= 262144 and N <= 64) or (M >= 32768 and N > 64)
 
 
 def _gemm_split_on():
@@ -285,8 +290,8 @@ class LayerSpec(object):
         self.has_bias, self.bn, self.relu = has_bias, bn, relu
 
 
-_C.register("s2c_rows_gemm_pool_raw", [_L, _I, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P])
-_C.register("s2c_pool_select", [_L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P])
+_C.register("s2c_rows_gemm_pool_raw", [_L, _I, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P])
+_C.register("s2c_pool_select", [_L, _I, _P, _P, _P, _P, _P])
 _C.register("s2c_bn_relu_max_bwd_stats", [_L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P])
 _C.register("s2c_pool_bwd_dk", [_L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_pool_bwd_sp", [_L, _I, _I, _I, _P, _P, _P, _P, _P])
@@ -470,8 +475,8 @@ class _MLPRows(Function):
                 nbg = _gemm_blocks(M, Cout)
                 gpart = torch.empty(nbg * 2 * Cout, device=dev)
                 J = M // pool_ns
-                raws = (torch.empty((J, Cout), device=dev), torch.empty((J, Cout), dtype=torch.int32, device=dev),
-                        torch.empty((J, Cout), device=dev), torch.empty((J, Cout), dtype=torch.int32, device=dev))
+                # the extremum BN + ReLU + max will select (by the sign of gamma) and its row
+                raws = (torch.empty((J, Cout), device=dev), torch.empty((J, Cout), dtype=torch.int32, device=dev))
                 if deferred is not None:
                     pY, pscale, pshift, prelu = deferred
                     deferred = None
@@ -483,9 +488,9 @@ class _MLPRows(Function):
                     pro = (None, None, 0, None, 0)
                 _call("s2c_rows_gemm_pool_raw", src, M, Cout, K_in, src.data_ptr(), src.stride(0),
                       pro[0], pro[1], pro[2], pro[3], pro[4], W.data_ptr(), W.stride(0), pool_ns,
-                      raws[0].data_ptr(), raws[1].data_ptr(), raws[2].data_ptr(), raws[3].data_ptr(),
-                      None, 0, gpart.data_ptr(),
-                      alg_bytes=4 * (M * K_in * (2 if pro[0] else 1) + 4 * J * Cout),
+                      _ptr(gamma),
+                      raws[0].data_ptr(), raws[1].data_ptr(), None, 0, gpart.data_ptr(),
+                      alg_bytes=4 * (M * K_in * (2 if pro[0] else 1) + 2 * J * Cout),
                       alg_flops=2 * M * K_in * Cout)
                 Y = None
                 pooled_raw = raws
@@ -552,15 +557,11 @@ class _MLPRows(Function):
                 if last and pool_ns > 0 and pooled_raw is not None:
                     J = M // pool_ns
                     out = torch.empty((J, Cout), device=dev)
-                    arg = torch.empty((J, Cout), dtype=torch.int32, device=dev)
-                    ymax = torch.empty((J, Cout), device=dev)
                     _call("s2c_pool_select", out, J, Cout, pooled_raw[0].data_ptr(),
-                          pooled_raw[1].data_ptr(), pooled_raw[2].data_ptr(),
-                          pooled_raw[3].data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                          out.data_ptr(), arg.data_ptr(), ymax.data_ptr(),
-                          alg_bytes=4 * 7 * J * Cout)
-                    rec["arg"] = arg
-                    rec["ymax"] = ymax
+                          scale.data_ptr(), shift.data_ptr(), out.data_ptr(),
+                          alg_bytes=4 * 2 * J * Cout)
+                    rec["arg"] = pooled_raw[1]
+                    rec["ymax"] = pooled_raw[0]
                     rec["algebra"] = True
                 elif last and pool_ns > 0:
                     J = M // pool_ns
