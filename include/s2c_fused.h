@@ -325,6 +325,13 @@ int s2c_attn_x2_fwd(int R, int K, int H, int F, int E, const float *M, const flo
                     const float *wa, const float *mask, const float *O, const float *Wl, int ldw,
                     const float *bias, const float *add, int ld_add, float *alpha, float *att,
                     int lda, float *x2, int ldx2, void *stream);
+/* backward mirror for K <= 32 keys: datt = W_lang^T[:F] da2 formed inside the attention backward
+ * (one launch instead of s2c_small_linear_pair + s2c_attn_bwd); dM / dwa_rows accumulate, dq (row
+ * stride lddq) is overwritten.  F a power of two in 32..256, E <= 512. */
+int s2c_attn_bwd_x2(int R, int K, int H, int F, int E, const float *da2, int ldda,
+                    const float *WlT, int ldw, const float *att, int lda, const float *alpha,
+                    const float *O, const float *M, const float *q, int ldq, const float *wa,
+                    float *dM, float *dq, int lddq, float *dwa_rows, void *stream);
 
 /* its backward from datt (R x F) and the saved forward output att (R x F):
  * dM (R x K x H) and dwa_rows (R x H; dwa = its sum over rows) ACCUMULATE (caller

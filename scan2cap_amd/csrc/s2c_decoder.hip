@@ -646,6 +646,147 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(
   }
 }
 
+// Few keys (K <= AX_MAXK), backward: the transposed map_lang product that yields datt and the
+// whole attention backward in ONE launch (the mirror of attn_x2_kernel: both sides of that
+// boundary only mix data of one batch row):
+//   datt[f] = <WlT[f, :], da2[row, :]>      (WlT = W_lang^T, rows f < F: the att columns)
+//   ds[k]   = alpha[k] * (<O[k, :], datt> - <datt, att>)
+//   dM[k, h] += ds[k] wa[h] (1 - tanh^2(M[k, h] + q[h])),  dq[h] = sum_k (same),  dwa[h] += sum_k ds[k] tanh(.)
+// ONE workgroup of 1024 threads per row: the F x E weights (150 KB) are read once per row, every
+// load of a phase is in flight before the first use (a first version with 4 x 256-thread
+// workgroups per row re-read the weights four times in two dependent batches: 8.6 us, no gain
+// over the two launches it replaced).
+constexpr int ABX_T = 1024;
+__global__ __launch_bounds__(ABX_T) void attn_bwd_x2_kernel(
+    int K, int H, int F, int E, const float *__restrict__ da2, int ldda,
+    const float *__restrict__ WlT, int ldw, const float *__restrict__ att, int lda,
+    const float *__restrict__ alpha, const float *__restrict__ O, const float *__restrict__ M,
+    const float *__restrict__ q, int ldq, const float *__restrict__ wa, float *__restrict__ dM,
+    float *__restrict__ dq, int lddq, float *__restrict__ dwa_rows) {
+  __shared__ __attribute__((aligned(16))) float s_x[512];
+  __shared__ __attribute__((aligned(16))) float s_datt[AX_MAXF];
+  __shared__ float s_red[ABX_T / 64];
+  __shared__ float s_ds[AX_MAXK];
+  __shared__ float4 s_sq[8][128], s_sw[8][128];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int e = tid; e < E; e += ABX_T) s_x[e] = da2[(size_t)row * ldda + e];
+  __syncthreads();
+  // (1) datt: 1024 / F threads per output (8 at F = 128: <= 10 weight loads each, all in flight)
+  {
+    const int tpf = ABX_T / F;                   // F a power of two in 32 .. 256
+    const int f = tid / tpf, part = tid - f * tpf;
+    const float4 *w4 = reinterpret_cast<const float4 *>(WlT + (size_t)f * ldw);
+    const float4 *x4 = reinterpret_cast<const float4 *>(s_x);
+    const int E4 = E >> 2;
+    float acc = 0.0f;
+    for (int j0 = part; j0 < E4; j0 += 12 * tpf) {
+      float4 wv[12];
+#pragma unroll
+      for (int u = 0; u < 12; ++u)
+        wv[u] = j0 + u * tpf < E4 ? w4[j0 + u * tpf] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < 12; ++u)
+        if (j0 + u * tpf < E4) acc += dot4(wv[u], x4[j0 + u * tpf]);
+    }
+    for (int off = 1; off < tpf; off <<= 1) acc += __shfl_xor(acc, off, 64);
+    if (part == 0) s_datt[f] = acc;
+  }
+  __syncthreads();
+  float part = 0.0f;
+  for (int f = tid; f < F; f += ABX_T) part += s_datt[f] * att[(size_t)row * lda + f];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+  if (lane == 0) s_red[wave] = part;
+  __syncthreads();
+  float dot = 0.0f;
+#pragma unroll
+  for (int w = 0; w < ABX_T / 64; ++w) dot += s_red[w];
+  // (2) ds: wave w takes keys w and w + 16; lanes over the F / 4 float4s of a key's features
+  {
+    const int F4 = F >> 2;
+    const float4 d4 = lane < F4 ? reinterpret_cast<const float4 *>(s_datt)[lane]
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 o[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int k = wave + 16 * kk;
+      o[kk] = (k < K && lane < F4)
+                  ? reinterpret_cast<const float4 *>(O)[((size_t)row * K + k) * F4 + lane]
+                  : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int k = wave + 16 * kk;
+      if (k < K) {                               // wave-uniform
+        float da = dot4(o[kk], d4);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) da += __shfl_xor(da, off, 64);
+        if (lane == 0) s_ds[k] = alpha[(size_t)row * K + k] * (da - dot);
+      }
+    }
+  }
+  __syncthreads();
+  // (3) thread = (float4 of hidden units, key group of 8): keys kg, kg + 8, ...
+  const int H4 = H >> 2;
+  const int hl = tid & 127, kg = tid >> 7;
+  for (int h0 = 0; h0 < H4; h0 += 128) {
+    const int h4 = h0 + hl;
+    const bool ok = h4 < H4;
+    float4 sq = make_float4(0.f, 0.f, 0.f, 0.f), sw = sq;
+    if (ok) {
+      const float4 qh = reinterpret_cast<const float4 *>(q + (size_t)row * ldq)[h4];
+      const float4 wh = reinterpret_cast<const float4 *>(wa)[h4];
+      constexpr int KT = AX_MAXK / 8;
+      float4 m[KT], dm[KT];
+      float d[KT];
+#pragma unroll
+      for (int j = 0; j < KT; ++j) {
+        const int k = kg + 8 * j;
+        d[j] = k < K ? s_ds[k] : 0.0f;
+        if (d[j] != 0.0f) {
+          const size_t e4 = ((size_t)row * K + k) * H4 + h4;
+          m[j] = reinterpret_cast<const float4 *>(M)[e4];
+          dm[j] = reinterpret_cast<const float4 *>(dM)[e4];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < KT; ++j) {
+        if (d[j] == 0.0f) continue;
+        const int k = kg + 8 * j;
+        const size_t e4 = ((size_t)row * K + k) * H4 + h4;
+        const float cx = fast_tanh(m[j].x + qh.x), cy = fast_tanh(m[j].y + qh.y),
+                    cz = fast_tanh(m[j].z + qh.z), cw = fast_tanh(m[j].w + qh.w);
+        float4 dp;
+        dp.x = d[j] * wh.x * (1.0f - cx * cx);
+        dp.y = d[j] * wh.y * (1.0f - cy * cy);
+        dp.z = d[j] * wh.z * (1.0f - cz * cz);
+        dp.w = d[j] * wh.w * (1.0f - cw * cw);
+        dm[j].x += dp.x; dm[j].y += dp.y; dm[j].z += dp.z; dm[j].w += dp.w;
+        reinterpret_cast<float4 *>(dM)[e4] = dm[j];
+        sq.x += dp.x; sq.y += dp.y; sq.z += dp.z; sq.w += dp.w;
+        sw.x += d[j] * cx; sw.y += d[j] * cy; sw.z += d[j] * cz; sw.w += d[j] * cw;
+      }
+    }
+    if (h0 > 0) __syncthreads();                 // the previous chunk's sums have been read
+    s_sq[kg][hl] = sq;
+    s_sw[kg][hl] = sw;
+    __syncthreads();
+    if (tid < 128 && ok) {
+      float4 a = s_sq[0][tid], b = s_sw[0][tid];
+      for (int g = 1; g < 8; ++g) {                // fixed order: deterministic
+        const float4 u = s_sq[g][tid], v = s_sw[g][tid];
+        a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+        b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+      }
+      reinterpret_cast<float4 *>(dq + (size_t)row * lddq)[h4] = a;
+      float4 *dw = reinterpret_cast<float4 *>(dwa_rows + (size_t)row * H) + h4;
+      float4 w0 = *dw;
+      w0.x += b.x; w0.y += b.y; w0.z += b.z; w0.w += b.w;
+      *dw = w0;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Greedy decoding of every proposal (caption_module.py:502-592) attends over the
 // L = num_locals gathered objects of each row: R = B*K rows (2048..8192) per step.
@@ -877,6 +1018,26 @@ extern "C" int s2c_attn_bwd(int R, int K, int H, int F, const float *datt, int l
                      (hipStream_t)stream, K, H, F, datt, ldd, att, lda, alpha, O, M, q,
                      ldq, wa, dM, dq, dwa_rows);
   return chk("attn_bwd");
+}
+
+// The attention backward of a step for K <= 32 keys with the map_lang^T product in front (see
+// attn_bwd_x2_kernel): da2 (R x E, row stride ldda) = the gradient of map_lang's pre-activation,
+// WlT = W_lang^T ((F + H) x E, rows f < F are read).  dM / dwa_rows accumulate, dq (row stride
+// lddq) is overwritten.
+extern "C" int s2c_attn_bwd_x2(int R, int K, int H, int F, int E, const float *da2, int ldda,
+                               const float *WlT, int ldw, const float *att, int lda,
+                               const float *alpha, const float *O, const float *M,
+                               const float *q, int ldq, const float *wa, float *dM, float *dq,
+                               int lddq, float *dwa_rows, void *stream) {
+  if (R <= 0 || K <= 0 || K > AX_MAXK || F < 32 || F > AX_MAXF || (F & (F - 1)) || (H & 3) ||
+      E <= 0 || E > 512 || (E & 3) || (ldq & 3) || (ldw & 3) || (lddq & 3) || !da2 || !WlT || !att ||
+      !alpha || !O || !M || !q || !wa || !dM || !dq || !dwa_rows ||
+      (((uintptr_t)WlT | (uintptr_t)O | (uintptr_t)M | (uintptr_t)q | (uintptr_t)wa |
+        (uintptr_t)dM | (uintptr_t)dq | (uintptr_t)dwa_rows) & 15))
+    return -1;
+  hipLaunchKernelGGL(attn_bwd_x2_kernel, dim3(R), dim3(ABX_T), 0, (hipStream_t)stream, K, H, F, E, da2, ldda, WlT, ldw, att, lda, alpha, O, M,
+                     q, ldq, wa, dM, dq, lddq, dwa_rows);
+  return chk("attn_bwd_x2");
 }
 
 extern "C" int s2c_attn_local_fwd(int R, int L, int H, int F, const float *mapped,

@@ -97,6 +97,11 @@ FUSE_ATTN_X2 = _os.environ.get("S2C_FUSE_ATTN_X2", "1") != "0"
 ATTN_X2_MAX_K = 32
 _C.register("s2c_attn_x2_fwd", [_I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P,
                                 _P, _I, _P, _I, _P])
+# ... and its backward mirror: the transposed map_lang product inside the attention backward
+# (6 -> 5 dependent launches per backward step); S2C_FUSE_ATTN_X2_BWD=0: the two launches
+FUSE_ATTN_X2_BWD = _os.environ.get("S2C_FUSE_ATTN_X2_BWD", "1") != "0"
+_C.register("s2c_attn_bwd_x2", [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P,
+                                _P, _I, _P, _P])
 
 
 def supported(emb, hid, feat, K):
@@ -232,11 +237,19 @@ class TopDownDecode(Function):
             _batch_prep(srcs, WTs, (dM, dwa_rows, dh1c))
             WT_ih2, WT_hh2, WT_lang, WT_h, WT_ih1, WT_hh1, WT_td_h2 = WTs
             dh2_part = e(R, H)
-            DA1, DA2 = e(T, R, E), e(T, R, E)
+            DA1 = e(T, R, E)
+            # [dq | da2] side by side: one operand of the concatenated dh1 product below
+            DQA = e(T, R, H + E)
+            DQ, DA2 = DQA[:, :, :H], DQA[:, :, H:]
             DGI1, DGH1 = e(T, R, 3 * H), e(T, R, 3 * H)
             DGI2, DGH2 = e(T, R, 3 * H), e(T, R, 3 * H)
-            DQ = e(T, R, H)
-            DV = e(T, R, F + H)               # [datt | dh1 via map_lang]
+            fuse_bwd = (FUSE_ATTN_X2_BWD and K <= ATTN_X2_MAX_K and 32 <= F <= 256
+                        and F & (F - 1) == 0 and E <= 512)
+            # not fused: DV = [datt | dh1 via map_lang]; fused: datt never leaves the attention
+            # backward and dh1 = [W_h^T | W_lang[:, F:]^T] [dq | da2] is ONE product
+            DV = None if fuse_bwd else e(T, R, F + H)
+            WT_hl = torch.cat([WT_h, WT_lang[F:]], 1) if fuse_bwd else None     # (H, H + E)
+            DQc = None if fuse_bwd else e(T, R, H)
             dh2_direct, dh1_direct = e(R, H), e(R, H)
             # 6 launches per step.  GRU-2's gate gradients of step t-1 come out of the
             # epilogue of step t's last product (value = dh2 of step t-1); only the
@@ -246,18 +259,27 @@ class TopDownDecode(Function):
                   _p(DGI2[T - 1]), _p(DGH2[T - 1]), _p(dh2_direct))
             for t in range(T - 1, -1, -1):
                 _lin_pair(R,
-                          _desc(E, 3 * H, WT_ih2, 3 * H, DGI2[t], 3 * H, DA2[t], E,
+                          _desc(E, 3 * H, WT_ih2, 3 * H, DGI2[t], 3 * H, DA2[t], H + E,
                                 gate=X2[t], ldg=E, epi=2),
                           _desc(H, 3 * H, WT_hh2, 3 * H, DGH2[t], 3 * H, dh2_part, H,
                                 add1=dh2_direct, ld1=H))
-                _lin_pair(R, _desc(F + H, E, WT_lang, E, DA2[t], E, DV[t], F + H))
-                _call("s2c_attn_bwd", R, K, H, F, _p(DV[t]), F + H, _p(ATT[t]), F,
-                      _p(ALPHA[t]), _p(O), _p(M), _p(QL[t]), H + E, _p(wa), _p(dM),
-                      _p(DQ[t]), _p(dwa_rows),
-                      alg_bytes=4 * (R * K * (3 * H + F) + R * (2 * H + 2 * K + 2 * F)))
-                _lin_pair(R, _desc(H, H, WT_h, H, DQ[t], H, None, H, add1=DV[t][:, F:],
-                                   ld1=F + H, add2=dh1c, ld2=H),
-                          gates=_gates(S1, t, H1[t], DGI1[t], DGH1[t], dh1_direct))
+                if fuse_bwd:
+                    _call("s2c_attn_bwd_x2", R, K, H, F, E, _p(DA2[t]), H + E, _p(WT_lang), E,
+                          _p(ATT[t]), F, _p(ALPHA[t]), _p(O), _p(M), _p(QL[t]), H + E, _p(wa),
+                          _p(dM), _p(DQ[t]), H + E, _p(dwa_rows),
+                          alg_bytes=4 * (F * E + R * K * (3 * H + F) + R * (2 * H + 2 * K + F + E)))
+                    _lin_pair(R, _desc(H, H + E, WT_hl, H + E, DQA[t], H + E, None, H,
+                                       add1=dh1c, ld1=H),
+                              gates=_gates(S1, t, H1[t], DGI1[t], DGH1[t], dh1_direct))
+                else:
+                    _lin_pair(R, _desc(F + H, E, WT_lang, E, DA2[t], H + E, DV[t], F + H))
+                    _call("s2c_attn_bwd", R, K, H, F, _p(DV[t]), F + H, _p(ATT[t]), F,
+                          _p(ALPHA[t]), _p(O), _p(M), _p(QL[t]), H + E, _p(wa), _p(dM),
+                          _p(DQc[t]), _p(dwa_rows),
+                          alg_bytes=4 * (R * K * (3 * H + F) + R * (2 * H + 2 * K + 2 * F)))
+                    _lin_pair(R, _desc(H, H, WT_h, H, DQc[t], H, None, H, add1=DV[t][:, F:],
+                                       ld1=F + H, add2=dh1c, ld2=H),
+                              gates=_gates(S1, t, H1[t], DGI1[t], DGH1[t], dh1_direct))
                 _lin_pair(R,
                           _desc(E, 3 * H, WT_ih1, 3 * H, DGI1[t], 3 * H, DA1[t], E,
                                 gate=X1[t], ldg=E, epi=2),
@@ -270,7 +292,8 @@ class TopDownDecode(Function):
                                            DGH2[t - 1], dh2_direct))
             # every bias gradient (and the sum over time of DA1) in ONE launch
             TR = T * R
-            da1, da2 = DA1.view(TR, E), DA2.view(TR, E)
+            da1, da2 = DA1.view(TR, E), DQA.view(TR, H + E)[:, H:]
+            dq_all = DQA.view(TR, H + E)[:, :H] if fuse_bwd else DQc.view(TR, H)
             gi1, gh1 = DGI1.view(TR, 3 * H), DGH1.view(TR, 3 * H)
             gi2, gh2 = DGI2.view(TR, 3 * H), DGH2.view(TR, 3 * H)
             (db_cls, DA1s, db_td, db_ih1, db_hh1, db_lang, db_ih2, db_hh2, dwa) = \
@@ -278,7 +301,9 @@ class TopDownDecode(Function):
             DA1s = DA1s.view(R, E)
             # no recurrence through these two: hoisted out of the time loop
             dtf = torch.mm(DA1s, W_td[:, E + H:])                             # (R,F)
-            dO = torch.bmm(ALPHA.permute(1, 2, 0), DV[:, :, :F].permute(1, 0, 2))
+            # datt of every step (no recurrence through it): the not-fused path has it in DV
+            DATT = (torch.matmul(da2, WT_lang[:F].t()).view(T, R, F) if fuse_bwd else DV[:, :, :F])
+            dO = torch.bmm(ALPHA.permute(1, 2, 0), DATT.permute(1, 0, 2))
             # ---- every weight gradient: one stacked GEMM each ------------------
             # (column blocks written in place by the GEMMs: `out=` on a row-strided view is a
             # plain ldc for the library -- no temporaries, no copy kernels)
@@ -289,7 +314,7 @@ class TopDownDecode(Function):
             dW_ih1 = torch.mm(gi1.t(), X1.view(TR, E))
             dW_hh1 = torch.mm(gh1.t(), H1[:-1].reshape(TR, H))
             h1n = H1[1:].reshape(TR, H)
-            dW_h = torch.mm(DQ.view(TR, H).t(), h1n)
+            dW_h = torch.mm(dq_all.t(), h1n)
             dW_lang = torch.empty_like(W_lang)
             torch.mm(da2.t(), ATT.view(TR, F), out=dW_lang[:, :F])
             torch.mm(da2.t(), h1n, out=dW_lang[:, F:])
