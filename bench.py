@@ -79,9 +79,10 @@ class LossConfig(object):
 
 # entry point -> device kernels it launches (for the PMC traffic lookup)
 _GEMM_PLAIN = tuple("rows_gemm%s_kernel<%s, %d>" % (v, g, p)
-                    for v in ("", "_x3") for g in ("2, 2", "4, 1") for p in (0, 1))
+                    for v in ("", "_x3") for g in ("2, 2", "4, 1") for p in (0, 1)) + \
+    ("rows_gemm_c64_kernel<0>", "rows_gemm_c64_kernel<1>")
 _GEMM_GATHER = tuple("rows_gemm%s_kernel<%s, 2>" % (v, g)
-                     for v in ("", "_x3") for g in ("2, 2", "4, 1"))
+                     for v in ("", "_x3") for g in ("2, 2", "4, 1")) + ("rows_gemm_c64_kernel<2>",)
 KERNELS_OF = {
     "s2c_bn_relu_bwd": ("bn_bwd_stats_kernel", "bn_bwd_apply_kernel"),
     "s2c_bn_relu_max_bwd": ("pool_bwd_stats_kernel", "pool_bwd_apply_kernel"),
@@ -100,6 +101,8 @@ KERNELS_OF = {
     "s2c_small_linear_pair": ("small_linear_kernel",),
     "s2c_gru_fwd": ("gru_fwd_kernel",),
     "s2c_attn_bwd": ("attn_bwd_kernel",),
+    "s2c_attn_bwd_x2": ("attn_bwd_x2_kernel",),
+    "s2c_attn_x2_fwd": ("attn_x2_kernel",),
     "s2c_ball_query": ("ball_query_kernel",),
     "s2c_ball_query_grid": ("bq_grid_build_kernel", "ball_query_grid_kernel"),
     "s2c_furthest_point_sampling_bucketed": ("fps_bucket_kernel",),
@@ -418,7 +421,7 @@ GEMM_FAMILY = ("s2c_rows_gemm", "s2c_rows_gemm_bn_relu_side", "s2c_sa_gather_gem
                "s2c_bn_bwd_gemm", "s2c_rows_gemm_bn_eval", "s2c_sa_gather_gemm_bn_eval",
                "s2c_sa_fused_eval")
 _DECODER_CHAIN = ("s2c_small_linear", "s2c_small_linear_pair", "s2c_gru_fwd", "s2c_attn_fwd",
-                  "s2c_attn_bwd", "s2c_gru_gates_bwd")
+                  "s2c_attn_bwd", "s2c_gru_gates_bwd", "s2c_attn_x2_fwd", "s2c_attn_bwd_x2")
 
 
 def family_roofline(table_k, ms_per_step):
@@ -441,7 +444,7 @@ def family_roofline(table_k, ms_per_step):
             # hardware view of the same kernels: matrix-pipe busy cycles (PMC, bf16 pipe:
             # 6 plane products per fp32 product)
             "mfma_busy": pmc_mfma_busy(("rows_stream_gemm_kernel", "rows_gemm_x3_kernel",
-                                        "rows_gemm_kernel")),
+                                        "rows_gemm_c64_kernel", "rows_gemm_kernel")),
             "parts": {k["kernel"]: {"ms_per_step": k["ms_per_step"], "alg_GBps": k["alg_GBps"],
                                     "avg_launch_us": k["avg_us"]} for k in parts}}
 
