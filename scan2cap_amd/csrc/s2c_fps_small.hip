@@ -125,6 +125,139 @@ __global__ __launch_bounds__(T) void fps_small_kernel(int n, int m, int bs, int 
   }
 }
 
+// ---- up to 2048 points: four waves, 32-bit reductions, ONE LDS exchange per round ------------
+// The vote aggregation samples 256 of 1024 votes INSIDE the train / inference step (it cannot run
+// ahead on the geometry stream), 255 strictly serial rounds.  fps_small_kernel spends a round on
+// latency, not work (0.70 us at 1024 points whatever the thread count): 64-bit DPP reductions
+// (two moves, a 64-bit compare and two selects per step, twice per round), an LDS slot write, the
+// barrier, an LDS read, a second reduction, and ANOTHER LDS read for the winner's coordinates.
+// Same selection rule here -- max over (bits(d2) + 1, ~rank), i.e. the reference's first-maximum
+// tree order (sampling_gpu.cu:58-173) -- as two 32-bit passes with a DPP operand (v_max_u32 per
+// step), the winner's coordinates by v_readlane, and one exchange: every wave publishes
+// {hi, lo, x, y, z}, every lane reads the four slots (broadcast) and picks in registers.
+// Diagnostics (PROF instance only): thread 0 of workgroup 0 adds up the cycles of a round's three
+// phases in g_qprof ({own points + wave reductions, publish + barrier, read + pick, rounds}).
+// First reading at 1024 points: 843 + 220 + 672 cycles -- every dependent VALU / DPP / readlane
+// step costs 10-20 cycles with one wave per SIMD, so the round is its dependent-instruction count:
+// the second reduction runs only when two lanes tie on the distance, and the decoding of the
+// winner's index (bit reversal, shifts, a global store: 150-200 cycles in the wave every other
+// wave then waits for at the barrier) is deferred to one parallel pass after the last round.
+__device__ long long *g_qprof = nullptr;
+#define QP_NOW() ([&]() { __builtin_amdgcn_sched_barrier(0); long long t_ = (long long)__builtin_amdgcn_s_memtime(); \
+                          __builtin_amdgcn_sched_barrier(0); return t_; }())
+constexpr int QUAD_MAX_M = 2048;
+template <int PPT, bool PROF>
+__global__ __launch_bounds__(256) void fps_quad_kernel(int n, int m, int bs, int log2bs,
+                                                       const float *__restrict__ xyz,
+                                                       int *__restrict__ idx,
+                                                       const int *__restrict__ verified) {
+  __shared__ uint4 s_a[2][4];      // {hi, lo, bits(x), bits(y)} per wave, double-buffered
+  __shared__ float s_z[2][4];
+  __shared__ u32 s_pick[QUAD_MAX_M];   // ~rank of every round's winner (0: none), decoded at the end
+  if (m <= 0) return;
+  const int b = blockIdx.x;
+  xyz += (size_t)b * n * 3;
+  idx += (size_t)b * m;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (verified != nullptr && verified[b] == 0) {
+    for (int j = t; j < m; j += 256) idx[j] = j;
+    return;
+  }
+  float px[PPT], py[PPT], pz[PPT], mind[PPT];
+  u32 nrank[PPT];  // ~rank
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int k = t + i * 256;
+    const int kk = k < n ? k : n - 1;
+    const float x = xyz[kk * 3 + 0], y = xyz[kk * 3 + 1], z = xyz[kk * 3 + 2];
+    const float mag = sq3(x, y, z);
+    const bool skip = ((double)mag <= 1e-3) || (k >= n);   // sampling_gpu.cu:100-101
+    mind[i] = skip ? -1.0f : 1e10f;
+    px[i] = x; py[i] = y; pz[i] = z;
+    const u32 rank = (bitrev_n((u32)kk & (u32)(bs - 1), log2bs) << 22) | ((u32)kk >> log2bs);
+    nrank[i] = 0xFFFFFFFFu - rank;
+  }
+  const float x0 = xyz[0], y0 = xyz[1], z0 = xyz[2];
+  float cx = x0, cy = y0, cz = z0;
+  long long *qp = g_qprof;
+  const bool qon = PROF && qp != nullptr && blockIdx.x == 0 && wave == 0;
+  long long qa = 0, qb = 0, qc = 0, q0 = 0, q1 = 0, q2 = 0;
+
+  for (int j = 1; j < m; ++j) {
+    if (PROF && qon) q0 = QP_NOW();
+    u32 hi[PPT];
+    u32 hl = 0u;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const float d = sq3(px[i] - cx, py[i] - cy, pz[i] - cz);
+      const float d2 = fminf(d, mind[i]);
+      mind[i] = d2;
+      hi[i] = d2 < 0.0f ? 0u : __float_as_uint(d2) + 1u;    // skipped points never win
+      hl = hi[i] > hl ? hi[i] : hl;
+    }
+    const u32 mhi = wave_umax32(hl);
+    // this lane's candidate among its own points: the largest ~rank at the maximum distance
+    u32 ll = 0u;
+    float bx = 0.f, by = 0.f, bz = 0.f;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const bool w = hi[i] == mhi && nrank[i] > ll;
+      ll = w ? nrank[i] : ll;
+      bx = w ? px[i] : bx; by = w ? py[i] : by; bz = w ? pz[i] : bz;
+    }
+    u64 wl = __ballot(hl == mhi);
+    if (__builtin_popcountll(wl) > 1) {      // (wave-uniform, rare) lanes tie on the distance
+      const u32 mlo = wave_umax32(hl == mhi ? ll : 0u);
+      wl = __ballot(hl == mhi && ll == mlo);
+    }
+    const int src = (int)__builtin_ctzll(wl);       // (mhi == 0: every lane ties with ll = 0)
+    const u32 wlo = (u32)__builtin_amdgcn_readlane((int)ll, src);
+    const float wx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bx), src));
+    const float wy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, by), src));
+    const float wz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bz), src));
+    if (PROF && qon) q1 = QP_NOW();
+    if (lane == 0) {
+      s_a[j & 1][wave] = make_uint4(mhi, mhi ? wlo : 0u, __float_as_uint(wx), __float_as_uint(wy));
+      s_z[j & 1][wave] = wz;
+    }
+    __syncthreads();
+    if (PROF && qon) q2 = QP_NOW();
+    // (component-wise selects: a ternary on the whole uint4 went through scratch memory)
+    u32 b_hi, b_lo, b_x, b_y;
+    float b_z;
+    {
+      const uint4 c0 = s_a[j & 1][0];
+      b_hi = c0.x; b_lo = c0.y; b_x = c0.z; b_y = c0.w; b_z = s_z[j & 1][0];
+    }
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const uint4 c = s_a[j & 1][w];
+      const float czz = s_z[j & 1][w];
+      const bool gt = c.x > b_hi || (c.x == b_hi && c.y > b_lo);
+      b_hi = gt ? c.x : b_hi; b_lo = gt ? c.y : b_lo;
+      b_x = gt ? c.z : b_x; b_y = gt ? c.w : b_y;
+      b_z = gt ? czz : b_z;
+    }
+    if (b_hi == 0u) {                        // nothing selectable: the reference keeps index 0
+      cx = x0; cy = y0; cz = z0;
+    } else {
+      cx = __uint_as_float(b_x); cy = __uint_as_float(b_y); cz = b_z;
+    }
+    if (t == 255) s_pick[j] = b_hi != 0u ? b_lo : 0u;      // (~rank is never 0: rank < 2^31)
+    if (PROF && qon) { const long long q3 = QP_NOW(); qa += q1 - q0; qb += q2 - q1; qc += q3 - q2; }
+  }
+  if (PROF && qon && lane == 0) { qp[0] = qa; qp[1] = qb; qp[2] = qc; qp[3] = m - 1; }
+  __syncthreads();
+  for (int j = t; j < m; j += 256) {
+    int old = 0;
+    if (j > 0 && s_pick[j] != 0u) {
+      const u32 r = 0xFFFFFFFFu - s_pick[j];
+      old = (int)(((r & 0x3FFFFFu) << log2bs) | bitrev_n(r >> 22, log2bs));
+    }
+    idx[j] = old;
+  }
+}
+
 // ---- "is the answer 0, 1, ..., m-1 ?" ------------------------------------------------------
 // FPS of a point set that is already in FPS pick order returns arange(m):
 // SA2 samples SA1's centres, SA3 SA2's, SA4 SA3's (backbone_module.py:106-115), so three of
@@ -237,6 +370,8 @@ __global__ void fps_prefix_set_kernel(int *flag, int b, int v) {
   for (int i = threadIdx.x; i < b; i += blockDim.x) flag[i] = v;
 }
 
+bool g_qprof_host = false;      // host mirror of g_qprof != nullptr (picks the PROF instance)
+
 int ref_opt_n_threads(int work_size) {
   const int pow_2 = (int)(log((double)work_size) / log(2.0));  // cuda_utils.h:13-19
   int t = 1 << pow_2;
@@ -252,6 +387,12 @@ int ref_opt_n_threads(int work_size) {
                      log2bs, xyz, idx, verified)
 
 extern "C" int s2c_fps_small_limit(void) { return 8192; }
+
+// diagnostics of fps_quad_kernel (see g_qprof); prof == NULL switches it off
+extern "C" int s2c_fps_quad_set_profile(long long *prof) {
+  g_qprof_host = prof != nullptr;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_qprof), &prof, sizeof(prof)) == hipSuccess ? 0 : -1;
+}
 
 // threads = 0: heuristic.  Otherwise one of 64/128/256/512/1024 (ceil(n/threads)
 // must be <= 8).
@@ -311,6 +452,33 @@ static int fps_small_launch(int b, int n, int m, const float *xyz, int *idx, int
     if (e) T = atoi(e);
   }
   if (T == 0) {
+    // the four-wave kernel with 32-bit reductions up to 2048 points (S2C_FPS_QUAD=0: off)
+    static int quad = -1;
+    if (quad < 0) {
+      const char *q = getenv("S2C_FPS_QUAD");
+      quad = q ? atoi(q) : 1;
+    }
+    if (quad && n <= 2048 && m <= QUAD_MAX_M) {
+      const int ppt = (n + 255) / 256;
+      const bool prof = g_qprof_host;
+#define FPS_QUAD(P_)                                                                          \
+  do {                                                                                        \
+    if (prof) hipLaunchKernelGGL((fps_quad_kernel<P_, true>), dim3(b), dim3(256), 0, st, n, m, bs, \
+                                 log2bs, xyz, idx, verified);                                 \
+    else hipLaunchKernelGGL((fps_quad_kernel<P_, false>), dim3(b), dim3(256), 0, st, n, m, bs,     \
+                            log2bs, xyz, idx, verified);                                      \
+  } while (0)
+      if (ppt <= 1) FPS_QUAD(1);
+      else if (ppt <= 2) FPS_QUAD(2);
+      else if (ppt <= 4) FPS_QUAD(4);
+      else FPS_QUAD(8);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) {
+        fprintf(stderr, "s2c: fps_quad launch failed: %s\n", hipGetErrorString(e));
+        return (int)e;
+      }
+      return 0;
+    }
     // measured on MI355X (us/round): a single wave (no LDS, no barrier) wins up to
     // 512 points (0.53), 512 threads for 1k..4k points (0.68 / 0.83), 1024 above
     T = n <= 512 ? 64 : (n <= 4096 ? 512 : 1024);
