@@ -23,6 +23,11 @@
 namespace {
 
 constexpr int NPART = 14;
+// One scene = NSEC workgroups (blockIdx.y): sections 0 .. NSEC - 3 share the seeds of the vote
+// loss, NSEC - 2 takes the proposals, NSEC - 1 the ground-truth boxes -- the three loops are
+// independent, and one workgroup per scene ran them one after the other (56 us of dependent
+// global loads on 8 CUs for a few hundred KB of inputs).  partial = (B, NSEC, NPART).
+constexpr int NSEC = 6;
 constexpr int MAXG = 256, MAXK = 1024;
 
 __device__ __forceinline__ float huber1(float e) {   // nn_distance.py:13-30, delta = 1
@@ -57,18 +62,21 @@ __global__ __launch_bounds__(256) void detloss_fwd_kernel(s2c_detloss_args a) {
   __shared__ float s_gt[MAXG * 3];
   __shared__ float s_c[MAXK * 3];
   __shared__ float s_red[4 * NPART];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.x, tid = threadIdx.x, sec = blockIdx.y;
   const int K = a.K, G = a.G;
-  for (int i = tid; i < G * 3; i += 256)
-    s_gt[i] = a.center_label[((size_t)b * G + i / 3) * a.ld_center_label + i % 3];
-  for (int i = tid; i < K * 3; i += 256) s_c[i] = a.center[(size_t)b * K * 3 + i];
+  if (sec >= NSEC - 2) {
+    for (int i = tid; i < G * 3; i += 256)
+      s_gt[i] = a.center_label[((size_t)b * G + i / 3) * a.ld_center_label + i % 3];
+    for (int i = tid; i < K * 3; i += 256) s_c[i] = a.center[(size_t)b * K * 3 + i];
+  }
   __syncthreads();
   float acc[NPART];
 #pragma unroll
   for (int i = 0; i < NPART; ++i) acc[i] = 0.0f;
 
   // ---- vote loss (loss_helper.py:24-69): seeds of this scene
-  for (int s = tid; s < a.S; s += 256) {
+  if (sec < NSEC - 2)
+  for (int s = sec * 256 + tid; s < a.S; s += 256 * (NSEC - 2)) {
     const int idx = a.seed_inds[(size_t)b * a.S + s];
     const float m = (float)a.vote_label_mask[(size_t)b * a.N + idx];
     const float *sx = a.seed_xyz + ((size_t)b * a.S + s) * 3;
@@ -92,6 +100,7 @@ __global__ __launch_bounds__(256) void detloss_fwd_kernel(s2c_detloss_args a) {
   }
 
   // ---- per proposal: objectness (:71-111) and box / class terms (:113-187)
+  if (sec == NSEC - 2)
   for (int k = tid; k < K; k += 256) {
     const size_t bk = (size_t)b * K + k;
     const float *ax = a.agg_xyz + bk * 3;
@@ -153,6 +162,7 @@ __global__ __launch_bounds__(256) void detloss_fwd_kernel(s2c_detloss_args a) {
   }
 
   // ---- per GT box: nearest predicted centre (second chamfer direction)
+  if (sec == NSEC - 1)
   for (int g = tid; g < G; g += 256) {
     const float gx = s_gt[3 * g], gy = s_gt[3 * g + 1], gz = s_gt[3 * g + 2];
     float d2 = 0.0f;
@@ -170,7 +180,7 @@ __global__ __launch_bounds__(256) void detloss_fwd_kernel(s2c_detloss_args a) {
 
   block_sums(acc, s_red);
   if (tid < NPART)
-    a.partial[(size_t)b * NPART + tid] =
+    a.partial[((size_t)b * NSEC + sec) * NPART + tid] =
         (s_red[tid] + s_red[NPART + tid]) + (s_red[2 * NPART + tid] + s_red[3 * NPART + tid]);
 }
 
@@ -183,7 +193,7 @@ __global__ void detloss_finalize_kernel(int B, int K, const float *__restrict__ 
   __shared__ double s_p[NPART];
   if (threadIdx.x < NPART) {
     double s = 0.0;
-    for (int b = 0; b < B; ++b) s += (double)partial[(size_t)b * NPART + threadIdx.x];
+    for (int b = 0; b < B * NSEC; ++b) s += (double)partial[(size_t)b * NPART + threadIdx.x];
     s_p[threadIdx.x] = s;
   }
   __syncthreads();
@@ -214,19 +224,25 @@ __global__ __launch_bounds__(256) void detloss_bwd_kernel(s2c_detloss_args a,
   __shared__ float s_gt[MAXG * 3];
   __shared__ float s_blm[MAXG];
   __shared__ int s_k2[MAXG];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.x, tid = threadIdx.x, sec = blockIdx.y;
   const int K = a.K, G = a.G;
-  for (int i = tid; i < G * 3; i += 256)
-    s_gt[i] = a.center_label[((size_t)b * G + i / 3) * a.ld_center_label + i % 3];
-  for (int i = tid; i < G; i += 256) {
-    s_blm[i] = a.box_label_mask[(size_t)b * G + i];
-    s_k2[i] = a.center_k2[(size_t)b * G + i];
+  // sections NSEC - 2 .. NSEC + 1: the proposals, one group of output tensors each (objectness +
+  // centre | heading | size | semantic class): a thread per proposal wrote ~100 strided floats
+  const int part = sec - (NSEC - 2);
+  if (part == 0) {
+    for (int i = tid; i < G * 3; i += 256)
+      s_gt[i] = a.center_label[((size_t)b * G + i / 3) * a.ld_center_label + i % 3];
+    for (int i = tid; i < G; i += 256) {
+      s_blm[i] = a.box_label_mask[(size_t)b * G + i];
+      s_k2[i] = a.center_k2[(size_t)b * G + i];
+    }
   }
   __syncthreads();
   const float up = gup[0] * 10.0f;
   const float den_v = a.stats[13], den_o = a.stats[14], den_l = a.stats[15], den_b = a.stats[16];
 
-  for (int s = tid; s < a.S; s += 256) {
+  if (sec < NSEC - 2)
+  for (int s = sec * 256 + tid; s < a.S; s += 256 * (NSEC - 2)) {
     const int idx = a.seed_inds[(size_t)b * a.S + s];
     const float m = (float)a.vote_label_mask[(size_t)b * a.N + idx];
     const int arg = a.vote_arg[(size_t)b * a.S + s];
@@ -244,6 +260,7 @@ __global__ __launch_bounds__(256) void detloss_bwd_kernel(s2c_detloss_args a,
     }
   }
 
+  if (part >= 0)
   for (int k = tid; k < K; k += 256) {
     const size_t bk = (size_t)b * K + k;
     const float label = (float)a.objectness_label[bk];
@@ -251,7 +268,7 @@ __global__ __launch_bounds__(256) void detloss_bwd_kernel(s2c_detloss_args a,
     const int g1 = (int)a.object_assignment[bk];
     const size_t bg = (size_t)b * G + g1;
     // objectness scores (weight 0.5)
-    {
+    if (part == 0) {
       const float *os = a.objectness_scores + bk * LD(2);
       const int y = label > 0.0f ? 1 : 0;
       const float w = y ? a.obj_w1 : a.obj_w0;
@@ -262,7 +279,7 @@ __global__ __launch_bounds__(256) void detloss_bwd_kernel(s2c_detloss_args a,
     }
     const float cl = up * label / den_l;
     // centre (both chamfer directions)
-    {
+    if (part == 0) {
       const float *c = a.center + bk * 3;
       const int cg = a.center_g1[bk];
       float gx = 2.0f * (c[0] - s_gt[3 * cg]) * (label / den_l);
@@ -280,7 +297,7 @@ __global__ __launch_bounds__(256) void detloss_bwd_kernel(s2c_detloss_args a,
       d.center[bk * LD(3) + 2] = up * gz;
     }
     // heading (class weight 0.1, residual weight 1)
-    {
+    if (part == 1) {
       const int hc = (int)a.heading_class_label[bg];
       const float *hs = a.heading_scores + bk * LD(a.NH);
       const float l = lse_of(hs, a.NH);
@@ -292,7 +309,7 @@ __global__ __launch_bounds__(256) void detloss_bwd_kernel(s2c_detloss_args a,
       }
     }
     // size (class weight 0.1, residual weight 1, mean over 3 axes)
-    {
+    if (part == 2) {
       const int sc = (int)a.size_class_label[bg];
       const float *ss = a.size_scores + bk * LD(a.NS);
       const float l = lse_of(ss, a.NS);
@@ -309,7 +326,7 @@ __global__ __launch_bounds__(256) void detloss_bwd_kernel(s2c_detloss_args a,
       }
     }
     // semantic class (weight 0.1)
-    {
+    if (part == 3) {
       const int cc = (int)a.sem_cls_label[bg];
       const float *cs = a.sem_cls_scores + bk * LD(a.NC);
       const float l = lse_of(cs, a.NC);
@@ -336,12 +353,12 @@ static bool bad_args(const s2c_detloss_args *a) {
          a->NH > 64 || a->NS > 64 || a->NC > 64 || a->ld_center_label < 3;
 }
 
-extern "C" int s2c_detection_loss_partial_floats(void) { return NPART; }
+extern "C" int s2c_detection_loss_partial_floats(void) { return NPART * NSEC; }
 
 extern "C" int s2c_detection_loss_fwd(const s2c_detloss_args *a, void *stream) {
   if (bad_args(a)) return -1;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(detloss_fwd_kernel, dim3(a->B), dim3(256), 0, st, *a);
+  hipLaunchKernelGGL(detloss_fwd_kernel, dim3(a->B, NSEC), dim3(256), 0, st, *a);
   hipLaunchKernelGGL(detloss_finalize_kernel, dim3(1), dim3(64), 0, st, a->B, a->K,
                      a->partial, a->stats);
   return chk3("detection_loss_fwd");
@@ -351,7 +368,7 @@ extern "C" int s2c_detection_loss_bwd(const s2c_detloss_args *a,
                                       const s2c_detloss_grads *d, const float *gup,
                                       void *stream) {
   if (bad_args(a) || !d || !gup) return -1;
-  hipLaunchKernelGGL(detloss_bwd_kernel, dim3(a->B), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(detloss_bwd_kernel, dim3(a->B, NSEC + 2), dim3(256), 0, (hipStream_t)stream,
                      *a, *d, gup);
   return chk3("detection_loss_bwd");
 }
