@@ -165,20 +165,29 @@ __global__ __launch_bounds__(256) void edge_rows_kernel(
 }
 
 // dx[b,j,:] += dR[e,:F] - dR[e,F:] ; dx[b,i,:] += dR[e,F:]      (dx zeroed by the caller)
+// One wave per CENTRE i: its L edges' contributions to dx[b,i] are summed in registers and added
+// once (L + 1 float atomics per centre and feature instead of 2 L, and the L same-address adds
+// of consecutive waves -- which the memory side serialises -- are gone: 42 -> 25 us at
+// 8 x 256 x 10 edges x 128 features).
 __global__ __launch_bounds__(256) void edge_rows_grad_kernel(
     int K, int L, int F, const float *__restrict__ dR, const long long *__restrict__ nbr,
     float *__restrict__ dx, long long E) {
   const int lane = threadIdx.x & 63;
-  for (long long e = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); e < E;
-       e += (long long)gridDim.x * 4) {
-    const long long bi = e / L, b = bi / K;
-    const long long j = nbr[e];
-    const float *g = dR + e * 2 * F;
-    float *di = dx + bi * F, *dj = dx + (b * K + j) * F;
+  const long long nodes = E / L;
+  for (long long bi = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); bi < nodes;
+       bi += (long long)gridDim.x * 4) {
+    const long long b = bi / K;
+    float *di = dx + bi * F;
     for (int f = lane; f < F; f += 64) {
-      const float a = g[f], d = g[F + f];
-      atomicAdd(dj + f, a - d);
-      atomicAdd(di + f, d);
+      float acc = 0.0f;
+      for (int l = 0; l < L; ++l) {
+        const long long e = bi * L + l;
+        const float *g = dR + e * 2 * F;
+        const float a = g[f], d = g[F + f];
+        atomicAdd(dx + (b * K + nbr[e]) * F + f, a - d);
+        acc += d;
+      }
+      atomicAdd(di + f, acc);
     }
   }
 }
@@ -272,7 +281,7 @@ extern "C" int s2c_edge_rows_grad(int B, int K, int L, int F, const float *d_row
   hipStream_t st = (hipStream_t)stream;
   if (zero_async(dx, sizeof(float) * (size_t)B * K * F, st) != hipSuccess) return -1;
   const long long E = (long long)B * K * L;
-  hipLaunchKernelGGL(edge_rows_grad_kernel, dim3(edge_grid(E)), dim3(256), 0, st, K, L, F,
+  hipLaunchKernelGGL(edge_rows_grad_kernel, dim3(edge_grid(E / L)), dim3(256), 0, st, K, L, F,
                      d_rows, nbr, dx, E);
   return chk_graph("edge_rows_grad");
 }
