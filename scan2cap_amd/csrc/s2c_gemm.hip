@@ -770,6 +770,10 @@ __device__ __forceinline__ float4 mid_load4(const float *__restrict__ row, int k
 //    NEXT chunk in flight while this one is multiplied: half the barriers of the 32-k slices
 //    and twice the bytes in flight per workgroup, two workgroups per CU (70 KB of LDS, <= 256
 //    VGPRs) so that one's loads and stores run under the other's MFMAs.
+// (Also tried: a persistent grid of two workgroups per CU walking the tiles, the first chunk of
+// the NEXT tile requested before the current tile's stores -- slower everywhere, (65536,128,128)
+// 25 -> 34 us, (262144,256,128) 161 -> 180 us: the hardware's dispatch of one workgroup per tile
+// already overlaps one tile's stores with its neighbour's loads, and balances the tail.)
 // The timeline of the 32-k-slice kernel at (262144, 256, 128) (tools/prof_gemm.py) showed what
 // this replaces: 19-27 us per 128 x 128 x 128 tile, of which 3-8 us to issue the first two
 // slices, 1.6 us to issue each later one and 4 us of epilogue -- against 2.6 us of MFMA time.
