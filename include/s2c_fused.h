@@ -148,6 +148,7 @@ int s2c_rows_stream_supported(long long M, int N, int K, int gather);
  * operand also written to side (M x K, row stride ld_side; may be NULL): the previous layer's
  * s2c_bn_relu pass folded into this layer's streaming GEMM (pytorch_utils.py:100-120 between
  * two convs).  Returns -2 when the shape is not one the streaming kernel takes. */
+int s2c_rows_gemm_side_supported(long long M, int N, int K);   /* 1: the call below takes it (relu = 1) */
 int s2c_rows_gemm_bn_relu_side(long long M, int N, int K, const float *A, int lda,
                                const float *scale, const float *shift, int relu, float *side,
                                int ld_side, const float *W, int ldw, float *Y, int ldy,

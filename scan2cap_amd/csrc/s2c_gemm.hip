@@ -786,7 +786,7 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_c64_kernel(
     long long M, int N, int K, const float *__restrict__ A, int lda,
     const float *__restrict__ W, int ldw, const float *__restrict__ pscale,
     const float *__restrict__ pshift, GatherArgs ga, float *__restrict__ Y, int ldy,
-    float *__restrict__ partial, EpiArgs ep) {
+    float *__restrict__ partial, EpiArgs ep, float *__restrict__ side, int ld_side) {
   constexpr int WM = 2, WN = 2, BN = 128;
   extern __shared__ __attribute__((aligned(16))) float c64_smem[];
   __shared__ float s_stat[2][WM][BN];
@@ -883,6 +883,20 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_c64_kernel(
         v.z = k + 2 < K ? fmaxf(v.z * sc.z + sh.z, 0.f) : 0.f;
         v.w = k + 3 < K ? fmaxf(v.w * sc.w + sh.w, 0.f) : 0.f;
         ra[i] = v;
+        // the activated operand leaves as a side output (the weight gradient needs it): the
+        // separate BN+ReLU pass over the pre-activation tensor is gone
+        const long long row = m0 + 16 * i + lr;
+        if (side != nullptr && by == 0 && row < M && k < K) {
+          float *dst = side + row * ld_side + k;
+          if (k + 4 <= K && (ld_side & 3) == 0) {
+            *reinterpret_cast<float4 *>(dst) = v;
+          } else {
+            dst[0] = v.x;
+            if (k + 1 < K) dst[1] = v.y;
+            if (k + 2 < K) dst[2] = v.z;
+            if (k + 3 < K) dst[3] = v.w;
+          }
+        }
       }
     }
 #pragma unroll
@@ -992,7 +1006,8 @@ static bool c64_on() {
 template <int PRO>
 int launch_c64(long long M, int N, int K, const float *A, int lda, const float *W, int ldw,
                const float *pscale, const float *pshift, const GatherArgs &ga, float *Y, int ldy,
-               float *partial, hipStream_t st, const EpiArgs &ep) {
+               float *partial, hipStream_t st, const EpiArgs &ep, float *side = nullptr,
+               int ld_side = 0) {
   static int attr_state[64];                   // per device: 0 unknown, 1 ok, -1 refused
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -1007,7 +1022,7 @@ int launch_c64(long long M, int N, int K, const float *A, int lda, const float *
   const long long nbx = (M + 127) / 128, nby = (N + 127) / 128;
   dim3 grid((unsigned)(8 * ((nbx + 7) / 8) * nby));
   hipLaunchKernelGGL((rows_gemm_c64_kernel<PRO>), grid, dim3(256), C64_LDS_BYTES, st, M, N, K, A,
-                     lda, W, ldw, pscale, pshift, ga, Y, ldy, partial, ep);
+                     lda, W, ldw, pscale, pshift, ga, Y, ldy, partial, ep, side, ld_side);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     fprintf(stderr, "s2c_rows_gemm(c64) launch failed: %s\n", hipGetErrorString(e));
@@ -1240,6 +1255,25 @@ extern "C" int s2c_gemm_set_c64(int on) {
   const int old = c64_on() ? 1 : 0;
   g_c64 = on ? 1 : 0;
   return old;
+}
+
+// s2c_rows_gemm_bn_relu_side (s2c_gemm2.hip) for the shapes its streaming kernel leaves: N > 64
+// on the 64-k-chunk kernel, the activated operand written by the column-block-0 workgroups
+// while they stage it.  -2: not taken (N <= 64, split products or the kernel switched off).
+extern "C" int s2c_rows_gemm_c64_bn_relu_side(long long M, int N, int K, const float *A, int lda,
+                                              const float *scale, const float *shift,
+                                              float *side, int ld_side, const float *W, int ldw,
+                                              float *Y, int ldy, float *partial, void *stream) {
+  if (!use_split() || !c64_on() || N <= 64) return -2;
+  if (M <= 0 || K <= 0 || !A || !W || !Y || !scale || !shift || lda < K || ldw < K ||
+      (side && ld_side < K))
+    return -1;
+  GatherArgs ga = {};
+  return launch_c64<PRO_BNRELU>(M, N, K, A, lda, W, ldw, scale, shift, ga, Y, ldy, partial,
+                                (hipStream_t)stream, EpiArgs(), side, ld_side);
+}
+extern "C" int s2c_rows_gemm_c64_supported(long long M, int N, int K) {
+  return use_split() && c64_on() && M > 0 && N > 64 && K > 0;
 }
 
 /* 1: bf16x3 split products (default), 0: exact fp32 MFMA chain.  Returns the previous

@@ -783,6 +783,12 @@ int launch_stream(const StreamArgs &a, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int s2c_rows_gemm_c64_bn_relu_side(long long M, int N, int K, const float *A, int lda,
+                                              const float *scale, const float *shift,
+                                              float *side, int ld_side, const float *W, int ldw,
+                                              float *Y, int ldy, float *partial, void *stream);
+extern "C" int s2c_rows_gemm_c64_supported(long long M, int N, int K);
+
 // 1 when s2c_rows_gemm / s2c_sa_gather_gemm hand this shape to the streaming kernel
 // (plain operand: K, lda multiples of 4 and 16-byte aligned A; gather: C a multiple of 4,
 // C >= 100, ns in {16, 32, 64}).
@@ -886,13 +892,23 @@ extern "C" int s2c_rows_gemm_bn_relu_side(long long M, int N, int K, const float
   if (M <= 0 || N <= 0 || K <= 0 || !A || !W || !Y || !scale || !shift || lda < K || ldw < K)
     return -1;
   if (!s2c_rows_stream_supported(M, N, K, 0) || (lda & 3) || ((uintptr_t)A & 15) ||
-      (ldy & 3) || ((uintptr_t)Y & 15) || (side && ((ld_side & 3) || ((uintptr_t)side & 15))))
+      (ldy & 3) || ((uintptr_t)Y & 15) || (side && ((ld_side & 3) || ((uintptr_t)side & 15)))) {
+    // mid-size / wide layers: the 64-k-chunk kernel of s2c_gemm.hip (ReLU prologue only)
+    if (relu && ((uintptr_t)scale & 15) == 0 && ((uintptr_t)shift & 15) == 0)
+      return s2c_rows_gemm_c64_bn_relu_side(M, N, K, A, lda, scale, shift, side, ld_side, W, ldw,
+                                            Y, ldy, partial, stream);
     return -2;
+  }
   StreamArgs a = {};
   a.M = M; a.N = N; a.K = K; a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.Y = Y; a.ldy = ldy;
   a.partial = partial; a.partial_rows = s2c_rows_gemm_blocks(M, N);
   a.scale = scale; a.shift = shift; a.relu = relu; a.side = side; a.ld_side = ld_side;
   return launch_stream<SPRO_BNRELU>(a, (hipStream_t)stream);
+}
+
+// 1 when s2c_rows_gemm_bn_relu_side takes (M, N, K) with a ReLU prologue on one of its kernels
+extern "C" int s2c_rows_gemm_side_supported(long long M, int N, int K) {
+  return s2c_rows_stream_supported(M, N, K, 0) || s2c_rows_gemm_c64_supported(M, N, K);
 }
 
 // The pooled LAST layer of a training stack: products as s2c_rows_gemm_bn_relu_side (scale ==

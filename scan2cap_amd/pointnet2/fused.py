@@ -396,6 +396,14 @@ def _next_takes_prologue(specs, params, pi, li, M, K):
             and (bn.training or bn.running_mean is None) and W.stride(1) == 1
             and W.dtype == torch.float32 and W.is_cuda):
         return False
+    if nsp is not None and specs[li].relu:
+        # ReLU prologue: also the 64-k-chunk kernel (N > 64 layers the streaming kernel leaves)
+        lib = _C.load()
+        if not hasattr(lib, "_s2c_side_sig"):
+            lib.s2c_rows_gemm_side_supported.argtypes = [_L, _I, _I]
+            lib.s2c_rows_gemm_side_supported.restype = _I
+            lib._s2c_side_sig = True
+        return bool(lib.s2c_rows_gemm_side_supported(M, W.shape[0], K))
     return _stream_takes(M, W.shape[0], K)
 
 
