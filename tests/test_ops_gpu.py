@@ -84,6 +84,30 @@ def test_fps_bucketed_adversarial(ext, oracle, monkeypatch, impl):
         np.testing.assert_array_equal(brute, want, err_msg=name + " (brute)")
 
 
+@pytest.mark.parametrize("n,m", [(200, 64), (1024, 256), (2048, 300), (777, 777)])
+def test_fps_quad_kernel_ties_and_skips(ext, oracle, n, m):
+    """The four-wave kernel of the default dispatch up to 2048 points (fps_quad_kernel: 32-bit
+    two-pass arg-max, second pass only on a distance tie, deferred index decoding) on inputs made
+    of ties: every point identical, a regular lattice (masses of bit-equal distances, within a
+    lane, across lanes and across waves), scenes where all but a few points are skipped by the
+    |p|^2 <= 1e-3 rule, all points skipped, and a vote-like cloud."""
+    rng = np.random.default_rng(n + m)
+    same = np.full((2, n, 3), 1.25, np.float32)
+    side = int(round(n ** (1.0 / 3.0))) + 1
+    g = np.stack(np.meshgrid(np.arange(side), np.arange(side), np.arange(side), indexing="ij"),
+                 -1).reshape(-1, 3)[:n]
+    lattice = (g.astype(np.float32) * 0.125 + 0.5)[None]
+    skipped = rng.uniform(-0.015, 0.015, size=(2, n, 3)).astype(np.float32)
+    skipped[0, n // 2:n // 2 + 7] = rng.uniform(1, 2, size=(7, 3))
+    votes = (rng.normal(0, 0.05, size=(3, n, 3)) +
+             rng.uniform(-3, 3, size=(3, 1, 3)).repeat(n, 1) * (rng.random((3, n, 1)) < 0.5)
+             ).astype(np.float32)
+    for name, xyz in (("same", same), ("lattice", lattice), ("skipped", skipped), ("votes", votes)):
+        want = oracle.furthest_point_sampling(xyz, m)
+        got = ext.furthest_point_sampling(dev(xyz), m).cpu().numpy()
+        np.testing.assert_array_equal(got, want, err_msg=name)
+
+
 @pytest.mark.parametrize("threads", [64, 128, 256, 512, 1024])
 def test_fps_small_any_geometry(ext, oracle, threads, monkeypatch):
     """The tie-break emulation must not depend on the launch geometry."""
