@@ -114,6 +114,22 @@ int s2c_bn_relu_bwd(long long M, int C, const float *dA, const float *Y,
  * -- one pass over (dA, Y) instead of an apply pass plus a GEMM that re-reads dY (reference:
  * autograd of Conv -> BatchNorm -> ReLU, lib/pointnet2/pytorch_utils.py:67-120).
  * s2c_bn_bwd_gemm returns -2 when the bf16x3 GEMM is switched off. */
+/* ... and with the statistics half formed elsewhere: s2c_bn_bwd_gemm_next_stats leaves the column
+ * sums of the PREVIOUS layer's BatchNorm backward (its upstream gradient is that GEMM's output) in
+ * `npartial` (s2c_rows_gemm_blocks(M, N) rows of [s1 | s2]); s2c_bn_bwd_finalize_partials turns
+ * them into coef / dgamma / dbeta, s2c_bn_relu_bwd_apply is the apply half on its own. */
+int s2c_bn_bwd_gemm_next_stats(long long M, int C, int N, const float *dA, const float *Y,
+                               const float *scale, const float *shift, const float *mean,
+                               const float *invstd, const float *coef, int relu, const float *Wt,
+                               int ldw, float *dY, float *dX, int ldx, const float *nY,
+                               const float *nscale, const float *nshift, const float *nmean,
+                               const float *ninvstd, int nrelu, float *npartial, void *stream);
+int s2c_bn_bwd_finalize_partials(int nblk, long long M, int C, const float *partial, int frozen,
+                                 const float *gamma, const float *invstd, float *coef,
+                                 float *dgamma, float *dbeta, void *stream);
+int s2c_bn_relu_bwd_apply(long long M, int C, const float *dA, const float *Y, const float *scale,
+                          const float *shift, const float *mean, const float *invstd,
+                          const float *coef, int relu, float *dY, void *stream);
 int s2c_bn_relu_bwd_stats(long long M, int C, const float *dA, const float *Y,
                           const float *scale, const float *shift, const float *mean,
                           const float *invstd, const float *gamma, int relu, int frozen,

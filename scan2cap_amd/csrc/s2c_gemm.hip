@@ -84,6 +84,15 @@ struct BwdArgs {
   const float *scale, *shift, *mean, *invstd, *coef;   // K each; coef = 3 K
   float *dY;                      // (M x K) side output, may be nullptr
   int relu;
+  // The GEMM's output dX IS the upstream gradient of the PREVIOUS layer (N channels), whose own
+  // BatchNorm backward starts with two column sums over (dX, that layer's pre-activation nY):
+  //   s1 = sum dz, s2 = sum dz * (nY - nmean) * ninvstd,  dz = dX * [nY * nscale + nshift > 0]
+  // (the arithmetic of bn_bwd_stats_kernel, s2c_sa.hip).  nY != nullptr: the epilogue forms
+  // them from the accumulators -- the statistics pass of the previous layer (a read of dX and
+  // nY, 512 MB at SA1) shrinks to a read of nY here -- and writes them where the forward
+  // statistics go (`partial`: one [s1 | s2] row per row block).
+  const float *nY, *nscale, *nshift, *nmean, *ninvstd;
+  int nrelu;
 };
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -671,10 +680,32 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_x3_kernel(
   // (Wide stores were tried here -- the tile transposed through LDS or with 4x4 DPP
   // exchanges into dwordx4 row pieces -- and LOSE in this skeleton: (1M,64,64) 136 -> 154 us,
   // (262144,128,128) 94 -> 107 us.  They pay in the streaming kernel of s2c_gemm2.hip.)
+  const bool next_stats = PRO == PRO_BNBWD && bw.nY != nullptr;
+  // the previous layer's pre-activations of this lane's 64 elements: every load in flight before
+  // the first store (one round trip, not one per 32 x 32 sub-tile)
+  float ny[PRO == PRO_BNBWD ? 2 : 1][PRO == PRO_BNBWD ? 2 : 1][PRO == PRO_BNBWD ? 16 : 1];
+  if (next_stats) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + li;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const long long row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+          ny[PRO == PRO_BNBWD ? j : 0][PRO == PRO_BNBWD ? i : 0][PRO == PRO_BNBWD ? e : 0] =
+              (row < M && col < N) ? bw.nY[row * (long long)N + col] : 0.f;
+        }
+    }
+  }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = n0 + wn * 64 + j * 32 + li;
     float s1 = 0.f, s2 = 0.f;
+    float nsc = 0.f, nsh = 0.f, nmu = 0.f, nis = 0.f;
+    if (next_stats && col < N) {
+      nsc = bw.nscale[col]; nsh = bw.nshift[col]; nmu = bw.nmean[col]; nis = bw.ninvstd[col];
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -683,8 +714,16 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_x3_kernel(
         const float v = acc[i][j][e];
         if (row < M && col < N) {
           Y[row * ldy + col] = v;
-          s1 += v;
-          s2 += v * v;
+          if (next_stats) {
+            const float y = ny[PRO == PRO_BNBWD ? j : 0][PRO == PRO_BNBWD ? i : 0][PRO == PRO_BNBWD ? e : 0];
+            float dz = v;
+            if (bw.nrelu && !(y * nsc + nsh > 0.f)) dz = 0.f;
+            s1 += dz;
+            s2 += dz * ((y - nmu) * nis);
+          } else {
+            s1 += v;
+            s2 += v * v;
+          }
         }
       }
     }
@@ -1236,8 +1275,37 @@ extern "C" int s2c_bn_bwd_gemm(long long M, int C, int N, const float *dA, const
     return -1;
   }
   GatherArgs ga = {};
-  BwdArgs bw = {Y, scale, shift, mean, invstd, coef, dY, relu};
+  BwdArgs bw = {Y, scale, shift, mean, invstd, coef, dY, relu, nullptr, nullptr, nullptr, nullptr,
+                nullptr, 0};
   return launch_x3<PRO_BNBWD>(M, N, C, dA, C, Wt, ldw, nullptr, nullptr, ga, dX, ldx, nullptr,
+                              (hipStream_t)stream, EpiArgs(), bw);
+}
+
+// The same with the statistics half of the PREVIOUS layer's BatchNorm backward out of the
+// epilogue (BwdArgs::nY): nY (M x N, contiguous) = that layer's pre-activations, nscale / nshift
+// / nmean / ninvstd its N per-channel vectors, npartial = s2c_rows_gemm_blocks(M, N) x 2N floats
+// for s2c_bn_bwd_finalize_partials.  dX must be contiguous (ldx == N).
+extern "C" int s2c_bn_bwd_gemm_next_stats(long long M, int C, int N, const float *dA,
+                                          const float *Y, const float *scale, const float *shift,
+                                          const float *mean, const float *invstd,
+                                          const float *coef, int relu, const float *Wt, int ldw,
+                                          float *dY, float *dX, int ldx, const float *nY,
+                                          const float *nscale, const float *nshift,
+                                          const float *nmean, const float *ninvstd, int nrelu,
+                                          float *npartial, void *stream) {
+  if (!use_split()) return -2;
+  if (M <= 0 || C <= 0 || (C & 3) || N <= 0 || !dA || !Y || !scale || !shift || !mean ||
+      !invstd || !coef || !Wt || !dX || ldw < C || ldx != N || !nY || !nscale || !nshift ||
+      !nmean || !ninvstd || !npartial ||
+      (((uintptr_t)dA | (uintptr_t)Y | (uintptr_t)scale | (uintptr_t)shift | (uintptr_t)mean |
+        (uintptr_t)invstd | (uintptr_t)coef | (uintptr_t)dY) & 15)) {
+    fprintf(stderr, "s2c_bn_bwd_gemm_next_stats: bad arguments\n");
+    return -1;
+  }
+  GatherArgs ga = {};
+  BwdArgs bw = {Y, scale, shift, mean, invstd, coef, dY, relu, nY, nscale, nshift, nmean, ninvstd,
+                nrelu};
+  return launch_x3<PRO_BNBWD>(M, N, C, dA, C, Wt, ldw, nullptr, nullptr, ga, dX, ldx, npartial,
                               (hipStream_t)stream, EpiArgs(), bw);
 }
 

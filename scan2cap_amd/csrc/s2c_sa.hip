@@ -773,6 +773,33 @@ extern "C" int s2c_bn_relu_bwd_stats(long long M, int C, const float *dA, const 
   return check2("bn_relu_bwd_stats");
 }
 
+// The two halves on their own, for a caller whose column sums already exist (formed in the
+// epilogue of the GEMM that produced dA: s2c_bn_bwd_gemm_next_stats): `partial` = nblk rows of
+// [s1 (C) | s2 (C)].
+extern "C" int s2c_bn_bwd_finalize_partials(int nblk, long long M, int C, const float *partial,
+                                            int frozen, const float *gamma, const float *invstd,
+                                            float *coef, float *dgamma, float *dbeta,
+                                            void *stream) {
+  if (nblk <= 0 || M <= 0 || C <= 0 || !partial || !invstd || !coef)
+    return fail2("bn_bwd_finalize_partials: sizes / null pointer");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(FIN_BLOCK), 0, (hipStream_t)stream,
+                     partial, nblk, C, M, frozen, gamma, invstd, dgamma, dbeta, coef);
+  return check2("bn_bwd_finalize_partials");
+}
+
+extern "C" int s2c_bn_relu_bwd_apply(long long M, int C, const float *dA, const float *Y,
+                                     const float *scale, const float *shift, const float *mean,
+                                     const float *invstd, const float *coef, int relu, float *dY,
+                                     void *stream) {
+  if (M <= 0 || C <= 0 || (C & 3) || !dA || !Y || !coef || !dY)
+    return fail2("bn_relu_bwd_apply: C%4==0 / null pointer");
+  const long long total4 = M * (C >> 2);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid1d(total4, 256)), dim3(256), 0,
+                     (hipStream_t)stream, dA, Y, scale, shift, mean, invstd, coef, dY, total4,
+                     C >> 2, C, relu);
+  return check2("bn_relu_bwd_apply");
+}
+
 // max-pool variant: upstream dOut (J x C), arg (J x C); rows M = J*ns.
 __global__ __launch_bounds__(STAT_BLOCK) void pool_bwd_stats_kernel(
     const float *__restrict__ dOut, const float *__restrict__ ymax,

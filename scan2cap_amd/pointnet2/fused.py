@@ -292,6 +292,14 @@ class LayerSpec(object):
 
 _C.register("s2c_rows_gemm_pool_raw", [_L, _I, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P])
 _C.register("s2c_pool_select", [_L, _I, _P, _P, _P, _P, _P])
+_C.register("s2c_bn_bwd_gemm_next_stats", [_L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _I,
+                                           _P, _P, _P, _P, _P, _I, _P, _P])
+_C.register("s2c_bn_bwd_finalize_partials", [_I, _L, _I, _P, _I, _P, _P, _P, _P, _P, _P])
+_C.register("s2c_bn_relu_bwd_apply", [_L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P])
+# the column sums of a layer's BatchNorm backward out of the epilogue of the GEMM that produces
+# its upstream gradient (s2c_bn_bwd_gemm_next_stats) instead of a statistics pass over (dA, Y);
+# S2C_BWD_STATS_IN_GEMM=0: the separate pass
+BWD_STATS_IN_GEMM = _os.environ.get("S2C_BWD_STATS_IN_GEMM", "1") != "0"
 _C.register("s2c_bn_relu_max_bwd_stats", [_L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P])
 _C.register("s2c_pool_bwd_dk", [_L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_pool_bwd_sp", [_L, _I, _I, _I, _P, _P, _P, _P, _P])
@@ -621,11 +629,14 @@ class _MLPRows(Function):
         partial = None
         nl = len(specs)
         gather = ctx.gather
+        prestats = None      # (partial, rows) of THIS layer's BN-backward sums, left by the GEMM
+                             # that produced dA (s2c_bn_bwd_gemm_next_stats)
         for li in range(nl - 1, -1, -1):
             rec, sp = saved[li], specs[li]
             W, A_in = rec["W"], rec["A_in"]
             lazy_dw = False
             fused_dA = None
+            pre, prestats = prestats, None
             if A_in is None:
                 if gather.needs_grad or not SCATTER_DW:
                     # first layer of a gather-fused stack: rebuild its operand now
@@ -659,14 +670,24 @@ class _MLPRows(Function):
                 dY = None if (lazy_dw and FUSE_DY_SCATTER and not (li == nl - 1 and pool_ns > 0)
                               and not rec["has_bias"] and dA.stride(1) == 1
                               and dA.stride(0) == Cout) else torch.empty_like(Y)
-                if dY is None:
-                    # statistics only; dY itself is formed inside GatherSpec.weight_grad
+                def statistics():
+                    """coef / dgamma / dbeta of this layer: from the sums the producing GEMM left,
+                    or by the statistics pass over (dA, Y)"""
+                    if pre is not None:
+                        _call("s2c_bn_bwd_finalize_partials", Y, pre[1], M, Cout, pre[0].data_ptr(),
+                              int(rec["frozen"]), _ptr(rec["gamma"]), rec["invstd"].data_ptr(),
+                              coef.data_ptr(), _ptr(dgamma), _ptr(dbeta))
+                        return
                     _call("s2c_bn_relu_bwd_stats", Y, M, Cout, dA.data_ptr(), Y.data_ptr(),
                           rec["scale"].data_ptr(), rec["shift"].data_ptr(),
                           rec["mean"].data_ptr(), rec["invstd"].data_ptr(),
                           _ptr(rec["gamma"]), int(rec["relu"]), int(rec["frozen"]),
                           partial.data_ptr(), coef.data_ptr(), _ptr(dgamma),
                           _ptr(dbeta), alg_bytes=4 * 2 * M * Cout)
+
+                if dY is None:
+                    # statistics only; dY itself is formed inside GatherSpec.weight_grad
+                    statistics()
                     lazy_bn = (dA, Y, rec["scale"], rec["shift"], rec["mean"], rec["invstd"],
                                coef, int(rec["relu"]))
                 elif li == nl - 1 and pool_ns > 0:
@@ -684,21 +705,43 @@ class _MLPRows(Function):
                       and dA.stride(0) == Cout and _fused_bwd_pays(M, Cout, W.shape[1])
                       and _gemm_split_on()):
                     # statistics, then dY and the input gradient dX = dY W in ONE pass
-                    _call("s2c_bn_relu_bwd_stats", Y, M, Cout, dA.data_ptr(), Y.data_ptr(),
-                          rec["scale"].data_ptr(), rec["shift"].data_ptr(),
-                          rec["mean"].data_ptr(), rec["invstd"].data_ptr(),
-                          _ptr(rec["gamma"]), int(rec["relu"]), int(rec["frozen"]),
-                          partial.data_ptr(), coef.data_ptr(), _ptr(dgamma),
-                          _ptr(dbeta), alg_bytes=4 * 2 * M * Cout)
+                    statistics()
                     Cin = W.shape[1]
                     Wt = W.t().contiguous()
                     fused_dA = torch.empty((M, Cin), device=dev)
-                    _call("s2c_bn_bwd_gemm", Y, M, Cout, Cin, dA.data_ptr(), Y.data_ptr(),
+                    prev = saved[li - 1] if li > 0 else None
+                    if (BWD_STATS_IN_GEMM and prev is not None and specs[li - 1].bn is not None
+                            and not prev.get("algebra") and prev.get("Y") is not None
+                            and prev["Y"].shape == (M, Cin) and prev["Y"].is_contiguous()
+                            and Cin % 4 == 0):
+                        # ... and the column sums of the PREVIOUS layer's BatchNorm backward out
+                        # of the same GEMM's epilogue (its upstream gradient is this output)
+                        nbg = _gemm_blocks(M, Cin)
+                        npart = torch.empty(nbg * 2 * Cin, device=dev)
+                        _call("s2c_bn_bwd_gemm_next_stats", Y, M, Cout, Cin, dA.data_ptr(),
+                              Y.data_ptr(), rec["scale"].data_ptr(), rec["shift"].data_ptr(),
+                              rec["mean"].data_ptr(), rec["invstd"].data_ptr(), coef.data_ptr(),
+                              int(rec["relu"]), Wt.data_ptr(), Wt.stride(0), dY.data_ptr(),
+                              fused_dA.data_ptr(), Cin, prev["Y"].data_ptr(),
+                              prev["scale"].data_ptr(), prev["shift"].data_ptr(),
+                              prev["mean"].data_ptr(), prev["invstd"].data_ptr(),
+                              int(prev["relu"]), npart.data_ptr(),
+                              alg_bytes=4 * M * (3 * Cout + 2 * Cin),
+                              alg_flops=2 * M * Cout * Cin)
+                        prestats = (npart, nbg)
+                    else:
+                        _call("s2c_bn_bwd_gemm", Y, M, Cout, Cin, dA.data_ptr(), Y.data_ptr(),
+                              rec["scale"].data_ptr(), rec["shift"].data_ptr(),
+                              rec["mean"].data_ptr(), rec["invstd"].data_ptr(), coef.data_ptr(),
+                              int(rec["relu"]), Wt.data_ptr(), Wt.stride(0), dY.data_ptr(),
+                              fused_dA.data_ptr(), Cin,
+                              alg_bytes=4 * M * (3 * Cout + Cin), alg_flops=2 * M * Cout * Cin)
+                elif pre is not None and Cout % 4 == 0:
+                    statistics()
+                    _call("s2c_bn_relu_bwd_apply", Y, M, Cout, dA.data_ptr(), Y.data_ptr(),
                           rec["scale"].data_ptr(), rec["shift"].data_ptr(),
                           rec["mean"].data_ptr(), rec["invstd"].data_ptr(), coef.data_ptr(),
-                          int(rec["relu"]), Wt.data_ptr(), Wt.stride(0), dY.data_ptr(),
-                          fused_dA.data_ptr(), Cin,
-                          alg_bytes=4 * M * (3 * Cout + Cin), alg_flops=2 * M * Cout * Cin)
+                          int(rec["relu"]), dY.data_ptr(), alg_bytes=4 * 3 * M * Cout)
                 else:
                     _call("s2c_bn_relu_bwd", Y, M, Cout, dA.data_ptr(), Y.data_ptr(),
                           rec["scale"].data_ptr(), rec["shift"].data_ptr(),
