@@ -124,6 +124,12 @@ int s2c_bn_bwd_gemm_next_stats(long long M, int C, int N, const float *dA, const
                                int ldw, float *dY, float *dX, int ldx, const float *nY,
                                const float *nscale, const float *nshift, const float *nmean,
                                const float *ninvstd, int nrelu, float *npartial, void *stream);
+/* the plain input-gradient GEMM dX = dY W (as s2c_rows_gemm with Wt) with the same epilogue, for
+ * N > 64 (-2 otherwise): the layer in front of a pooled / BN-free layer */
+int s2c_rows_gemm_next_stats(long long M, int N, int K, const float *A, int lda, const float *W,
+                             int ldw, float *Y, const float *nY, const float *nscale,
+                             const float *nshift, const float *nmean, const float *ninvstd,
+                             int nrelu, float *npartial, void *stream);
 int s2c_bn_bwd_finalize_partials(int nblk, long long M, int C, const float *partial, int frozen,
                                  const float *gamma, const float *invstd, float *coef,
                                  float *dgamma, float *dbeta, void *stream);

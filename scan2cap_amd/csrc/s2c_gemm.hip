@@ -817,6 +817,13 @@ __device__ __forceinline__ float4 mid_load4(const float *__restrict__ row, int k
 // this replaces: 19-27 us per 128 x 128 x 128 tile, of which 3-8 us to issue the first two
 // slices, 1.6 us to issue each later one and 4 us of epilogue -- against 2.6 us of MFMA time.
 // Same products in the same k order as the kernel above: bit-identical results.
+// the column sums of the next BatchNorm backward out of the epilogue (see BwdArgs::nY): the
+// GEMM's output is the upstream gradient of a layer whose pre-activations are Y
+struct NextStats {
+  const float *Y, *scale, *shift, *mean, *invstd;   // Y == nullptr: off
+  int relu;
+};
+
 constexpr int C64_LD = 68;
 constexpr size_t C64_LDS_BYTES = 2 * 128 * C64_LD * sizeof(float);     // 69632
 
@@ -825,7 +832,8 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_c64_kernel(
     long long M, int N, int K, const float *__restrict__ A, int lda,
     const float *__restrict__ W, int ldw, const float *__restrict__ pscale,
     const float *__restrict__ pshift, GatherArgs ga, float *__restrict__ Y, int ldy,
-    float *__restrict__ partial, EpiArgs ep, float *__restrict__ side, int ld_side) {
+    float *__restrict__ partial, EpiArgs ep, float *__restrict__ side, int ld_side,
+    NextStats nx) {
   constexpr int WM = 2, WN = 2, BN = 128;
   extern __shared__ __attribute__((aligned(16))) float c64_smem[];
   __shared__ float s_stat[2][WM][BN];
@@ -985,20 +993,41 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_c64_kernel(
     return;
   }
   // C/D layout of 32x32: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+  const bool next_stats = PRO == PRO_NONE && nx.Y != nullptr;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = n0 + wn * 64 + j * 32 + li;
     float s1 = 0.f, s2 = 0.f;
+    float nsc = 0.f, nsh = 0.f, nmu = 0.f, nis = 0.f;
+    if (next_stats && col < N) {
+      nsc = nx.scale[col]; nsh = nx.shift[col]; nmu = nx.mean[col]; nis = nx.invstd[col];
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+      float ny[PRO == PRO_NONE ? 16 : 1];
+      if (next_stats) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const long long row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+          ny[PRO == PRO_NONE ? e : 0] = (row < M && col < N) ? nx.Y[row * (long long)N + col] : 0.f;
+        }
+      }
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const long long row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
         const float v = acc[i][j][e];
         if (row < M && col < N) {
           Y[row * ldy + col] = v;
-          s1 += v;
-          s2 += v * v;
+          if (next_stats) {
+            const float y = ny[PRO == PRO_NONE ? e : 0];
+            float dz = v;
+            if (nx.relu && !(y * nsc + nsh > 0.f)) dz = 0.f;
+            s1 += dz;
+            s2 += dz * ((y - nmu) * nis);
+          } else {
+            s1 += v;
+            s2 += v * v;
+          }
         }
       }
     }
@@ -1046,7 +1075,7 @@ template <int PRO>
 int launch_c64(long long M, int N, int K, const float *A, int lda, const float *W, int ldw,
                const float *pscale, const float *pshift, const GatherArgs &ga, float *Y, int ldy,
                float *partial, hipStream_t st, const EpiArgs &ep, float *side = nullptr,
-               int ld_side = 0) {
+               int ld_side = 0, const NextStats &nx = NextStats()) {
   static int attr_state[64];                   // per device: 0 unknown, 1 ok, -1 refused
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -1061,7 +1090,7 @@ int launch_c64(long long M, int N, int K, const float *A, int lda, const float *
   const long long nbx = (M + 127) / 128, nby = (N + 127) / 128;
   dim3 grid((unsigned)(8 * ((nbx + 7) / 8) * nby));
   hipLaunchKernelGGL((rows_gemm_c64_kernel<PRO>), grid, dim3(256), C64_LDS_BYTES, st, M, N, K, A,
-                     lda, W, ldw, pscale, pshift, ga, Y, ldy, partial, ep, side, ld_side);
+                     lda, W, ldw, pscale, pshift, ga, Y, ldy, partial, ep, side, ld_side, nx);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     fprintf(stderr, "s2c_rows_gemm(c64) launch failed: %s\n", hipGetErrorString(e));
@@ -1340,6 +1369,24 @@ extern "C" int s2c_rows_gemm_c64_bn_relu_side(long long M, int N, int K, const f
   return launch_c64<PRO_BNRELU>(M, N, K, A, lda, W, ldw, scale, shift, ga, Y, ldy, partial,
                                 (hipStream_t)stream, EpiArgs(), side, ld_side);
 }
+// Y (M x N, contiguous) = A W^T on the 64-k-chunk kernel with the column sums of the BatchNorm
+// backward whose upstream gradient Y is (nY etc.: that layer, N channels) in `npartial`
+// (s2c_rows_gemm_blocks(M, N) rows, for s2c_bn_bwd_finalize_partials).  -2: not taken (N <= 64).
+extern "C" int s2c_rows_gemm_next_stats(long long M, int N, int K, const float *A, int lda,
+                                        const float *W, int ldw, float *Y, const float *nY,
+                                        const float *nscale, const float *nshift,
+                                        const float *nmean, const float *ninvstd, int nrelu,
+                                        float *npartial, void *stream) {
+  if (!use_split() || !c64_on() || N <= 64) return -2;
+  if (M <= 0 || K <= 0 || !A || !W || !Y || lda < K || ldw < K || !nY || !nscale || !nshift ||
+      !nmean || !ninvstd || !npartial)
+    return -1;
+  GatherArgs ga = {};
+  const NextStats nx = {nY, nscale, nshift, nmean, ninvstd, nrelu};
+  return launch_c64<PRO_NONE>(M, N, K, A, lda, W, ldw, nullptr, nullptr, ga, Y, N, npartial,
+                              (hipStream_t)stream, EpiArgs(), nullptr, 0, nx);
+}
+
 extern "C" int s2c_rows_gemm_c64_supported(long long M, int N, int K) {
   return use_split() && c64_on() && M > 0 && N > 64 && K > 0;
 }

@@ -295,6 +295,7 @@ _C.register("s2c_pool_select", [_L, _I, _P, _P, _P, _P, _P])
 _C.register("s2c_bn_bwd_gemm_next_stats", [_L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _I,
                                            _P, _P, _P, _P, _P, _I, _P, _P])
 _C.register("s2c_bn_bwd_finalize_partials", [_I, _L, _I, _P, _I, _P, _P, _P, _P, _P, _P])
+_C.register("s2c_rows_gemm_next_stats", [_L, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P])
 _C.register("s2c_bn_relu_bwd_apply", [_L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P])
 # the column sums of a layer's BatchNorm backward out of the epilogue of the GEMM that produces
 # its upstream gradient (s2c_bn_bwd_gemm_next_stats) instead of a statistics pass over (dA, Y);
@@ -772,7 +773,28 @@ class _MLPRows(Function):
             elif (HAND_DA_GEMM and dY.is_cuda and dY.dtype == torch.float32
                   and W.dtype == torch.float32 and dY.stride(1) == 1
                   and _hand_da_pays(M, Cout, W.shape[1])):
-                dA = _input_grad_gemm(dY, W)
+                Cin = W.shape[1]
+                prev = saved[li - 1] if li > 0 else None
+                dA = None
+                if (BWD_STATS_IN_GEMM and Cin > 64 and prev is not None
+                        and specs[li - 1].bn is not None and not prev.get("algebra")
+                        and prev.get("Y") is not None and prev["Y"].shape == (M, Cin)
+                        and prev["Y"].is_contiguous() and Cin % 4 == 0 and _gemm_split_on()):
+                    # the previous layer's BN-backward column sums out of this GEMM's epilogue
+                    Wt = W.t().contiguous()
+                    nbg = _gemm_blocks(M, Cin)
+                    npart = torch.empty(nbg * 2 * Cin, device=dev)
+                    dX = torch.empty((M, Cin), device=dev)
+                    rc = _C.call("s2c_rows_gemm_next_stats", M, Cin, Cout, dY.data_ptr(),
+                                 dY.stride(0), Wt.data_ptr(), Wt.stride(0), dX.data_ptr(),
+                                 prev["Y"].data_ptr(), prev["scale"].data_ptr(),
+                                 prev["shift"].data_ptr(), prev["mean"].data_ptr(),
+                                 prev["invstd"].data_ptr(), int(prev["relu"]), npart.data_ptr(),
+                                 _C.stream_ptr(), allow=(-2,))
+                    if rc == 0:
+                        dA, prestats = dX, (npart, nbg)
+                if dA is None:
+                    dA = _input_grad_gemm(dY, W)
             else:
                 dA = torch.mm(dY, W)
             g = [dW]
