@@ -126,6 +126,13 @@ int s2c_bn_bwd_gemm_next_stats(long long M, int C, int N, const float *dA, const
                                const float *ninvstd, int nrelu, float *npartial, void *stream);
 /* the plain input-gradient GEMM dX = dY W (as s2c_rows_gemm with Wt) with the same epilogue, for
  * N > 64 (-2 otherwise): the layer in front of a pooled / BN-free layer */
+int s2c_pool_bwd_input_grad_next_stats(long long M, int N, int KA, int C3, int ns, const float *A,
+                                       int lda, const short *arg, const float *dk,
+                                       const float *Wcat, int ldw, const float *cvec, float *dA,
+                                       int ldd, const float *nY, const float *nscale,
+                                       const float *nshift, const float *nmean,
+                                       const float *ninvstd, int nrelu, float *npartial,
+                                       void *stream);
 int s2c_rows_gemm_next_stats(long long M, int N, int K, const float *A, int lda, const float *W,
                              int ldw, float *Y, const float *nY, const float *nscale,
                              const float *nshift, const float *nmean, const float *ninvstd,

@@ -79,6 +79,10 @@ struct StreamArgs {
   // ~1100 VALU instructions against 156 in its four k-steps -- 45 % issue-active waves, two per
   // SIMD: the kernel was bound by the vector ALU, not by memory or the matrix cores.)
   float *ext; int *aext; const float *ext_sign;
+  // EPI_NEXT (nY != nullptr): the output Y is the upstream gradient of a layer whose BatchNorm
+  // backward starts with s1 = sum dz, s2 = sum dz (nY - nmean) ninvstd, dz = Y [nY nscale + nshift
+  // > 0] (bn_bwd_stats_kernel, s2c_sa.hip): those sums go to `partial` instead of (sum, sumsq)
+  const float *nY, *nscale, *nshift, *nmean, *ninvstd; int nrelu;
   // SPRO_POOLBWD: input gradient of a max-pooled BatchNorm layer WITHOUT its (M x C3) tensors.
   // With Y3 = A W3^T the layer's dY3 = dkrow - g (.) Y3 + e per channel (g = k0 k2 invstd,
   // e = g mean - k0 k1; dkrow = k0 * routed upstream gradient, one nonzero per centre and
@@ -140,7 +144,8 @@ __device__ __forceinline__ void split8(const float4 &va, const float4 &vb, bf16x
 // training layer), 2 = inference epilogue (BatchNorm + ReLU (+ max-pool)).  A template parameter
 // because each keeps its own per-lane state: as run-time branches the three together spilled
 // the NT = 4 kernels to scratch.
-enum { EPI_TRAIN = 0, EPI_RAW = 1, EPI_EVAL = 2 };
+// EPI_NEXT: EPI_TRAIN whose two column sums are those of the NEXT BatchNorm backward (StreamArgs::nY)
+enum { EPI_TRAIN = 0, EPI_RAW = 1, EPI_EVAL = 2, EPI_NEXT = 3 };
 
 // Diagnostics (tools/prof_stream.py): wave 0 of workgroup g_sprof_block adds up the shader-clock
 // cycles it spends per tile waiting for its ring chunks / in the k-steps / in the epilogue:
@@ -375,6 +380,17 @@ __global__ __launch_bounds__(64 * WAVES, (NT == 4 && WAVES == 4) ? 1 : 2) void r
     for (int h = 0; h < 2; ++h) { rmax[j][h] = -INFINITY; ramax[j][h] = 0; }
   }
 
+  constexpr int NX = EPI == EPI_NEXT ? NT : 1;
+  float nsc[NX], nsh[NX], nmu[NX], nis[NX];
+  if constexpr (EPI == EPI_NEXT) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = 32 * j + li;
+      const bool ok = col < N;
+      nsc[j] = ok ? p.nscale[col] : 0.f; nsh[j] = ok ? p.nshift[col] : 0.f;
+      nmu[j] = ok ? p.nmean[col] : 0.f; nis[j] = ok ? p.ninvstd[col] : 0.f;
+    }
+  }
   const int swz = (li >> 1) & 7;
   int slot = 0, par = 0;
   long long *sprof = g_sprof;
@@ -606,11 +622,48 @@ __global__ __launch_bounds__(64 * WAVES, (NT == 4 && WAVES == 4) ? 1 : 2) void r
     }
     // ---- epilogue: statistics, 4x4 DPP transposes, dwordx4 stores -------------------------
     // C/D layout of 32x32: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+    float ny[NX][EPI == EPI_NEXT ? 16 : 1];
+    if constexpr (EPI == EPI_NEXT) {              // every load in flight before the first use
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const long long row = r0 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+          const int col = 32 * j + li;
+          ny[j][e] = (row < M && col < N) ? p.nY[row * (long long)N + col] : 0.f;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int col = 32 * j + li;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
+        if constexpr (EPI == EPI_NEXT) {
+          float a4[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float v = acc[j][4 * g + i];
+            a4[i] = v;
+            const float y = ny[j][4 * g + i];
+            float dz = v;
+            if (p.nrelu && !(y * nsc[j] + nsh[j] > 0.f)) dz = 0.f;
+            if (r0 + 8 * g + 4 * lk + i < M) { s1[j] += dz; s2[j] += dz * ((y - nmu[j]) * nis[j]); }
+          }
+          quad_transpose(a4, lane);
+          const long long row = r0 + 8 * g + 4 * lk + (lane & 3);
+          const int c0 = 32 * j + (li & ~3);
+          if (row < M) {
+            float *dst = p.Y + row * p.ldy + c0;
+            if (c0 + 3 < N) {
+              *reinterpret_cast<float4 *>(dst) = make_float4(a4[0], a4[1], a4[2], a4[3]);
+            } else {
+              if (c0 < N) dst[0] = a4[0];
+              if (c0 + 1 < N) dst[1] = a4[1];
+              if (c0 + 2 < N) dst[2] = a4[2];
+            }
+          }
+          continue;
+        }
         // (columns >= N meet zero weight planes: they add exact zeros, no predicate; rows are
         // checked in a ragged last tile only -- per element the 64-bit compare and the select
         // tripled the vector-ALU work of this loop)
@@ -751,8 +804,10 @@ int launch_cfg(const StreamArgs &a, int cfg, int blocks, size_t lds, hipStream_t
 // gather x eval; gather x train; pool-backward x train
 template <int NT, int PRO>
 int launch_epi(const StreamArgs &a, int cfg, int blocks, size_t lds, hipStream_t st) {
-  const int epi = a.ext != nullptr ? EPI_RAW : (a.ep_mean != nullptr ? EPI_EVAL : EPI_TRAIN);
+  const int epi = a.ext != nullptr ? EPI_RAW : (a.ep_mean != nullptr ? EPI_EVAL : (a.nY != nullptr ? EPI_NEXT : EPI_TRAIN));
   if (epi == EPI_TRAIN) return launch_cfg<NT, PRO, EPI_TRAIN>(a, cfg, blocks, lds, st);
+  if constexpr (PRO == SPRO_POOLBWD)
+    if (epi == EPI_NEXT) return launch_cfg<NT, PRO, EPI_NEXT>(a, cfg, blocks, lds, st);
   if constexpr (PRO == SPRO_NONE || PRO == SPRO_BNRELU)
     if (epi == EPI_RAW) return launch_cfg<NT, PRO, EPI_RAW>(a, cfg, blocks, lds, st);
   if constexpr (PRO == SPRO_NONE || PRO == SPRO_GATHER)
@@ -961,6 +1016,33 @@ extern "C" int s2c_pool_bwd_input_grad(long long M, int N, int KA, int C3, int n
   StreamArgs a = {};
   a.M = M; a.N = N; a.K = KA + C3; a.A = A; a.lda = lda; a.W = Wcat; a.ldw = ldw; a.Y = dA; a.ldy = ldd;
   a.pb_arg = arg; a.pb_dk = dk; a.bias = cvec; a.pb_ka = KA; a.pb_c3 = C3; a.pb_ns = ns;
+  return launch_stream<SPRO_POOLBWD>(a, (hipStream_t)stream);
+}
+
+// ... with the column sums of the PREVIOUS layer's BatchNorm backward (its upstream gradient is
+// this dA) out of the epilogue: nY (M x N contiguous) etc. = that layer; npartial =
+// s2c_rows_gemm_blocks(M, N) rows of [s1 | s2] for s2c_bn_bwd_finalize_partials.  ldd == N.
+extern "C" int s2c_pool_bwd_input_grad_next_stats(long long M, int N, int KA, int C3, int ns,
+                                                  const float *A, int lda, const short *arg,
+                                                  const float *dk, const float *Wcat, int ldw,
+                                                  const float *cvec, float *dA, int ldd,
+                                                  const float *nY, const float *nscale,
+                                                  const float *nshift, const float *nmean,
+                                                  const float *ninvstd, int nrelu,
+                                                  float *npartial, void *stream) {
+  if (M <= 0 || N <= 0 || KA <= 0 || C3 <= 0 || !A || !arg || !dk || !Wcat || !dA ||
+      lda < KA || ldw < KA + C3 || !(ns == 16 || ns == 32 || ns == 64) || M % ns || ldd != N ||
+      !nY || !nscale || !nshift || !nmean || !ninvstd || !npartial)
+    return -1;
+  if (!stream_on() || (KA & 15) || (C3 & 7) || C3 > 128 || (lda & 3) || ((uintptr_t)A & 15) ||
+      (ldd & 3) || ((uintptr_t)dA & 15) || ((uintptr_t)arg & 15) || ((uintptr_t)dk & 15) ||
+      pick_cfg(M, N, KA + C3, SPRO_POOLBWD) < 0)
+    return -2;
+  StreamArgs a = {};
+  a.M = M; a.N = N; a.K = KA + C3; a.A = A; a.lda = lda; a.W = Wcat; a.ldw = ldw; a.Y = dA; a.ldy = ldd;
+  a.pb_arg = arg; a.pb_dk = dk; a.bias = cvec; a.pb_ka = KA; a.pb_c3 = C3; a.pb_ns = ns;
+  a.nY = nY; a.nscale = nscale; a.nshift = nshift; a.nmean = nmean; a.ninvstd = ninvstd;
+  a.nrelu = nrelu; a.partial = npartial; a.partial_rows = s2c_rows_gemm_blocks(M, N);
   return launch_stream<SPRO_POOLBWD>(a, (hipStream_t)stream);
 }
 

@@ -295,6 +295,8 @@ _C.register("s2c_pool_select", [_L, _I, _P, _P, _P, _P, _P])
 _C.register("s2c_bn_bwd_gemm_next_stats", [_L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _I,
                                            _P, _P, _P, _P, _P, _I, _P, _P])
 _C.register("s2c_bn_bwd_finalize_partials", [_I, _L, _I, _P, _I, _P, _P, _P, _P, _P, _P])
+_C.register("s2c_pool_bwd_input_grad_next_stats", [_L, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _P, _I,
+                                                   _P, _P, _P, _P, _P, _I, _P, _P])
 _C.register("s2c_rows_gemm_next_stats", [_L, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P])
 _C.register("s2c_bn_relu_bwd_apply", [_L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P])
 # the column sums of a layer's BatchNorm backward out of the epilogue of the GEMM that produces
@@ -332,7 +334,7 @@ def pool_algebra_takes(M, Cout, K_in, pool_ns):
 
 
 def pooled_layer_backward(dOut, arg, ymax, scale, shift, mean, invstd, gamma, frozen, A, W, ns,
-                          need_dA=True):
+                          need_dA=True, next_bn=None):
     """Gradients of out = max over ns rows of relu(BN(A W^T)) w.r.t. A (M x K), W (C3 x K),
     gamma, beta, given dOut (J x C3) -- without Y3 = A W^T or dY3 (M x C3 each):
         dY3 = dkrow - g (.) Y3 + e   per channel, g = k0 k2 invstd, e = g mean - k0 k1,
@@ -368,10 +370,24 @@ def pooled_layer_backward(dOut, arg, ymax, scale, shift, mean, invstd, gamma, fr
         _call("s2c_pool_bwd_prep", W, C3, K, coef.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
               W.data_ptr(), Wcat.data_ptr(), cvec.data_ptr(), ge.data_ptr())
         dA = torch.empty((M, K), device=dev)
-        _call("s2c_pool_bwd_input_grad", A, M, K, K, C3, ns, A.data_ptr(), A.stride(0),
-              arg16.data_ptr(), dk.data_ptr(), Wcat.data_ptr(), Wcat.stride(0), cvec.data_ptr(),
-              dA.data_ptr(), K, alg_bytes=4 * (2 * M * K + 2 * J * C3),
-              alg_flops=2 * M * K * (K + C3))
+        if next_bn is not None:
+            # next_bn = the record of the layer whose upstream gradient this dA is: its
+            # BatchNorm-backward column sums leave with the GEMM (next_bn["prestats"])
+            nbg = _gemm_blocks(M, K)
+            npart = torch.empty(nbg * 2 * K, device=dev)
+            _call("s2c_pool_bwd_input_grad_next_stats", A, M, K, K, C3, ns, A.data_ptr(),
+                  A.stride(0), arg16.data_ptr(), dk.data_ptr(), Wcat.data_ptr(), Wcat.stride(0),
+                  cvec.data_ptr(), dA.data_ptr(), K, next_bn["Y"].data_ptr(),
+                  next_bn["scale"].data_ptr(), next_bn["shift"].data_ptr(),
+                  next_bn["mean"].data_ptr(), next_bn["invstd"].data_ptr(),
+                  int(next_bn["relu"]), npart.data_ptr(),
+                  alg_bytes=4 * (3 * M * K + 2 * J * C3), alg_flops=2 * M * K * (K + C3))
+            next_bn["prestats"] = (npart, nbg)
+        else:
+            _call("s2c_pool_bwd_input_grad", A, M, K, K, C3, ns, A.data_ptr(), A.stride(0),
+                  arg16.data_ptr(), dk.data_ptr(), Wcat.data_ptr(), Wcat.stride(0),
+                  cvec.data_ptr(), dA.data_ptr(), K, alg_bytes=4 * (2 * M * K + 2 * J * C3),
+                  alg_flops=2 * M * K * (K + C3))
     # ---- weight gradient -------------------------------------------------------------------
     lib = _C.load()
     lib.s2c_pool_bwd_sp_blocks.argtypes = [_L]
@@ -650,9 +666,19 @@ class _MLPRows(Function):
             if rec.get("algebra"):
                 # pooled last layer without Y3 / dY3 (pooled_layer_backward)
                 need_dA = li > 0 or ctx.x_needs_grad
+                prev = saved[li - 1] if li > 0 else None
+                Kin = W.shape[1]
+                nbn = None
+                if (BWD_STATS_IN_GEMM and need_dA and prev is not None
+                        and specs[li - 1].bn is not None and prev.get("Y") is not None
+                        and prev["Y"].shape == (M, Kin) and prev["Y"].is_contiguous()):
+                    nbn = prev
                 dA, dW, dgamma, dbeta = pooled_layer_backward(
                     dA, rec["arg"], rec["ymax"], rec["scale"], rec["shift"], rec["mean"],
-                    rec["invstd"], rec["gamma"], rec["frozen"], A_in, W, pool_ns, need_dA=need_dA)
+                    rec["invstd"], rec["gamma"], rec["frozen"], A_in, W, pool_ns, need_dA=need_dA,
+                    next_bn=nbn)
+                if nbn is not None:
+                    prestats = nbn.pop("prestats", None)
                 g = [dW]
                 if sp.bn is not None:
                     g += [dgamma, dbeta]
