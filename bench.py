@@ -418,8 +418,8 @@ def named_roofline(table_k):
 
 
 GEMM_FAMILY = ("s2c_rows_gemm", "s2c_rows_gemm_bn_relu_side", "s2c_sa_gather_gemm",
-               "s2c_bn_bwd_gemm", "s2c_rows_gemm_bn_eval", "s2c_sa_gather_gemm_bn_eval",
-               "s2c_sa_fused_eval")
+               "s2c_bn_bwd_gemm", "s2c_bn_bwd_gemm_next_stats", "s2c_rows_gemm_next_stats",
+               "s2c_rows_gemm_bn_eval", "s2c_sa_gather_gemm_bn_eval", "s2c_sa_fused_eval")
 _DECODER_CHAIN = ("s2c_small_linear", "s2c_small_linear_pair", "s2c_gru_fwd", "s2c_attn_fwd",
                   "s2c_attn_bwd", "s2c_gru_gates_bwd", "s2c_attn_x2_fwd", "s2c_attn_bwd_x2")
 
