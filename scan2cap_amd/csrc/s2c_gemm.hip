@@ -824,6 +824,18 @@ struct NextStats {
   int relu;
 };
 
+// pooled training layer on the 64-k-chunk kernel: besides Y and the statistics, per centre (ns =
+// 16 / 32 / 64 consecutive rows) and column the extremum of Y that BatchNorm + ReLU + max-pool will
+// select -- the maximum of sign * Y, sign = the sign of the layer's gamma (StreamArgs::ext of
+// s2c_gemm2.hip; here the sign is applied to the accumulators, not folded into the weights: Y is
+// written as well) -- and its first row: the pooled pass over Y (s2c_bn_relu_max) shrinks to
+// s2c_pool_select on J x N values.
+struct PoolExt {
+  float *ext; int *aext;          // (J x N); ext == nullptr: off
+  const float *sign;              // gamma (N) or nullptr = all positive
+  int ns;
+};
+
 constexpr int C64_LD = 68;
 constexpr size_t C64_LDS_BYTES = 2 * 128 * C64_LD * sizeof(float);     // 69632
 
@@ -833,7 +845,7 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_c64_kernel(
     const float *__restrict__ W, int ldw, const float *__restrict__ pscale,
     const float *__restrict__ pshift, GatherArgs ga, float *__restrict__ Y, int ldy,
     float *__restrict__ partial, EpiArgs ep, float *__restrict__ side, int ld_side,
-    NextStats nx) {
+    NextStats nx, PoolExt px) {
   constexpr int WM = 2, WN = 2, BN = 128;
   extern __shared__ __attribute__((aligned(16))) float c64_smem[];
   __shared__ float s_stat[2][WM][BN];
@@ -992,6 +1004,66 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_c64_kernel(
     affine_epilogue(acc, ep, M, N, m0 + wm * 64, n0 + wn * 64, li, lk);
     return;
   }
+  if (PRO != PRO_GATHER && px.ext != nullptr) {
+    // ---- pooled layer: per centre and column the maximum of sign * y and its first row -----
+    const int ns = px.ns;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + li;
+      const float sgn = (px.sign != nullptr && col < N && px.sign[col] < 0.f) ? -1.f : 1.f;
+      float gv[2][2];
+      int ga2[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          float bv = -INFINITY;
+          int ba = 0;
+#pragma unroll
+          for (int e8 = 0; e8 < 8; ++e8) {        // ascending rows, strict compare: first maximum
+            const int ro = (e8 & 3) + 8 * (e8 >> 2) + 4 * lk;
+            const long long row = m0 + wm * 64 + i * 32 + 16 * h + ro;
+            const float t = acc[i][j][8 * h + e8] * sgn;
+            if (row < M && t > bv) { bv = t; ba = ro; }
+          }
+          const float ov = __shfl_xor(bv, 32, 64);
+          const int oa = __shfl_xor(ba, 32, 64);
+          if (ov > bv || (ov == bv && oa < ba)) { bv = ov; ba = oa; }
+          gv[i][h] = bv; ga2[i][h] = ba;
+        }
+      const long long J = M / ns;
+      auto put = [&](long long centre, float v, int a) {
+        if (lk == 0 && col < N && centre < J) {
+          px.ext[centre * N + col] = v * sgn;
+          px.aext[centre * N + col] = a;
+        }
+      };
+      const long long rbase = m0 + wm * 64;
+      if (ns == 16) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) put((rbase + 32 * i + 16 * h) / 16, gv[i][h], ga2[i][h]);
+      } else {
+        float v32[2];
+        int a32[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          v32[i] = gv[i][0]; a32[i] = ga2[i][0];
+          if (gv[i][1] > v32[i]) { v32[i] = gv[i][1]; a32[i] = 16 + ga2[i][1]; }
+        }
+        if (ns == 32) {
+          put((rbase) / 32, v32[0], a32[0]);
+          put((rbase + 32) / 32, v32[1], a32[1]);
+        } else {                                   // 64: the wave's 64 rows are one centre
+          float v = v32[0];
+          int a = a32[0];
+          if (v32[1] > v) { v = v32[1]; a = 32 + a32[1]; }
+          put(rbase / 64, v, a);
+        }
+      }
+    }
+  }
   // C/D layout of 32x32: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
   const bool next_stats = PRO == PRO_NONE && nx.Y != nullptr;
 #pragma unroll
@@ -1075,7 +1147,7 @@ template <int PRO>
 int launch_c64(long long M, int N, int K, const float *A, int lda, const float *W, int ldw,
                const float *pscale, const float *pshift, const GatherArgs &ga, float *Y, int ldy,
                float *partial, hipStream_t st, const EpiArgs &ep, float *side = nullptr,
-               int ld_side = 0, const NextStats &nx = NextStats()) {
+               int ld_side = 0, const NextStats &nx = NextStats(), const PoolExt &px = PoolExt()) {
   static int attr_state[64];                   // per device: 0 unknown, 1 ok, -1 refused
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -1090,7 +1162,7 @@ int launch_c64(long long M, int N, int K, const float *A, int lda, const float *
   const long long nbx = (M + 127) / 128, nby = (N + 127) / 128;
   dim3 grid((unsigned)(8 * ((nbx + 7) / 8) * nby));
   hipLaunchKernelGGL((rows_gemm_c64_kernel<PRO>), grid, dim3(256), C64_LDS_BYTES, st, M, N, K, A,
-                     lda, W, ldw, pscale, pshift, ga, Y, ldy, partial, ep, side, ld_side, nx);
+                     lda, W, ldw, pscale, pshift, ga, Y, ldy, partial, ep, side, ld_side, nx, px);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     fprintf(stderr, "s2c_rows_gemm(c64) launch failed: %s\n", hipGetErrorString(e));
@@ -1385,6 +1457,27 @@ extern "C" int s2c_rows_gemm_next_stats(long long M, int N, int K, const float *
   const NextStats nx = {nY, nscale, nshift, nmean, ninvstd, nrelu};
   return launch_c64<PRO_NONE>(M, N, K, A, lda, W, ldw, nullptr, nullptr, ga, Y, N, npartial,
                               (hipStream_t)stream, EpiArgs(), nullptr, 0, nx);
+}
+
+// s2c_rows_gemm_pool_raw (s2c_gemm2.hip) for the shapes its streaming kernel leaves, with Y
+// written (the materialised backward reads it): N > 64 on the 64-k-chunk kernel.  scale == NULL:
+// plain operand.  -2: not taken.
+extern "C" int s2c_rows_gemm_c64_pool_ext(long long M, int N, int K, const float *A, int lda,
+                                          const float *scale, const float *shift, float *side,
+                                          int ld_side, const float *W, int ldw, int pool_ns,
+                                          const float *gamma, float *ext, int *aext, float *Y,
+                                          int ldy, float *partial, void *stream) {
+  if (!use_split() || !c64_on() || N <= 64 || !Y) return -2;
+  if (M <= 0 || K <= 0 || !A || !W || !ext || !aext || lda < K || ldw < K ||
+      !(pool_ns == 16 || pool_ns == 32 || pool_ns == 64) || M % pool_ns || (side && ld_side < K))
+    return -1;
+  GatherArgs ga = {};
+  const PoolExt px = {ext, aext, gamma, pool_ns};
+  if (scale != nullptr)
+    return launch_c64<PRO_BNRELU>(M, N, K, A, lda, W, ldw, scale, shift, ga, Y, ldy, partial,
+                                  (hipStream_t)stream, EpiArgs(), side, ld_side, NextStats(), px);
+  return launch_c64<PRO_NONE>(M, N, K, A, lda, W, ldw, nullptr, nullptr, ga, Y, ldy, partial,
+                              (hipStream_t)stream, EpiArgs(), nullptr, 0, NextStats(), px);
 }
 
 extern "C" int s2c_rows_gemm_c64_supported(long long M, int N, int K) {

@@ -843,6 +843,11 @@ extern "C" int s2c_rows_gemm_c64_bn_relu_side(long long M, int N, int K, const f
                                               float *side, int ld_side, const float *W, int ldw,
                                               float *Y, int ldy, float *partial, void *stream);
 extern "C" int s2c_rows_gemm_c64_supported(long long M, int N, int K);
+extern "C" int s2c_rows_gemm_c64_pool_ext(long long M, int N, int K, const float *A, int lda,
+                                          const float *scale, const float *shift, float *side,
+                                          int ld_side, const float *W, int ldw, int pool_ns,
+                                          const float *gamma, float *ext, int *aext, float *Y,
+                                          int ldy, float *partial, void *stream);
 
 // 1 when s2c_rows_gemm / s2c_sa_gather_gemm hand this shape to the streaming kernel
 // (plain operand: K, lda multiples of 4 and 16-byte aligned A; gather: C a multiple of 4,
@@ -981,8 +986,13 @@ extern "C" int s2c_rows_gemm_pool_raw(long long M, int N, int K, const float *A,
     return -1;
   if (!s2c_rows_stream_supported(M, N, K, 0) || (lda & 3) || ((uintptr_t)A & 15) ||
       (Y && ((ldy & 3) || ((uintptr_t)Y & 15))) ||
-      (side && ((ld_side & 3) || ((uintptr_t)side & 15))))
+      (side && ((ld_side & 3) || ((uintptr_t)side & 15)))) {
+    // wide layers with Y materialised: the 64-k-chunk kernel of s2c_gemm.hip
+    if (Y != nullptr && (scale == nullptr || relu))
+      return s2c_rows_gemm_c64_pool_ext(M, N, K, A, lda, scale, shift, side, ld_side, W, ldw,
+                                        pool_ns, gamma, ext, aext, Y, ldy, partial, stream);
     return -2;
+  }
   StreamArgs a = {};
   a.M = M; a.N = N; a.K = K; a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.Y = Y; a.ldy = ldy;
   a.partial = partial; a.partial_rows = s2c_rows_gemm_blocks(M, N);

@@ -303,6 +303,9 @@ _C.register("s2c_bn_relu_bwd_apply", [_L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P
 # its upstream gradient (s2c_bn_bwd_gemm_next_stats) instead of a statistics pass over (dA, Y);
 # S2C_BWD_STATS_IN_GEMM=0: the separate pass
 BWD_STATS_IN_GEMM = _os.environ.get("S2C_BWD_STATS_IN_GEMM", "1") != "0"
+# the extremum a pooled BatchNorm + ReLU layer will select out of the GEMM's epilogue also when Y
+# is materialised (wide layers, 64-k-chunk kernel); S2C_POOL_EXT_IN_GEMM=0: s2c_bn_relu_max over Y
+POOL_EXT_IN_GEMM = _os.environ.get("S2C_POOL_EXT_IN_GEMM", "1") != "0"
 _C.register("s2c_bn_relu_max_bwd_stats", [_L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P])
 _C.register("s2c_pool_bwd_dk", [_L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_pool_bwd_sp", [_L, _I, _I, _I, _P, _P, _P, _P, _P])
@@ -469,6 +472,7 @@ class _MLPRows(Function):
         out = None
         deferred = None     # (Y, scale, shift, relu) of the previous layer: BN+ReLU not applied yet
         pooled_raw = None   # raw per-centre extrema of the last layer (pool algebra path)
+        pooled_ext = None   # the same out of the 64-k-chunk kernel, Y materialised
         for li, sp in enumerate(specs):
             W = params[pi]; pi += 1
             bias = None
@@ -527,6 +531,43 @@ class _MLPRows(Function):
                       alg_flops=2 * M * K_in * Cout)
                 Y = None
                 pooled_raw = raws
+            elif (POOL_EXT_IN_GEMM and li == nl - 1 and pool_ns in (16, 32, 64) and gemm_stats
+                  and M % pool_ns == 0 and Cout > 64 and _gemm_split_on()
+                  and (deferred is not None or (A.stride(1) == 1 and A.dtype == torch.float32))
+                  and (deferred is None or deferred[3])):
+                # pooled last layer, Y materialised (the backward reads it): the extremum that BN +
+                # ReLU + max will select leaves with the GEMM (64-k-chunk kernel), the pooled pass
+                # over Y (s2c_bn_relu_max) shrinks to s2c_pool_select on J x Cout values
+                nbg = _gemm_blocks(M, Cout)
+                gpart = torch.empty(nbg * 2 * Cout, device=dev)
+                Y = torch.empty((M, Cout), device=dev)
+                J = M // pool_ns
+                raws = (torch.empty((J, Cout), device=dev),
+                        torch.empty((J, Cout), dtype=torch.int32, device=dev))
+                if deferred is not None:
+                    pY, pscale, pshift, prelu = deferred
+                    deferred = None
+                    A = torch.empty_like(pY)
+                    src, K_in = pY, pY.shape[1]
+                    pro = (pscale.data_ptr(), pshift.data_ptr(), int(prelu), A.data_ptr(), K_in)
+                else:
+                    src, K_in = A, A.shape[1]
+                    pro = (None, None, 0, None, 0)
+                rc = _C.call("s2c_rows_gemm_pool_raw", M, Cout, K_in, src.data_ptr(), src.stride(0),
+                             pro[0], pro[1], pro[2], pro[3], pro[4], W.data_ptr(), W.stride(0),
+                             pool_ns, _ptr(gamma), raws[0].data_ptr(), raws[1].data_ptr(),
+                             Y.data_ptr(), Cout, gpart.data_ptr(), _C.stream_ptr(), allow=(-2,))
+                if rc == 0:
+                    pooled_ext = raws
+                elif pro[0] is not None:
+                    # not taken: the two-launch form of the same layer
+                    _call("s2c_rows_gemm_bn_relu_side", Y, M, Cout, K_in, src.data_ptr(),
+                          src.stride(0), pro[0], pro[1], pro[2], pro[3], pro[4], W.data_ptr(),
+                          W.stride(0), Y.data_ptr(), Cout, gpart.data_ptr())
+                else:
+                    _call("s2c_rows_gemm", Y, M, Cout, K_in, src.data_ptr(), src.stride(0),
+                          W.data_ptr(), W.stride(0), None, None, Y.data_ptr(), Cout,
+                          gpart.data_ptr())
             elif deferred is not None:
                 # the previous layer's BN+ReLU happens in THIS layer's operand load; the
                 # activation (needed for the weight gradient) leaves as a side output
@@ -596,6 +637,14 @@ class _MLPRows(Function):
                     rec["arg"] = pooled_raw[1]
                     rec["ymax"] = pooled_raw[0]
                     rec["algebra"] = True
+                elif last and pool_ns > 0 and pooled_ext is not None:
+                    J = M // pool_ns
+                    out = torch.empty((J, Cout), device=dev)
+                    _call("s2c_pool_select", out, J, Cout, pooled_ext[0].data_ptr(),
+                          scale.data_ptr(), shift.data_ptr(), out.data_ptr(),
+                          alg_bytes=4 * 2 * J * Cout)
+                    rec["arg"] = pooled_ext[1]
+                    rec["ymax"] = pooled_ext[0]
                 elif last and pool_ns > 0:
                     J = M // pool_ns
                     out = torch.empty((J, Cout), device=dev)
