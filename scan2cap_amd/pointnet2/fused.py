@@ -85,7 +85,9 @@ def _gemm_blocks(M, N):
 # use the hand-written MFMA GEMM (statistics in its epilogue) for BN layers
 USE_MFMA_GEMM = True
 # weight gradient of a gather-fused first layer from point-indexed sums when its
-# inputs need no gradient (no re-materialised operand)
+# inputs need no gradient (no re-materialised operand).  (With input gradients -- SA2-SA4, where
+# dY exists anyway -- the same sums were measured in round 3 and do not pay: 124 us of float
+# atomics at SA2 against 91 us of re-materialising + the split-K product; step 9.86 vs 9.84 ms.)
 SCATTER_DW = True
 # the first layer's dY (it has no input gradient to feed) formed inside the point-sum kernel
 # from (dA, Y) instead of written by the BN-backward pass and read back: S2C_FUSE_DY_SCATTER=0 = off
