@@ -1343,7 +1343,15 @@ extern "C" int s2c_sa_gather_gemm(int b, int n, int m, int ns, int C,
   ga.xyz = xyz; ga.new_xyz = new_xyz; ga.feats = feats; ga.idx = idx;
   ga.frs = feat_row_stride; ga.fbs = feat_batch_stride;
   ga.n = n; ga.m = m; ga.ns = ns; ga.radius = radius; ga.normalize = normalize;
-  if (use_split()) {
+  // wide first layers (N > 64) up to S2C_GATHER_C64_ROWS rows (default 262144: SA2) run on the
+  // 64-k-chunk kernel, not the streaming one (its 4-wave N = 128 configuration keeps 32 KB in
+  // flight per CU: 135 vs 122 us at SA2); 0 = the streaming kernel wherever it takes the shape
+  static long long c64_rows = -1;
+  if (c64_rows < 0) {
+    const char *e = getenv("S2C_GATHER_C64_ROWS");
+    c64_rows = e ? atoll(e) : 262144;
+  }
+  if (use_split() && !(N > 64 && M <= c64_rows && c64_on())) {
     const int rc = s2c_sa_gather_stream_gemm(b, n, m, ns, C, feat_row_stride, feat_batch_stride,
                                              radius, normalize, xyz, new_xyz, feats, idx, N, W,
                                              ldw, Y, ldy, partial, s2c_rows_gemm_blocks(M, N),
