@@ -149,13 +149,14 @@ enum { EPI_TRAIN = 0, EPI_RAW = 1, EPI_EVAL = 2, EPI_NEXT = 3 };
 
 // Diagnostics (tools/prof_stream.py): wave 0 of workgroup g_sprof_block adds up the shader-clock
 // cycles it spends per tile waiting for its ring chunks / in the k-steps / in the epilogue:
-// g_sprof[0..3] = {waits, k-steps, epilogue, tiles}, [4] = whole life.
+// g_sprof[0..3] = {waits, k-steps, epilogue, tiles}, [4] = life of the tile loop, [5] = prologue.
 __device__ long long *g_sprof = nullptr;
 __device__ int g_sprof_block = 0;
 #define SP_NOW() ([&]() { __builtin_amdgcn_sched_barrier(0); long long t_ = (long long)__builtin_amdgcn_s_memtime(); \
                           __builtin_amdgcn_sched_barrier(0); return t_; }())
 template <int NT, int PRO, int WAVES, int SLOTS, int EPI>
 __global__ __launch_bounds__(64 * WAVES, (NT == 4 && WAVES == 4) ? 1 : 2) void rows_stream_gemm_kernel(StreamArgs p) {
+  const long long sp_entry = g_sprof != nullptr ? (long long)__builtin_amdgcn_s_memtime() : 0;
   constexpr int NP = 32 * NT;
   constexpr int DEPTH = SLOTS - 1;
   constexpr int AUXB = PRO == SPRO_GATHER ? AUX_BYTES : (PRO == SPRO_POOLBWD ? PB_AUX_BYTES : 0);
@@ -709,6 +710,7 @@ __global__ __launch_bounds__(64 * WAVES, (NT == 4 && WAVES == 4) ? 1 : 2) void r
   if (sp_on && lane == 0) {
     sprof[0] = sp_wait; sprof[1] = sp_k - sp_wait; sprof[2] = sp_epi; sprof[3] = sp_tiles;
     sprof[4] = SP_NOW() - sp_life0;
+    sprof[5] = sp_life0 - sp_entry;              // prologue: W staging, ring set-up, first issues
   }
   if (p.partial != nullptr) {
 #pragma unroll
