@@ -409,6 +409,20 @@ __global__ __launch_bounds__(64 * WAVES, (NT == 4 && WAVES == 4) ? 1 : 2) void r
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
     const long long r0 = t * 32;
+    // EPI_NEXT: the next layer's pre-activations of this lane's accumulator elements, requested
+    // BEFORE the k-steps (they are first used in the epilogue: requested there, every tile paid
+    // one exposed memory round trip -- 87 us of the launch at SA1)
+    float ny[NX][EPI == EPI_NEXT ? 16 : 1];
+    if constexpr (EPI == EPI_NEXT) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const long long row = r0 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+          const int col = 32 * j + li;
+          ny[j][e] = (row < M && col < N) ? p.nY[row * (long long)N + col] : 0.f;
+        }
+    }
 
 #pragma unroll 1
     for (int c = 0; c < KCT; ++c) {
@@ -623,17 +637,6 @@ __global__ __launch_bounds__(64 * WAVES, (NT == 4 && WAVES == 4) ? 1 : 2) void r
     }
     // ---- epilogue: statistics, 4x4 DPP transposes, dwordx4 stores -------------------------
     // C/D layout of 32x32: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
-    float ny[NX][EPI == EPI_NEXT ? 16 : 1];
-    if constexpr (EPI == EPI_NEXT) {              // every load in flight before the first use
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const long long row = r0 + (e & 3) + 8 * (e >> 2) + 4 * lk;
-          const int col = 32 * j + li;
-          ny[j][e] = (row < M && col < N) ? p.nY[row * (long long)N + col] : 0.f;
-        }
-    }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int col = 32 * j + li;
