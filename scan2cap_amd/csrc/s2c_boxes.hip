@@ -350,7 +350,14 @@ __global__ __launch_bounds__(256) void multi_colsum_kernel(s2c_colsum_args a) {
       if (e < n) {
         const float *p = a.part[j] + e;
         int s = ph;
-        for (; s + 12 < S; s += 16) {         // four independent chains, fixed order
+        for (; s + 28 < S; s += 32) {         // eight loads in flight, four chains, fixed order
+          float v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = p[(long long)(s + 4 * u) * n];
+          s0 += v[0]; s1 += v[1]; s2 += v[2]; s3 += v[3];
+          s0 += v[4]; s1 += v[5]; s2 += v[6]; s3 += v[7];
+        }
+        for (; s + 12 < S; s += 16) {
           s0 += p[(long long)s * n];
           s1 += p[(long long)(s + 4) * n];
           s2 += p[(long long)(s + 8) * n];
