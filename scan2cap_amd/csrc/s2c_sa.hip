@@ -417,6 +417,29 @@ __device__ __forceinline__ void block_sum2(double &a, double &b) {
   }
 }
 
+// this thread's share of column c of a partial table (nblk rows of [s1 (C) | s2 (C)]): rows
+// threadIdx.x, + FIN_BLOCK, ... in that order, eight rows (16 loads) in flight -- one row at a
+// time the 4096-8192 rows of an SA1 layer were 16-32 dependent round trips (20 us per launch)
+__device__ __forceinline__ void fin_column_sums(const float *__restrict__ partial, int nblk, int C,
+                                                int c, double &s1, double &s2) {
+  int k = threadIdx.x;
+  for (; k + 7 * FIN_BLOCK < nblk; k += 8 * FIN_BLOCK) {
+    float a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float *row = partial + (long long)(k + u * FIN_BLOCK) * 2 * C;
+      a[u] = row[c];
+      b[u] = row[C + c];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { s1 += (double)a[u]; s2 += (double)b[u]; }
+  }
+  for (; k < nblk; k += FIN_BLOCK) {
+    s1 += (double)partial[(long long)k * 2 * C + c];
+    s2 += (double)partial[(long long)k * 2 * C + C + c];
+  }
+}
+
 __global__ __launch_bounds__(FIN_BLOCK) void bn_finalize_kernel(
     const float *__restrict__ partial, int nblk, int C, long long M, float eps,
     float momentum, const float *__restrict__ gamma,
@@ -426,10 +449,7 @@ __global__ __launch_bounds__(FIN_BLOCK) void bn_finalize_kernel(
     float *__restrict__ save_invstd, long long *__restrict__ num_batches_tracked) {
   const int c = blockIdx.x;
   double s1 = 0.0, s2 = 0.0;
-  for (int k = threadIdx.x; k < nblk; k += FIN_BLOCK) {
-    s1 += (double)partial[(long long)k * 2 * C + c];
-    s2 += (double)partial[(long long)k * 2 * C + C + c];
-  }
+  fin_column_sums(partial, nblk, C, c, s1, s2);
   block_sum2(s1, s2);
   if (threadIdx.x != 0) return;
   if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;   // nn.BatchNorm bookkeeping
@@ -686,10 +706,7 @@ __global__ __launch_bounds__(FIN_BLOCK) void bn_bwd_finalize_kernel(
     float *__restrict__ coef) {
   const int c = blockIdx.x;
   double s1 = 0.0, s2 = 0.0;
-  for (int k = threadIdx.x; k < nblk; k += FIN_BLOCK) {
-    s1 += (double)partial[(long long)k * 2 * C + c];
-    s2 += (double)partial[(long long)k * 2 * C + C + c];
-  }
+  fin_column_sums(partial, nblk, C, c, s1, s2);
   block_sum2(s1, s2);
   if (threadIdx.x != 0) return;
   if (dbeta) dbeta[c] = (float)s1;
