@@ -832,6 +832,71 @@ def test_bn_bwd_gemm_matches_the_separate_passes(M, C, N, relu):
     assert _rel(dX0.double(), ref) < 1e-5
 
 
+@pytest.mark.parametrize("M,C,N,nrelu", [(4196, 64, 64, 1), (5000, 128, 132, 1), (33000, 128, 128, 0)])
+def test_bn_bwd_gemm_leaves_the_previous_layers_column_sums(M, C, N, nrelu):
+    """s2c_bn_bwd_gemm_next_stats = s2c_bn_bwd_gemm (dY, dX bit for bit) + in `npartial` the two
+    column sums of the PREVIOUS layer's BatchNorm backward over (dX, nY): after
+    s2c_bn_bwd_finalize_partials the coef / dgamma / dbeta of s2c_bn_relu_bwd_stats(dX, nY)."""
+    from scan2cap_amd.pointnet2 import fused
+    _C, lib = _stream_lib()
+    g = torch.Generator(device="cuda").manual_seed(M + C + N)
+    r = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    Y, dA, W = r(M, C) * 2 + 0.5, r(M, C), r(C, N) * 0.2
+    gamma, mean = torch.rand(C, device="cuda", generator=g) + 0.5, Y.mean(0)
+    invstd = 1.0 / torch.sqrt(Y.var(0, unbiased=False) + 1e-5)
+    scale = gamma * invstd
+    shift = r(C) * 0.1 - mean * scale
+    nY = r(M, N) * 1.5 - 0.2
+    ngamma, nmean = torch.rand(N, device="cuda", generator=g) + 0.5, nY.mean(0)
+    ninvstd = 1.0 / torch.sqrt(nY.var(0, unbiased=False) + 1e-5)
+    nscale = ngamma * ninvstd
+    nshift = r(N) * 0.1 - nmean * nscale
+    nb = fused._stat_blocks(M)
+    partial = torch.empty(nb * 2 * max(C, N, 256), device="cuda")
+    coef, dgam, dbet = (torch.empty(3 * C, device="cuda"), torch.empty(C, device="cuda"),
+                        torch.empty(C, device="cuda"))
+    common = (dA.data_ptr(), Y.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+              invstd.data_ptr())
+    fused._call("s2c_bn_relu_bwd_stats", Y, M, C, *common, gamma.data_ptr(), 1, 0,
+                partial.data_ptr(), coef.data_ptr(), dgam.data_ptr(), dbet.data_ptr())
+    Wt = W.t().contiguous()
+    outs = []
+    for nxt in (False, True):
+        dY = torch.full((M, C), float("nan"), device="cuda")
+        dX = torch.full((M, N), float("nan"), device="cuda")
+        if not nxt:
+            fused._call("s2c_bn_bwd_gemm", Y, M, C, N, *common, coef.data_ptr(), 1, Wt.data_ptr(),
+                        Wt.stride(0), dY.data_ptr(), dX.data_ptr(), N)
+            outs.append((dY, dX, None))
+        else:
+            nbg = lib.s2c_rows_gemm_blocks(M, N)
+            npart = torch.full((nbg * 2 * N,), float("nan"), device="cuda")
+            fused._call("s2c_bn_bwd_gemm_next_stats", Y, M, C, N, *common, coef.data_ptr(), 1,
+                        Wt.data_ptr(), Wt.stride(0), dY.data_ptr(), dX.data_ptr(), N, nY.data_ptr(),
+                        nscale.data_ptr(), nshift.data_ptr(), nmean.data_ptr(), ninvstd.data_ptr(),
+                        nrelu, npart.data_ptr())
+            outs.append((dY, dX, (npart, nbg)))
+    (dY0, dX0, _), (dY1, dX1, (npart, nbg)) = outs
+    assert torch.equal(dY0, dY1) and torch.equal(dX0, dX1)
+    c1, g1, b1 = (torch.empty(3 * N, device="cuda"), torch.empty(N, device="cuda"),
+                  torch.empty(N, device="cuda"))
+    fused._call("s2c_bn_bwd_finalize_partials", dX1, nbg, M, N, npart.data_ptr(), 0,
+                ngamma.data_ptr(), ninvstd.data_ptr(), c1.data_ptr(), g1.data_ptr(), b1.data_ptr())
+    c0, g0, b0 = torch.empty_like(c1), torch.empty_like(g1), torch.empty_like(b1)
+    fused._call("s2c_bn_relu_bwd_stats", dX0, M, N, dX0.data_ptr(), nY.data_ptr(),
+                nscale.data_ptr(), nshift.data_ptr(), nmean.data_ptr(), ninvstd.data_ptr(),
+                ngamma.data_ptr(), nrelu, 0, partial.data_ptr(), c0.data_ptr(), g0.data_ptr(),
+                b0.data_ptr())
+    torch.cuda.synchronize()
+    # sums of M terms in another order: compare against the size of what is summed (with no
+    # ReLU in front the column sums of dX are rounding noise around 0: sum(dY) = 0 by construction)
+    S = float(dX0.abs().sum(0).max())
+    for a, b, tol in ((g1, g0, 4e-6 * S * 4), (b1, b0, 4e-6 * S), (c1[N:], c0[N:], 4e-6 * S * 4 / M)):
+        assert torch.isfinite(a).all()
+        assert float((a - b).abs().max()) <= tol
+    assert torch.equal(c1[:N], c0[:N])
+
+
 def test_weight_grad_partials_and_hand_input_grad_match_torch():
     from scan2cap_amd.pointnet2 import fused
     torch.manual_seed(2)
@@ -937,6 +1002,108 @@ def test_chunk64_gemm_matches_fp64_and_the_slice_kernel(M, N, K, lda, pro):
         assert float((p[0] - ref.sum(0)).abs().max()) <= 1e-4 * float(ref.abs().sum(0).max())
         assert float((p[1] - (ref * ref).sum(0)).abs().max()) <= 1e-5 * float((ref * ref).sum(0).max())
     assert torch.equal(outs[0][0], outs[1][0])
+
+
+@pytest.mark.parametrize("M,N,K,relu", [(4160, 128, 256, 1), (33000, 256, 128, 1), (1000, 132, 64, 0)])
+def test_next_layer_statistics_out_of_the_gemm_epilogue(M, N, K, relu):
+    """s2c_rows_gemm_next_stats: dX = dY W on the 64-k-chunk kernel whose epilogue also forms the
+    two column sums of the BatchNorm backward that dX feeds (layer with pre-activations nY);
+    s2c_bn_bwd_finalize_partials on them must give the coef / dgamma / dbeta of
+    s2c_bn_relu_bwd_stats over (dX, nY) -- same per-element arithmetic, another summation order
+    -- on ragged M (not a multiple of 128) and N that is no multiple of 128."""
+    import ctypes
+    from scan2cap_amd.pointnet2 import fused
+    _C, lib = _stream_lib()
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    r = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    dY, W = r(M, K), r(K, N) * 0.2                       # dX (M x N) = dY (M x K) W (K x N)
+    nY = r(M, N) * 2 + 0.3
+    gamma = torch.rand(N, device="cuda", generator=g) + 0.5
+    mean = nY.mean(0)
+    invstd = 1.0 / torch.sqrt(nY.var(0, unbiased=False) + 1e-5)
+    scale = gamma * invstd
+    shift = r(N) * 0.1 - mean * scale
+    Wt = W.t().contiguous()
+    nbg = lib.s2c_rows_gemm_blocks(M, N)
+    npart = torch.full((nbg * 2 * N,), float("nan"), device="cuda")
+    dX = torch.full((M, N), float("nan"), device="cuda")
+    rc = _C.call("s2c_rows_gemm_next_stats", M, N, K, dY.data_ptr(), K, Wt.data_ptr(), K,
+                 dX.data_ptr(), nY.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+                 invstd.data_ptr(), relu, npart.data_ptr(), _C.stream_ptr(), allow=(-2,))
+    assert rc == 0
+    coef, dg, db = (torch.empty(3 * N, device="cuda"), torch.empty(N, device="cuda"),
+                    torch.empty(N, device="cuda"))
+    fused._call("s2c_bn_bwd_finalize_partials", dX, nbg, M, N, npart.data_ptr(), 0,
+                gamma.data_ptr(), invstd.data_ptr(), coef.data_ptr(), dg.data_ptr(), db.data_ptr())
+    # reference: the plain GEMM (same kernel, no epilogue statistics) + the statistics pass
+    dX0 = torch.empty(M, N, device="cuda")
+    _C.call("s2c_rows_gemm", M, N, K, dY.data_ptr(), K, Wt.data_ptr(), K, None, None,
+            dX0.data_ptr(), N, None, _C.stream_ptr())
+    nb = fused._stat_blocks(M)
+    part0 = torch.empty(nb * 2 * max(N, 256), device="cuda")
+    coef0, dg0, db0 = torch.empty_like(coef), torch.empty_like(dg), torch.empty_like(db)
+    fused._call("s2c_bn_relu_bwd_stats", dX0, M, N, dX0.data_ptr(), nY.data_ptr(),
+                scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                gamma.data_ptr(), relu, 0, part0.data_ptr(), coef0.data_ptr(), dg0.data_ptr(),
+                db0.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(dX, dX0)
+    S = float(dX0.abs().sum(0).max())            # the size of what is summed (another order)
+    for a, b, tol in ((dg, dg0, 4e-6 * S * 4), (db, db0, 4e-6 * S),
+                      (coef[N:], coef0[N:], 4e-6 * S * 4 / M)):
+        assert torch.isfinite(a).all()
+        assert float((a - b).abs().max()) <= tol
+    assert torch.equal(coef[:N], coef0[:N])
+
+
+@pytest.mark.parametrize("M,N,K,ns,pro", [(4096 + 128, 256, 128, 32, 0), (2048 + 64, 128, 128, 16, 1),
+                                          (4096 + 192, 259, 96, 64, 0)])
+def test_pooled_extremum_out_of_the_chunk_kernel(M, N, K, ns, pro):
+    """s2c_rows_gemm_pool_raw with Y materialised on wide layers (64-k-chunk kernel): Y, the
+    statistics partials and, per centre and column, the extremum that BatchNorm + ReLU + max-pool
+    selects (maximum of sign(gamma) * y, first row) -- against s2c_rows_gemm + a torch reduction
+    over the materialised Y, gammas of both signs, ns = 16 / 32 / 64, ragged last row block."""
+    import ctypes
+    _C, lib = _stream_lib()
+    I, L, P = ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p
+    _C.register("s2c_rows_gemm_pool_raw", [L, I, I, P, I, P, P, I, P, I, P, I, I, P, P, P, P, I, P, P])
+    _C.register("s2c_bn_relu", [L, I, P, P, P, P, I, P])
+    torch.manual_seed(M + N + ns)
+    Yp = torch.randn(M, K, device="cuda")
+    psc, psh = torch.rand(K, device="cuda") + 0.5, torch.randn(K, device="cuda") * 0.3
+    W = torch.randn(N, K, device="cuda") * 0.2
+    gamma = torch.randn(N, device="cuda")
+    J = M // ns
+    nb = lib.s2c_rows_gemm_blocks(M, N)
+    if pro:
+        A = torch.empty_like(Yp)
+        _C.call("s2c_bn_relu", M, K, Yp.data_ptr(), psc.data_ptr(), psh.data_ptr(), A.data_ptr(), 1,
+                _C.stream_ptr())
+    else:
+        A = Yp
+    Y0 = torch.empty(M, N, device="cuda"); p0 = torch.empty(nb * 2 * N, device="cuda")
+    _C.call("s2c_rows_gemm", M, N, K, A.data_ptr(), K, W.data_ptr(), K, None, None, Y0.data_ptr(), N,
+            p0.data_ptr(), _C.stream_ptr())
+    Y = torch.full((M, N), float("nan"), device="cuda")
+    p1 = torch.full((nb * 2 * N,), float("nan"), device="cuda")
+    ext = torch.full((J, N), float("nan"), device="cuda")
+    aext = torch.full((J, N), -1, dtype=torch.int32, device="cuda")
+    side = torch.empty_like(Yp) if pro else None
+    rc = _C.call("s2c_rows_gemm_pool_raw", M, N, K, Yp.data_ptr(), K, psc.data_ptr() if pro else None,
+                 psh.data_ptr() if pro else None, 1, side.data_ptr() if pro else None, K, W.data_ptr(),
+                 K, ns, gamma.data_ptr(), ext.data_ptr(), aext.data_ptr(), Y.data_ptr(), N,
+                 p1.data_ptr(), _C.stream_ptr(), allow=(-2,))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(Y, Y0)
+    assert torch.equal(p1.view(nb, 2, N), p0.view(nb, 2, N))
+    if pro:
+        assert torch.equal(side, A)
+    Y3 = Y0.view(J, ns, N)
+    neg = gamma < 0
+    want = torch.where(neg, Y3.min(1)[0], Y3.max(1)[0])
+    assert torch.equal(ext, want)
+    assert torch.equal(aext.long(), (Y3 == want.unsqueeze(1)).int().argmax(1))      # FIRST extremum
 
 
 @pytest.mark.parametrize("B,n,m,ns,C,N,normalize", [(2, 20000, 1024, 64, 132, 64, 1),
