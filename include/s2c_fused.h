@@ -355,6 +355,39 @@ int s2c_attn_x2_fwd(int R, int K, int H, int F, int E, const float *M, const flo
                     const float *wa, const float *mask, const float *O, const float *Wl, int ldw,
                     const float *bias, const float *add, int ld_add, float *alpha, float *att,
                     int lda, float *x2, int ldx2, void *stream);
+/* The decoder's whole forward recurrence (T steps of caption_module.py:250-292) as ONE persistent
+ * kernel: 256 co-resident workgroups exchange the five per-step vectors as tagged 8-byte values
+ * (csrc/s2c_decoder_persist.hip) instead of meeting at 5 T launch boundaries.  Same operands and
+ * saved tensors as the s2c_small_linear / s2c_gru_fwd / s2c_attn_x2_fwd chain; R <= 8 rows,
+ * K <= 32 keys, H, E <= 512, F <= 256 (all multiples of 4), T <= 62.
+ *   xbuf    s2c_decoder_fwd_persist_xbuf_pairs(H, E) 8-byte words, zeroed ONCE at allocation
+ *   nonce   one uint32 (zeroed once), advanced by every launch;  started, fail: one uint32, zero
+ * Returns -2 (nothing launched) when s2c_decoder_fwd_persist_supported says no: shapes outside the
+ * limits, S2C_DECODER_PERSIST=0, or a device on which the grid would not be co-resident. */
+typedef struct s2c_dec_fwd_args {
+  int R, K, H, E, F, T, ldtd, ldlang;
+  int backoff, pad_;              /* x 64 cycles between two polls of the same data (0: measured best) */
+  const float *W_td_h2;           /* (E, H) column block of map_topdown, row stride ldtd */
+  const float *Pw, *Ptf;          /* (R, T, E) word projections, (R, E) target projection + bias */
+  const float *W_ih1, *W_hh1, *b_ih1, *b_hh1;
+  const float *Wqh;               /* (H + E, H): [map_hidd ; map_lang[:, F:]] */
+  const float *M, *wa, *mask, *O; /* (R, K, H), (H), (R, K), (R, K, F) */
+  const float *W_lang, *b_lang;   /* (E, ldlang): the first F columns are used */
+  const float *W_ih2, *W_hh2, *b_ih2, *b_hh2;
+  float *H1, *H2;                 /* (T + 1, R, H), slice 0 = initial state (zeros) */
+  float *X1, *X2;                 /* (T, R, E) */
+  float *S1[4], *S2[4];           /* (T, R, H) each: r, z, n, gh_n */
+  float *QL;                      /* (T, R, H + E) */
+  float *ALPHA, *ATT;             /* (T, R, K), (T, R, F) */
+  unsigned long long *xbuf;
+  unsigned long long *prof;       /* NULL, or 8 x T x 16 words: phase stamps of workgroup 0 */
+  unsigned int *nonce, *started, *fail;   /* fail: raised (1) when a poll gave up -- results invalid */
+} s2c_dec_fwd_args;
+int s2c_decoder_fwd_persist(const s2c_dec_fwd_args *a, void *stream);
+int s2c_decoder_fwd_persist_supported(int R, int K, int H, int E, int F, int T);
+long long s2c_decoder_fwd_persist_xbuf_pairs(int H, int E);
+void s2c_decoder_persist_set(int on);   /* 0: always refuse (the launch chain runs) */
+
 /* backward mirror for K <= 32 keys: datt = W_lang^T[:F] da2 formed inside the attention backward
  * (one launch instead of s2c_small_linear_pair + s2c_attn_bwd); dM / dwa_rows accumulate, dq (row
  * stride lddq) is overwritten.  F a power of two in 32..256, E <= 512. */

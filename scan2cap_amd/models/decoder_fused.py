@@ -104,6 +104,59 @@ _C.register("s2c_attn_bwd_x2", [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, 
                                 _P, _I, _P, _P])
 
 
+# The whole forward recurrence as ONE persistent kernel (csrc/s2c_decoder_persist.hip): 128
+# co-resident workgroups exchange the per-step vectors as tagged values instead of meeting at
+# 5 T launch boundaries.  S2C_DECODER_PERSIST=0 (or set_persist(False)): the launch chain.
+class _DecFwdArgs(ctypes.Structure):
+    """include/s2c_fused.h: s2c_dec_fwd_args"""
+    _fields_ = ([(n, _I) for n in ("R", "K", "H", "E", "F", "T", "ldtd", "ldlang", "backoff",
+                                   "pad_")] +
+                [(n, _P) for n in ("W_td_h2", "Pw", "Ptf", "W_ih1", "W_hh1", "b_ih1", "b_hh1",
+                                   "Wqh", "M", "wa", "mask", "O", "W_lang", "b_lang", "W_ih2",
+                                   "W_hh2", "b_ih2", "b_hh2", "H1", "H2", "X1", "X2")] +
+                [("S1", _P * 4), ("S2", _P * 4)] +
+                [(n, _P) for n in ("QL", "ALPHA", "ATT", "xbuf", "prof", "nonce", "started", "fail")])
+
+
+_C.register("s2c_decoder_fwd_persist", [_P, _P])
+PERSIST_BACKOFF = int(_os.environ.get("S2C_PERSIST_BACKOFF", "0"))
+PROF = None     # tools/bench_decoder_persist.py: an int64 tensor (8 * T * 16) of phase stamps
+_XBUF = {}      # (device index, H, E) -> (exchange buffer, [nonce, started]); zeroed once
+
+
+def _plib():
+    lib = _C.load()
+    if not getattr(lib, "_s2c_persist_typed", False):
+        lib.s2c_decoder_fwd_persist_supported.argtypes = [_I] * 6
+        lib.s2c_decoder_fwd_persist_supported.restype = _I
+        lib.s2c_decoder_fwd_persist_xbuf_pairs.argtypes = [_I, _I]
+        lib.s2c_decoder_fwd_persist_xbuf_pairs.restype = ctypes.c_longlong
+        lib.s2c_decoder_persist_set.argtypes = [_I]
+        lib.s2c_decoder_persist_set.restype = None
+        lib._s2c_persist_typed = True
+    return lib
+
+
+def persist_failed(dev=None):
+    """True if a launch of the persistent kernel gave up on a poll (its results are invalid).
+    Synchronises; for tests and smoke()."""
+    return any(int(ctl[2].item()) != 0 for k, (_, ctl) in _XBUF.items()
+               if dev is None or k[0] == torch.device(dev).index)
+
+
+def set_persist(on):
+    _plib().s2c_decoder_persist_set(int(bool(on)))
+
+
+def _persist_scratch(dev, H, E):
+    key = (dev.index, H, E)
+    if key not in _XBUF:
+        pairs = int(_plib().s2c_decoder_fwd_persist_xbuf_pairs(H, E))
+        _XBUF[key] = (torch.zeros(pairs, dtype=torch.int64, device=dev),
+                      torch.zeros(4, dtype=torch.int32, device=dev))
+    return _XBUF[key]
+
+
 def supported(emb, hid, feat, K):
     return (ENABLED and emb % 4 == 0 and hid % 4 == 0 and feat in (32, 64, 128, 256) and K <= 1024
             and hid <= 512 and emb <= 512)     # register-resident input slices
@@ -171,7 +224,30 @@ class TopDownDecode(Function):
             ATT = e(T, R, F)
             ldtd, ldlang = W_td.shape[1], W_lang.shape[1]
             td_h2 = W_td[:, E:E + H]          # column block, row stride ldtd
-            for t in range(T):
+            persist = (ldtd % 4 == 0 and ldlang % 4 == 0 and
+                       _plib().s2c_decoder_fwd_persist_supported(R, K, H, E, F, T) == 1)
+            if persist:
+                xbuf, ctl = _persist_scratch(dev, H, E)
+                a = _DecFwdArgs()
+                a.R, a.K, a.H, a.E, a.F, a.T, a.ldtd, a.ldlang = R, K, H, E, F, T, ldtd, ldlang
+                for n, v in (("W_td_h2", td_h2), ("Pw", Pw), ("Ptf", Ptf), ("W_ih1", W_ih1),
+                             ("W_hh1", W_hh1), ("b_ih1", b_ih1), ("b_hh1", b_hh1), ("Wqh", Wqh),
+                             ("M", M), ("wa", wa), ("mask", mask), ("O", O), ("W_lang", W_lang),
+                             ("b_lang", b_lang), ("W_ih2", W_ih2), ("W_hh2", W_hh2),
+                             ("b_ih2", b_ih2), ("b_hh2", b_hh2), ("H1", H1), ("H2", H2),
+                             ("X1", X1), ("X2", X2), ("QL", QL), ("ALPHA", ALPHA), ("ATT", ATT),
+                             ("xbuf", xbuf)):
+                    assert v.is_contiguous() or n == "W_td_h2", n
+                    setattr(a, n, v.data_ptr())
+                a.backoff = PERSIST_BACKOFF
+                a.prof = PROF.data_ptr() if PROF is not None else None
+                a.nonce, a.started, a.fail = ctl.data_ptr(), ctl.data_ptr() + 4, ctl.data_ptr() + 8
+                for j in range(4):
+                    a.S1[j], a.S2[j] = S1[j].data_ptr(), S2[j].data_ptr()
+                if _C.TIMER.enabled:
+                    _C.TIMER.alg_bytes = 0
+                _C.call("s2c_decoder_fwd_persist", ctypes.byref(a), _C.stream_ptr())
+            for t in range(0 if not persist else T, T):
                 _lin(R, E, H, td_h2, ldtd, H2[t], H, X1[t], E, add1=Pw[:, t],
                      ld1=T * E, add2=Ptf, ld2=E, epi=1)
                 _call("s2c_gru_fwd", R, H, E, _p(W_ih1), _p(W_hh1), _p(b_ih1),

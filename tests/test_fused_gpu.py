@@ -137,15 +137,109 @@ def test_fused_decoder_matches_torch_loop(K):
     attention kernel); K = 64: scores + softmax kernels."""
     from scan2cap_amd.models import decoder_fused
     from scan2cap_amd.models.caption_module import TopDownSceneCaptionModule
-    if K == 10:      # exercise the one-pass kernel too (off by default: see decoder_fused.py)
-        import pytest as _pt
-        mp = _pt.MonkeyPatch()
-        mp.setattr(decoder_fused, "LOCAL_ATTN_MAX_K", 32)
+    decoder_fused.set_persist(False)      # the launch chain (the persistent kernel: test below)
+    try:
+        if K == 10:      # exercise the one-pass kernel too (off by default: see decoder_fused.py)
+            import pytest as _pt
+            mp = _pt.MonkeyPatch()
+            mp.setattr(decoder_fused, "LOCAL_ATTN_MAX_K", 32)
+            mp.setattr(decoder_fused, "FUSE_ATTN_X2", False)
+            try:
+                return _decoder_vs_torch_loop(K)
+            finally:
+                mp.undo()
+        return _decoder_vs_torch_loop(K)
+    finally:
+        decoder_fused.set_persist(True)
+
+
+@pytest.mark.parametrize("R,K,H,E,F,T", [(8, 10, 512, 300, 128, 9), (5, 7, 256, 128, 64, 6),
+                                         (3, 4, 128, 64, 32, 5), (8, 16, 384, 256, 128, 3),
+                                         (1, 1, 512, 300, 128, 31)])
+def test_persistent_decoder_forward(R, K, H, E, F, T):
+    """The forward recurrence as ONE persistent kernel (s2c_decoder_fwd_persist: 128 workgroups
+    exchanging tagged values) against the launch chain it replaces and the module's own step
+    loop: logits, attention, every gradient (the backward consumes what the kernel saved).
+    Launched three times in a row (the launch nonce / buffer parity must carry over) and once
+    more from a captured graph replayed twice."""
+    from scan2cap_amd.models import decoder_fused
+    from scan2cap_amd.models.caption_module import TopDownSceneCaptionModule
+    torch.manual_seed(R * 100 + K)
+    V = 40
+    words = ["w%d" % i for i in range(V)]
+    vocab = {"word2idx": {w: i for i, w in enumerate(words)},
+             "idx2word": {str(i): w for i, w in enumerate(words)}}
+    emb = {w: np.random.randn(E).astype(np.float32) for w in words}
+    mod = TopDownSceneCaptionModule(vocab, emb, E, F, H, K, num_locals=K).cuda()
+    word_embs = torch.randn(R, 32, E, device="cuda") * 0.3
+    obj = (torch.randn(R, K, F, device="cuda") * 0.5).requires_grad_(True)
+    tgt = (torch.randn(R, F, device="cuda") * 0.5).requires_grad_(True)
+    masks = (torch.rand(R, K, device="cuda") > 0.5).float()
+    masks[:, 0] = 1.0
+    assert decoder_fused._plib().s2c_decoder_fwd_persist_supported(R, K, H, E, F, T) == 1
+    g = None
+
+    def run(persist):
+        nonlocal g
+        decoder_fused.set_persist(persist)
         try:
-            return _decoder_vs_torch_loop(K)
+            mod.zero_grad()
+            obj.grad = tgt.grad = None
+            got, attn = decoder_fused.decode(mod, word_embs, tgt, obj, masks, T)
+            if g is None:
+                g = torch.randn_like(got)
+            stash = []
+            for v in got.grad_fn.stash:
+                stash.extend([x.clone() for x in v] if isinstance(v, list) else [v.clone()])
+            (got * g).sum().backward()
+            grads = {n: p.grad.clone() for n, p in mod.named_parameters()}
+            grads["obj"], grads["tgt"] = obj.grad.clone(), tgt.grad.clone()
+            return got.detach().clone(), attn.detach().clone(), grads, stash
         finally:
-            mp.undo()
-    return _decoder_vs_torch_loop(K)
+            decoder_fused.set_persist(True)
+
+    want, want_attn, want_grads, want_stash = run(False)
+    for rep in range(3):
+        got, attn, grads, stash = run(True)
+        assert not decoder_fused.persist_failed()
+        assert _rel(got, want) < 2e-5, rep
+        assert _rel(attn, want_attn) < 2e-5, rep
+        # everything the kernel saved for the backward pass (hidden states, gates, attention)
+        for j, (x, y) in enumerate(zip(stash, want_stash)):
+            assert _rel(x, y) < 5e-6, (rep, j)
+        # the backward pass is the same code on these saved tensors; its result can differ by more
+        # than rounding only where a ReLU input (x1, x2: saved tensors 7 and 8) within 1e-7 of
+        # zero falls on the other side -- compare the gradients when no gate flipped
+        flips = sum(int(((stash[j] > 0) != (want_stash[j] > 0)).sum()) for j in (7, 8))
+        assert flips <= 2, flips
+        if flips == 0:
+            for n in want_grads:
+                assert _rel(grads[n], want_grads[n]) < 1e-4, (rep, n)
+    # ... and against the module's own step loop
+    mapped = mod.map_feat(obj)
+    h1 = torch.zeros(R, H, device="cuda")
+    h2 = torch.zeros(R, H, device="cuda")
+    outs = []
+    with torch.no_grad():
+        for t in range(T):
+            h1, h2, m = mod._step(word_embs[:, t], tgt, obj, h1, h2, masks.unsqueeze(-1), mapped)
+            outs.append(mod.classifier(h2).unsqueeze(1))
+    assert _rel(got, torch.cat(outs, 1)) < 1e-4
+    # replayed from a graph: the nonce advances on the device, not in the (frozen) arguments
+    with torch.no_grad():
+        decoder_fused.decode(mod, word_embs, tgt, obj, masks, T)      # scratch exists before capture
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            with torch.cuda.graph(gr, stream=s):
+                out_g, _ = decoder_fused.decode(mod, word_embs, tgt, obj, masks, T)
+        for _ in range(2):
+            out_g.zero_()
+            gr.replay()
+            torch.cuda.synchronize()
+            assert not decoder_fused.persist_failed()
+            assert _rel(out_g, want) < 2e-5
 
 
 def _decoder_vs_torch_loop(K):
