@@ -376,7 +376,9 @@ typedef struct s2c_dec_fwd_args {
   const float *W_ih2, *W_hh2, *b_ih2, *b_hh2;
   float *H1, *H2;                 /* (T + 1, R, H), slice 0 = initial state (zeros) */
   float *X1, *X2;                 /* (T, R, E) */
-  float *S1[4], *S2[4];           /* (T, R, H) each: r, z, n, gh_n */
+  float *S;                       /* (2 cells, 4, T, R, H): r, z, n, gh_n of GRU cell 1, then of cell 2 */
+  float *C;                       /* NULL or (2, 4, T, R, H): cr, cz, cn, cnr with d(gi) = dh' [cr | cz | cn],
+                                     d(gh) = dh' [cr | cz | cnr] -- what s2c_decoder_bwd_persist reads */
   float *QL;                      /* (T, R, H + E) */
   float *ALPHA, *ATT;             /* (T, R, K), (T, R, F) */
   unsigned long long *xbuf;
@@ -387,6 +389,32 @@ int s2c_decoder_fwd_persist(const s2c_dec_fwd_args *a, void *stream);
 int s2c_decoder_fwd_persist_supported(int R, int K, int H, int E, int F, int T);
 long long s2c_decoder_fwd_persist_xbuf_pairs(int H, int E);
 void s2c_decoder_persist_set(int on);   /* 0: always refuse (the launch chain runs) */
+
+/* ... and its back-propagation through time (the 5-launches-per-step chain of decoder_fused.py's
+ * backward) as one persistent kernel.  Needs the coefficient arrays C1 / C2 written by
+ * s2c_decoder_fwd_persist, and two products formed before the loop:
+ *   P (R, K, E) = O W_lang[:, :F]^T,   Latt (T, R, E) = ATT W_lang[:, :F]^T
+ * (the attention backward needs datt = W_lang[:, :F]^T da2 only inside <datt, O_k> = <da2, P_k> and
+ * <datt, att_t> = <da2, Latt_t>).  Transposed weights as s2c_batch_prep leaves them; WT_hl (H, H + E) =
+ * [W_h^T | W_lang[:, F:]^T].  Outputs: DA1 (T, R, E), DQA (T, R, H + E) = [dq | da2], DG = DGI1, DGH1,
+ * DGI2, DGH2 (4, T, R, 3H), dM (R, K, H) and dwa_rows (R, H) -- the last two written once, complete.
+ * xbuf: s2c_decoder_bwd_persist_xbuf_pairs(H, E) 8-byte words zeroed once; nonce / started / fail as
+ * in the forward kernel (its own three words). */
+typedef struct s2c_dec_bwd_args {
+  int R, K, H, E, T, pad_;
+  const float *dH2;                 /* (T, R, H) gradient of the classifier input */
+  const float *C, *S;               /* (2, 4, T, R, H) each, as s2c_dec_fwd_args left them */
+  const float *X1, *X2;             /* (T, R, E) */
+  const float *QL, *ALPHA, *M, *wa; /* (T, R, H + E), (T, R, K), (R, K, H), (H) */
+  const float *P, *Latt;            /* (R, K, E), (T, R, E) */
+  const float *WT_ih2, *WT_hh2, *WT_hl, *WT_ih1, *WT_hh1, *WT_td;
+  float *DA1, *DQA, *DG, *dM, *dwa_rows;   /* DG (4, T, R, 3H): DGI1, DGH1, DGI2, DGH2 */
+  unsigned long long *xbuf;
+  unsigned int *nonce, *started, *fail;
+} s2c_dec_bwd_args;
+int s2c_decoder_bwd_persist(const s2c_dec_bwd_args *a, void *stream);
+int s2c_decoder_bwd_persist_supported(int R, int K, int H, int E, int T);
+long long s2c_decoder_bwd_persist_xbuf_pairs(int H, int E);
 
 /* backward mirror for K <= 32 keys: datt = W_lang^T[:F] da2 formed inside the attention backward
  * (one launch instead of s2c_small_linear_pair + s2c_attn_bwd); dM / dwa_rows accumulate, dq (row

@@ -107,17 +107,18 @@ __device__ __host__ __forceinline__ XOff xoff(int H, int E) {
 // Poll rows r0 .. r0+3 (those < R) of a tagged (8 x I) vector: this lane's float4 slots lane and
 // lane + 64 (those < n4).  All sixteen 16-byte loads are in flight together; a row's base goes
 // through the scalar offset, the slot through the instruction's immediate.
+template <int NR>
 __device__ __forceinline__ void poll_rows(__amdgpu_buffer_rsrc_t rs, int base_pairs, int I, int n4,
-                                          int r0, int R, u32 tag, float4 (&x)[4][2],
+                                          int r0, int R, u32 tag, float4 (&x)[NR][2],
                                           volatile int *s_dead, int backoff) {
   const int lane = threadIdx.x & 63;
   const int voff = lane * 32;
-  u32x4 raw[4][2][2];
+  u32x4 raw[NR][2][2];
   bool stale;
   int spins = 0;
   do {
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
+    for (int rr = 0; rr < NR; ++rr) {
       const int soff = __builtin_amdgcn_readfirstlane((base_pairs + (r0 + rr) * I) * 8);
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -132,7 +133,7 @@ __device__ __forceinline__ void poll_rows(__amdgpu_buffer_rsrc_t rs, int base_pa
     }
     stale = false;
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr)
+    for (int rr = 0; rr < NR; ++rr)
 #pragma unroll
       for (int s = 0; s < 2; ++s)
         stale |= (raw[rr][s][0].y != tag) | (raw[rr][s][0].w != tag) | (raw[rr][s][1].y != tag) |
@@ -145,7 +146,7 @@ __device__ __forceinline__ void poll_rows(__amdgpu_buffer_rsrc_t rs, int base_pa
       for (int i = 0; i < backoff; ++i) __builtin_amdgcn_s_sleep(1);
   } while (stale);
 #pragma unroll
-  for (int rr = 0; rr < 4; ++rr)
+  for (int rr = 0; rr < NR; ++rr)
 #pragma unroll
     for (int s = 0; s < 2; ++s)
       x[rr][s] = make_float4(__uint_as_float(raw[rr][s][0].x), __uint_as_float(raw[rr][s][0].z),
@@ -240,6 +241,7 @@ __device__ __forceinline__ float red4(const float (*s_red)[4], int v) {
 
 struct GruOut {
   float *h, *sr, *sz, *sn, *sghn;   // plain (R x H) destinations of this step
+  float *c[4];                      // NULL or: gate-gradient coefficients (see s2c_dec_bwd_args)
 };
 
 // GRUCell epilogue on the item lanes of a part-0 wave (lane = unit j * 4 + row rr); `bias` =
@@ -260,10 +262,18 @@ __device__ __forceinline__ void gru_epilogue(const float (*s_h)[4], const float 
     const float r = p_sigmoid(gir + ghr), z = p_sigmoid(giz + ghz);
     const float n = p_tanh(gin + r * ghn);
     const float hn = (1.0f - z) * n + z * hp;
-    hp = hn;
     st_tag(xb + (size_t)row * H + u, hn, tag);
     const size_t e = (size_t)row * H + u;
     o.h[e] = hn; o.sr[e] = r; o.sz[e] = z; o.sn[e] = n; o.sghn[e] = ghn;
+    if (o.c[0]) {
+      // d(pre-activations) = dh' * c:  dgi = dh' [cr | cz | cn],  dgh = dh' [cr | cz | cnr]
+      const float cn = (1.0f - z) * (1.0f - n * n);
+      o.c[0][e] = cn * ghn * (r * (1.0f - r));
+      o.c[1][e] = (hp - n) * (z * (1.0f - z));
+      o.c[2][e] = cn;
+      o.c[3][e] = cn * r;
+    }
+    hp = hn;
   }
 }
 
@@ -394,7 +404,7 @@ __global__ __launch_bounds__(PT, 2) void decoder_fwd_persist_kernel(s2c_dec_fwd_
       if (item) e_add = a.Pw[((size_t)row * T + t) * E + o] + a.Ptf[(size_t)row * E + o];
       float4 x[4][2];
       if (t > 0 && up == 0) {
-        poll_rows(rs[par ^ 1], xo.h2, H, n4h, r0, R, tag - 1u, x, &s_dead, a.backoff);
+        poll_rows<4>(rs[par ^ 1], xo.h2, H, n4h, r0, R, tag - 1u, x, &s_dead, a.backoff);
         P_STAMP(1);
 #pragma unroll
         for (int rr2 = 0; rr2 < 4; ++rr2)
@@ -444,7 +454,7 @@ __global__ __launch_bounds__(PT, 2) void decoder_fwd_persist_kernel(s2c_dec_fwd_
         // x1 cannot exist before this workgroup's own share has been published (all workgroups
         // run in step): do not load the fabric with polls until then
         flag_wait(&s_flag[2][rq], t + 1, &s_dead);
-        poll_rows(rs[par], xo.x1, E, n4e, r0, R, tag, x, &s_dead, a.backoff);
+        poll_rows<4>(rs[par], xo.x1, E, n4e, r0, R, tag, x, &s_dead, a.backoff);
       }
       P_STAMP(3);
       gru_partials(g1, x, s_red[0][wv]);
@@ -452,8 +462,10 @@ __global__ __launch_bounds__(PT, 2) void decoder_fwd_persist_kernel(s2c_dec_fwd_
       __syncthreads();
       P_STAMP(5);
       if (part == 0) {
-        GruOut o = {a.H1 + (size_t)(t + 1) * RH, a.S1[0] + (size_t)t * RH, a.S1[1] + (size_t)t * RH,
-                    a.S1[2] + (size_t)t * RH, a.S1[3] + (size_t)t * RH};
+        float *S = a.S + (size_t)t * RH, *C = a.C ? a.C + (size_t)t * RH : nullptr;
+        const size_t TRH = (size_t)T * RH;
+        GruOut o = {a.H1 + (size_t)(t + 1) * RH, S, S + TRH, S + 2 * TRH, S + 3 * TRH,
+                    {C, C + TRH, C + 2 * TRH, C + 3 * TRH}};
         gru_epilogue(s_red[0][wv], s_red[0][wv + 1], H, R, r0, u0, P_UB * up, ub, s_bias[0], hp1,
                      o, xb + xo.h1, tag);
       }
@@ -463,7 +475,7 @@ __global__ __launch_bounds__(PT, 2) void decoder_fwd_persist_kernel(s2c_dec_fwd_
     if (part == 0) {
       float4 x[4][2];
       if (up == 0) {
-        poll_rows(rs[par], xo.h1, H, n4h, r0, R, tag, x, &s_dead, a.backoff);
+        poll_rows<4>(rs[par], xo.h1, H, n4h, r0, R, tag, x, &s_dead, a.backoff);
         P_STAMP(7);
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr)
@@ -578,14 +590,16 @@ __global__ __launch_bounds__(PT, 2) void decoder_fwd_persist_kernel(s2c_dec_fwd_
                            ? reinterpret_cast<const float4 *>(sH2 + (size_t)(r0 + rr) * H)[lane + 64 * s]
                            : make_float4(0.f, 0.f, 0.f, 0.f);
       } else {
-        poll_rows(rs[par], xo.x2, E, n4e, r0, R, tag, x, &s_dead, a.backoff);
+        poll_rows<4>(rs[par], xo.x2, E, n4e, r0, R, tag, x, &s_dead, a.backoff);
       }
       P_STAMP(11);
       gru_partials_lds(sG2w, part ? E : H, x, s_red[1][wv]);
       __syncthreads();
       if (part == 0) {
-        GruOut o = {a.H2 + (size_t)(t + 1) * RH, a.S2[0] + (size_t)t * RH, a.S2[1] + (size_t)t * RH,
-                    a.S2[2] + (size_t)t * RH, a.S2[3] + (size_t)t * RH};
+        const size_t TRH = (size_t)T * RH;
+        float *S = a.S + 4 * TRH + (size_t)t * RH, *C = a.C ? a.C + 4 * TRH + (size_t)t * RH : nullptr;
+        GruOut o = {a.H2 + (size_t)(t + 1) * RH, S, S + TRH, S + 2 * TRH, S + 3 * TRH,
+                    {C, C + TRH, C + 2 * TRH, C + 3 * TRH}};
         gru_epilogue(s_red[1][wv], s_red[1][wv + 1], H, R, r0, u0, P_UB * up, ub, s_bias[1], hp2,
                      o, xb + xo.h2, tag);
       }
@@ -601,6 +615,473 @@ __global__ __launch_bounds__(PT, 2) void decoder_fwd_persist_kernel(s2c_dec_fwd_
     __hip_atomic_store(a.started, 0u, __ATOMIC_RELAXED, S2C_AG);
     __hip_atomic_store(a.nonce, s_nonce + 1u, __ATOMIC_RELAXED, S2C_AG);
   }
+}
+
+// ============================================================================================
+// Back-propagation through time of the same recurrence as ONE kernel (the launch chain:
+// 5 dependent launches per step, decoder_fused.py).  Per step t = T-1 .. 0, five exchanges:
+//   B1  gates of cell 2 from dh2'(t) -> da2 = (W_ih2^T dgi) * (x2 > 0),  dh2_part = W_hh2^T dgh + dh2' z
+//   B2  attention backward of row w % 8 (row-local) from da2 -> dq; dM / dwa accumulate in registers
+//   B3  dh1'(t) = [W_h^T | W_lang[:, F:]^T] [dq | da2] + dh1c
+//   B4  gates of cell 1 from dh1' -> da1 = (W_ih1^T dgi) * (x1 > 0),  dh1c = W_hh1^T dgh + dh1' z
+//   B5  dh2'(t-1) = W_td[:, h2 block]^T da1 + dh2_part + dH2[t-1]
+// What makes the exchanged vectors small: a consumer needs the gate gradients dgi / dgh (3 H
+// values per row) only as dh' * c with c = the coefficient arrays the forward kernel saved
+// (s2c_dec_fwd_args.C1 / C2) -- so dh' (H values) travels and every workgroup forms the products
+// itself; and the attention backward needs datt = W_lang[:, :F]^T da2 only inside two inner
+// products, <datt, O_k> = <da2, P_k> and <datt, att_t> = <da2, Latt_t> with P = O W_lang[:, :F]^T and
+// Latt = ATT W_lang[:, :F]^T formed by two GEMMs before the loop.
+// Wave = (row quad rq, job).  In B1 / B4 job g takes gate block g of the 3 H reduction (r, z, n
+// for dgi, n*r for dgh) for all of the workgroup's outputs, the blocks are summed through LDS; in
+// B3 / B5 job j takes hidden unit j of the workgroup's four.  One wave per row quad polls, the
+// others wait on an LDS flag and read the operand from the LDS stash.
+// ============================================================================================
+constexpr int B_OBE = 4;   // e-outputs (da1 / da2 columns) per workgroup  (E <= 512)
+constexpr int B_UB = 4;    // hidden units per workgroup                   (H <= 512)
+
+struct BOff {
+  int dh2, da2, dq, dh1, da1, total;
+};
+__device__ __host__ __forceinline__ BOff boff(int H, int E) {
+  BOff o;
+  o.dh2 = 0;
+  o.da2 = 8 * H;
+  o.dq = o.da2 + 8 * E;
+  o.dh1 = o.dq + 8 * H;
+  o.da1 = o.dh1 + 8 * H;
+  o.total = o.da1 + 8 * E;
+  return o;
+}
+
+template <int NR>
+__device__ __forceinline__ void stash_put(float *sX, int I, int n4, int r0, const float4 (&x)[NR][2]) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int rr = 0; rr < NR; ++rr)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+      if (lane + 64 * s < n4) reinterpret_cast<float4 *>(sX + (size_t)(r0 + rr) * I)[lane + 64 * s] = x[rr][s];
+}
+__device__ __forceinline__ void stash_get(const float *sX, int I, int n4, int r0, float4 (&x)[4][2]) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+      x[rr][s] = lane + 64 * s < n4
+                     ? reinterpret_cast<const float4 *>(sX + (size_t)(r0 + rr) * I)[lane + 64 * s]
+                     : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+struct GateIO {
+  const float *C[4];          // coefficient arrays of the cell at step t (R x H each)
+  const float *Z;             // update gate z of the cell at step t (R x H)
+  const float *X;             // the ReLU output whose sign gates da (R x E at step t)
+  float *dgi, *dgh;           // plain (R x 3H) at step t
+  float *da;                  // plain da destination of step t, row stride ld_da
+  int ld_da;
+  u64 *xb_da;                 // tagged da destination (8 x E)
+  const float *plain_dh;      // step T-1 of cell 2: dh' = dH2[T-1] (R x H), else NULL
+  int src_off;                // tagged dh' source (pairs) inside rs_src
+  u32 src_tag, tag;
+};
+
+// B1 / B4.  The weight rows of the e-outputs are in LDS (sWe: [output][3H]); those of the
+// h-outputs in registers (REGS: this wave's gate block in Wh) or in LDS (sWh).
+template <bool REGS>
+__device__ __forceinline__ void gate_phase(const GateIO &io, __amdgpu_buffer_rsrc_t rs_src,
+                                           const float4 (&Wh)[B_UB][2], const float *sWe,
+                                           const float *sWh,
+                                           int R, int H, int E, int obe, int ub, int e0, int u0,
+                                           float *sD, float (*s_red)[32][4], float (*s_dhp)[4],
+                                           volatile int *flag, int flagv, volatile int *s_dead) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, job = wv & 3, r0 = 4 * (wv >> 2);
+  const int n4h = H >> 2;
+  const float *Cg = io.C[job];
+  // (1) this wave's coefficient slice, (2) the item lanes' coefficients, (3) epilogue operands
+  float4 c[4][2];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+      c[rr][s] = (lane + 64 * s < n4h && r0 + rr < R)
+                     ? reinterpret_cast<const float4 *>(Cg + (size_t)(r0 + rr) * H)[lane + 64 * s]
+                     : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int ij = (lane & 15) >> 2, irr = lane & 3, irow = r0 + irr;
+  const bool item = lane < 16 && ij < ub && irow < R && u0 + ij < H;
+  const float ci = item ? Cg[(size_t)irow * H + u0 + ij] : 0.0f;
+  const bool eok = job == 0 && lane < 16 && ij < obe && irow < R && e0 + ij < E;
+  const bool hok = job == 0 && lane >= 16 && lane < 32 && ij < ub && irow < R && u0 + ij < H;
+  float e_op = 0.0f;
+  if (eok) e_op = io.X[(size_t)irow * E + e0 + ij];
+  if (hok) e_op = io.Z[(size_t)irow * H + u0 + ij];
+  // (4) operand dh'
+  float4 x[4][2];
+  if (job < 2) {                               // jobs 0, 1 fetch two rows each
+    float4 y[2][2];
+    const int ry = r0 + 2 * job;
+    if (io.plain_dh) {
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+          y[rr][s] = (lane + 64 * s < n4h && ry + rr < R)
+                         ? reinterpret_cast<const float4 *>(io.plain_dh + (size_t)(ry + rr) * H)[lane + 64 * s]
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      poll_rows<2>(rs_src, io.src_off, H, n4h, ry, R, io.src_tag, y, s_dead, 0);
+    }
+    stash_put<2>(sD, H, n4h, ry, y);
+    flag_raise(flag + job, flagv);
+  }
+  flag_wait(flag, flagv, s_dead);
+  flag_wait(flag + 1, flagv, s_dead);
+  stash_get(sD, H, n4h, r0, x);
+  // (5) gate gradients of this block
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      x[rr][s].x *= c[rr][s].x; x[rr][s].y *= c[rr][s].y;
+      x[rr][s].z *= c[rr][s].z; x[rr][s].w *= c[rr][s].w;
+    }
+  // (6) this block's share of every output
+  const int gblk = (job < 3 ? job : 2) * H;
+#pragma unroll
+  for (int o8 = 0; o8 < B_OBE + B_UB; ++o8) {
+    const bool isE = o8 < B_OBE;
+    const int k = isE ? o8 : o8 - B_OBE;
+    const bool use = isE ? (k < obe && job != 3) : (k < ub && job != 2);   // wave-uniform
+    if (!use) continue;
+    float4 w0, w1;
+    if (REGS && !isE) {
+      w0 = Wh[k][0]; w1 = Wh[k][1];
+    } else {
+      const float4 *wr =
+          reinterpret_cast<const float4 *>((isE ? sWe : sWh) + (size_t)k * 3 * H + gblk);
+      w0 = lane < n4h ? wr[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+      w1 = lane + 64 < n4h ? wr[lane + 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      float acc = fdot4(w0, x[rr][0], 0.0f);
+      acc = fdot4(w1, x[rr][1], acc);
+      acc = row16_sum(acc);
+      if ((lane & 15) == 0) s_red[wv][o8 * 4 + rr][lane >> 4] = acc;
+    }
+  }
+  // (7) the gate gradients of the workgroup's own units, for the weight-gradient GEMMs
+  if (item) {
+    const int u = u0 + ij;
+    const float v = sD[(size_t)irow * H + u] * ci;
+    float *gi = io.dgi + (size_t)irow * 3 * H, *gh = io.dgh + (size_t)irow * 3 * H;
+    if (job == 0) { gi[u] = v; gh[u] = v; }
+    else if (job == 1) { gi[H + u] = v; gh[H + u] = v; }
+    else if (job == 2) gi[2 * H + u] = v;
+    else gh[2 * H + u] = v;
+  }
+  __syncthreads();
+  // (8) sum of the three blocks; da is published, the h-path stays in the workgroup
+  if (eok) {
+    const int v8 = ij * 4 + irr;
+    float v = (red4(s_red[wv], v8) + red4(s_red[wv + 1], v8)) + red4(s_red[wv + 2], v8);
+    v = e_op > 0.0f ? v : 0.0f;
+    st_tag(io.xb_da + (size_t)irow * E + e0 + ij, v, io.tag);
+    io.da[(size_t)irow * io.ld_da + e0 + ij] = v;
+  }
+  if (hok) {
+    const int v8 = (B_OBE + ij) * 4 + irr;
+    const float v = (red4(s_red[wv], v8) + red4(s_red[wv + 1], v8)) + red4(s_red[wv + 3], v8);
+    s_dhp[irow][ij] = v + sD[(size_t)irow * H + u0 + ij] * e_op;
+  }
+}
+
+__global__ __launch_bounds__(PT, 2) void decoder_bwd_persist_kernel(s2c_dec_bwd_args a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ float s_red[2][PW][32][4];     // [cell][wave][output x row][16-lane row]
+  __shared__ float s_one[2][PW][4][4];      // B3 / B5 partials (the same wave writes and reads)
+  __shared__ float s_dhp[2][8][B_UB];       // [dh2_part | dh1c][row][unit of the workgroup]
+  __shared__ float s_sc[P_MAXK + 1][PT / 16], s_dal[P_MAXK + 1], s_alpha[P_MAXK];
+  __shared__ float s_dpre[P_MAXK][32], s_dsc[P_MAXK][32];
+  __shared__ int s_flag[5][2][2];           // [dh2' | dq | da2 | dh1' | da1 stash ready][row quad][half]
+  __shared__ u32 s_nonce;
+  __shared__ int s_dead;
+  const int R = a.R, K = a.K, H = a.H, E = a.E, T = a.T;
+  const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int job = wv & 3, rq = wv >> 2, r0 = 4 * rq;
+  const int n4h = H >> 2, n4e = E >> 2, HE = H + E;
+  const int obe = (E + PG - 1) / PG, ub = (H + PG - 1) / PG;
+  const int e0 = w * obe, u0 = w * ub;
+  const int row4 = w & 7, hs0 = 32 * (w >> 3);
+  float *sW4 = smem;                           // (obe + ub) x 3H  cell 1: W_ih1^T / W_hh1^T rows
+  float *sWe2 = sW4 + (size_t)(obe + ub) * 3 * H;  // obe x 3H     cell 2: W_ih2^T rows
+  float *sW3 = sWe2 + (size_t)obe * 3 * H;     // ub x (H + E)  [W_h^T | W_lang[:, F:]^T] rows
+  float *sP = sW3 + (size_t)ub * HE;           // K x E    O[row4] W_lang[:, :F]^T
+  float *sMs = sP + (size_t)K * E;             // K x 32   map_feat(obj_feats)[row4, :, h slice]
+  // operand stashes.  dh' (B1, B4) and dq (B3) share one, da2 (B3) and da1 (B5) the other: a stash
+  // is rewritten only after a poll that cannot complete before every wave of this workgroup has
+  // published what it computed from the previous content
+  float *sD = sMs + (size_t)K * 32;            // 8 x H
+  float *sDQ = sD;
+  float *sDA2 = sD + 8 * H;                    // 8 x E
+  float *sDA1 = sDA2;
+  if (tid == 0) {
+    s_dead = 0;
+    s_nonce = __hip_atomic_load(a.nonce, __ATOMIC_RELAXED, S2C_AG);
+    __hip_atomic_fetch_add(a.started, 1u, __ATOMIC_RELAXED, S2C_AG);
+  }
+  if (tid < 20) (&s_flag[0][0][0])[tid] = 0;
+  if (tid < 2 * 8 * B_UB) (&s_dhp[0][0][0])[tid] = 0.0f;
+  // ---- resident operands ----------------------------------------------------------------
+  const int gblk = (job < 3 ? job : 2) * H;
+  float4 Wh[B_UB][2];                          // cell 2, h-outputs, this wave's gate block
+#pragma unroll
+  for (int k = 0; k < B_UB; ++k)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+      Wh[k][s] = (k < ub && job != 2 && lane + 64 * s < n4h)
+                     ? reinterpret_cast<const float4 *>(a.WT_hh2 + (size_t)min(u0 + k, H - 1) * 3 * H +
+                                                        gblk)[lane + 64 * s]
+                     : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = tid; i < obe * 3 * n4h; i += PT) {
+    const int o = i / (3 * n4h), q = i - o * 3 * n4h;
+    reinterpret_cast<float4 *>(sWe2)[i] =
+        reinterpret_cast<const float4 *>(a.WT_ih2 + (size_t)min(e0 + o, E - 1) * 3 * H)[q];
+  }
+  float4 Wtd[2];                               // B5: W_td[:, h2 block]^T row of unit `job`
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+    Wtd[s] = (job < ub && lane + 64 * s < n4e)
+                 ? reinterpret_cast<const float4 *>(a.WT_td + (size_t)min(u0 + job, H - 1) * E)[lane + 64 * s]
+                 : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = tid; i < (obe + ub) * 3 * n4h; i += PT) {
+    const int o = i / (3 * n4h), q = i - o * 3 * n4h;
+    const float *row = o < obe ? a.WT_ih1 + (size_t)min(e0 + o, E - 1) * 3 * H
+                               : a.WT_hh1 + (size_t)min(u0 + o - obe, H - 1) * 3 * H;
+    reinterpret_cast<float4 *>(sW4)[i] = reinterpret_cast<const float4 *>(row)[q];
+  }
+  for (int i = tid; i < ub * (HE >> 2); i += PT) {
+    const int j = i / (HE >> 2), q = i - j * (HE >> 2);
+    reinterpret_cast<float4 *>(sW3)[i] =
+        reinterpret_cast<const float4 *>(a.WT_hl + (size_t)min(u0 + j, H - 1) * HE)[q];
+  }
+  if (row4 < R) {
+    for (int i = tid; i < K * n4e; i += PT)
+      reinterpret_cast<float4 *>(sP)[i] = reinterpret_cast<const float4 *>(a.P + (size_t)row4 * K * E)[i];
+    for (int i = tid; i < K * 32; i += PT) {
+      const int k = i >> 5, h = hs0 + (i & 31);
+      sMs[i] = h < H ? a.M[((size_t)row4 * K + k) * H + h] : 0.0f;
+    }
+  }
+  // attention items of this thread: (key, hidden unit of the slice) i = tid, tid + PT
+  bool iok[2];
+  float wah[2], dMacc[2] = {0.f, 0.f}, dwa_acc = 0.f;
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int i = tid + PT * m, h = hs0 + (i & 31);
+    iok[m] = row4 < R && i < 32 * K && h < H;
+    wah[m] = iok[m] ? a.wa[h] : 0.0f;
+  }
+  __syncthreads();
+  const u32 base = (s_nonce << 6) + 1u;
+  const BOff bo = boff(H, E);
+  __amdgpu_buffer_rsrc_t rs[2];
+  rs[0] = __builtin_amdgcn_make_buffer_rsrc((void *)a.xbuf, 0, bo.total * 8, 0x00020000);
+  rs[1] = __builtin_amdgcn_make_buffer_rsrc((void *)(a.xbuf + bo.total), 0, bo.total * 8,
+                                            0x00020000);
+  const size_t RH = (size_t)R * H, RE = (size_t)R * E;
+  const float4 nowh[B_UB][2] = {};
+
+  for (int st = 0; st < T; ++st) {
+    const int t = T - 1 - st, par = st & 1;
+    const u32 tag = base + (u32)st;
+    u64 *xb = a.xbuf + (size_t)par * bo.total;
+    // ================= B1: cell 2 ==========================================================
+    {
+      GateIO io;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) io.C[g] = a.C + (size_t)(4 + g) * T * RH + (size_t)t * RH;
+      io.Z = a.S + (size_t)5 * T * RH + (size_t)t * RH;
+      io.X = a.X2 + (size_t)t * RE;
+      io.dgi = a.DG + (size_t)(2 * T + t) * 3 * RH;
+      io.dgh = a.DG + (size_t)(3 * T + t) * 3 * RH;
+      io.da = a.DQA + (size_t)t * R * HE + H;
+      io.ld_da = HE;
+      io.xb_da = xb + bo.da2;
+      io.plain_dh = st == 0 ? a.dH2 + (size_t)t * RH : nullptr;
+      io.src_off = bo.dh2;
+      io.src_tag = tag - 1u;
+      io.tag = tag;
+      gate_phase<true>(io, rs[par ^ 1], Wh, sWe2, nullptr, R, H, E, obe, ub, e0, u0, sD, s_red[0],
+                       s_dhp[0], &s_flag[0][rq][0], st + 1, &s_dead);
+    }
+    // ================= B2: attention backward of row4, hidden slice hs0 .. hs0 + 31 ==========
+    if (row4 < R) {
+      const size_t tr = (size_t)t * R + row4;
+      const float latt = tid < E ? a.Latt[tr * E + tid] : 0.0f;
+      float qv[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+        qv[m] = iok[m] ? a.QL[tr * HE + hs0 + ((tid + PT * m) & 31)] : 0.0f;
+      if (tid < K) s_alpha[tid] = a.ALPHA[tr * K + tid];
+      u64 kd = (u64)tag << 32;
+      {
+        const u64 *pd = xb + bo.da2 + (size_t)row4 * E + (tid < E ? tid : 0);
+        int spins = 0;
+        bool stale;
+        do {
+          if (tid < E) kd = __hip_atomic_load(pd, __ATOMIC_RELAXED, S2C_AG);
+          stale = (u32)(kd >> 32) != tag;
+          if (stale && (++spins > P_SPIN_MAX || *(volatile int *)&s_dead)) {
+            *(volatile int *)&s_dead = 1;
+            break;
+          }
+        } while (stale);
+      }
+      const float d = tid < E ? __uint_as_float((u32)kd) : 0.0f;
+      for (int k = 0; k <= K; ++k) {             // <da2, P_k> and (k = K) <da2, Latt_t>
+        float p = k < K ? (tid < E ? d * sP[(size_t)k * E + tid] : 0.0f) : d * latt;
+        p = row16_sum(p);
+        if ((lane & 15) == 0) s_sc[k][tid >> 4] = p;
+      }
+      __syncthreads();
+      for (int i = tid; i < 32 * (K + 1); i += PT) {
+        float v = row16_sum(s_sc[i >> 5][i & 31]);
+        v += __shfl_xor(v, 16, 64);
+        if ((i & 31) == 0) s_dal[i >> 5] = v;
+      }
+      __syncthreads();
+      const float c0 = s_dal[K];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+        if (iok[m]) {
+          const int i = tid + PT * m, k = i >> 5, hh = i & 31;
+          const float ds = s_alpha[k] * (s_dal[k] - c0);
+          const float c = p_tanh(sMs[i] + qv[m]);
+          const float dpre = ds * wah[m] * (1.0f - c * c);
+          dMacc[m] += dpre;
+          s_dpre[k][hh] = dpre;
+          s_dsc[k][hh] = ds * c;
+        }
+      __syncthreads();
+      if (tid < 32 && hs0 + tid < H) {
+        float dq = 0.0f, dw = 0.0f;
+        for (int k = 0; k < K; ++k) { dq += s_dpre[k][tid]; dw += s_dsc[k][tid]; }
+        dwa_acc += dw;
+        st_tag(xb + bo.dq + (size_t)row4 * H + hs0 + tid, dq, tag);
+        a.DQA[tr * HE + hs0 + tid] = dq;
+      }
+    }
+    // ================= B3: dh1' = [W_h^T | W_lang[:, F:]^T] [dq | da2] + dh1c ==================
+    {
+      float4 xq[4][2], xa[4][2];
+      {                                          // jobs 0, 1: dq rows; jobs 2, 3: da2 rows
+        float4 y[2][2];
+        const int half = job & 1, ry = r0 + 2 * half;
+        if (job < 2) {
+          poll_rows<2>(rs[par], bo.dq, H, n4h, ry, R, tag, y, &s_dead, 0);
+          stash_put<2>(sDQ, H, n4h, ry, y);
+          flag_raise(&s_flag[1][rq][half], st + 1);
+        } else {
+          poll_rows<2>(rs[par], bo.da2, E, n4e, ry, R, tag, y, &s_dead, 0);
+          stash_put<2>(sDA2, E, n4e, ry, y);
+          flag_raise(&s_flag[2][rq][half], st + 1);
+        }
+      }
+      flag_wait(&s_flag[1][rq][0], st + 1, &s_dead);
+      flag_wait(&s_flag[1][rq][1], st + 1, &s_dead);
+      flag_wait(&s_flag[2][rq][0], st + 1, &s_dead);
+      flag_wait(&s_flag[2][rq][1], st + 1, &s_dead);
+      stash_get(sDQ, H, n4h, r0, xq);
+      stash_get(sDA2, E, n4e, r0, xa);
+      const float4 *wr = reinterpret_cast<const float4 *>(sW3 + (size_t)min(job, ub - 1) * HE);
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 wq0 = lane < n4h ? wr[lane] : z4, wq1 = lane + 64 < n4h ? wr[lane + 64] : z4;
+      const float4 wa0 = lane < n4e ? wr[n4h + lane] : z4,
+                   wa1 = lane + 64 < n4e ? wr[n4h + lane + 64] : z4;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        float acc = fdot4(wq0, xq[rr][0], 0.0f);
+        acc = fdot4(wq1, xq[rr][1], acc);
+        acc = fdot4(wa0, xa[rr][0], acc);
+        acc = fdot4(wa1, xa[rr][1], acc);
+        acc = row16_sum(acc);
+        if ((lane & 15) == 0) s_one[0][wv][rr][lane >> 4] = acc;
+      }
+      __builtin_amdgcn_wave_barrier();
+      const int row = r0 + lane, u = u0 + job;
+      if (lane < 4 && job < ub && u < H && row < R)
+        st_tag(xb + bo.dh1 + (size_t)row * H + u, red4(s_one[0][wv], lane) + s_dhp[1][row][job], tag);
+    }
+    // ================= B4: cell 1 ==========================================================
+    {
+      GateIO io;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) io.C[g] = a.C + (size_t)g * T * RH + (size_t)t * RH;
+      io.Z = a.S + (size_t)T * RH + (size_t)t * RH;
+      io.X = a.X1 + (size_t)t * RE;
+      io.dgi = a.DG + (size_t)t * 3 * RH;
+      io.dgh = a.DG + (size_t)(T + t) * 3 * RH;
+      io.da = a.DA1 + (size_t)t * RE;
+      io.ld_da = E;
+      io.xb_da = xb + bo.da1;
+      io.plain_dh = nullptr;
+      io.src_off = bo.dh1;
+      io.src_tag = tag;
+      io.tag = tag;
+      gate_phase<false>(io, rs[par], nowh, sW4, sW4 + (size_t)obe * 3 * H, R, H, E, obe, ub, e0, u0, sD, s_red[1], s_dhp[1],
+                        &s_flag[3][rq][0], st + 1, &s_dead);
+    }
+    // ================= B5: dh2'(t-1) = W_td[:, h2 block]^T da1 + dh2_part + dH2[t-1] ==========
+    if (t > 0) {
+      const int row = r0 + lane, u = u0 + job;
+      const bool ok = lane < 4 && job < ub && u < H && row < R;
+      const float dprev = ok ? a.dH2[(size_t)(t - 1) * RH + (size_t)row * H + u] : 0.0f;
+      float4 x[4][2];
+      if (job < 2) {
+        float4 y[2][2];
+        poll_rows<2>(rs[par], bo.da1, E, n4e, r0 + 2 * job, R, tag, y, &s_dead, 0);
+        stash_put<2>(sDA1, E, n4e, r0 + 2 * job, y);
+        flag_raise(&s_flag[4][rq][job], st + 1);
+      }
+      flag_wait(&s_flag[4][rq][0], st + 1, &s_dead);
+      flag_wait(&s_flag[4][rq][1], st + 1, &s_dead);
+      stash_get(sDA1, E, n4e, r0, x);
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        float acc = fdot4(Wtd[0], x[rr][0], 0.0f);
+        acc = fdot4(Wtd[1], x[rr][1], acc);
+        acc = row16_sum(acc);
+        if ((lane & 15) == 0) s_one[1][wv][rr][lane >> 4] = acc;
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (ok)
+        st_tag(xb + bo.dh2 + (size_t)row * H + u,
+               (red4(s_one[1][wv], lane) + s_dhp[0][row][job]) + dprev, tag);
+    }
+  }
+  // ---- accumulated attention gradients ----------------------------------------------------
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+    if (iok[m]) {
+      const int i = tid + PT * m;
+      a.dM[((size_t)row4 * K + (i >> 5)) * H + hs0 + (i & 31)] = dMacc[m];
+    }
+  if (row4 < R && tid < 32 && hs0 + tid < H) a.dwa_rows[(size_t)row4 * H + hs0 + tid] = dwa_acc;
+  __syncthreads();
+  if (tid == 0 && s_dead) __hip_atomic_store(a.fail, 1u, __ATOMIC_RELAXED, S2C_AG);
+  if (w == 0 && tid == 0) {
+    int spins = 0;
+    while (__hip_atomic_load(a.started, __ATOMIC_RELAXED, S2C_AG) < (u32)PG && ++spins < P_SPIN_MAX) {}
+    __hip_atomic_store(a.started, 0u, __ATOMIC_RELAXED, S2C_AG);
+    __hip_atomic_store(a.nonce, s_nonce + 1u, __ATOMIC_RELAXED, S2C_AG);
+  }
+}
+
+size_t persist_bwd_lds_bytes(int K, int H, int E) {
+  const int obe = (E + PG - 1) / PG, ub = (H + PG - 1) / PG;
+  return sizeof(float) * ((size_t)(2 * obe + ub) * 3 * H + (size_t)ub * (H + E) + (size_t)K * E +
+                          (size_t)K * 32 + 8 * (size_t)H + 8 * (size_t)E);
 }
 
 size_t persist_lds_bytes(int K, int H, int E, int F) {
@@ -661,6 +1142,60 @@ extern "C" int s2c_decoder_fwd_persist(const s2c_dec_fwd_args *a, void *stream) 
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     fprintf(stderr, "s2c_decoder_fwd_persist launch failed: %s\n", hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
+extern "C" long long s2c_decoder_bwd_persist_xbuf_pairs(int H, int E) {
+  return 2LL * boff(H, E).total;
+}
+
+extern "C" int s2c_decoder_bwd_persist_supported(int R, int K, int H, int E, int T) {
+  if (g_persist < 0) {
+    const char *e = getenv("S2C_DECODER_PERSIST");
+    g_persist = e ? atoi(e) : 1;
+  }
+  static int g_bwd = -1;
+  if (g_bwd < 0) {
+    const char *e = getenv("S2C_DECODER_PERSIST_BWD");
+    g_bwd = e ? atoi(e) : 1;
+  }
+  if (!g_persist || !g_bwd) return 0;
+  if (R < 1 || R > 8 || K < 1 || K > P_MAXK || T < 1 || T > 62) return 0;
+  if (H % 4 || E % 4 || H < 4 || H > 512 || E < 4 || E > 512) return 0;
+  const size_t lds = persist_bwd_lds_bytes(K, H, E);
+  static int state[64];
+  static size_t lds_set[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  if (state[dev] == 0 || lds > lds_set[dev]) {
+    state[dev] = -1;
+    if (hipFuncSetAttribute((const void *)decoder_bwd_persist_kernel,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      (void)hipGetLastError();
+      return 0;
+    }
+    lds_set[dev] = lds;
+    state[dev] = 1;
+  }
+  int per_cu = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)decoder_bwd_persist_kernel,
+                                                   PT, lds) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return (long long)per_cu * (cus - 16) >= PG ? 1 : 0;
+}
+
+extern "C" int s2c_decoder_bwd_persist(const s2c_dec_bwd_args *a, void *stream) {
+  if (!a || !s2c_decoder_bwd_persist_supported(a->R, a->K, a->H, a->E, a->T)) return -2;
+  const size_t lds = persist_bwd_lds_bytes(a->K, a->H, a->E);
+  hipLaunchKernelGGL(decoder_bwd_persist_kernel, dim3(PG), dim3(PT), lds, (hipStream_t)stream, *a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    fprintf(stderr, "s2c_decoder_bwd_persist launch failed: %s\n", hipGetErrorString(e));
     return (int)e;
   }
   return 0;

@@ -113,9 +113,21 @@ class _DecFwdArgs(ctypes.Structure):
                                    "pad_")] +
                 [(n, _P) for n in ("W_td_h2", "Pw", "Ptf", "W_ih1", "W_hh1", "b_ih1", "b_hh1",
                                    "Wqh", "M", "wa", "mask", "O", "W_lang", "b_lang", "W_ih2",
-                                   "W_hh2", "b_ih2", "b_hh2", "H1", "H2", "X1", "X2")] +
-                [("S1", _P * 4), ("S2", _P * 4)] +
-                [(n, _P) for n in ("QL", "ALPHA", "ATT", "xbuf", "prof", "nonce", "started", "fail")])
+                                   "W_hh2", "b_ih2", "b_hh2", "H1", "H2", "X1", "X2", "S", "C",
+                                   "QL", "ALPHA", "ATT", "xbuf", "prof", "nonce", "started",
+                                   "fail")])
+
+
+class _DecBwdArgs(ctypes.Structure):
+    """include/s2c_fused.h: s2c_dec_bwd_args"""
+    _fields_ = ([(n, _I) for n in ("R", "K", "H", "E", "T", "pad_")] +
+                [(n, _P) for n in ("dH2", "C", "S", "X1", "X2", "QL", "ALPHA", "M", "wa", "P",
+                                   "Latt", "WT_ih2", "WT_hh2", "WT_hl", "WT_ih1", "WT_hh1",
+                                   "WT_td", "DA1", "DQA", "DG", "dM", "dwa_rows", "xbuf", "nonce",
+                                   "started", "fail")])
+
+
+_C.register("s2c_decoder_bwd_persist", [_P, _P])
 
 
 _C.register("s2c_decoder_fwd_persist", [_P, _P])
@@ -131,6 +143,10 @@ def _plib():
         lib.s2c_decoder_fwd_persist_supported.restype = _I
         lib.s2c_decoder_fwd_persist_xbuf_pairs.argtypes = [_I, _I]
         lib.s2c_decoder_fwd_persist_xbuf_pairs.restype = ctypes.c_longlong
+        lib.s2c_decoder_bwd_persist_supported.argtypes = [_I] * 5
+        lib.s2c_decoder_bwd_persist_supported.restype = _I
+        lib.s2c_decoder_bwd_persist_xbuf_pairs.argtypes = [_I, _I]
+        lib.s2c_decoder_bwd_persist_xbuf_pairs.restype = ctypes.c_longlong
         lib.s2c_decoder_persist_set.argtypes = [_I]
         lib.s2c_decoder_persist_set.restype = None
         lib._s2c_persist_typed = True
@@ -148,10 +164,11 @@ def set_persist(on):
     _plib().s2c_decoder_persist_set(int(bool(on)))
 
 
-def _persist_scratch(dev, H, E):
-    key = (dev.index, H, E)
+def _persist_scratch(dev, H, E, bwd=False):
+    key = (dev.index, H, E, bwd)
     if key not in _XBUF:
-        pairs = int(_plib().s2c_decoder_fwd_persist_xbuf_pairs(H, E))
+        pairs = int(_plib().s2c_decoder_bwd_persist_xbuf_pairs(H, E) if bwd else
+                    _plib().s2c_decoder_fwd_persist_xbuf_pairs(H, E))
         _XBUF[key] = (torch.zeros(pairs, dtype=torch.int64, device=dev),
                       torch.zeros(4, dtype=torch.int32, device=dev))
     return _XBUF[key]
@@ -217,8 +234,9 @@ class TopDownDecode(Function):
             e = lambda *s: torch.empty(*s, device=dev)
             H1, H2 = z(T + 1, R, H), z(T + 1, R, H)
             X1, X2 = e(T, R, E), e(T, R, E)
-            S1 = [e(T, R, H) for _ in range(4)]   # r, z, n, gh_n of GRU 1
-            S2 = [e(T, R, H) for _ in range(4)]
+            S = e(2, 4, T, R, H)                  # r, z, n, gh_n of GRU 1, then of GRU 2
+            S1, S2 = [S[0, j] for j in range(4)], [S[1, j] for j in range(4)]
+            COEF = None
             QL = e(T, R, H + E)
             ALPHA, SC = e(T, R, K), e(R, K)
             ATT = e(T, R, F)
@@ -228,6 +246,9 @@ class TopDownDecode(Function):
                        _plib().s2c_decoder_fwd_persist_supported(R, K, H, E, F, T) == 1)
             if persist:
                 xbuf, ctl = _persist_scratch(dev, H, E)
+                if any(ctx.needs_input_grad) and \
+                        _plib().s2c_decoder_bwd_persist_supported(R, K, H, E, T) == 1:
+                    COEF = e(2, 4, T, R, H)       # gate-gradient coefficients for the backward kernel
                 a = _DecFwdArgs()
                 a.R, a.K, a.H, a.E, a.F, a.T, a.ldtd, a.ldlang = R, K, H, E, F, T, ldtd, ldlang
                 for n, v in (("W_td_h2", td_h2), ("Pw", Pw), ("Ptf", Ptf), ("W_ih1", W_ih1),
@@ -236,14 +257,13 @@ class TopDownDecode(Function):
                              ("b_lang", b_lang), ("W_ih2", W_ih2), ("W_hh2", W_hh2),
                              ("b_ih2", b_ih2), ("b_hh2", b_hh2), ("H1", H1), ("H2", H2),
                              ("X1", X1), ("X2", X2), ("QL", QL), ("ALPHA", ALPHA), ("ATT", ATT),
-                             ("xbuf", xbuf)):
+                             ("S", S), ("xbuf", xbuf)):
                     assert v.is_contiguous() or n == "W_td_h2", n
                     setattr(a, n, v.data_ptr())
                 a.backoff = PERSIST_BACKOFF
                 a.prof = PROF.data_ptr() if PROF is not None else None
                 a.nonce, a.started, a.fail = ctl.data_ptr(), ctl.data_ptr() + 4, ctl.data_ptr() + 8
-                for j in range(4):
-                    a.S1[j], a.S2[j] = S1[j].data_ptr(), S2[j].data_ptr()
+                a.C = COEF.data_ptr() if COEF is not None else None
                 if _C.TIMER.enabled:
                     _C.TIMER.alg_bytes = 0
                 _C.call("s2c_decoder_fwd_persist", ctypes.byref(a), _C.stream_ptr())
@@ -289,6 +309,7 @@ class TopDownDecode(Function):
             ctx.save_for_backward(*params)
             ctx.stash = (words, tf, O, M, wa, H1, H2, X1, X2, S1, S2, QL, ALPHA, ATT, H2n)
             ctx.dims = (R, K, F, E, H, T)
+            ctx.coef = (COEF, S)
             ctx.words_need_grad = ctx.needs_input_grad[0]
         ctx.mark_non_differentiable(attn)
         return logits, attn
@@ -317,23 +338,47 @@ class TopDownDecode(Function):
             # [dq | da2] side by side: one operand of the concatenated dh1 product below
             DQA = e(T, R, H + E)
             DQ, DA2 = DQA[:, :, :H], DQA[:, :, H:]
-            DGI1, DGH1 = e(T, R, 3 * H), e(T, R, 3 * H)
-            DGI2, DGH2 = e(T, R, 3 * H), e(T, R, 3 * H)
-            fuse_bwd = (FUSE_ATTN_X2_BWD and K <= ATTN_X2_MAX_K and 32 <= F <= 256
-                        and F & (F - 1) == 0 and E <= 512)
+            DG = e(4, T, R, 3 * H)
+            DGI1, DGH1, DGI2, DGH2 = DG[0], DG[1], DG[2], DG[3]
+            COEF, S = ctx.coef
+            persist = (COEF is not None and
+                       _plib().s2c_decoder_bwd_persist_supported(R, K, H, E, T) == 1)
+            fuse_bwd = persist or (FUSE_ATTN_X2_BWD and K <= ATTN_X2_MAX_K and 32 <= F <= 256
+                                   and F & (F - 1) == 0 and E <= 512)
             # not fused: DV = [datt | dh1 via map_lang]; fused: datt never leaves the attention
             # backward and dh1 = [W_h^T | W_lang[:, F:]^T] [dq | da2] is ONE product
             DV = None if fuse_bwd else e(T, R, F + H)
             WT_hl = torch.cat([WT_h, WT_lang[F:]], 1) if fuse_bwd else None     # (H, H + E)
             DQc = None if fuse_bwd else e(T, R, H)
             dh2_direct, dh1_direct = e(R, H), e(R, H)
+            if persist:
+                # the whole recurrence in one kernel (csrc/s2c_decoder_persist.hip); the attention
+                # backward's datt only enters through <da2, P_k> and <da2, Latt_t>
+                P = torch.matmul(O, W_lang[:, :F].t()).contiguous()          # (R,K,E)
+                Latt = torch.matmul(ATT, W_lang[:, :F].t()).contiguous()     # (T,R,E)
+                xbuf, ctl = _persist_scratch(dev, H, E, bwd=True)
+                a = _DecBwdArgs()
+                a.R, a.K, a.H, a.E, a.T = R, K, H, E, T
+                for n, v in (("dH2", dH2), ("C", COEF), ("S", S), ("X1", X1), ("X2", X2),
+                             ("QL", QL), ("ALPHA", ALPHA), ("M", M), ("wa", wa), ("P", P),
+                             ("Latt", Latt), ("WT_ih2", WT_ih2), ("WT_hh2", WT_hh2),
+                             ("WT_hl", WT_hl), ("WT_ih1", WT_ih1), ("WT_hh1", WT_hh1),
+                             ("WT_td", WT_td_h2), ("DA1", DA1), ("DQA", DQA), ("DG", DG),
+                             ("dM", dM), ("dwa_rows", dwa_rows), ("xbuf", xbuf)):
+                    assert v.is_contiguous(), n
+                    setattr(a, n, v.data_ptr())
+                a.nonce, a.started, a.fail = ctl.data_ptr(), ctl.data_ptr() + 4, ctl.data_ptr() + 8
+                if _C.TIMER.enabled:
+                    _C.TIMER.alg_bytes = 0
+                _C.call("s2c_decoder_bwd_persist", ctypes.byref(a), _C.stream_ptr())
             # 6 launches per step.  GRU-2's gate gradients of step t-1 come out of the
             # epilogue of step t's last product (value = dh2 of step t-1); only the
             # very first needs its own launch.
-            _call("s2c_gru_gates_bwd", R, H, _p(dH2[T - 1]), None, _p(S2[0][T - 1]),
-                  _p(S2[1][T - 1]), _p(S2[2][T - 1]), _p(S2[3][T - 1]), _p(H2[T - 1]),
-                  _p(DGI2[T - 1]), _p(DGH2[T - 1]), _p(dh2_direct))
-            for t in range(T - 1, -1, -1):
+            if not persist:
+                _call("s2c_gru_gates_bwd", R, H, _p(dH2[T - 1]), None, _p(S2[0][T - 1]),
+                      _p(S2[1][T - 1]), _p(S2[2][T - 1]), _p(S2[3][T - 1]), _p(H2[T - 1]),
+                      _p(DGI2[T - 1]), _p(DGH2[T - 1]), _p(dh2_direct))
+            for t in range(T - 1 if not persist else -1, -1, -1):
                 _lin_pair(R,
                           _desc(E, 3 * H, WT_ih2, 3 * H, DGI2[t], 3 * H, DA2[t], H + E,
                                 gate=X2[t], ldg=E, epi=2),
