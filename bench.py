@@ -585,6 +585,11 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     _C.load()
+    from scan2cap_amd.models import decoder_fused
+    if world > torch.cuda.device_count():
+        # ranks share a device (gloo rehearsal): two persistent decoder kernels of different
+        # processes could each hold part of the CUs and wait for the rest -- the launch chain
+        decoder_fused.set_persist(False)
 
     wl = WORKLOADS[args.workload]
     B = wl["B"]
@@ -891,6 +896,8 @@ def main():
         except Exception as e:          # reported, never fatal for the headline
             fed = {"error": "%s: %s" % (type(e).__name__, e)}
 
+    if decoder_fused.persist_failed():
+        raise SystemExit("bench.py: a persistent decoder kernel gave up on a poll -- results invalid")
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = B * world * args.steps / elapsed
