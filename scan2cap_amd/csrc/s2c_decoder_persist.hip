@@ -197,21 +197,27 @@ __device__ __forceinline__ void load_gru_w(GruW &g, const float *W, int I, int H
       }
 }
 
-// partial gate sums of 4 rows x P_UB units x 3 gates -> the 16-lane-row totals in s_red[v][0..3]
+// partial gate sums of 4 rows x P_UB units x 3 gates -> the 16-lane-row totals in s_red[v][0..3].
+// Per unit: all dot products first, then the DPP folds (twelve independent chains the scheduler
+// can interleave), then the stores under ONE exec mask.
 __device__ __forceinline__ void gru_partials(const GruW &g, const float4 (&x)[4][2],
                                              float (*s_red)[4]) {
   const int lane = threadIdx.x & 63;
 #pragma unroll
-  for (int j = 0; j < P_UB; ++j)
+  for (int j = 0; j < P_UB; ++j) {
+    float acc[12];
 #pragma unroll
     for (int k = 0; k < 3; ++k)
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        float a = fdot4(g.w[j][k][0], x[rr][0], 0.0f);
-        a = fdot4(g.w[j][k][1], x[rr][1], a);
-        a = row16_sum(a);
-        if ((lane & 15) == 0) s_red[(j * 3 + k) * 4 + rr][lane >> 4] = a;
-      }
+      for (int rr = 0; rr < 4; ++rr)
+        acc[k * 4 + rr] = fdot4(g.w[j][k][1], x[rr][1], fdot4(g.w[j][k][0], x[rr][0], 0.0f));
+#pragma unroll
+    for (int v = 0; v < 12; ++v) acc[v] = row16_sum(acc[v]);
+    if ((lane & 15) == 0) {
+#pragma unroll
+      for (int v = 0; v < 12; ++v) s_red[j * 12 + v][lane >> 4] = acc[v];
+    }
+  }
 }
 // the same with the weight rows in LDS (sW: [unit j][gate k][I floats] of this wave's part / unit
 // pair): GRU cell 2 -- both cells' rows in registers do not fit 256 VGPRs next to a poll in flight
@@ -219,7 +225,8 @@ __device__ __forceinline__ void gru_partials_lds(const float *sW, int I, const f
                                                  float (*s_red)[4]) {
   const int lane = threadIdx.x & 63, n4 = I >> 2;
 #pragma unroll
-  for (int j = 0; j < P_UB; ++j)
+  for (int j = 0; j < P_UB; ++j) {
+    float acc[12];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const float4 *wr = reinterpret_cast<const float4 *>(sW + (size_t)(j * 3 + k) * I);
@@ -227,13 +234,15 @@ __device__ __forceinline__ void gru_partials_lds(const float *sW, int I, const f
       if (lane < n4) w0 = wr[lane];
       if (lane + 64 < n4) w1 = wr[lane + 64];
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        float a = fdot4(w0, x[rr][0], 0.0f);
-        a = fdot4(w1, x[rr][1], a);
-        a = row16_sum(a);
-        if ((lane & 15) == 0) s_red[(j * 3 + k) * 4 + rr][lane >> 4] = a;
-      }
+      for (int rr = 0; rr < 4; ++rr) acc[k * 4 + rr] = fdot4(w1, x[rr][1], fdot4(w0, x[rr][0], 0.0f));
     }
+#pragma unroll
+    for (int v = 0; v < 12; ++v) acc[v] = row16_sum(acc[v]);
+    if ((lane & 15) == 0) {
+#pragma unroll
+      for (int v = 0; v < 12; ++v) s_red[j * 12 + v][lane >> 4] = acc[v];
+    }
+  }
 }
 __device__ __forceinline__ float red4(const float (*s_red)[4], int v) {
   return (s_red[v][0] + s_red[v][1]) + (s_red[v][2] + s_red[v][3]);
@@ -282,18 +291,20 @@ template <int NK>
 __device__ __forceinline__ void lds_rows_partials(const float *sW, int H, int n4,
                                                   const float4 (&x)[4][2], float (*so)[4]) {
   const int lane = threadIdx.x & 63;
+  float acc[NK * 4];
 #pragma unroll
   for (int k2 = 0; k2 < NK; ++k2) {
     float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0;
     if (lane < n4) w0 = reinterpret_cast<const float4 *>(sW + (size_t)k2 * H)[lane];
     if (lane + 64 < n4) w1 = reinterpret_cast<const float4 *>(sW + (size_t)k2 * H)[lane + 64];
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      float acc = fdot4(w0, x[rr][0], 0.0f);
-      acc = fdot4(w1, x[rr][1], acc);
-      acc = row16_sum(acc);
-      if ((lane & 15) == 0) so[k2 * 4 + rr][lane >> 4] = acc;
-    }
+    for (int rr = 0; rr < 4; ++rr) acc[k2 * 4 + rr] = fdot4(w1, x[rr][1], fdot4(w0, x[rr][0], 0.0f));
+  }
+#pragma unroll
+  for (int v = 0; v < NK * 4; ++v) acc[v] = row16_sum(acc[v]);
+  if ((lane & 15) == 0) {
+#pragma unroll
+    for (int v = 0; v < NK * 4; ++v) so[v][lane >> 4] = acc[v];
   }
 }
 
@@ -302,7 +313,7 @@ __global__ __launch_bounds__(PT, 2) void decoder_fwd_persist_kernel(s2c_dec_fwd_
   __shared__ float s_red[2][PW][24][4];    // [GRU cell][wave][value][16-lane row]
   __shared__ float s_one[2][PW][16][4];    // P1 / P3 partials (the same wave writes and reads)
   __shared__ float s_bias[2][2][3][4];     // [cell][ih | hh][gate][unit of the workgroup]
-  __shared__ float s_sc[P_MAXK][PT / 16], s_s[P_MAXK], s_add[P_MAXOC];
+  __shared__ float s_sc[P_MAXK][PT / 16], s_s[P_MAXK], s_add[P_MAXOC], s_mask[P_MAXK];
   static_assert(PT / 16 == 32, "score partials: one 32-lane group per key");
   __shared__ __attribute__((aligned(16))) float s_att[256];
   __shared__ u32 s_nonce;
@@ -375,8 +386,14 @@ __global__ __launch_bounds__(PT, 2) void decoder_fwd_persist_kernel(s2c_dec_fwd_
     const float *b = c == 0 ? (ih == 0 ? a.b_ih1 : a.b_hh1) : (ih == 0 ? a.b_ih2 : a.b_hh2);
     s_bias[c][ih][k][ju] = b[k * H + u];
   }
-  // attention constant of this thread: hidden unit tid
+  // attention constants of this thread: hidden unit tid; the bias of its map_lang output
   const float wa0 = tid < H ? a.wa[tid] : 0.0f;
+  float bl = 0.0f;
+  if (row4 < R) {
+    const int o = slice * oc4 + (tid >> 4);
+    if ((tid >> 4) < oc4 && o < E) bl = a.b_lang[o];
+    if (tid < K) s_mask[tid] = a.mask[(size_t)row4 * K + tid];
+  }
   float hp1 = 0.f, hp2 = 0.f;                  // h of the item lanes' (row, unit)
   // h1, h2 of step 0 are zero
   for (int i = tid; i < 2 * 8 * n4h; i += PT)
@@ -528,18 +545,23 @@ __global__ __launch_bounds__(PT, 2) void decoder_fwd_persist_kernel(s2c_dec_fwd_
       P_STAMP(9);
       const float q0 = __uint_as_float((u32)kq);
       if (tid < oc4) s_add[tid] = __uint_as_float((u32)ka);
-      for (int k = 0; k < K; ++k) {
-        float p = 0.0f;
-        if (has_q) p = wa0 * p_tanh(sM[(size_t)k * H + tid] + q0);
-        p = row16_sum(p);
-        if ((lane & 15) == 0) s_sc[k][tid >> 4] = p;
+      for (int k0 = 0; k0 < K; k0 += 4) {        // four independent chains in flight
+        float p[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          p[j] = (has_q && k0 + j < K) ? sM[(size_t)(k0 + j) * H + tid] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p[j] = row16_sum(has_q ? wa0 * p_tanh(p[j] + q0) : 0.0f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if ((lane & 15) == 0 && k0 + j < K) s_sc[k0 + j][tid >> 4] = p[j];
       }
       __syncthreads();
       for (int i = tid; i < 32 * K; i += PT) {   // 32 row partials per key: one more DPP pass
         const int k = i >> 5;
         float v = row16_sum(s_sc[k][i & 31]);
         v += __shfl_xor(v, 16, 64);
-        if ((i & 31) == 0) s_s[k] = a.mask[(size_t)row4 * K + k] == 0.0f ? -1e30f : v;
+        if ((i & 31) == 0) s_s[k] = s_mask[k] == 0.0f ? -1e30f : v;
       }
       __syncthreads();
       {
@@ -571,7 +593,7 @@ __global__ __launch_bounds__(PT, 2) void decoder_fwd_persist_kernel(s2c_dec_fwd_
                         reinterpret_cast<const float4 *>(s_att)[f4], acc);
         acc = row16_sum(acc);
         if (pr == 0 && ol < oc4 && o < E) {
-          const float v = fmaxf(acc + a.b_lang[o] + s_add[ol], 0.0f);
+          const float v = fmaxf(acc + bl + s_add[ol], 0.0f);
           st_tag(xb + xo.x2 + (size_t)row4 * E + o, v, tag);
           a.X2[(size_t)t * RE + (size_t)row4 * E + o] = v;
         }
@@ -745,29 +767,36 @@ __device__ __forceinline__ void gate_phase(const GateIO &io, __amdgpu_buffer_rsr
       x[rr][s].x *= c[rr][s].x; x[rr][s].y *= c[rr][s].y;
       x[rr][s].z *= c[rr][s].z; x[rr][s].w *= c[rr][s].w;
     }
-  // (6) this block's share of every output
+  // (6) this block's share of every output, two outputs (eight independent fold chains) at a time
   const int gblk = (job < 3 ? job : 2) * H;
 #pragma unroll
-  for (int o8 = 0; o8 < B_OBE + B_UB; ++o8) {
-    const bool isE = o8 < B_OBE;
-    const int k = isE ? o8 : o8 - B_OBE;
-    const bool use = isE ? (k < obe && job != 3) : (k < ub && job != 2);   // wave-uniform
-    if (!use) continue;
-    float4 w0, w1;
-    if (REGS && !isE) {
-      w0 = Wh[k][0]; w1 = Wh[k][1];
-    } else {
-      const float4 *wr =
-          reinterpret_cast<const float4 *>((isE ? sWe : sWh) + (size_t)k * 3 * H + gblk);
-      w0 = lane < n4h ? wr[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-      w1 = lane + 64 < n4h ? wr[lane + 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int o2 = 0; o2 < B_OBE + B_UB; o2 += 2) {
+    float acc[8];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const int o8 = o2 + d;
+      const bool isE = o8 < B_OBE;
+      const int k = isE ? o8 : o8 - B_OBE;
+      const bool use = isE ? (k < obe && job != 3) : (k < ub && job != 2);   // wave-uniform
+      float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0;
+      if (use) {
+        if (REGS && !isE) {
+          w0 = Wh[k][0]; w1 = Wh[k][1];
+        } else {
+          const float4 *wr =
+              reinterpret_cast<const float4 *>((isE ? sWe : sWh) + (size_t)k * 3 * H + gblk);
+          if (lane < n4h) w0 = wr[lane];
+          if (lane + 64 < n4h) w1 = wr[lane + 64];
+        }
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) acc[d * 4 + rr] = fdot4(w1, x[rr][1], fdot4(w0, x[rr][0], 0.0f));
     }
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      float acc = fdot4(w0, x[rr][0], 0.0f);
-      acc = fdot4(w1, x[rr][1], acc);
-      acc = row16_sum(acc);
-      if ((lane & 15) == 0) s_red[wv][o8 * 4 + rr][lane >> 4] = acc;
+    for (int v = 0; v < 8; ++v) acc[v] = row16_sum(acc[v]);
+    if ((lane & 15) == 0) {
+#pragma unroll
+      for (int v = 0; v < 8; ++v) s_red[wv][o2 * 4 + v][lane >> 4] = acc[v];
     }
   }
   // (7) the gate gradients of the workgroup's own units, for the weight-gradient GEMMs
@@ -814,8 +843,8 @@ __global__ __launch_bounds__(PT, 2) void decoder_bwd_persist_kernel(s2c_dec_bwd_
   const int e0 = w * obe, u0 = w * ub;
   const int row4 = w & 7, hs0 = 32 * (w >> 3);
   float *sW4 = smem;                           // (obe + ub) x 3H  cell 1: W_ih1^T / W_hh1^T rows
-  float *sWe2 = sW4 + (size_t)(obe + ub) * 3 * H;  // obe x 3H     cell 2: W_ih2^T rows
-  float *sW3 = sWe2 + (size_t)obe * 3 * H;     // ub x (H + E)  [W_h^T | W_lang[:, F:]^T] rows
+  float *sWe2 = sW4 + (size_t)(obe + ub) * 3 * H;  // (obe + ub) x 3H  cell 2: W_ih2^T / W_hh2^T rows
+  float *sW3 = sWe2 + (size_t)(obe + ub) * 3 * H;  // ub x (H + E)  [W_h^T | W_lang[:, F:]^T] rows
   float *sP = sW3 + (size_t)ub * HE;           // K x E    O[row4] W_lang[:, :F]^T
   float *sMs = sP + (size_t)K * E;             // K x 32   map_feat(obj_feats)[row4, :, h slice]
   // operand stashes.  dh' (B1, B4) and dq (B3) share one, da2 (B3) and da1 (B5) the other: a stash
@@ -833,20 +862,11 @@ __global__ __launch_bounds__(PT, 2) void decoder_bwd_persist_kernel(s2c_dec_bwd_
   if (tid < 20) (&s_flag[0][0][0])[tid] = 0;
   if (tid < 2 * 8 * B_UB) (&s_dhp[0][0][0])[tid] = 0.0f;
   // ---- resident operands ----------------------------------------------------------------
-  const int gblk = (job < 3 ? job : 2) * H;
-  float4 Wh[B_UB][2];                          // cell 2, h-outputs, this wave's gate block
-#pragma unroll
-  for (int k = 0; k < B_UB; ++k)
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-      Wh[k][s] = (k < ub && job != 2 && lane + 64 * s < n4h)
-                     ? reinterpret_cast<const float4 *>(a.WT_hh2 + (size_t)min(u0 + k, H - 1) * 3 * H +
-                                                        gblk)[lane + 64 * s]
-                     : make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int i = tid; i < obe * 3 * n4h; i += PT) {
+  for (int i = tid; i < (obe + ub) * 3 * n4h; i += PT) {
     const int o = i / (3 * n4h), q = i - o * 3 * n4h;
-    reinterpret_cast<float4 *>(sWe2)[i] =
-        reinterpret_cast<const float4 *>(a.WT_ih2 + (size_t)min(e0 + o, E - 1) * 3 * H)[q];
+    const float *row = o < obe ? a.WT_ih2 + (size_t)min(e0 + o, E - 1) * 3 * H
+                               : a.WT_hh2 + (size_t)min(u0 + o - obe, H - 1) * 3 * H;
+    reinterpret_cast<float4 *>(sWe2)[i] = reinterpret_cast<const float4 *>(row)[q];
   }
   float4 Wtd[2];                               // B5: W_td[:, h2 block]^T row of unit `job`
 #pragma unroll
@@ -912,7 +932,7 @@ __global__ __launch_bounds__(PT, 2) void decoder_bwd_persist_kernel(s2c_dec_bwd_
       io.src_off = bo.dh2;
       io.src_tag = tag - 1u;
       io.tag = tag;
-      gate_phase<true>(io, rs[par ^ 1], Wh, sWe2, nullptr, R, H, E, obe, ub, e0, u0, sD, s_red[0],
+      gate_phase<false>(io, rs[par ^ 1], nowh, sWe2, sWe2 + (size_t)obe * 3 * H, R, H, E, obe, ub, e0, u0, sD, s_red[0],
                        s_dhp[0], &s_flag[0][rq][0], st + 1, &s_dead);
     }
     // ================= B2: attention backward of row4, hidden slice hs0 .. hs0 + 31 ==========
@@ -939,10 +959,20 @@ __global__ __launch_bounds__(PT, 2) void decoder_bwd_persist_kernel(s2c_dec_bwd_
         } while (stale);
       }
       const float d = tid < E ? __uint_as_float((u32)kd) : 0.0f;
-      for (int k = 0; k <= K; ++k) {             // <da2, P_k> and (k = K) <da2, Latt_t>
-        float p = k < K ? (tid < E ? d * sP[(size_t)k * E + tid] : 0.0f) : d * latt;
-        p = row16_sum(p);
-        if ((lane & 15) == 0) s_sc[k][tid >> 4] = p;
+      for (int k0 = 0; k0 <= K; k0 += 4) {       // <da2, P_k> and (k = K) <da2, Latt_t>
+        float p[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = k0 + j;
+          p[j] = k < K ? (tid < E ? d * sP[(size_t)k * E + tid] : 0.0f) : (k == K ? d * latt : 0.0f);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p[j] = row16_sum(p[j]);
+        if ((lane & 15) == 0) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (k0 + j <= K) s_sc[k0 + j][tid >> 4] = p[j];
+        }
       }
       __syncthreads();
       for (int i = tid; i < 32 * (K + 1); i += PT) {
@@ -999,14 +1029,15 @@ __global__ __launch_bounds__(PT, 2) void decoder_bwd_persist_kernel(s2c_dec_bwd_
       const float4 wq0 = lane < n4h ? wr[lane] : z4, wq1 = lane + 64 < n4h ? wr[lane + 64] : z4;
       const float4 wa0 = lane < n4e ? wr[n4h + lane] : z4,
                    wa1 = lane + 64 < n4e ? wr[n4h + lane + 64] : z4;
+      float acc[4];
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        float acc = fdot4(wq0, xq[rr][0], 0.0f);
-        acc = fdot4(wq1, xq[rr][1], acc);
-        acc = fdot4(wa0, xa[rr][0], acc);
-        acc = fdot4(wa1, xa[rr][1], acc);
-        acc = row16_sum(acc);
-        if ((lane & 15) == 0) s_one[0][wv][rr][lane >> 4] = acc;
+      for (int rr = 0; rr < 4; ++rr)
+        acc[rr] = fdot4(wa1, xa[rr][1], fdot4(wa0, xa[rr][0], fdot4(wq1, xq[rr][1], fdot4(wq0, xq[rr][0], 0.0f))));
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) acc[rr] = row16_sum(acc[rr]);
+      if ((lane & 15) == 0) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) s_one[0][wv][rr][lane >> 4] = acc[rr];
       }
       __builtin_amdgcn_wave_barrier();
       const int row = r0 + lane, u = u0 + job;
@@ -1047,12 +1078,14 @@ __global__ __launch_bounds__(PT, 2) void decoder_bwd_persist_kernel(s2c_dec_bwd_
       flag_wait(&s_flag[4][rq][0], st + 1, &s_dead);
       flag_wait(&s_flag[4][rq][1], st + 1, &s_dead);
       stash_get(sDA1, E, n4e, r0, x);
+      float acc[4];
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        float acc = fdot4(Wtd[0], x[rr][0], 0.0f);
-        acc = fdot4(Wtd[1], x[rr][1], acc);
-        acc = row16_sum(acc);
-        if ((lane & 15) == 0) s_one[1][wv][rr][lane >> 4] = acc;
+      for (int rr = 0; rr < 4; ++rr) acc[rr] = fdot4(Wtd[1], x[rr][1], fdot4(Wtd[0], x[rr][0], 0.0f));
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) acc[rr] = row16_sum(acc[rr]);
+      if ((lane & 15) == 0) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) s_one[1][wv][rr][lane >> 4] = acc[rr];
       }
       __builtin_amdgcn_wave_barrier();
       if (ok)
@@ -1080,7 +1113,7 @@ __global__ __launch_bounds__(PT, 2) void decoder_bwd_persist_kernel(s2c_dec_bwd_
 
 size_t persist_bwd_lds_bytes(int K, int H, int E) {
   const int obe = (E + PG - 1) / PG, ub = (H + PG - 1) / PG;
-  return sizeof(float) * ((size_t)(2 * obe + ub) * 3 * H + (size_t)ub * (H + E) + (size_t)K * E +
+  return sizeof(float) * ((size_t)2 * (obe + ub) * 3 * H + (size_t)ub * (H + E) + (size_t)K * E +
                           (size_t)K * 32 + 8 * (size_t)H + 8 * (size_t)E);
 }
 
