@@ -308,13 +308,20 @@ __device__ __forceinline__ void lds_rows_partials(const float *sW, int H, int n4
   }
 }
 
-__global__ __launch_bounds__(PT, 2) void decoder_fwd_persist_kernel(s2c_dec_fwd_args a) {
+// Two grids.  <128, 512> (default): two unit pairs per workgroup, the second pair's waves read the
+// polled operands from the LDS stash of the first.  <256, 256>: at most 256 VGPRs and <= 80 KB of
+// LDS, so two fit one CU when another stream's kernel holds some; its h-part waves re-poll h1 /
+// h2 instead of keeping a stash.  Taken when the first grid's LDS request does not fit.
+template <int PGc, int PTc>
+__global__ __launch_bounds__(PTc, 2) void decoder_fwd_persist_kernel(s2c_dec_fwd_args a) {
+  constexpr int PG = PGc, PT = PTc, PW = PT / 64, UPS = PT / 256, P_NSL = PG / 8,
+                P_MAXOC = 512 / P_NSL, NH = 512 / PT, NP = PT / 16;
+  constexpr bool STASH = UPS == 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ float s_red[2][PW][24][4];    // [GRU cell][wave][value][16-lane row]
   __shared__ float s_one[2][PW][16][4];    // P1 / P3 partials (the same wave writes and reads)
   __shared__ float s_bias[2][2][3][4];     // [cell][ih | hh][gate][unit of the workgroup]
   __shared__ float s_sc[P_MAXK][PT / 16], s_s[P_MAXK], s_add[P_MAXOC], s_mask[P_MAXK];
-  static_assert(PT / 16 == 32, "score partials: one 32-lane group per key");
   __shared__ __attribute__((aligned(16))) float s_att[256];
   __shared__ u32 s_nonce;
   __shared__ int s_dead;
@@ -329,10 +336,10 @@ __global__ __launch_bounds__(PT, 2) void decoder_fwd_persist_kernel(s2c_dec_fwd_
   const int oc4 = (E + P_NSL - 1) / P_NSL;
   // dynamic LDS carve-up (floats)
   float *sW1 = smem;                           // 2 P_OB1 x H  map_topdown's h2 block
-  float *sW3 = sW1 + 2 * P_OB1 * H;            // 2 P_OB3 x H  [map_hidd ; map_lang's h block]
-  float *sH1 = sW3 + 2 * P_OB3 * H;            // 8 x H        h1 of the current step
-  float *sH2 = sH1 + 8 * H;                    // 8 x H        h2
-  float *sM = sH2 + 8 * H;                     // K x H        map_feat(obj_feats) of row4
+  float *sW3 = sW1 + UPS * P_OB1 * H;          // UPS P_OB3 x H  [map_hidd ; map_lang's h block]
+  float *sH1 = sW3 + UPS * P_OB3 * H;          // 8 x H        h1 of the current step (STASH)
+  float *sH2 = sH1 + (STASH ? 8 * H : 0);      // 8 x H        h2                     (STASH)
+  float *sM = sH2 + (STASH ? 8 * H : 0);       // K x H        map_feat(obj_feats) of row4
   float *sO = sM + K * H;                      // K x F        obj_feats of row4
   float *sWl = sO + K * F;                     // P_MAXOC x F  map_lang's attended-feature block
   float *sG2 = sWl + P_MAXOC * F;              // GRU cell 2: [unit pair][hh: 6 x H | ih: 6 x E]
@@ -347,7 +354,7 @@ __global__ __launch_bounds__(PT, 2) void decoder_fwd_persist_kernel(s2c_dec_fwd_
   // ---- resident operands ----------------------------------------------------------------
   GruW g1;
   load_gru_w(g1, part ? a.W_ih1 : a.W_hh1, part ? E : H, H, u0 + P_UB * up);
-  for (int c = 0; c < 4; ++c) {                // (unit pair, part) blocks of cell 2
+  for (int c = 0; c < 2 * UPS; ++c) {          // (unit pair, part) blocks of cell 2
     const int cup = c >> 1, cpart = c & 1, I = cpart ? E : H, n4 = I >> 2;
     const float *W = cpart ? a.W_ih2 : a.W_hh2;
     float *dst = sG2 + (size_t)cup * 6 * (H + E) + (cpart ? 6 * H : 0);
@@ -358,12 +365,12 @@ __global__ __launch_bounds__(PT, 2) void decoder_fwd_persist_kernel(s2c_dec_fwd_
           reinterpret_cast<const float4 *>(W + (size_t)(k * H + u) * I)[q];
     }
   }
-  for (int i = tid; i < 2 * P_OB1 * n4h; i += PT) {
+  for (int i = tid; i < UPS * P_OB1 * n4h; i += PT) {
     const int k = i / n4h, q = i - k * n4h, o = min(w * ob1 + k, E - 1);
     reinterpret_cast<float4 *>(sW1)[i] =
         reinterpret_cast<const float4 *>(a.W_td_h2 + (size_t)o * a.ldtd)[q];
   }
-  for (int i = tid; i < 2 * P_OB3 * n4h; i += PT) {
+  for (int i = tid; i < UPS * P_OB3 * n4h; i += PT) {
     const int k = i / n4h, q = i - k * n4h, o = min(w * ob3 + k, H + E - 1);
     reinterpret_cast<float4 *>(sW3)[i] = reinterpret_cast<const float4 *>(a.Wqh + (size_t)o * H)[q];
   }
@@ -387,7 +394,9 @@ __global__ __launch_bounds__(PT, 2) void decoder_fwd_persist_kernel(s2c_dec_fwd_
     s_bias[c][ih][k][ju] = b[k * H + u];
   }
   // attention constants of this thread: hidden unit tid; the bias of its map_lang output
-  const float wa0 = tid < H ? a.wa[tid] : 0.0f;
+  float wa_[NH];
+#pragma unroll
+  for (int m = 0; m < NH; ++m) wa_[m] = tid + PT * m < H ? a.wa[tid + PT * m] : 0.0f;
   float bl = 0.0f;
   if (row4 < R) {
     const int o = slice * oc4 + (tid >> 4);
@@ -396,8 +405,9 @@ __global__ __launch_bounds__(PT, 2) void decoder_fwd_persist_kernel(s2c_dec_fwd_
   }
   float hp1 = 0.f, hp2 = 0.f;                  // h of the item lanes' (row, unit)
   // h1, h2 of step 0 are zero
-  for (int i = tid; i < 2 * 8 * n4h; i += PT)
-    reinterpret_cast<float4 *>(sH1)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (STASH)
+    for (int i = tid; i < 2 * 8 * n4h; i += PT)
+      reinterpret_cast<float4 *>(sH1)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
   const u32 base = (s_nonce << 6) + 1u;
   const XOff xo = xoff(H, E);
@@ -423,13 +433,15 @@ __global__ __launch_bounds__(PT, 2) void decoder_fwd_persist_kernel(s2c_dec_fwd_
       if (t > 0 && up == 0) {
         poll_rows<4>(rs[par ^ 1], xo.h2, H, n4h, r0, R, tag - 1u, x, &s_dead, a.backoff);
         P_STAMP(1);
+        if (STASH) {
 #pragma unroll
-        for (int rr2 = 0; rr2 < 4; ++rr2)
+          for (int rr2 = 0; rr2 < 4; ++rr2)
 #pragma unroll
-          for (int s = 0; s < 2; ++s)
-            if (lane + 64 * s < n4h)
-              reinterpret_cast<float4 *>(sH2 + (size_t)(r0 + rr2) * H)[lane + 64 * s] = x[rr2][s];
-        flag_raise(&s_flag[0][rq], t + 1);
+            for (int s = 0; s < 2; ++s)
+              if (lane + 64 * s < n4h)
+                reinterpret_cast<float4 *>(sH2 + (size_t)(r0 + rr2) * H)[lane + 64 * s] = x[rr2][s];
+          flag_raise(&s_flag[0][rq], t + 1);
+        }
       } else if (t > 0) {
         flag_wait(&s_flag[0][rq], t + 1, &s_dead);
 #pragma unroll
@@ -453,20 +465,29 @@ __global__ __launch_bounds__(PT, 2) void decoder_fwd_persist_kernel(s2c_dec_fwd_
         st_tag(xb + xo.x1 + (size_t)row * E + o, v, tag);
         a.X1[(size_t)t * RE + (size_t)row * E + o] = v;
       }
-      if (up == 1) flag_raise(&s_flag[2][rq], t + 1);
+      if (up == UPS - 1) flag_raise(&s_flag[2][rq], t + 1);
       P_STAMP(2);
     }
     // ================= P2: GRUCell 1 =====================================================
     {
       float4 x[4][2];
       if (part == 0) {
+        if (STASH) {
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr)
+          for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-          for (int s = 0; s < 2; ++s)
-            x[rr][s] = lane + 64 * s < n4h
-                           ? reinterpret_cast<const float4 *>(sH1 + (size_t)(r0 + rr) * H)[lane + 64 * s]
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int s = 0; s < 2; ++s)
+              x[rr][s] = lane + 64 * s < n4h
+                             ? reinterpret_cast<const float4 *>(sH1 + (size_t)(r0 + rr) * H)[lane + 64 * s]
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else if (t > 0) {                      // h1 of the previous step: complete, one pass
+          poll_rows<4>(rs[par ^ 1], xo.h1, H, n4h, r0, R, tag - 1u, x, &s_dead, a.backoff);
+        } else {
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) x[rr][s] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
       } else {
         // x1 cannot exist before this workgroup's own share has been published (all workgroups
         // run in step): do not load the fabric with polls until then
@@ -494,13 +515,15 @@ __global__ __launch_bounds__(PT, 2) void decoder_fwd_persist_kernel(s2c_dec_fwd_
       if (up == 0) {
         poll_rows<4>(rs[par], xo.h1, H, n4h, r0, R, tag, x, &s_dead, a.backoff);
         P_STAMP(7);
+        if (STASH) {
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr)
+          for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-          for (int s = 0; s < 2; ++s)
-            if (lane + 64 * s < n4h)
-              reinterpret_cast<float4 *>(sH1 + (size_t)(r0 + rr) * H)[lane + 64 * s] = x[rr][s];
-        flag_raise(&s_flag[1][rq], t + 1);
+            for (int s = 0; s < 2; ++s)
+              if (lane + 64 * s < n4h)
+                reinterpret_cast<float4 *>(sH1 + (size_t)(r0 + rr) * H)[lane + 64 * s] = x[rr][s];
+          flag_raise(&s_flag[1][rq], t + 1);
+        }
       } else {
         flag_wait(&s_flag[1][rq], t + 1, &s_dead);
 #pragma unroll
@@ -525,45 +548,61 @@ __global__ __launch_bounds__(PT, 2) void decoder_fwd_persist_kernel(s2c_dec_fwd_
     }
     // ================= P4: attention of row4 + this slice of map_lang =======================
     if (row4 < R) {
-      // q[row4, tid] and the slice's lang-h addends: one tagged value each
+      // q[row4, tid (+ PT)] and the slice's lang-h addends: one tagged value each
       const int o_add = slice * oc4 + tid;
-      const bool has_q = tid < H, has_add = tid < oc4 && o_add < E;
-      const u64 *pq = xb + xo.ql + (size_t)row4 * (H + E) + (has_q ? tid : 0);
+      const bool has_add = tid < oc4 && o_add < E;
       const u64 *pa = xb + xo.ql + (size_t)row4 * (H + E) + H + (has_add ? o_add : 0);
-      u64 kq = (u64)tag << 32, ka = (u64)tag << 32;
+      u64 kq[NH], ka = (u64)tag << 32;
       bool stale;
       int spins = 0;
       do {
-        if (has_q) kq = __hip_atomic_load(pq, __ATOMIC_RELAXED, S2C_AG);
+        stale = false;
+#pragma unroll
+        for (int m = 0; m < NH; ++m) {
+          const int h = tid + PT * m;
+          kq[m] = h < H ? __hip_atomic_load(xb + xo.ql + (size_t)row4 * (H + E) + h, __ATOMIC_RELAXED,
+                                            S2C_AG)
+                        : (u64)tag << 32;
+        }
         if (has_add) ka = __hip_atomic_load(pa, __ATOMIC_RELAXED, S2C_AG);
-        stale = ((u32)(kq >> 32) != tag) | ((u32)(ka >> 32) != tag);
+#pragma unroll
+        for (int m = 0; m < NH; ++m) stale |= (u32)(kq[m] >> 32) != tag;
+        stale |= (u32)(ka >> 32) != tag;
         if (stale && (++spins > P_SPIN_MAX || *(volatile int *)&s_dead)) {
           *(volatile int *)&s_dead = 1;
           break;
         }
       } while (stale);
       P_STAMP(9);
-      const float q0 = __uint_as_float((u32)kq);
       if (tid < oc4) s_add[tid] = __uint_as_float((u32)ka);
       for (int k0 = 0; k0 < K; k0 += 4) {        // four independent chains in flight
-        float p[4];
+        float p[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          p[j] = (has_q && k0 + j < K) ? sM[(size_t)(k0 + j) * H + tid] : 0.0f;
+        for (int m = 0; m < NH; ++m) {
+          const int h = tid + PT * m;
+          const float qm = __uint_as_float((u32)kq[m]);
+          float mv[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) p[j] = row16_sum(has_q ? wa0 * p_tanh(p[j] + q0) : 0.0f);
+          for (int j = 0; j < 4; ++j) mv[j] = (h < H && k0 + j < K) ? sM[(size_t)(k0 + j) * H + h] : 0.0f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) p[j] += h < H ? wa_[m] * p_tanh(mv[j] + qm) : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p[j] = row16_sum(p[j]);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if ((lane & 15) == 0 && k0 + j < K) s_sc[k0 + j][tid >> 4] = p[j];
       }
+      P_STAMP(13);
       __syncthreads();
-      for (int i = tid; i < 32 * K; i += PT) {   // 32 row partials per key: one more DPP pass
-        const int k = i >> 5;
-        float v = row16_sum(s_sc[k][i & 31]);
-        v += __shfl_xor(v, 16, 64);
-        if ((i & 31) == 0) s_s[k] = s_mask[k] == 0.0f ? -1e30f : v;
+      for (int i = tid; i < NP * K; i += PT) {   // NP row partials per key: one more DPP pass
+        const int k = i / NP;
+        float v = row16_sum(s_sc[k][i % NP]);
+        if (NP == 32) v += __shfl_xor(v, 16, 64);
+        if (i % NP == 0) s_s[k] = s_mask[k] == 0.0f ? -1e30f : v;
       }
       __syncthreads();
+      P_STAMP(14);
       {
         float mx = -INFINITY;
         for (int k = 0; k < K; ++k) mx = fmaxf(mx, s_s[k]);
@@ -583,6 +622,7 @@ __global__ __launch_bounds__(PT, 2) void decoder_fwd_persist_kernel(s2c_dec_fwd_
           if (slice == 0) a.ATT[(size_t)t * R * F + (size_t)row4 * F + tid] = acc * inv;
         }
       }
+      P_STAMP(15);
       __syncthreads();
       {
         const int ol = tid >> 4, pr = tid & 15, o = slice * oc4 + ol;
@@ -604,13 +644,22 @@ __global__ __launch_bounds__(PT, 2) void decoder_fwd_persist_kernel(s2c_dec_fwd_
     {
       float4 x[4][2];
       if (part == 0) {
+        if (STASH) {
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr)
+          for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-          for (int s = 0; s < 2; ++s)
-            x[rr][s] = lane + 64 * s < n4h
-                           ? reinterpret_cast<const float4 *>(sH2 + (size_t)(r0 + rr) * H)[lane + 64 * s]
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int s = 0; s < 2; ++s)
+              x[rr][s] = lane + 64 * s < n4h
+                             ? reinterpret_cast<const float4 *>(sH2 + (size_t)(r0 + rr) * H)[lane + 64 * s]
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else if (t > 0) {                      // h2 of the previous step: complete, one pass
+          poll_rows<4>(rs[par ^ 1], xo.h2, H, n4h, r0, R, tag - 1u, x, &s_dead, a.backoff);
+        } else {
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) x[rr][s] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
       } else {
         poll_rows<4>(rs[par], xo.x2, E, n4e, r0, R, tag, x, &s_dead, a.backoff);
       }
@@ -1117,9 +1166,11 @@ size_t persist_bwd_lds_bytes(int K, int H, int E) {
                           (size_t)K * 32 + 8 * (size_t)H + 8 * (size_t)E);
 }
 
-size_t persist_lds_bytes(int K, int H, int E, int F) {
-  return sizeof(float) * ((size_t)(2 * P_OB1 + 2 * P_OB3 + 16) * H + (size_t)K * H + (size_t)K * F +
-                          (size_t)P_MAXOC * F + (size_t)12 * (H + E));
+size_t persist_lds_bytes(int K, int H, int E, int F, int grid) {
+  const int ups = grid == 256 ? 1 : 2, maxoc = grid == 256 ? 16 : 32;
+  return sizeof(float) * ((size_t)ups * (P_OB1 + P_OB3) * H + (ups == 2 ? 16 * (size_t)H : 0) +
+                          (size_t)K * H + (size_t)K * F + (size_t)maxoc * F +
+                          (size_t)ups * 6 * (H + E));
 }
 
 int g_persist = -1;
@@ -1132,8 +1183,9 @@ extern "C" long long s2c_decoder_fwd_persist_xbuf_pairs(int H, int E) {
   return 2LL * xoff(H, E).total;
 }
 
-// 1 = the persistent kernel can take these shapes on the current device (whole grid co-resident)
-extern "C" int s2c_decoder_fwd_persist_supported(int R, int K, int H, int E, int F, int T) {
+// grid of the forward kernel for these shapes on the current device: 256 (x 256 threads), 128
+// (x 512 threads) or 0 = not taken.  S2C_DECODER_PERSIST_GRID=128|256 forces one.
+static int fwd_persist_grid(int R, int K, int H, int E, int F, int T) {
   if (g_persist < 0) {
     const char *e = getenv("S2C_DECODER_PERSIST");
     g_persist = e ? atoi(e) : 1;
@@ -1141,37 +1193,59 @@ extern "C" int s2c_decoder_fwd_persist_supported(int R, int K, int H, int E, int
   if (!g_persist) return 0;
   if (R < 1 || R > 8 || K < 1 || K > P_MAXK || T < 1 || T > 62) return 0;
   if (H % 4 || E % 4 || F % 4 || H < 4 || H > 512 || E < 4 || E > 512 || F < 4 || F > 256) return 0;
-  const size_t lds = persist_lds_bytes(K, H, E, F);
-  static int state[64];           // per device: 0 unknown, 1 ok, -1 refused
-  static size_t lds_set[64];
-  int dev = 0;
+  static int forced = -1;
+  if (forced < 0) {
+    const char *e = getenv("S2C_DECODER_PERSIST_GRID");
+    forced = e ? atoi(e) : 0;
+  }
+  int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
-  if (state[dev] == 0 || lds > lds_set[dev]) {
-    state[dev] = -1;
-    if (hipFuncSetAttribute((const void *)decoder_fwd_persist_kernel,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      (void)hipGetLastError();
-      return 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  static size_t lds_set[2][64];
+  // 128 x 512 first: measured 778 vs 780 us alone and 9.35 vs 9.40 ms per training step -- the
+  // phases are no faster with one wave per SIMD (forced by padding the LDS request: the same
+  // 2340 cycles for a GRU cell's partial sums), so the second grid only buys headroom in LDS
+  for (int cc = 0; cc < 2; ++cc) {
+    const int c = 1 - cc;
+    const int grid = c == 0 ? 256 : 128;
+    if (forced && forced != grid) continue;
+    const void *fn = c == 0 ? (const void *)decoder_fwd_persist_kernel<256, 256>
+                            : (const void *)decoder_fwd_persist_kernel<128, 512>;
+    const size_t lds = persist_lds_bytes(K, H, E, F, grid);
+    if (lds > lds_set[c][dev]) {
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        (void)hipGetLastError();
+        continue;
+      }
+      lds_set[c][dev] = lds;
     }
-    lds_set[dev] = lds;
-    state[dev] = 1;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, c == 0 ? 256 : 512, lds) !=
+        hipSuccess) {
+      (void)hipGetLastError();
+      continue;
+    }
+    // every workgroup resident at once, with a margin of CUs for the kernels of other streams
+    if ((long long)per_cu * (cus - 16) >= grid) return grid;
   }
-  int per_cu = 0, cus = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)decoder_fwd_persist_kernel,
-                                                   PT, lds) != hipSuccess ||
-      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
-    (void)hipGetLastError();
-    return 0;
-  }
-  // every workgroup must be resident at once, with a margin of CUs for kernels of other streams
-  return (long long)per_cu * (cus - 16) >= PG ? 1 : 0;
+  return 0;
+}
+
+extern "C" int s2c_decoder_fwd_persist_supported(int R, int K, int H, int E, int F, int T) {
+  return fwd_persist_grid(R, K, H, E, F, T) ? 1 : 0;
 }
 
 extern "C" int s2c_decoder_fwd_persist(const s2c_dec_fwd_args *a, void *stream) {
-  if (!a || !s2c_decoder_fwd_persist_supported(a->R, a->K, a->H, a->E, a->F, a->T)) return -2;
-  if (a->ldtd % 4 || a->ldlang % 4) return -2;
-  const size_t lds = persist_lds_bytes(a->K, a->H, a->E, a->F);
-  hipLaunchKernelGGL(decoder_fwd_persist_kernel, dim3(PG), dim3(PT), lds, (hipStream_t)stream, *a);
+  if (!a || a->ldtd % 4 || a->ldlang % 4) return -2;
+  const int grid = fwd_persist_grid(a->R, a->K, a->H, a->E, a->F, a->T);
+  if (!grid) return -2;
+  const size_t lds = persist_lds_bytes(a->K, a->H, a->E, a->F, grid);
+  if (grid == 256)
+    hipLaunchKernelGGL((decoder_fwd_persist_kernel<256, 256>), dim3(256), dim3(256), lds,
+                       (hipStream_t)stream, *a);
+  else
+    hipLaunchKernelGGL((decoder_fwd_persist_kernel<128, 512>), dim3(128), dim3(512), lds,
+                       (hipStream_t)stream, *a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     fprintf(stderr, "s2c_decoder_fwd_persist launch failed: %s\n", hipGetErrorString(e));

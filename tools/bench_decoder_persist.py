@@ -55,12 +55,13 @@ def main():
     names = {0: "step start", 1: "P1 h2 polled", 2: "P1 x1 published", 3: "P2 operand ready",
              4: "P2 partials", 5: "P2 barrier", 6: "P2 h1 published", 7: "P3 h1 polled",
              8: "P3 q published", 9: "P4 q polled", 10: "P4 x2 published", 11: "P5 operand ready",
-             12: "P5 h2 published"}
+             12: "P5 h2 published", 13: "P4 scores done", 14: "P4 scores summed",
+             15: "P4 att done"}
     for wv, label in ((0, "wave 0 (h part, polls)"), (1, "wave 1 (x part)"), (4, "wave 4 (h part, LDS)"), (5, "wave 5 (x part)")):
         print(label)
         t0 = p[wv, 1:, 0]
         prev = np.zeros_like(t0)
-        for slot in range(13):
+        for slot in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 13, 14, 15, 10, 11, 12):
             v = p[wv, 1:, slot]
             if (v == 0).all():
                 continue
