@@ -59,10 +59,11 @@ constexpr int P_SPIN_MAX = 1 << 20;
 
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
+// old = 0 with bound_ctrl: lets the DPP combiner fold the move into the add (v_add_f32_dpp); every
+// control used here has a valid source lane for every lane
 template <int CTRL>
 __device__ __forceinline__ float dppf(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL,
-                                                    0xF, 0xF, false));
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
 // every lane of a 16-lane row receives the row's sum
 __device__ __forceinline__ float row16_sum(float v) {
@@ -114,6 +115,11 @@ __device__ __forceinline__ void poll_rows(__amdgpu_buffer_rsrc_t rs, int base_pa
   const int lane = threadIdx.x & 63;
   const int voff = lane * 32;
   u32x4 raw[NR][2][2];
+#pragma unroll
+  for (int rr = 0; rr < NR; ++rr)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)              // slots this lane does not own: valid from the start
+      raw[rr][s][0] = raw[rr][s][1] = (u32x4){0u, tag, 0u, tag};
   bool stale;
   int spins = 0;
   do {
@@ -126,8 +132,6 @@ __device__ __forceinline__ void poll_rows(__amdgpu_buffer_rsrc_t rs, int base_pa
           raw[rr][s][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 2048 * s, soff, P_AUX);
           raw[rr][s][1] =
               __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 2048 * s + 16, soff, P_AUX);
-        } else {
-          raw[rr][s][0] = raw[rr][s][1] = (u32x4){0u, tag, 0u, tag};
         }
       }
     }

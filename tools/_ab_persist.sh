@@ -1,3 +1,3 @@
-for g in 256 128; do echo grid=$g; S2C_DECODER_PERSIST_GRID=$g timeout 300 python -m pytest tests/test_fused_gpu.py -x -q -k "persistent_decoder" 2>&1 | tail -1
-S2C_DECODER_PERSIST_GRID=$g timeout 300 python tools/bench_decoder_persist.py | head -2; done
-for g in 256 128 256 128; do S2C_DECODER_PERSIST_GRID=$g S2C_BENCH_WINDOWS=3 timeout 600 python bench.py --no-cpu-baseline --no-fed --steps 20 --warmup 5 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('grid=$g', d['value'], d['ms_per_step'], d.get('windows',{}).get('median_ms_per_step'))"; done
+timeout 300 python -m pytest tests/test_fused_gpu.py -x -q -k "persistent_decoder" 2>&1 | tail -1
+timeout 300 python tools/bench_decoder_persist.py | head -2
+R=$(pwd); cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pp -o s -- python $R/bench.py --no-cpu-baseline --no-fed --steps 5 --warmup 2 --no-graph > /dev/null 2>&1; grep -i "persist" /tmp/pp/s_kernel_stats.csv | cut -c1-120
