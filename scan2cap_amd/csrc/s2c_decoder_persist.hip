@@ -249,7 +249,8 @@ __device__ __forceinline__ void gru_partials_lds(const float *sW, int I, const f
   }
 }
 __device__ __forceinline__ float red4(const float (*s_red)[4], int v) {
-  return (s_red[v][0] + s_red[v][1]) + (s_red[v][2] + s_red[v][3]);
+  const float4 q = *reinterpret_cast<const float4 *>(s_red[v]);    // one 16-byte LDS read
+  return (q.x + q.y) + (q.z + q.w);
 }
 
 struct GruOut {
@@ -322,8 +323,8 @@ __global__ __launch_bounds__(PTc, 2) void decoder_fwd_persist_kernel(s2c_dec_fwd
                 P_MAXOC = 512 / P_NSL, NH = 512 / PT, NP = PT / 16;
   constexpr bool STASH = UPS == 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  __shared__ float s_red[2][PW][24][4];    // [GRU cell][wave][value][16-lane row]
-  __shared__ float s_one[2][PW][16][4];    // P1 / P3 partials (the same wave writes and reads)
+  __shared__ __attribute__((aligned(16))) float s_red[2][PW][24][4];   // [GRU cell][wave][value][16-lane row]
+  __shared__ __attribute__((aligned(16))) float s_one[2][PW][16][4];    // P1 / P3 partials (the same wave writes and reads)
   __shared__ float s_bias[2][2][3][4];     // [cell][ih | hh][gate][unit of the workgroup]
   __shared__ float s_sc[P_MAXK][PT / 16], s_s[P_MAXK], s_add[P_MAXOC], s_mask[P_MAXK];
   __shared__ __attribute__((aligned(16))) float s_att[256];
@@ -609,14 +610,28 @@ __global__ __launch_bounds__(PTc, 2) void decoder_fwd_persist_kernel(s2c_dec_fwd
       P_STAMP(14);
       {
         float mx = -INFINITY;
-        for (int k = 0; k < K; ++k) mx = fmaxf(mx, s_s[k]);
+        for (int k0 = 0; k0 < K; k0 += 4) {      // four LDS reads in flight
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = k0 + j < K ? s_s[k0 + j] : -INFINITY;
+          mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+        }
         // one exponential per key and thread: the weighted sum and the normaliser in one pass
         const int f = tid < F ? tid : 0;
         float sum = 0.0f, acc = 0.0f;
-        for (int k = 0; k < K; ++k) {
-          const float e = __expf(s_s[k] - mx);
-          sum += e;
-          acc = __builtin_fmaf(e, sO[(size_t)k * F + f], acc);
+        for (int k0 = 0; k0 < K; k0 += 4) {
+          float v[4], o[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[j] = k0 + j < K ? s_s[k0 + j] : -INFINITY;
+            o[j] = k0 + j < K ? sO[(size_t)(k0 + j) * F + f] : 0.0f;
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float e = __expf(v[j] - mx);
+            sum += e;
+            acc = __builtin_fmaf(e, o[j], acc);
+          }
         }
         const float inv = 1.0f / sum;
         if (slice == 0 && tid < K)
@@ -880,8 +895,8 @@ __device__ __forceinline__ void gate_phase(const GateIO &io, __amdgpu_buffer_rsr
 
 __global__ __launch_bounds__(PT, 2) void decoder_bwd_persist_kernel(s2c_dec_bwd_args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  __shared__ float s_red[2][PW][32][4];     // [cell][wave][output x row][16-lane row]
-  __shared__ float s_one[2][PW][4][4];      // B3 / B5 partials (the same wave writes and reads)
+  __shared__ __attribute__((aligned(16))) float s_red[2][PW][32][4];    // [cell][wave][output x row][16-lane row]
+  __shared__ __attribute__((aligned(16))) float s_one[2][PW][4][4];      // B3 / B5 partials (the same wave writes and reads)
   __shared__ float s_dhp[2][8][B_UB];       // [dh2_part | dh1c][row][unit of the workgroup]
   __shared__ float s_sc[P_MAXK + 1][PT / 16], s_dal[P_MAXK + 1], s_alpha[P_MAXK];
   __shared__ float s_dpre[P_MAXK][32], s_dsc[P_MAXK][32];
