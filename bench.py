@@ -103,6 +103,8 @@ KERNELS_OF = {
     "s2c_attn_bwd": ("attn_bwd_kernel",),
     "s2c_attn_bwd_x2": ("attn_bwd_x2_kernel",),
     "s2c_attn_x2_fwd": ("attn_x2_kernel",),
+    "s2c_decoder_fwd_persist": ("decoder_fwd_persist_kernel",),
+    "s2c_decoder_bwd_persist": ("decoder_bwd_persist_kernel",),
     "s2c_ball_query": ("ball_query_kernel",),
     "s2c_ball_query_grid": ("bq_grid_build_kernel", "ball_query_grid_kernel"),
     "s2c_furthest_point_sampling_bucketed": ("fps_bucket_kernel",),
@@ -374,8 +376,10 @@ def roofline_of(top, ms_per_step, wl):
     if top["kernel"] in _DECODER_CHAIN:
         roof["regime"] = {"kind": "latency",
                           "note": "teacher-forced decoder: %d rows x ~30 strictly sequential "
-                                  "steps of 13 dependent launches; one launch streams a few MB "
-                                  "of weights from L2 in ~5 us (DESIGN 4.4)" % wl["B"]}
+                                  "steps of 5 + 5 dependent mat-vec stages -- two persistent "
+                                  "kernels exchanging tagged vectors between 128 workgroups "
+                                  "(~2.5 us per stage), or 10 launches per step (DESIGN 4.4)"
+                                  % wl["B"]}
     rounds = _FPS_ROUNDS.get(top["kernel"])
     if rounds:
         us = top["avg_us"] / rounds
@@ -421,7 +425,8 @@ GEMM_FAMILY = ("s2c_rows_gemm", "s2c_rows_gemm_bn_relu_side", "s2c_sa_gather_gem
                "s2c_bn_bwd_gemm", "s2c_bn_bwd_gemm_next_stats", "s2c_rows_gemm_next_stats",
                "s2c_rows_gemm_bn_eval", "s2c_sa_gather_gemm_bn_eval", "s2c_sa_fused_eval")
 _DECODER_CHAIN = ("s2c_small_linear", "s2c_small_linear_pair", "s2c_gru_fwd", "s2c_attn_fwd",
-                  "s2c_attn_bwd", "s2c_gru_gates_bwd", "s2c_attn_x2_fwd", "s2c_attn_bwd_x2")
+                  "s2c_attn_bwd", "s2c_gru_gates_bwd", "s2c_attn_x2_fwd", "s2c_attn_bwd_x2",
+                  "s2c_decoder_fwd_persist", "s2c_decoder_bwd_persist")
 
 
 def family_roofline(table_k, ms_per_step):

@@ -264,8 +264,9 @@ class TopDownDecode(Function):
                 a.prof = PROF.data_ptr() if PROF is not None else None
                 a.nonce, a.started, a.fail = ctl.data_ptr(), ctl.data_ptr() + 4, ctl.data_ptr() + 8
                 a.C = COEF.data_ptr() if COEF is not None else None
-                if _C.TIMER.enabled:
-                    _C.TIMER.alg_bytes = 0
+                if _C.TIMER.enabled:     # weights once + everything saved for the backward pass
+                    _C.TIMER.alg_bytes = 4 * (E * H + 6 * H * (E + H) + (H + E) * H + E * F +
+                                              T * R * (11 * H + 3 * E + K + F))
                 _C.call("s2c_decoder_fwd_persist", ctypes.byref(a), _C.stream_ptr())
             for t in range(0 if not persist else T, T):
                 _lin(R, E, H, td_h2, ldtd, H2[t], H, X1[t], E, add1=Pw[:, t],
@@ -368,8 +369,10 @@ class TopDownDecode(Function):
                     assert v.is_contiguous(), n
                     setattr(a, n, v.data_ptr())
                 a.nonce, a.started, a.fail = ctl.data_ptr(), ctl.data_ptr() + 4, ctl.data_ptr() + 8
-                if _C.TIMER.enabled:
-                    _C.TIMER.alg_bytes = 0
+                if _C.TIMER.enabled:     # transposed weights once + saved tensors in, gradients out
+                    _C.TIMER.alg_bytes = 4 * (E * H + 6 * H * (E + H) + (H + E) * H +
+                                              T * R * (10 * H + 4 * E + K) +
+                                              T * R * (13 * H + 2 * E))
                 _C.call("s2c_decoder_bwd_persist", ctypes.byref(a), _C.stream_ptr())
             # 6 launches per step.  GRU-2's gate gradients of step t-1 come out of the
             # epilogue of step t's last product (value = dh2 of step t-1); only the

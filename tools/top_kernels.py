@@ -14,7 +14,7 @@ for r in rows[:int(sys.argv[3]) if len(sys.argv) > 3 else 30]:
 CATS = [
     ("geometry: FPS (side stream)", ("fps_",)),
     ("geometry: ball query / 3-NN", ("ball_query", "three_nn")),
-    ("decoder kernels", ("small_linear", "gru_", "attn_")),
+    ("decoder kernels", ("small_linear", "gru_", "attn_", "decoder_fwd_persist", "decoder_bwd_persist")),
     ("BN stats/apply/pool (fwd+bwd)", ("bn_", "col_stats", "pool_bwd")),
     ("hand MFMA GEMM", ("rows_gemm", "rows_stream_gemm", "dw_x3", "sa_fused_eval")),
     ("gather/scatter rows, interpolate", ("sa_gather", "sa_scatter", "three_interpolate", "gather_points", "group_points")),
