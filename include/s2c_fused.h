@@ -410,6 +410,7 @@ typedef struct s2c_dec_bwd_args {
   const float *WT_ih2, *WT_hh2, *WT_hl, *WT_ih1, *WT_hh1, *WT_td;
   float *DA1, *DQA, *DG, *dM, *dwa_rows;   /* DG (4, T, R, 3H): DGI1, DGH1, DGI2, DGH2 */
   unsigned long long *xbuf;
+  unsigned long long *prof;         /* NULL, or 8 x T x 16 words: phase stamps of workgroup 0 */
   unsigned int *nonce, *started, *fail;
 } s2c_dec_bwd_args;
 int s2c_decoder_bwd_persist(const s2c_dec_bwd_args *a, void *stream);

@@ -160,9 +160,21 @@ __device__ __forceinline__ void poll_rows(__amdgpu_buffer_rsrc_t rs, int base_pa
 // phase stamps (s_memtime, shader cycles) of workgroup 0's waves: prof[(wave * T + t) * 16 + slot]
 #define P_STAMP(slot)                                                                  \
   do {                                                                                 \
-    if (a.prof && w == 0 && lane == 0)                                                 \
-      a.prof[((size_t)wv * T + t) * 16 + (slot)] = __builtin_readcyclecounter();       \
+    if (PROF) {                                                                        \
+      if (a.prof && w == 0 && lane == 0)                                               \
+        a.prof[((size_t)wv * T + t) * 16 + (slot)] = __builtin_readcyclecounter();     \
+    } else {                                                                           \
+      /* measured: without the stamps the scheduler moves code across the phases and the   \
+         forward kernel loses 6 % (636 -> 674 us); keep the phase boundaries */            \
+      __builtin_amdgcn_sched_barrier(0);                                               \
+    }                                                                                  \
   } while (0)
+
+// Workgroup barrier of the step loops.  Measured: an LDS-only variant (s_waitcnt lgkmcnt(0) + s_barrier,
+// i.e. without __syncthreads()'s wait for the wave's outstanding global stores) is not faster (fwd
+// 637 -> 650 us, bwd 662 -> 681 us): what a wave waits for at these barriers is the other row quad,
+// which runs ~1800 cycles behind through every exchange, not its own stores.
+__device__ __forceinline__ void lds_barrier() { __syncthreads(); }
 
 // workgroup-local step flags: the polling wave of a row quad raises flag = step + 1 once the
 // operand is in the LDS stash; the other waves of the quad wait on LDS instead of polling memory
@@ -317,7 +329,7 @@ __device__ __forceinline__ void lds_rows_partials(const float *sW, int H, int n4
 // polled operands from the LDS stash of the first.  <256, 256>: at most 256 VGPRs and <= 80 KB of
 // LDS, so two fit one CU when another stream's kernel holds some; its h-part waves re-poll h1 /
 // h2 instead of keeping a stash.  Taken when the first grid's LDS request does not fit.
-template <int PGc, int PTc>
+template <int PGc, int PTc, bool PROF>
 __global__ __launch_bounds__(PTc, 2) void decoder_fwd_persist_kernel(s2c_dec_fwd_args a) {
   constexpr int PG = PGc, PT = PTc, PW = PT / 64, UPS = PT / 256, P_NSL = PG / 8,
                 P_MAXOC = 512 / P_NSL, NH = 512 / PT, NP = PT / 16;
@@ -502,7 +514,7 @@ __global__ __launch_bounds__(PTc, 2) void decoder_fwd_persist_kernel(s2c_dec_fwd
       P_STAMP(3);
       gru_partials(g1, x, s_red[0][wv]);
       P_STAMP(4);
-      __syncthreads();
+      lds_barrier();
       P_STAMP(5);
       if (part == 0) {
         float *S = a.S + (size_t)t * RH, *C = a.C ? a.C + (size_t)t * RH : nullptr;
@@ -599,14 +611,14 @@ __global__ __launch_bounds__(PTc, 2) void decoder_fwd_persist_kernel(s2c_dec_fwd
           if ((lane & 15) == 0 && k0 + j < K) s_sc[k0 + j][tid >> 4] = p[j];
       }
       P_STAMP(13);
-      __syncthreads();
+      lds_barrier();
       for (int i = tid; i < NP * K; i += PT) {   // NP row partials per key: one more DPP pass
         const int k = i / NP;
         float v = row16_sum(s_sc[k][i % NP]);
         if (NP == 32) v += __shfl_xor(v, 16, 64);
         if (i % NP == 0) s_s[k] = s_mask[k] == 0.0f ? -1e30f : v;
       }
-      __syncthreads();
+      lds_barrier();
       P_STAMP(14);
       {
         float mx = -INFINITY;
@@ -642,7 +654,7 @@ __global__ __launch_bounds__(PTc, 2) void decoder_fwd_persist_kernel(s2c_dec_fwd
         }
       }
       P_STAMP(15);
-      __syncthreads();
+      lds_barrier();
       {
         const int ol = tid >> 4, pr = tid & 15, o = slice * oc4 + ol;
         float acc = 0.0f;
@@ -684,7 +696,7 @@ __global__ __launch_bounds__(PTc, 2) void decoder_fwd_persist_kernel(s2c_dec_fwd
       }
       P_STAMP(11);
       gru_partials_lds(sG2w, part ? E : H, x, s_red[1][wv]);
-      __syncthreads();
+      lds_barrier();
       if (part == 0) {
         const size_t TRH = (size_t)T * RH;
         float *S = a.S + 4 * TRH + (size_t)t * RH, *C = a.C ? a.C + 4 * TRH + (size_t)t * RH : nullptr;
@@ -774,11 +786,21 @@ struct GateIO {
   const float *plain_dh;      // step T-1 of cell 2: dh' = dH2[T-1] (R x H), else NULL
   int src_off;                // tagged dh' source (pairs) inside rs_src
   u32 src_tag, tag;
+  u64 *prof;                  // NULL or this wave's stamp slots of the step (3 used from prof_slot)
+  int prof_slot;
 };
+#define G_STAMP(k)                                                               \
+  do {                                                                           \
+    if (PROF) {                                                                  \
+      if (io.prof && lane == 0) io.prof[io.prof_slot + (k)] = __builtin_readcyclecounter(); \
+    } else {                                                                     \
+      __builtin_amdgcn_sched_barrier(0);                                         \
+    }                                                                            \
+  } while (0)
 
 // B1 / B4.  The weight rows of the e-outputs are in LDS (sWe: [output][3H]); those of the
 // h-outputs in registers (REGS: this wave's gate block in Wh) or in LDS (sWh).
-template <bool REGS>
+template <bool REGS, bool PROF>
 __device__ __forceinline__ void gate_phase(const GateIO &io, __amdgpu_buffer_rsrc_t rs_src,
                                            const float4 (&Wh)[B_UB][2], const float *sWe,
                                            const float *sWh,
@@ -807,7 +829,7 @@ __device__ __forceinline__ void gate_phase(const GateIO &io, __amdgpu_buffer_rsr
   if (hok) e_op = io.Z[(size_t)irow * H + u0 + ij];
   // (4) operand dh'
   float4 x[4][2];
-  if (job < 2) {                               // jobs 0, 1 fetch two rows each
+  if (job < 2) {                               // jobs 0, 1 fetch two rows each (2, 3: measured no better)
     float4 y[2][2];
     const int ry = r0 + 2 * job;
     if (io.plain_dh) {
@@ -827,6 +849,7 @@ __device__ __forceinline__ void gate_phase(const GateIO &io, __amdgpu_buffer_rsr
   flag_wait(flag, flagv, s_dead);
   flag_wait(flag + 1, flagv, s_dead);
   stash_get(sD, H, n4h, r0, x);
+  G_STAMP(0);
   // (5) gate gradients of this block
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr)
@@ -867,6 +890,7 @@ __device__ __forceinline__ void gate_phase(const GateIO &io, __amdgpu_buffer_rsr
       for (int v = 0; v < 8; ++v) s_red[wv][o2 * 4 + v][lane >> 4] = acc[v];
     }
   }
+  G_STAMP(1);
   // (7) the gate gradients of the workgroup's own units, for the weight-gradient GEMMs
   if (item) {
     const int u = u0 + ij;
@@ -877,7 +901,8 @@ __device__ __forceinline__ void gate_phase(const GateIO &io, __amdgpu_buffer_rsr
     else if (job == 2) gi[2 * H + u] = v;
     else gh[2 * H + u] = v;
   }
-  __syncthreads();
+  lds_barrier();
+  G_STAMP(2);
   // (8) sum of the three blocks; da is published, the h-path stays in the workgroup
   if (eok) {
     const int v8 = ij * 4 + irr;
@@ -893,6 +918,7 @@ __device__ __forceinline__ void gate_phase(const GateIO &io, __amdgpu_buffer_rsr
   }
 }
 
+template <bool PROF>
 __global__ __launch_bounds__(PT, 2) void decoder_bwd_persist_kernel(s2c_dec_bwd_args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ __attribute__((aligned(16))) float s_red[2][PW][32][4];    // [cell][wave][output x row][16-lane row]
@@ -984,6 +1010,7 @@ __global__ __launch_bounds__(PT, 2) void decoder_bwd_persist_kernel(s2c_dec_bwd_
     const int t = T - 1 - st, par = st & 1;
     const u32 tag = base + (u32)st;
     u64 *xb = a.xbuf + (size_t)par * bo.total;
+    P_STAMP(0);
     // ================= B1: cell 2 ==========================================================
     {
       GateIO io;
@@ -1000,9 +1027,12 @@ __global__ __launch_bounds__(PT, 2) void decoder_bwd_persist_kernel(s2c_dec_bwd_
       io.src_off = bo.dh2;
       io.src_tag = tag - 1u;
       io.tag = tag;
-      gate_phase<false>(io, rs[par ^ 1], nowh, sWe2, sWe2 + (size_t)obe * 3 * H, R, H, E, obe, ub, e0, u0, sD, s_red[0],
+      io.prof = (a.prof && w == 0) ? a.prof + ((size_t)wv * T + t) * 16 : nullptr;
+      io.prof_slot = 9;
+      gate_phase<false, PROF>(io, rs[par ^ 1], nowh, sWe2, sWe2 + (size_t)obe * 3 * H, R, H, E, obe, ub, e0, u0, sD, s_red[0],
                        s_dhp[0], &s_flag[0][rq][0], st + 1, &s_dead);
     }
+    P_STAMP(1);
     // ================= B2: attention backward of row4, hidden slice hs0 .. hs0 + 31 ==========
     if (row4 < R) {
       const size_t tr = (size_t)t * R + row4;
@@ -1026,6 +1056,7 @@ __global__ __launch_bounds__(PT, 2) void decoder_bwd_persist_kernel(s2c_dec_bwd_
           }
         } while (stale);
       }
+      P_STAMP(2);
       const float d = tid < E ? __uint_as_float((u32)kd) : 0.0f;
       for (int k0 = 0; k0 <= K; k0 += 4) {       // <da2, P_k> and (k = K) <da2, Latt_t>
         float p[4];
@@ -1042,13 +1073,13 @@ __global__ __launch_bounds__(PT, 2) void decoder_bwd_persist_kernel(s2c_dec_bwd_
             if (k0 + j <= K) s_sc[k0 + j][tid >> 4] = p[j];
         }
       }
-      __syncthreads();
+      lds_barrier();
       for (int i = tid; i < 32 * (K + 1); i += PT) {
         float v = row16_sum(s_sc[i >> 5][i & 31]);
         v += __shfl_xor(v, 16, 64);
         if ((i & 31) == 0) s_dal[i >> 5] = v;
       }
-      __syncthreads();
+      lds_barrier();
       const float c0 = s_dal[K];
 #pragma unroll
       for (int m = 0; m < 2; ++m)
@@ -1061,15 +1092,25 @@ __global__ __launch_bounds__(PT, 2) void decoder_bwd_persist_kernel(s2c_dec_bwd_
           s_dpre[k][hh] = dpre;
           s_dsc[k][hh] = ds * c;
         }
-      __syncthreads();
+      lds_barrier();
       if (tid < 32 && hs0 + tid < H) {
         float dq = 0.0f, dw = 0.0f;
-        for (int k = 0; k < K; ++k) { dq += s_dpre[k][tid]; dw += s_dsc[k][tid]; }
+        for (int k0 = 0; k0 < K; k0 += 4) {        // eight LDS reads in flight
+          float u[4], v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            u[j] = k0 + j < K ? s_dpre[k0 + j][tid] : 0.0f;
+            v[j] = k0 + j < K ? s_dsc[k0 + j][tid] : 0.0f;
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { dq += u[j]; dw += v[j]; }
+        }
         dwa_acc += dw;
         st_tag(xb + bo.dq + (size_t)row4 * H + hs0 + tid, dq, tag);
         a.DQA[tr * HE + hs0 + tid] = dq;
       }
     }
+    P_STAMP(3);
     // ================= B3: dh1' = [W_h^T | W_lang[:, F:]^T] [dq | da2] + dh1c ==================
     {
       float4 xq[4][2], xa[4][2];
@@ -1092,6 +1133,7 @@ __global__ __launch_bounds__(PT, 2) void decoder_bwd_persist_kernel(s2c_dec_bwd_
       flag_wait(&s_flag[2][rq][1], st + 1, &s_dead);
       stash_get(sDQ, H, n4h, r0, xq);
       stash_get(sDA2, E, n4e, r0, xa);
+      P_STAMP(4);
       const float4 *wr = reinterpret_cast<const float4 *>(sW3 + (size_t)min(job, ub - 1) * HE);
       const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
       const float4 wq0 = lane < n4h ? wr[lane] : z4, wq1 = lane + 64 < n4h ? wr[lane + 64] : z4;
@@ -1112,6 +1154,7 @@ __global__ __launch_bounds__(PT, 2) void decoder_bwd_persist_kernel(s2c_dec_bwd_
       if (lane < 4 && job < ub && u < H && row < R)
         st_tag(xb + bo.dh1 + (size_t)row * H + u, red4(s_one[0][wv], lane) + s_dhp[1][row][job], tag);
     }
+    P_STAMP(5);
     // ================= B4: cell 1 ==========================================================
     {
       GateIO io;
@@ -1128,9 +1171,12 @@ __global__ __launch_bounds__(PT, 2) void decoder_bwd_persist_kernel(s2c_dec_bwd_
       io.src_off = bo.dh1;
       io.src_tag = tag;
       io.tag = tag;
-      gate_phase<false>(io, rs[par], nowh, sW4, sW4 + (size_t)obe * 3 * H, R, H, E, obe, ub, e0, u0, sD, s_red[1], s_dhp[1],
+      io.prof = (a.prof && w == 0) ? a.prof + ((size_t)wv * T + t) * 16 : nullptr;
+      io.prof_slot = 12;
+      gate_phase<false, PROF>(io, rs[par], nowh, sW4, sW4 + (size_t)obe * 3 * H, R, H, E, obe, ub, e0, u0, sD, s_red[1], s_dhp[1],
                         &s_flag[3][rq][0], st + 1, &s_dead);
     }
+    P_STAMP(6);
     // ================= B5: dh2'(t-1) = W_td[:, h2 block]^T da1 + dh2_part + dH2[t-1] ==========
     if (t > 0) {
       const int row = r0 + lane, u = u0 + job;
@@ -1146,6 +1192,7 @@ __global__ __launch_bounds__(PT, 2) void decoder_bwd_persist_kernel(s2c_dec_bwd_
       flag_wait(&s_flag[4][rq][0], st + 1, &s_dead);
       flag_wait(&s_flag[4][rq][1], st + 1, &s_dead);
       stash_get(sDA1, E, n4e, r0, x);
+      P_STAMP(7);
       float acc[4];
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) acc[rr] = fdot4(Wtd[1], x[rr][1], fdot4(Wtd[0], x[rr][0], 0.0f));
@@ -1159,6 +1206,7 @@ __global__ __launch_bounds__(PT, 2) void decoder_bwd_persist_kernel(s2c_dec_bwd_
       if (ok)
         st_tag(xb + bo.dh2 + (size_t)row * H + u,
                (red4(s_one[1][wv], lane) + s_dhp[0][row][job]) + dprev, tag);
+      P_STAMP(8);
     }
   }
   // ---- accumulated attention gradients ----------------------------------------------------
@@ -1228,11 +1276,14 @@ static int fwd_persist_grid(int R, int K, int H, int E, int F, int T) {
     const int c = 1 - cc;
     const int grid = c == 0 ? 256 : 128;
     if (forced && forced != grid) continue;
-    const void *fn = c == 0 ? (const void *)decoder_fwd_persist_kernel<256, 256>
-                            : (const void *)decoder_fwd_persist_kernel<128, 512>;
+    const void *fn = c == 0 ? (const void *)decoder_fwd_persist_kernel<256, 256, false>
+                            : (const void *)decoder_fwd_persist_kernel<128, 512, false>;
+    const void *fnp = c == 0 ? (const void *)decoder_fwd_persist_kernel<256, 256, true>
+                             : (const void *)decoder_fwd_persist_kernel<128, 512, true>;
     const size_t lds = persist_lds_bytes(K, H, E, F, grid);
     if (lds > lds_set[c][dev]) {
-      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+          hipFuncSetAttribute(fnp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         (void)hipGetLastError();
         continue;
       }
@@ -1259,11 +1310,17 @@ extern "C" int s2c_decoder_fwd_persist(const s2c_dec_fwd_args *a, void *stream) 
   const int grid = fwd_persist_grid(a->R, a->K, a->H, a->E, a->F, a->T);
   if (!grid) return -2;
   const size_t lds = persist_lds_bytes(a->K, a->H, a->E, a->F, grid);
-  if (grid == 256)
-    hipLaunchKernelGGL((decoder_fwd_persist_kernel<256, 256>), dim3(256), dim3(256), lds,
+  if (grid == 256 && a->prof)
+    hipLaunchKernelGGL((decoder_fwd_persist_kernel<256, 256, true>), dim3(256), dim3(256), lds,
+                       (hipStream_t)stream, *a);
+  else if (grid == 256)
+    hipLaunchKernelGGL((decoder_fwd_persist_kernel<256, 256, false>), dim3(256), dim3(256), lds,
+                       (hipStream_t)stream, *a);
+  else if (a->prof)
+    hipLaunchKernelGGL((decoder_fwd_persist_kernel<128, 512, true>), dim3(128), dim3(512), lds,
                        (hipStream_t)stream, *a);
   else
-    hipLaunchKernelGGL((decoder_fwd_persist_kernel<128, 512>), dim3(128), dim3(512), lds,
+    hipLaunchKernelGGL((decoder_fwd_persist_kernel<128, 512, false>), dim3(128), dim3(512), lds,
                        (hipStream_t)stream, *a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -1297,7 +1354,9 @@ extern "C" int s2c_decoder_bwd_persist_supported(int R, int K, int H, int E, int
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
   if (state[dev] == 0 || lds > lds_set[dev]) {
     state[dev] = -1;
-    if (hipFuncSetAttribute((const void *)decoder_bwd_persist_kernel,
+    if (hipFuncSetAttribute((const void *)decoder_bwd_persist_kernel<false>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)decoder_bwd_persist_kernel<true>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       (void)hipGetLastError();
       return 0;
@@ -1306,7 +1365,7 @@ extern "C" int s2c_decoder_bwd_persist_supported(int R, int K, int H, int E, int
     state[dev] = 1;
   }
   int per_cu = 0, cus = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)decoder_bwd_persist_kernel,
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)decoder_bwd_persist_kernel<false>,
                                                    PT, lds) != hipSuccess ||
       hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
     (void)hipGetLastError();
@@ -1318,7 +1377,10 @@ extern "C" int s2c_decoder_bwd_persist_supported(int R, int K, int H, int E, int
 extern "C" int s2c_decoder_bwd_persist(const s2c_dec_bwd_args *a, void *stream) {
   if (!a || !s2c_decoder_bwd_persist_supported(a->R, a->K, a->H, a->E, a->T)) return -2;
   const size_t lds = persist_bwd_lds_bytes(a->K, a->H, a->E);
-  hipLaunchKernelGGL(decoder_bwd_persist_kernel, dim3(PG), dim3(PT), lds, (hipStream_t)stream, *a);
+  if (a->prof)
+    hipLaunchKernelGGL(decoder_bwd_persist_kernel<true>, dim3(PG), dim3(PT), lds, (hipStream_t)stream, *a);
+  else
+    hipLaunchKernelGGL(decoder_bwd_persist_kernel<false>, dim3(PG), dim3(PT), lds, (hipStream_t)stream, *a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     fprintf(stderr, "s2c_decoder_bwd_persist launch failed: %s\n", hipGetErrorString(e));

@@ -123,8 +123,8 @@ class _DecBwdArgs(ctypes.Structure):
     _fields_ = ([(n, _I) for n in ("R", "K", "H", "E", "T", "pad_")] +
                 [(n, _P) for n in ("dH2", "C", "S", "X1", "X2", "QL", "ALPHA", "M", "wa", "P",
                                    "Latt", "WT_ih2", "WT_hh2", "WT_hl", "WT_ih1", "WT_hh1",
-                                   "WT_td", "DA1", "DQA", "DG", "dM", "dwa_rows", "xbuf", "nonce",
-                                   "started", "fail")])
+                                   "WT_td", "DA1", "DQA", "DG", "dM", "dwa_rows", "xbuf", "prof",
+                                   "nonce", "started", "fail")])
 
 
 _C.register("s2c_decoder_bwd_persist", [_P, _P])
@@ -132,6 +132,7 @@ _C.register("s2c_decoder_bwd_persist", [_P, _P])
 
 _C.register("s2c_decoder_fwd_persist", [_P, _P])
 PERSIST_BACKOFF = int(_os.environ.get("S2C_PERSIST_BACKOFF", "0"))
+PROF_BWD = None
 PROF = None     # tools/bench_decoder_persist.py: an int64 tensor (8 * T * 16) of phase stamps
 _XBUF = {}      # (device index, H, E) -> (exchange buffer, [nonce, started]); zeroed once
 
@@ -368,6 +369,7 @@ class TopDownDecode(Function):
                              ("dM", dM), ("dwa_rows", dwa_rows), ("xbuf", xbuf)):
                     assert v.is_contiguous(), n
                     setattr(a, n, v.data_ptr())
+                a.prof = PROF_BWD.data_ptr() if PROF_BWD is not None else None
                 a.nonce, a.started, a.fail = ctl.data_ptr(), ctl.data_ptr() + 4, ctl.data_ptr() + 8
                 if _C.TIMER.enabled:     # transposed weights once + saved tensors in, gradients out
                     _C.TIMER.alg_bytes = 4 * (E * H + 6 * H * (E + H) + (H + E) * H +

@@ -70,6 +70,31 @@ def main():
             prev = v - t0
     per = (p[0, 2:, 0] - p[0, 1:-1, 0]).mean()
     print("cycles per decoder step: %.0f" % per)
+    # the backward kernel (steps run t = T-1 .. 0; stamps of workgroup 0)
+    decoder_fused.PROF_BWD = torch.zeros(8 * T * 16, dtype=torch.int64, device="cuda")
+    objg = obj.clone().requires_grad_(True)
+    out, _ = decoder_fused.decode(mod, word_embs, tgt, objg, masks, T)
+    out.sum().backward()
+    torch.cuda.synchronize()
+    p = decoder_fused.PROF_BWD.cpu().numpy().reshape(8, T, 16).astype(np.float64)
+    decoder_fused.PROF_BWD = None
+    bn = {0: "step start", 1: "B1 done", 2: "B2 da2 polled", 3: "B2 dq published",
+          4: "B3 operands ready", 5: "B3 dh1 published", 6: "B4 done", 7: "B5 da1 ready",
+          8: "B5 dh2 published", 9: "B1 operand ready", 10: "B1 dots done", 11: "B1 barrier",
+          12: "B4 operand ready", 13: "B4 dots done", 14: "B4 barrier"}
+    for wv in (0, 2, 3, 4, 6):
+        print("backward, wave %d (job %d)" % (wv, wv & 3))
+        sel = slice(1, T - 1)                      # t = T-2 .. 1
+        t0 = p[wv, sel, 0]
+        prev = np.zeros_like(t0)
+        for slot in (0, 9, 10, 11, 1, 2, 3, 4, 5, 12, 13, 14, 6, 7, 8):
+            v = p[wv, sel, slot]
+            if (v == 0).all():
+                continue
+            rel = (v - t0).mean()
+            print("   %-20s +%7.0f cycles  (step %7.0f)" % (bn[slot], rel, rel - prev.mean()))
+            prev = v - t0
+    print("cycles per backward step: %.0f" % (p[0, 1:-2, 0] - p[0, 2:-1, 0]).mean())
 
 
 if __name__ == "__main__":
