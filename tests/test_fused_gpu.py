@@ -3,6 +3,7 @@ PyTorch fp32 reference of the same computation: the op-by-op path of the module
 (QueryAndGroup -> Conv2d/BatchNorm2d/ReLU -> max_pool2d, i.e. exactly the
 reference's formulation), forward and backward, train and eval statistics."""
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -151,6 +152,20 @@ def test_fused_decoder_matches_torch_loop(K):
         return _decoder_vs_torch_loop(K)
     finally:
         decoder_fused.set_persist(True)
+
+
+def test_persistent_decoder_forward_on_the_256_workgroup_grid():
+    """The forward kernel's second grid (256 workgroups x 256 threads, taken when the first one's
+    LDS request does not fit) is chosen once per process: run the benchmark-shape case of the test
+    below in a child process with S2C_DECODER_PERSIST_GRID=256."""
+    import subprocess
+    import sys
+    env = dict(os.environ, S2C_DECODER_PERSIST_GRID="256")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", os.path.abspath(__file__), "-k",
+                        "test_persistent_decoder_forward and 8-10-512-300-128-9"],
+                       env=env, capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("R,K,H,E,F,T", [(8, 10, 512, 300, 128, 9), (5, 7, 256, 128, 64, 6),
