@@ -345,7 +345,10 @@ __global__ __launch_bounds__(PTc, 2) void decoder_fwd_persist_kernel(s2c_dec_fwd
   __shared__ int s_flag[3][2];             // [h2 of P1 | h1 of P3 | x1 published][row quad]
   const int R = a.R, K = a.K, H = a.H, E = a.E, F = a.F, T = a.T;
   const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int part = wv & 1, rq = (wv >> 1) & 1, r0 = 4 * rq, up = wv >> 2;
+  // waves wv and wv + 4 share a SIMD: give them DIFFERENT parts -- the h-part of a GRU cell is
+  // formed while the x-part polls, and P1 / P3 are h-part work only, so the two never compete for
+  // issue slots outside the attention stage
+  const int part = wv / (PW / 2), rq = wv & 1, r0 = 4 * rq, up = (wv >> 1) & (UPS - 1);
   const int n4h = H >> 2, n4e = E >> 2;
   const int ub = (H + PG - 1) / PG, ob1 = (E + PG - 1) / PG, ob3 = (H + E + PG - 1) / PG;
   const int u0 = w * ub;                       // first hidden unit of the workgroup
@@ -521,7 +524,7 @@ __global__ __launch_bounds__(PTc, 2) void decoder_fwd_persist_kernel(s2c_dec_fwd
         const size_t TRH = (size_t)T * RH;
         GruOut o = {a.H1 + (size_t)(t + 1) * RH, S, S + TRH, S + 2 * TRH, S + 3 * TRH,
                     {C, C + TRH, C + 2 * TRH, C + 3 * TRH}};
-        gru_epilogue(s_red[0][wv], s_red[0][wv + 1], H, R, r0, u0, P_UB * up, ub, s_bias[0], hp1,
+        gru_epilogue(s_red[0][wv], s_red[0][wv + PW / 2], H, R, r0, u0, P_UB * up, ub, s_bias[0], hp1,
                      o, xb + xo.h1, tag);
       }
       P_STAMP(6);
@@ -702,7 +705,7 @@ __global__ __launch_bounds__(PTc, 2) void decoder_fwd_persist_kernel(s2c_dec_fwd
         float *S = a.S + 4 * TRH + (size_t)t * RH, *C = a.C ? a.C + 4 * TRH + (size_t)t * RH : nullptr;
         GruOut o = {a.H2 + (size_t)(t + 1) * RH, S, S + TRH, S + 2 * TRH, S + 3 * TRH,
                     {C, C + TRH, C + 2 * TRH, C + 3 * TRH}};
-        gru_epilogue(s_red[1][wv], s_red[1][wv + 1], H, R, r0, u0, P_UB * up, ub, s_bias[1], hp2,
+        gru_epilogue(s_red[1][wv], s_red[1][wv + PW / 2], H, R, r0, u0, P_UB * up, ub, s_bias[1], hp2,
                      o, xb + xo.h2, tag);
       }
       P_STAMP(12);

@@ -57,7 +57,7 @@ def main():
              8: "P3 q published", 9: "P4 q polled", 10: "P4 x2 published", 11: "P5 operand ready",
              12: "P5 h2 published", 13: "P4 scores done", 14: "P4 scores summed",
              15: "P4 att done"}
-    for wv, label in ((0, "wave 0 (h part, polls)"), (1, "wave 1 (x part)"), (4, "wave 4 (h part, LDS)"), (5, "wave 5 (x part)")):
+    for wv, label in ((0, "wave 0 (h part, polls)"), (4, "wave 4 (x part)"), (2, "wave 2 (h part, LDS)"), (6, "wave 6 (x part)")):
         print(label)
         t0 = p[wv, 1:, 0]
         prev = np.zeros_like(t0)
