@@ -29,7 +29,7 @@ def main():
     torch.cuda.synchronize()
     iters = 2000
     for G in (256, 128, 64, 32):
-        for mode, name in ((0, "counter"), (1, "flags"), (2, "tagged data"), (3, "tagged x8")):
+        for mode, name in ((0, "counter"), (1, "flags"), (2, "tagged data"), (3, "tagged x8"), (4, "x8 sys store")):
             for group in ((1,) if mode == 0 else (1, 8)):
                 for V in ((0,) if mode < 2 else (512, 4096)):
                     if mode >= 2 and V // (G // group) > 256:

@@ -36,7 +36,7 @@ extern "C" __global__ __launch_bounds__(256) void sync_probe_kernel(
         while (__hip_atomic_load(flags + src * 16, __ATOMIC_ACQUIRE, AG) < epoch) {}
       }
       __syncthreads();
-    } else if (mode == 3) {
+    } else if (mode == 3 || mode == 4) {
       // as mode 2, but every lane keeps ALL its polled 16-byte loads (two tagged values each) in
       // flight and re-polls only while some tag is stale: the decoder's 8 x 512 input vector
       const int ng = G / group, me = w / group, set = w % group;
@@ -46,7 +46,10 @@ extern "C" __global__ __launch_bounds__(256) void sync_probe_kernel(
         const float val = carry * 0.5f + (float)(me * per + tid) * 1e-6f;
         const unsigned long long pk =
             ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(val);
-        __hip_atomic_store(buf + me * per + tid, pk, __ATOMIC_RELAXED, AG);
+        if (mode == 4)   // system-scope store (sc0 sc1) instead of agent scope (sc1)
+          __hip_atomic_store(buf + me * per + tid, pk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        else
+          __hip_atomic_store(buf + me * per + tid, pk, __ATOMIC_RELAXED, AG);
       }
       constexpr int U = 8;     // 8 x 16 bytes x 256 lanes = 4096 tagged values
       uint4 v[U];
