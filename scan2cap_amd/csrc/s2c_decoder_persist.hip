@@ -778,6 +778,14 @@ __device__ __forceinline__ void stash_get(const float *sX, int I, int n4, int r0
                      : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// Wave -> (row quad, job).  Waves wv and wv + 4 share a SIMD; in the gate phases jobs 0, 1 (gate
+// blocks r, z: all seven outputs) carry twice the dot products of jobs 2, 3 (block n: the e- or the
+// h-outputs only), so every SIMD gets one of each.
+__device__ __forceinline__ int bwd_job(int wv) { return (wv >> 2) == 0 ? (wv & 1) : 2 + (wv & 1); }
+__device__ __forceinline__ int bwd_rq(int wv) {
+  return (wv >> 2) == 0 ? ((wv >> 1) & 1) : 1 - ((wv >> 1) & 1);
+}
+
 struct GateIO {
   const float *C[4];          // coefficient arrays of the cell at step t (R x H each)
   const float *Z;             // update gate z of the cell at step t (R x H)
@@ -810,7 +818,8 @@ __device__ __forceinline__ void gate_phase(const GateIO &io, __amdgpu_buffer_rsr
                                            int R, int H, int E, int obe, int ub, int e0, int u0,
                                            float *sD, float (*s_red)[32][4], float (*s_dhp)[4],
                                            volatile int *flag, int flagv, volatile int *s_dead) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, job = wv & 3, r0 = 4 * (wv >> 2);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, job = bwd_job(wv), r0 = 4 * bwd_rq(wv);
+  const int sl = 4 * bwd_rq(wv);             // s_red rows of this row quad, indexed by job
   const int n4h = H >> 2;
   const float *Cg = io.C[job];
   // (1) this wave's coefficient slice, (2) the item lanes' coefficients, (3) epilogue operands
@@ -890,7 +899,7 @@ __device__ __forceinline__ void gate_phase(const GateIO &io, __amdgpu_buffer_rsr
     for (int v = 0; v < 8; ++v) acc[v] = row16_sum(acc[v]);
     if ((lane & 15) == 0) {
 #pragma unroll
-      for (int v = 0; v < 8; ++v) s_red[wv][o2 * 4 + v][lane >> 4] = acc[v];
+      for (int v = 0; v < 8; ++v) s_red[sl + job][o2 * 4 + v][lane >> 4] = acc[v];
     }
   }
   G_STAMP(1);
@@ -909,14 +918,14 @@ __device__ __forceinline__ void gate_phase(const GateIO &io, __amdgpu_buffer_rsr
   // (8) sum of the three blocks; da is published, the h-path stays in the workgroup
   if (eok) {
     const int v8 = ij * 4 + irr;
-    float v = (red4(s_red[wv], v8) + red4(s_red[wv + 1], v8)) + red4(s_red[wv + 2], v8);
+    float v = (red4(s_red[sl], v8) + red4(s_red[sl + 1], v8)) + red4(s_red[sl + 2], v8);
     v = e_op > 0.0f ? v : 0.0f;
     st_tag(io.xb_da + (size_t)irow * E + e0 + ij, v, io.tag);
     io.da[(size_t)irow * io.ld_da + e0 + ij] = v;
   }
   if (hok) {
     const int v8 = (B_OBE + ij) * 4 + irr;
-    const float v = (red4(s_red[wv], v8) + red4(s_red[wv + 1], v8)) + red4(s_red[wv + 3], v8);
+    const float v = (red4(s_red[sl], v8) + red4(s_red[sl + 1], v8)) + red4(s_red[sl + 3], v8);
     s_dhp[irow][ij] = v + sD[(size_t)irow * H + u0 + ij] * e_op;
   }
 }
@@ -934,7 +943,7 @@ __global__ __launch_bounds__(PT, 2) void decoder_bwd_persist_kernel(s2c_dec_bwd_
   __shared__ int s_dead;
   const int R = a.R, K = a.K, H = a.H, E = a.E, T = a.T;
   const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int job = wv & 3, rq = wv >> 2, r0 = 4 * rq;
+  const int job = bwd_job(wv), rq = bwd_rq(wv), r0 = 4 * rq;
   const int n4h = H >> 2, n4e = E >> 2, HE = H + E;
   const int obe = (E + PG - 1) / PG, ub = (H + PG - 1) / PG;
   const int e0 = w * obe, u0 = w * ub;
