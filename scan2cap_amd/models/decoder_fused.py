@@ -166,10 +166,10 @@ def set_persist(on):
 
 
 def _persist_scratch(dev, H, E, bwd=False):
-    # one exchange buffer + nonce per (device, stream, kernel): launches on ONE stream are ordered;
-    # two streams must not share tags (and should not run two persistent kernels at once: each
-    # wants 128 CUs to itself)
-    key = (dev.index, H, E, bwd, torch.cuda.current_stream(dev).cuda_stream)
+    # one exchange buffer + nonce per (device, kernel), allocated ONCE (inside a graph capture the
+    # zero-fill would be replayed with every step).  Decoders of one device must therefore run on
+    # one stream at a time -- two persistent kernels at once would also fight for the same CUs.
+    key = (dev.index, H, E, bwd)
     if key not in _XBUF:
         pairs = int(_plib().s2c_decoder_bwd_persist_xbuf_pairs(H, E) if bwd else
                     _plib().s2c_decoder_fwd_persist_xbuf_pairs(H, E))
