@@ -135,13 +135,15 @@ __device__ __forceinline__ void poll_rows(__amdgpu_buffer_rsrc_t rs, int base_pa
         }
       }
     }
-    stale = false;
+    // a slot's tags only ever grow, so a stale tag is SMALLER than `tag` and cannot contain all of
+    // its bits: the AND of all tags equals `tag` iff every one of them does (one compare per pass)
+    u32 m = tag;
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr)
 #pragma unroll
       for (int s = 0; s < 2; ++s)
-        stale |= (raw[rr][s][0].y != tag) | (raw[rr][s][0].w != tag) | (raw[rr][s][1].y != tag) |
-                 (raw[rr][s][1].w != tag);
+        m &= (raw[rr][s][0].y & raw[rr][s][0].w) & (raw[rr][s][1].y & raw[rr][s][1].w);
+    stale = m != tag;
     if (stale && (++spins > P_SPIN_MAX || *s_dead)) {
       *s_dead = 1;
       break;
