@@ -187,7 +187,6 @@ __device__ __forceinline__ void flag_raise(volatile int *f, int v) {
 __device__ __forceinline__ void flag_wait(volatile int *f, int v, volatile int *s_dead) {
   int spins = 0;
   while (*f < v) {
-    __builtin_amdgcn_s_sleep(1);
     if (++spins > P_SPIN_MAX || *s_dead) {
       *s_dead = 1;
       break;
