@@ -172,16 +172,19 @@ __device__ __forceinline__ void poll_rows(__amdgpu_buffer_rsrc_t rs, int base_pa
     }                                                                                  \
   } while (0)
 
-// Workgroup barrier of the step loops.  Measured: an LDS-only variant (s_waitcnt lgkmcnt(0) + s_barrier,
-// i.e. without __syncthreads()'s wait for the wave's outstanding global stores) is not faster (fwd
-// 637 -> 650 us, bwd 662 -> 681 us): what a wave waits for at these barriers is the other row quad,
-// which runs ~1800 cycles behind through every exchange, not its own stores.
+// Workgroup barrier of the step loops.  Measured twice: an LDS-only variant (s_waitcnt lgkmcnt(0) +
+// s_barrier, i.e. without __syncthreads()'s wait for the wave's outstanding global stores) is SLOWER
+// (fwd 565 -> 588 us, bwd 642 -> 649 us), although the same relaxation of the LDS flags below gained
+// (fwd 580 -> 565 us): what a wave waits for at these barriers is the other row quad, which runs
+// ~1800 cycles behind through every exchange, not its own stores.
 __device__ __forceinline__ void lds_barrier() { __syncthreads(); }
 
 // workgroup-local step flags: the polling wave of a row quad raises flag = step + 1 once the
 // operand is in the LDS stash; the other waves of the quad wait on LDS instead of polling memory
+// (LDS is one in-order memory: the stash writes of this wave precede its flag write; a
+// workgroup-scope release fence would also wait for the wave's outstanding GLOBAL stores)
 __device__ __forceinline__ void flag_raise(volatile int *f, int v) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   if ((threadIdx.x & 63) == 0) *f = v;
 }
 __device__ __forceinline__ void flag_wait(volatile int *f, int v, volatile int *s_dead) {
@@ -192,7 +195,7 @@ __device__ __forceinline__ void flag_wait(volatile int *f, int v, volatile int *
       break;
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  asm volatile("" ::: "memory");
 }
 
 struct GruW {
