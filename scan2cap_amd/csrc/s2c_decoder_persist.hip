@@ -187,9 +187,13 @@ __device__ __forceinline__ void flag_raise(volatile int *f, int v) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   if ((threadIdx.x & 63) == 0) *f = v;
 }
+// NAP: sleep between looks -- for the long wait of the x-part waves (thousands of cycles, next to
+// h-part waves that are computing on the same SIMDs); the operand flags are waited for hot
+template <bool NAP = false>
 __device__ __forceinline__ void flag_wait(volatile int *f, int v, volatile int *s_dead) {
   int spins = 0;
   while (*f < v) {
+    if (NAP) __builtin_amdgcn_s_sleep(2);
     if (++spins > P_SPIN_MAX || *s_dead) {
       *s_dead = 1;
       break;
@@ -515,7 +519,7 @@ __global__ __launch_bounds__(PTc, 2) void decoder_fwd_persist_kernel(s2c_dec_fwd
       } else {
         // x1 cannot exist before this workgroup's own share has been published (all workgroups
         // run in step): do not load the fabric with polls until then
-        flag_wait(&s_flag[2][rq], t + 1, &s_dead);
+        flag_wait<true>(&s_flag[2][rq], t + 1, &s_dead);
         poll_rows<4>(rs[par], xo.x1, E, n4e, r0, R, tag, x, &s_dead, a.backoff);
       }
       P_STAMP(3);
