@@ -170,7 +170,8 @@ def test_persistent_decoder_forward_on_the_256_workgroup_grid():
 
 @pytest.mark.parametrize("R,K,H,E,F,T", [(8, 10, 512, 300, 128, 9), (5, 7, 256, 128, 64, 6),
                                          (3, 4, 128, 64, 32, 5), (8, 16, 384, 256, 128, 3),
-                                         (1, 1, 512, 300, 128, 31)])
+                                         (1, 1, 512, 300, 128, 31), (2, 32, 128, 512, 256, 2),
+                                         (8, 5, 260, 36, 64, 4), (1, 2, 64, 32, 32, 62)])
 def test_persistent_decoder_forward(R, K, H, E, F, T):
     """The forward recurrence as ONE persistent kernel (s2c_decoder_fwd_persist: 128 workgroups
     exchanging tagged values) against the launch chain it replaces and the module's own step
@@ -186,7 +187,7 @@ def test_persistent_decoder_forward(R, K, H, E, F, T):
              "idx2word": {str(i): w for i, w in enumerate(words)}}
     emb = {w: np.random.randn(E).astype(np.float32) for w in words}
     mod = TopDownSceneCaptionModule(vocab, emb, E, F, H, K, num_locals=K).cuda()
-    word_embs = torch.randn(R, 32, E, device="cuda") * 0.3
+    word_embs = torch.randn(R, max(32, T), E, device="cuda") * 0.3
     obj = (torch.randn(R, K, F, device="cuda") * 0.5).requires_grad_(True)
     tgt = (torch.randn(R, F, device="cuda") * 0.5).requires_grad_(True)
     masks = (torch.rand(R, K, device="cuda") > 0.5).float()
