@@ -383,7 +383,8 @@ typedef struct s2c_dec_fwd_args {
   float *ALPHA, *ATT;             /* (T, R, K), (T, R, F) */
   unsigned long long *xbuf;
   unsigned long long *prof;       /* NULL, or 8 x T x 16 words: phase stamps of workgroup 0 */
-  unsigned int *nonce, *started, *fail;   /* fail: raised (1) when a poll gave up -- results invalid */
+  unsigned int *nonce, *started, *fail;   /* fail: raised (1) when a poll gave up -- results invalid (and
+                                             H2[T, 0, 0] is set to NaN so that the loss shows it) */
 } s2c_dec_fwd_args;
 int s2c_decoder_fwd_persist(const s2c_dec_fwd_args *a, void *stream);
 int s2c_decoder_fwd_persist_supported(int R, int K, int H, int E, int F, int T);

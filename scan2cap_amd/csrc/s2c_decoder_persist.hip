@@ -720,7 +720,10 @@ __global__ __launch_bounds__(PTc, 2) void decoder_fwd_persist_kernel(s2c_dec_fwd
     }
   }
   __syncthreads();
-  if (tid == 0 && s_dead) __hip_atomic_store(a.fail, 1u, __ATOMIC_RELAXED, S2C_AG);
+  if (tid == 0 && s_dead) {                    // loud without a host check: the last hidden state
+    __hip_atomic_store(a.fail, 1u, __ATOMIC_RELAXED, S2C_AG);      // turns NaN, and with it the loss
+    a.H2[(size_t)T * R * H] = __builtin_nanf("");
+  }
   // ---- advance the nonce once every workgroup has read it -----------------------------------
   if (w == 0 && tid == 0) {
     int spins = 0;
@@ -1238,7 +1241,10 @@ __global__ __launch_bounds__(PT, 2) void decoder_bwd_persist_kernel(s2c_dec_bwd_
     }
   if (row4 < R && tid < 32 && hs0 + tid < H) a.dwa_rows[(size_t)row4 * H + hs0 + tid] = dwa_acc;
   __syncthreads();
-  if (tid == 0 && s_dead) __hip_atomic_store(a.fail, 1u, __ATOMIC_RELAXED, S2C_AG);
+  if (tid == 0 && s_dead) {                    // loud without a host check: a NaN gradient
+    __hip_atomic_store(a.fail, 1u, __ATOMIC_RELAXED, S2C_AG);
+    a.dwa_rows[0] = __builtin_nanf("");
+  }
   if (w == 0 && tid == 0) {
     int spins = 0;
     while (__hip_atomic_load(a.started, __ATOMIC_RELAXED, S2C_AG) < (u32)PG && ++spins < P_SPIN_MAX) {}
