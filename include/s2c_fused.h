@@ -390,6 +390,7 @@ int s2c_decoder_fwd_persist(const s2c_dec_fwd_args *a, void *stream);
 int s2c_decoder_fwd_persist_supported(int R, int K, int H, int E, int F, int T);
 long long s2c_decoder_fwd_persist_xbuf_pairs(int H, int E);
 void s2c_decoder_persist_set(int on);   /* 0: always refuse (the launch chain runs) */
+long long s2c_decoder_persist_args_sizeof(int which);   /* 0: s2c_dec_fwd_args, 1: s2c_dec_bwd_args */
 
 /* ... and its back-propagation through time (the 5-launches-per-step chain of decoder_fused.py's
  * backward) as one persistent kernel.  Needs the coefficient arrays C1 / C2 written by

@@ -1272,6 +1272,11 @@ int g_persist = -1;
 
 extern "C" void s2c_decoder_persist_set(int on) { g_persist = on; }
 
+// sizeof the argument structs (0: forward, 1: backward) -- for bindings to check their layout
+extern "C" long long s2c_decoder_persist_args_sizeof(int which) {
+  return which == 0 ? (long long)sizeof(s2c_dec_fwd_args) : (long long)sizeof(s2c_dec_bwd_args);
+}
+
 extern "C" long long s2c_decoder_fwd_persist_xbuf_pairs(int H, int E) {
   return 2LL * xoff(H, E).total;
 }

@@ -285,6 +285,38 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert lib.s2c_abi_version() == 1
 
 
+def test_persistent_decoder_argument_structs_match_the_header():
+    """The ctypes mirrors of s2c_dec_fwd_args / s2c_dec_bwd_args (models/decoder_fused.py) have the
+    size the C side compiled -- a silent layout drift would hand the kernels shifted pointers --
+    and the persistent kernels refuse shapes outside their limits without a GPU."""
+    import ctypes
+    from scan2cap_amd import _C
+    from scan2cap_amd.models import decoder_fused
+    lib = _C.load()
+    lib.s2c_decoder_persist_args_sizeof.argtypes = [ctypes.c_int]
+    lib.s2c_decoder_persist_args_sizeof.restype = ctypes.c_longlong
+    assert lib.s2c_decoder_persist_args_sizeof(0) == ctypes.sizeof(decoder_fused._DecFwdArgs)
+    assert lib.s2c_decoder_persist_args_sizeof(1) == ctypes.sizeof(decoder_fused._DecBwdArgs)
+    # field order = header order (names of the struct members, comments stripped)
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "s2c_fused.h")).read(), flags=re.S)
+    for cname, mirror in (("s2c_dec_fwd_args", decoder_fused._DecFwdArgs),
+                          ("s2c_dec_bwd_args", decoder_fused._DecBwdArgs)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), txt, flags=re.S).group(1)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            decl = re.sub(r"^(const\s+)?(unsigned\s+)?(long\s+long|float|int)\b", "", decl)
+            names += [re.sub(r"[\s\*]|\[\d+\]", "", n) for n in decl.split(",")]
+        assert names == [f[0] for f in mirror._fields_], cname
+    ok = decoder_fused._plib().s2c_decoder_fwd_persist_supported
+    assert ok(9, 10, 512, 300, 128, 30) == 0      # more than 8 rows
+    assert ok(8, 33, 512, 300, 128, 30) == 0      # more than 32 keys
+    assert ok(8, 10, 516, 300, 128, 30) == 0      # hidden size > 512
+    assert ok(8, 10, 512, 300, 128, 63) == 0      # more than 62 steps
+
+
 def test_streaming_gemm_dispatch_table():
     """Which layer shapes the streaming kernel of csrc/s2c_gemm2.hip takes is host logic (LDS
     budget: W planes + one LDS-DMA ring per wave): pinned here without a GPU."""
