@@ -304,7 +304,6 @@ def test_fps_cells_degenerate_geometry(ext, oracle):
     the cloud extends along (it used to collapse to ONE cell = one wave sweeping all points
     every round).  Exact picks; and the planar case must not be an order of magnitude slower
     than a volume of the same size."""
-    import time
     rng = np.random.default_rng(4)
     N, m = 12000, 400
     plane = rng.uniform(-3, 3, (1, N, 3)).astype(np.float32)
@@ -319,14 +318,21 @@ def test_fps_cells_degenerate_geometry(ext, oracle):
         got = ext.furthest_point_sampling(x, m)
         np.testing.assert_array_equal(got.cpu().numpy(), oracle.furthest_point_sampling(xyz, m),
                                       err_msg=name)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(3):
+        # device time of one call, best of five (a host hiccup inside a wall-clock window made the
+        # ratio below flaky once in ~10 runs of the suite)
+        best = float("inf")
+        for _ in range(5):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            a.record()
             ext.furthest_point_sampling(x, m)
-        torch.cuda.synchronize()
-        times[name] = (time.perf_counter() - t0) / 3
-    assert times["plane"] < 4 * times["volume"], times
-    assert times["line"] < 4 * times["volume"], times
+            b.record()
+            torch.cuda.synchronize()
+            best = min(best, a.elapsed_time(b))
+        times[name] = best
+    # the collapse this guards against was 50-100x
+    assert times["plane"] < 6 * times["volume"], times
+    assert times["line"] < 6 * times["volume"], times
 
 
 def test_ball_query_no_hit_rows_are_zero(ext, oracle):
