@@ -43,7 +43,8 @@ from scan2cap_amd.loss_helper import get_scene_cap_loss  # noqa: E402
 from scan2cap_amd.models import CapNet  # noqa: E402
 from scan2cap_amd.parallel import (BucketedGradAllReduce, FlatGradAllReduce,  # noqa: E402
                                    TwoStageBackward, init_from_env, split_detector_captioner)
-from scan2cap_amd.synthetic import scene_labels, scene_xyz  # noqa: E402
+from scan2cap_amd.synthetic import (aim_reference_boxes_at_proposals, scene_labels,  # noqa: E402
+                                    scene_xyz)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3  # dense f32-input MFMA peak
@@ -233,7 +234,7 @@ def make_feeder(wl, dd, depth, msa, device, num_scenes, rank, stream=None):
     the item picker (round-robin over scenes; the language entries of `dd` are reused so
     that the decoder length of every step equals the resident run's)."""
     from scan2cap_amd import scene_builder as sb
-    from tests.scene_common import make_scene
+    from scan2cap_amd.synthetic import make_scene
     B, N, C = wl["B"], wl["N"], wl["C"]
     mvw = 128 if C >= 132 else 0
     scenes = [make_scene(900 + 31 * rank + i, 140000 + 1777 * i, mvw, num_instances=48)
@@ -274,9 +275,20 @@ def to_device(batch, device):
     return dd
 
 
+# what the last executed train step saw of the caption branch: tensors (static outputs of a
+# captured graph, rewritten by every replay), read once after the timed region
+CAPTION_PROBE = {}
+
+
+def probe_caption(d, slot=0):
+    if "cap_loss" in d and "good_bbox_masks" in d:
+        CAPTION_PROBE[slot] = (d["cap_loss"].detach(), d["good_bbox_masks"])
+
+
 def make_step(model, wl, cfg_loss, optimizer, ddp, device, two_stage=None):
     """Eager step (also the un-captured body of the graphed step)."""
     def train_step(dd):
+        slot = dd.get("_slot", 0)
         dd = dict(dd)
         # fresh gradient tensors every step: no zero-fill and no accumulate
         # kernels (2 launches per parameter with preallocated .grad)
@@ -287,6 +299,7 @@ def make_step(model, wl, cfg_loss, optimizer, ddp, device, two_stage=None):
         dd = model(dd, use_tf=True, is_eval=False)
         dd = get_scene_cap_loss(dd, device, cfg_loss, None, detection=True,
                                 caption=True, orientation=False, distance=False)
+        probe_caption(dd, slot)
         dd["loss"].backward()
         if two_stage is not None:
             ddp.pack_grads(0)
@@ -574,6 +587,9 @@ def main():
                          "the device from HBM-resident synthetic scenes "
                          "(scan2cap_amd/scene_builder.py, SURVEY 8 f3), one batch ahead")
     ap.add_argument("--feed-scenes", type=int, default=12)
+    ap.add_argument("--batch", type=int, default=0,
+                    help="scenes per GPU instead of the workload's (README.md:145 trains at 12, "
+                         "slurm/train.job:24 at 16); the headline stays the workload's own B")
     ap.add_argument("--no-fed", action="store_true",
                     help="skip the second measurement (builder-fed step) of the default run")
     args = ap.parse_args()
@@ -590,13 +606,14 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     _C.load()
-    from scan2cap_amd.models import decoder_fused
-    if world > torch.cuda.device_count():
-        # ranks share a device (gloo rehearsal): two persistent decoder kernels of different
-        # processes could each hold part of the CUs and wait for the rest -- the launch chain
-        decoder_fused.set_persist(False)
+    from scan2cap_amd.models import decoder_fused   # (ranks sharing a device: init_from_env has
+    #                                                  switched the persistent decoder kernels off)
 
-    wl = WORKLOADS[args.workload]
+    wl = dict(WORKLOADS[args.workload])
+    if args.batch > 0 and args.batch != wl["B"]:
+        wl["desc"] = wl["desc"].replace("B=%d" % wl["B"], "B=%d" % args.batch) + \
+            " [--batch %d: not the BASELINE batch]" % args.batch
+        wl["B"] = args.batch
     B = wl["B"]
     vocabulary, embeddings, table = make_vocab(wl["V"])
     msa = np.random.Generator(np.random.PCG64(5)).uniform(0.3, 1.5, size=(18, 3))
@@ -634,6 +651,11 @@ def main():
         ddp.world = 2          # make reduce() issue the collective
     eager_step = make_step(model, wl, cfg_loss, optimizer, ddp, device, two_stage)
     dd = to_device(make_batch(wl, B, 42 + rank, table, msa), device)
+    if wl["train"]:
+        # a step that learns to caption: at random init no proposal reaches IoU 0.25 with the
+        # synthetic described box (good_bbox_masks all False, caption loss and every captioner /
+        # graph gradient exactly 0); describe the box the model predicts for proposal 0 instead
+        dd = aim_reference_boxes_at_proposals(model, dd)
 
     def barrier():
         if world > 1:
@@ -646,6 +668,15 @@ def main():
         if dbg:
             torch.cuda.synchronize()
             print("[bench] ok:", msg, file=sys.stderr, flush=True)
+
+    def read_caption_probe():
+        """cap_loss / number of scenes whose target box passes the IoU threshold, of the most
+        recently executed step of every slot (host read: only outside the timed region)."""
+        if not CAPTION_PROBE:
+            return None
+        torch.cuda.synchronize()
+        vals = [(float(c.item()), int(g.sum().item())) for c, g in CAPTION_PROBE.values()]
+        return {"cap_loss": max(v[0] for v in vals), "good_bbox_masks_sum": max(v[1] for v in vals)}
 
     def measure(feed, steps, warmup):
         """Set up the pipeline for `feed` ("resident": one batch in HBM replayed; "builder":
@@ -695,6 +726,7 @@ def main():
 
             def with_geometry(p):
                 d = dict(dd_sets[p])
+                d["_slot"] = p
                 if slots is not None:
                     d["_geometry"] = slots.geometry(p)
                 return d
@@ -711,6 +743,7 @@ def main():
                         ddp.drop_grads()
                         d = model(d, use_tf=True, is_eval=False)
                         d = get_scene_cap_loss(d, device, cfg_loss, None)
+                        probe_caption(d, p)
                         two_stage.stage1(d)       # captioner + graph gradients, d loss / d X
                         ddp.pack_grads(0)
                         return d["loss"]
@@ -737,6 +770,7 @@ def main():
                         ddp.drop_grads()
                         d = model(d, use_tf=True, is_eval=False)
                         d = get_scene_cap_loss(d, device, cfg_loss, None)
+                        probe_caption(d, p)
                         d["loss"].backward()
                         ddp.pack_grads()      # one multi-tensor copy into the flat bucket
                         return d["loss"]
@@ -823,6 +857,7 @@ def main():
             step(dd)
             trace("warmup step")
         barrier()
+        caption_first = read_caption_probe()
         if not use_graph:
             _C.TIMER.start()
         t0 = time.perf_counter()
@@ -847,6 +882,7 @@ def main():
             print("[bench] host ms per step:", {k: round(v / host_ms["n"], 3) for k, v in
                                                 host_ms.items() if k != "n"}, file=sys.stderr)
         return {"elapsed": elapsed, "overlap": overlap, "depth": depth,
+                "caption_first": caption_first, "caption_last": read_caption_probe(),
                 "group": slots.group if slots is not None else 1,
                 "fed": feeder is not None, "windows_ms": windows,
                 "pairs": pairs if use_graph else [], "g2": g2 if use_graph else None,
@@ -956,6 +992,13 @@ def main():
                                            % (ddp.flats[0].numel() * 4, ddp.flats[1].numel() * 4))
                                           if two_stage is not None else "1 flat bucket after "
                                           "backward") if ddp else "none"},
+            "caption_branch": {"after_warmup": head["caption_first"],
+                               "after_last_step": head["caption_last"],
+                               "note": "ref_box_corner_label = the box the model predicts for "
+                                       "proposal 0 at step 0 (synthetic.aim_reference_boxes_at_"
+                                       "proposals): cap_loss > 0 and good_bbox_masks.sum() > 0 mean "
+                                       "the captioner / relation-graph gradients of the timed steps "
+                                       "are live"} if wl["train"] else None,
             "roofline": roof,
             "roofline_main_stream": roof_main,
             "roofline_named": named_roofline(table_k),

@@ -452,6 +452,12 @@ int s2c_split_bf16x3(long long M, int K, const float *A, long long lda, void *ou
 int s2c_attn_local_fwd(int R, int L, int H, int F, const float *mapped, const float *q,
                        int ldq, const float *wa, float ba, const float *valid,
                        const float *feats, float *alpha, float *att, int lda, void *stream);
+/* the same, additionally (att may be NULL) writing att as bf16x3 planes (3 x R x ldp, plane stride
+ * pstride elements): the operand format of s2c_planes_gemm below */
+int s2c_attn_local_fwd_planes(int R, int L, int H, int F, const float *mapped, const float *q,
+                              int ldq, const float *wa, float ba, const float *valid,
+                              const float *feats, float *alpha, float *att, int lda,
+                              unsigned short *planes, long long pstride, int ldp, void *stream);
 
 /* ---------------------------------------------------------------------------
  * Detection loss of get_scene_cap_loss (lib/loss_helper.py:24-187, :381-491;
@@ -662,6 +668,55 @@ typedef struct s2c_rowsum_args {
   float *out[16];
 } s2c_rowsum_args;
 int s2c_multi_rowsum(const s2c_rowsum_args *a, void *stream);
+
+
+/* ---- fp32-accurate GEMMs on PRE-SPLIT bf16x3 planes (csrc/s2c_planes.hip) -------------------
+ * The greedy caption decoder (models/caption_module.py:502-592: R = B*K rows x 29 tokens; the
+ * products of `_step` :250-292, both GRU cells and the classifier :553) as hand-written MFMA
+ * kernels.  A matrix X (rows x K) is held as three bf16 planes hi / mid / lo (x = hi + mid + lo),
+ * row-major with row stride ld (a multiple of 32 >= K, zero beyond K), plane j at p + j * pstride;
+ * Y = A W^T is formed from the six plane products with i + j <= 2 in an fp32 accumulator
+ * (the arithmetic of the rows GEMMs in s2c_gemm.hip).  A = up to two K segments side by side
+ * ([x | h]: nothing is concatenated); segment 0 may be gathered by a row map. */
+typedef struct s2c_planes_seg {
+  const unsigned short *p;      /* plane 0 */
+  long long pstride;            /* elements from one plane to the next */
+  int ld;                       /* row stride in elements, a multiple of 8 */
+  int kc;                       /* number of 32-column chunks of this segment */
+  const int *rowmap;            /* NULL, or: output row r reads source row rowmap[r] */
+  int rowdiv, pad_;             /* > 0 (and rowmap NULL): output row r reads source row r / rowdiv */
+} s2c_planes_seg;
+
+typedef struct s2c_planes_gemm_args {
+  int M, N;                     /* output rows; output columns (gru: hidden units, a multiple of 32) */
+  int gru, relu, nseg, pad0_;
+  s2c_planes_seg seg[2];
+  /* greedy feedback: NULL, or (M x ntokkeys) arg-max keys as the `amax` output below leaves them;
+   * segment 0 then reads source row = the column of the row's largest key (first maximum) */
+  const unsigned long long *tokkeys;
+  int ntokkeys, ldw;
+  /* W planes: ceil(N / 128) * 128 rows (gru: 4 N rows) x ldw, ldw = 32 * (seg[0].kc + seg[1].kc);
+   * gru: rows 128 c .. 128 c + 127 = [r | z | n_i | n_h] of units 32 c .. 32 c + 31, the n_i rows
+   * zero in segment 1's columns and the n_h rows zero in segment 0's (those products are skipped) */
+  const unsigned short *W;
+  long long wpstride;
+  const float *bias;            /* NULL or (N); gru: (4, N) = b_ir + b_hr, b_iz + b_hz, b_in, b_hn */
+  const float *add;             /* NULL or (M x N) row stride ldadd: added before the ReLU */
+  float *C;                     /* NULL or fp32 output (M x N), row stride ldc */
+  unsigned short *P;            /* NULL or plane output: row stride ldp (multiple of 32 >= N), zero beyond N */
+  long long ppstride;
+  const float *hprev;           /* gru: previous hidden state (M x N) fp32, row stride ldh;
+                                   out = n + z (hprev - n) (ATen's fused GRU cell) */
+  unsigned long long *amax;     /* NULL or (M x namax): per 128-column tile the key of the row's maximum:
+                                   (order-preserving bits of the value) << 32 | (2^32 - 1 - column) */
+  int ldadd, ldc, ldp, ldh, namax, pad1_;
+} s2c_planes_gemm_args;
+int s2c_planes_gemm(const s2c_planes_gemm_args *a, void *stream);
+long long s2c_planes_args_sizeof(int which);   /* 0: s2c_planes_gemm_args, 1: s2c_planes_seg */
+/* planes of an fp32 matrix: X (rows_in x K, row stride ldx) -> P (3 x rows_out x ldp) bf16, zero in
+ * rows >= rows_in and columns >= K; ldp a multiple of 8 */
+int s2c_planes_split(long long rows_in, int K, const float *X, long long ldx, long long rows_out,
+                     int ldp, unsigned short *P, long long pstride, void *stream);
 
 #ifdef __cplusplus
 }

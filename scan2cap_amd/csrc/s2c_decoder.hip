@@ -804,7 +804,8 @@ __global__ __launch_bounds__(256) void attn_local_kernel(
     int R, int Lrt, int H, int F, const float *__restrict__ mapped,
     const float *__restrict__ q, int ldq, const float *__restrict__ wa, float ba,
     const float *__restrict__ valid, const float *__restrict__ feats,
-    float *__restrict__ alpha, float *__restrict__ att, int lda) {
+    float *__restrict__ alpha, float *__restrict__ att, int lda,
+    unsigned short *__restrict__ planes, long long pstride, int ldp) {
   constexpr int LM = LT > 0 ? LT : AL_MAXL;
   const int L = LT > 0 ? LT : Lrt;
   const int lane = threadIdx.x & 63;
@@ -860,7 +861,17 @@ __global__ __launch_bounds__(256) void attn_local_kernel(
 #pragma unroll
     for (int l = 0; l < LM; ++l)
       if (LT > 0 || l < L) a += sc[l] * v[l];
-    att[(size_t)r * lda + f] = a;
+    if (att != nullptr) att[(size_t)r * lda + f] = a;
+    if (planes != nullptr) {      // the bf16x3 planes of the attended vector (s2c_planes.hip's operand)
+      const __bf16 h = (__bf16)a;
+      const float r1 = a - (float)h;
+      const __bf16 m = (__bf16)r1;
+      const __bf16 lo = (__bf16)(r1 - (float)m);
+      unsigned short *pp = planes + (size_t)r * ldp + f;
+      pp[0] = __builtin_bit_cast(unsigned short, h);
+      pp[pstride] = __builtin_bit_cast(unsigned short, m);
+      pp[2 * pstride] = __builtin_bit_cast(unsigned short, lo);
+    }
   }
 }
 
@@ -1040,22 +1051,40 @@ extern "C" int s2c_attn_bwd_x2(int R, int K, int H, int F, int E, const float *d
   return chk("attn_bwd_x2");
 }
 
-extern "C" int s2c_attn_local_fwd(int R, int L, int H, int F, const float *mapped,
-                                  const float *q, int ldq, const float *wa, float ba,
-                                  const float *valid, const float *feats, float *alpha,
-                                  float *att, int lda, void *stream) {
+static int attn_local_launch(int R, int L, int H, int F, const float *mapped, const float *q,
+                             int ldq, const float *wa, float ba, const float *valid,
+                             const float *feats, float *alpha, float *att, int lda,
+                             unsigned short *planes, long long pstride, int ldp, void *stream) {
   if (R <= 0 || L <= 0 || L > AL_MAXL || (H & 3) || (ldq & 3) || F <= 0 || !mapped || !q ||
-      !wa || !feats || !alpha || !att)
+      !wa || !feats || !alpha || (!att && !planes))
     return -1;
   if (L == 10)       // CONF default num_locals (scripts/train.py:332)
     hipLaunchKernelGGL(attn_local_kernel<10>, dim3((R + 3) / 4), dim3(256), 0,
                        (hipStream_t)stream, R, L, H, F, mapped, q, ldq, wa, ba, valid, feats,
-                       alpha, att, lda);
+                       alpha, att, lda, planes, pstride, ldp);
   else
     hipLaunchKernelGGL(attn_local_kernel<0>, dim3((R + 3) / 4), dim3(256), 0,
                        (hipStream_t)stream, R, L, H, F, mapped, q, ldq, wa, ba, valid, feats,
-                       alpha, att, lda);
+                       alpha, att, lda, planes, pstride, ldp);
   return chk("attn_local_fwd");
+}
+
+extern "C" int s2c_attn_local_fwd(int R, int L, int H, int F, const float *mapped,
+                                  const float *q, int ldq, const float *wa, float ba,
+                                  const float *valid, const float *feats, float *alpha,
+                                  float *att, int lda, void *stream) {
+  return attn_local_launch(R, L, H, F, mapped, q, ldq, wa, ba, valid, feats, alpha, att, lda,
+                           nullptr, 0, 0, stream);
+}
+
+extern "C" int s2c_attn_local_fwd_planes(int R, int L, int H, int F, const float *mapped,
+                                         const float *q, int ldq, const float *wa, float ba,
+                                         const float *valid, const float *feats, float *alpha,
+                                         float *att, int lda, unsigned short *planes,
+                                         long long pstride, int ldp, void *stream) {
+  if (planes == nullptr || ldp < F) return -1;
+  return attn_local_launch(R, L, H, F, mapped, q, ldq, wa, ba, valid, feats, alpha, att, lda,
+                           planes, pstride, ldp, stream);
 }
 
 extern "C" int s2c_split_bf16x3(long long M, int K, const float *A, long long lda,

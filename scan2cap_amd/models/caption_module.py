@@ -25,13 +25,16 @@ import ctypes
 from .. import _C
 from ..box_util import box3d_iou_batch_tensor
 from ..config import CONF
-from . import decoder_fused
+from . import decoder_fused, greedy_fused
 from .graph_module import query_locals
 
 _I, _F32, _P = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 _C.register("s2c_attn_local_fwd", [_I, _I, _I, _I, _P, _P, _I, _P, _F32, _P, _P, _P, _P, _I, _P])
-# greedy decode: split-weight step + one-pass local attention kernel
-FUSE_EVAL_STEP = True
+# greedy decode: "planes" (default) = every product of the step on the hand-written bf16x3-plane MFMA
+# kernels (greedy_fused.py / csrc/s2c_planes.hip: 7 launches per token, no library GEMM, no ATen
+# kernel); True = split-weight step on library GEMMs + one-pass local attention kernel (the
+# round-1..3 path, kept as an A/B reference); False = the module's `_step` loop
+FUSE_EVAL_STEP = {"0": False, "1": True}.get(_os.environ.get("S2C_EVAL_STEP", "planes"), "planes")
 # greedy decode GEMMs (thousands of rows: on the fp32 MFMA roof) as ONE library bf16 GEMM
 # over the bf16x3 planes of both operands (csrc/s2c_decoder.hip: split_bf16x3)
 SPLIT_EVAL_GEMMS = True
@@ -415,15 +418,25 @@ class TopDownSceneCaptionModule(nn.Module):
             hit = (att_ids.unsqueeze(-1) == nbr.unsqueeze(-2)).to(rel.dtype)  # (B,K,La,Ln)
             local = local + torch.matmul(hit, rel)
         local = local.reshape(R, L, F_)
+        T = max_len - 1
+        ids = att_ids.reshape(R, L)
+        if (FUSE_EVAL_STEP == "planes" and dev.type == "cuda" and not torch.is_grad_enabled()
+                and greedy_fused.supported(self, L)):
+            cap_buf, alpha = greedy_fused.decode(self, word_embs[:, 0], K,
+                                                 obj_feats.reshape(R, F_), local, T)
+            attn = torch.zeros(R, K, T, device=dev)
+            attn.scatter_(1, ids.unsqueeze(-1).expand(R, L, T), alpha.permute(1, 2, 0))
+            data_dict["lang_cap"] = cap_buf.view(T, B, K, -1).permute(1, 2, 0, 3)  # (B,K,T,V)
+            data_dict["topdown_attn"] = attn.view(B, K, K, T)        # (B,K,K,T)
+            data_dict["valid_masks"] = valid                          # (B,K,K)
+            return data_dict
         mapped = self.map_feat(local)                                # (R,L,H)
         ones = torch.ones(R, L, 1, device=dev)
         target_feats = obj_feats.reshape(R, F_)
-        ids = att_ids.reshape(R, L)
 
         hidden_1 = torch.zeros(R, self.hidden_size, device=dev)
         hidden_2 = torch.zeros(R, self.hidden_size, device=dev)
         step_input = word_embs[:, 0].repeat_interleave(K, dim=0)         # sos
-        T = max_len - 1
         # logits are produced step-major (T,R,V) so that the classifier GEMM writes each
         # step in place; the (B,K,T,V) result is a permuted view of that buffer (no
         # 115 MB copy per step at cfg5)

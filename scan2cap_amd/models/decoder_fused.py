@@ -156,7 +156,9 @@ def _plib():
 
 def persist_failed(dev=None):
     """True if a launch of the persistent kernel gave up on a poll (its results are invalid).
-    Synchronises; for tests and smoke()."""
+    Synchronises; for tests, smoke() and training loops (check it once per step or per epoch,
+    outside any capture: the NaN poison of the kernels is the loud-by-default signal, this flag is
+    the reliable one)."""
     return any(int(ctl[2].item()) != 0 for k, (_, ctl) in _XBUF.items()
                if dev is None or k[0] == torch.device(dev).index)
 
@@ -165,16 +167,73 @@ def set_persist(on):
     _plib().s2c_decoder_persist_set(int(bool(on)))
 
 
+# The persistent kernels spin until all of their workgroups are co-resident.  They are ordinary
+# launches (an occupancy query sizes the grid), so NOTHING guarantees forward progress when a
+# second process holds CUs of the same device: each process takes an exclusive advisory lock per
+# device before its first persistent launch and silently uses the launch chain when another
+# process already holds it (two trainers, or an evaluation job beside a trainer, on one GPU).
+_DEVICE_LOCKS = {}      # device index -> open file object (lock held) or False (use the chain)
+
+
+def _device_lock_path(index):
+    try:
+        ident = str(torch.cuda.get_device_properties(index).uuid)
+    except Exception:
+        ident = "%s-%d" % (_os.environ.get("HIP_VISIBLE_DEVICES",
+                                           _os.environ.get("ROCR_VISIBLE_DEVICES", "all")), index)
+    ident = "".join(c if c.isalnum() else "_" for c in ident)
+    import tempfile
+    return _os.path.join(tempfile.gettempdir(), "s2c_persist_%s.lock" % ident)
+
+
+def persist_allowed(dev):
+    """This process may run the persistent decoder kernels on `dev` (it owns the device's lock).
+    `parallel.init_from_env` additionally switches them off when ranks share a device."""
+    index = torch.device(dev).index
+    if index is None:
+        index = torch.cuda.current_device()
+    got = _DEVICE_LOCKS.get(index)
+    if got is None:
+        got = False
+        if _os.environ.get("S2C_PERSIST_LOCK", "1") == "0":
+            got = True
+        else:
+            try:
+                import fcntl
+                f = open(_device_lock_path(index), "a+")
+                try:
+                    fcntl.flock(f, fcntl.LOCK_EX | fcntl.LOCK_NB)
+                    got = f                     # held until the process exits
+                except OSError:
+                    f.close()
+            except Exception:                   # no lock file possible: be conservative
+                got = False
+        _DEVICE_LOCKS[index] = got
+    return got is not False
+
+
+_LAST_STREAM = {}       # scratch key -> the stream of its previous launch
+
+
 def _persist_scratch(dev, H, E, bwd=False):
-    # one exchange buffer + nonce per (device, kernel), allocated ONCE (inside a graph capture the
-    # zero-fill would be replayed with every step).  Decoders of one device must therefore run on
-    # one stream at a time -- two persistent kernels at once would also fight for the same CUs.
+    # one exchange buffer + nonce per (device, kernel), allocated ONCE and never inside a capture
+    # (the zero-fill would be replayed with every step and land in the graph's private pool).
+    # Two launches that share the scratch must not overlap (same nonce -> same tags): a launch on
+    # another stream than the previous one first waits for that stream.
     key = (dev.index, H, E, bwd)
     if key not in _XBUF:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("persistent decoder scratch must exist before a graph capture: run "
+                               "the step once eagerly first (graphs.GraphedCallable does)")
         pairs = int(_plib().s2c_decoder_bwd_persist_xbuf_pairs(H, E) if bwd else
                     _plib().s2c_decoder_fwd_persist_xbuf_pairs(H, E))
         _XBUF[key] = (torch.zeros(pairs, dtype=torch.int64, device=dev),
                       torch.zeros(4, dtype=torch.int32, device=dev))
+    cur = torch.cuda.current_stream(dev)
+    last = _LAST_STREAM.get(key)
+    if last is not None and last != cur and not torch.cuda.is_current_stream_capturing():
+        cur.wait_stream(last)
+    _LAST_STREAM[key] = cur
     return _XBUF[key]
 
 
@@ -247,7 +306,8 @@ class TopDownDecode(Function):
             ldtd, ldlang = W_td.shape[1], W_lang.shape[1]
             td_h2 = W_td[:, E:E + H]          # column block, row stride ldtd
             persist = (ldtd % 4 == 0 and ldlang % 4 == 0 and
-                       _plib().s2c_decoder_fwd_persist_supported(R, K, H, E, F, T) == 1)
+                       _plib().s2c_decoder_fwd_persist_supported(R, K, H, E, F, T) == 1 and
+                       persist_allowed(dev))
             if persist:
                 xbuf, ctl = _persist_scratch(dev, H, E)
                 if any(ctx.needs_input_grad) and \

@@ -1,0 +1,241 @@
+"""Greedy decode of every proposal (models/caption_module.py:502-592) on the hand-written planes
+GEMMs of csrc/s2c_planes.hip: per token SEVEN launches for all R = B*K rows --
+
+    G1  x1 = relu(W_td[:, :E] emb[token] + W_td[:, E:E+H] h2 + P_tf)      (caption_module.py:252-253)
+    G2  h1 = GRUCell_1(x1, h1)         gates, biases and the cell in the GEMM's epilogue   (:254)
+    G3  q  = map_hidd(h1)                                                                   (:257)
+    ATT alpha, att = local attention over the L gathered objects (csrc/s2c_decoder.hip)  (:257-261)
+    G5  x2 = relu(W_lang[:, :F] att + W_lang[:, F:] h1 + b)                                  (:262)
+    G6  h2 = GRUCell_2(x2, h2)                                                               (:263)
+    G7  logits = classifier(h2) written in place + per-row arg-max keys            (:553, :559-566)
+
+-- every product formed from bf16x3 planes (fp32-accurate, see the kernel), every activation
+leaving its producer already split, the greedy feedback `embeddings[argmax]` resolved by G1's
+prologue from G7's keys.  No library GEMM, no ATen kernel inside the token loop.
+"""
+import ctypes
+
+import torch
+
+from .. import _C
+
+_I, _P, _LL = ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong
+
+
+class _Seg(ctypes.Structure):
+    """include/s2c_fused.h: s2c_planes_seg"""
+    _fields_ = [("p", _P), ("pstride", _LL), ("ld", _I), ("kc", _I), ("rowmap", _P),
+                ("rowdiv", _I), ("pad_", _I)]
+
+
+class _GemmArgs(ctypes.Structure):
+    """include/s2c_fused.h: s2c_planes_gemm_args"""
+    _fields_ = [("M", _I), ("N", _I), ("gru", _I), ("relu", _I), ("nseg", _I), ("pad0_", _I),
+                ("seg", _Seg * 2), ("tokkeys", _P), ("ntokkeys", _I), ("ldw", _I), ("W", _P),
+                ("wpstride", _LL), ("bias", _P), ("add", _P), ("C", _P), ("P", _P),
+                ("ppstride", _LL), ("hprev", _P), ("amax", _P), ("ldadd", _I), ("ldc", _I),
+                ("ldp", _I), ("ldh", _I), ("namax", _I), ("pad1_", _I)]
+
+
+_C.register("s2c_planes_gemm", [_P, _P])
+_C.register("s2c_planes_split", [_LL, _I, _P, _LL, _LL, _I, _P, _LL, _P])
+_C.register("s2c_attn_local_fwd_planes", [_I, _I, _I, _I, _P, _P, _I, _P, ctypes.c_float, _P, _P,
+                                          _P, _P, _I, _P, _LL, _I, _P])
+
+
+def _up(n, m):
+    return (n + m - 1) // m * m
+
+
+class Planes(object):
+    """bf16x3 planes of a (rows x K) matrix: tensor t (3, rows_alloc, ld) bf16."""
+
+    def __init__(self, rows, ld, device, zero=False):
+        self.rows, self.ld = rows, ld
+        self.t = (torch.zeros if zero else torch.empty)((3, rows, ld), dtype=torch.bfloat16,
+                                                        device=device)
+        self.pstride = rows * ld
+
+    def ptr(self):
+        return self.t.data_ptr()
+
+
+def split(x, rows_out=None, ld=None):
+    """fp32 (rows, K) [unit column stride] -> Planes, zero padded to (rows_out, ld)."""
+    assert x.dim() == 2 and x.dtype == torch.float32 and x.is_cuda
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    rows, K = x.shape
+    rows_out = rows if rows_out is None else rows_out
+    ld = _up(K, 32) if ld is None else ld
+    out = Planes(rows_out, ld, x.device)
+    with torch.cuda.device(x.device):
+        _C.call("s2c_planes_split", rows, K, x.data_ptr(), x.stride(0), rows_out, ld, out.ptr(),
+                out.pstride, _C.stream_ptr())
+    return out
+
+
+def gemm(M, N, segs, W, bias=None, add=None, relu=False, C=None, P=None, gru=False, hprev=None,
+         amax=None, tokkeys=None):
+    """One s2c_planes_gemm launch.  segs: list of (Planes, kc[, rowmap tensor | rowdiv int])."""
+    a = _GemmArgs()
+    a.M, a.N, a.gru, a.relu, a.nseg = M, N, int(gru), int(relu), len(segs)
+    kct = 0
+    for i, sg in enumerate(segs):
+        pl, kc = sg[0], sg[1]
+        a.seg[i].p, a.seg[i].pstride, a.seg[i].ld, a.seg[i].kc = pl.ptr(), pl.pstride, pl.ld, kc
+        assert 32 * kc <= pl.ld
+        if len(sg) > 2 and sg[2] is not None:
+            if torch.is_tensor(sg[2]):
+                assert sg[2].dtype == torch.int32 and sg[2].is_contiguous()
+                a.seg[i].rowmap = sg[2].data_ptr()
+            else:
+                a.seg[i].rowdiv = int(sg[2])
+        kct += kc
+    assert W.ld == 32 * kct, (W.ld, kct)
+    assert W.rows >= (4 * N if gru else _up(N, 128))
+    a.W, a.wpstride, a.ldw = W.ptr(), W.pstride, W.ld
+    if tokkeys is not None:
+        a.tokkeys, a.ntokkeys = tokkeys.data_ptr(), tokkeys.shape[1]
+    if bias is not None:
+        assert bias.is_contiguous() and bias.dtype == torch.float32
+        a.bias = bias.data_ptr()
+    if add is not None:
+        assert add.stride(1) == 1
+        a.add, a.ldadd = add.data_ptr(), add.stride(0)
+    if C is not None:
+        assert C.stride(1) == 1 and C.dtype == torch.float32
+        a.C, a.ldc = C.data_ptr(), C.stride(0)
+    if P is not None:
+        a.P, a.ppstride, a.ldp = P.ptr(), P.pstride, P.ld
+    if hprev is not None:
+        a.hprev, a.ldh = hprev.data_ptr(), hprev.stride(0)
+    if amax is not None:
+        a.amax, a.namax = amax.data_ptr(), amax.shape[1]
+    if _C.TIMER.enabled:
+        k = 32 * kct
+        cols = 3 * N if gru else N
+        _C.TIMER.alg_flops = 2.0 * M * cols * k
+        _C.TIMER.alg_bytes = 6 * (M * k + (4 * N if gru else N) * k) + 4 * M * N
+    _C.call("s2c_planes_gemm", ctypes.byref(a), _C.stream_ptr())
+
+
+def pack_gru(cell, Ep):
+    """GRUCell weights -> (4H, Ep + H) rows grouped per 32 hidden units as [r | z | n_i | n_h]
+    (the n_i rows multiply x only, the n_h rows h only), bias (4, H)."""
+    W_ih, W_hh = cell.weight_ih.detach(), cell.weight_hh.detach()
+    H, E = W_hh.shape[1], W_ih.shape[1]
+    assert H % 32 == 0
+    W = torch.zeros(4, H, Ep + H, device=W_ih.device)
+    W[0, :, :E], W[0, :, Ep:] = W_ih[:H], W_hh[:H]
+    W[1, :, :E], W[1, :, Ep:] = W_ih[H:2 * H], W_hh[H:2 * H]
+    W[2, :, :E] = W_ih[2 * H:]
+    W[3, :, Ep:] = W_hh[2 * H:]
+    W = W.view(4, H // 32, 32, Ep + H).permute(1, 0, 2, 3).reshape(4 * H, Ep + H)
+    b_ih, b_hh = cell.bias_ih.detach(), cell.bias_hh.detach()
+    bias = torch.stack([b_ih[:H] + b_hh[:H], b_ih[H:2 * H] + b_hh[H:2 * H], b_ih[2 * H:],
+                        b_hh[2 * H:]]).contiguous()
+    return split(W.contiguous(), rows_out=4 * H), bias
+
+
+def supported(mod, L):
+    return (mod.hidden_size % 32 == 0 and mod.feat_size % 4 == 0 and L <= 32
+            and mod.attend.bias is None and mod.map_topdown[0].bias is not None)
+
+
+_WEIGHTS = {}     # id(module) -> (version key, dict of planes)
+
+
+def _weights(mod):
+    """The planes of every weight of the step, split once per weight version (evaluation calls
+    the decoder once per scene batch with frozen weights)."""
+    ps = [mod.map_topdown[0].weight, mod.map_topdown[0].bias, mod.recurrent_cell_1.weight_ih,
+          mod.recurrent_cell_1.weight_hh, mod.recurrent_cell_1.bias_ih, mod.recurrent_cell_1.bias_hh,
+          mod.map_feat.weight, mod.map_hidd.weight, mod.attend.weight, mod.map_lang[0].weight,
+          mod.map_lang[0].bias, mod.recurrent_cell_2.weight_ih, mod.recurrent_cell_2.weight_hh,
+          mod.recurrent_cell_2.bias_ih, mod.recurrent_cell_2.bias_hh, mod.classifier.weight,
+          mod.classifier.bias, mod._emb_table]
+    key = tuple((p.data_ptr(), p._version, p.device) for p in ps)
+    hit = _WEIGHTS.get(id(mod))
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    E, H, F_ = mod.emb_size, mod.hidden_size, mod.feat_size
+    Ep, Fp = _up(E, 32), _up(F_, 32)
+    dev = ps[0].device
+    with torch.no_grad():
+        W_td = mod.map_topdown[0].weight.detach()
+        W1 = torch.zeros(E, Ep + H, device=dev)
+        W1[:, :E], W1[:, Ep:] = W_td[:, :E], W_td[:, E:E + H]
+        W_lang = mod.map_lang[0].weight.detach()
+        W5 = torch.zeros(E, Fp + H, device=dev)
+        W5[:, :F_], W5[:, Fp:] = W_lang[:, :F_], W_lang[:, F_:]
+        w = {"Ep": Ep, "Fp": Fp}
+        w["W1"] = split(W1, rows_out=_up(E, 128))
+        w["Wtf"] = split(W_td[:, E + H:], rows_out=_up(E, 128), ld=Fp)
+        w["b_td"] = mod.map_topdown[0].bias.detach().contiguous()
+        w["Wg1"], w["bg1"] = pack_gru(mod.recurrent_cell_1, Ep)
+        w["Wm"] = split(mod.map_feat.weight.detach(), rows_out=_up(H, 128), ld=Fp)
+        w["Wq"] = split(mod.map_hidd.weight.detach(), rows_out=_up(H, 128))
+        w["wa"] = mod.attend.weight.detach().reshape(-1).contiguous()
+        w["W5"] = split(W5, rows_out=_up(E, 128))
+        w["b_lang"] = mod.map_lang[0].bias.detach().contiguous()
+        w["Wg2"], w["bg2"] = pack_gru(mod.recurrent_cell_2, Ep)
+        V = mod.classifier.weight.shape[0]
+        w["Wc"] = split(mod.classifier.weight.detach(), rows_out=_up(V, 128))
+        w["b_cls"] = mod.classifier.bias.detach().contiguous()
+        w["emb"] = split(mod._emb_table.detach(), ld=Ep)
+    _WEIGHTS[id(mod)] = (key, w)
+    return w
+
+
+def decode(mod, sos, rows_per_scene, target_feats, local, T):
+    """sos (B,E): the first input word of every scene (lang_feat[:, 0]); target_feats (R,F);
+    local (R,L,F): the attended objects of every row (relation features added).
+    Returns logits (T,R,V) step-major and alpha (T,R,L)."""
+    dev = local.device
+    R, L, F_ = local.shape
+    E, H, V = mod.emb_size, mod.hidden_size, mod.num_vocabs
+    with torch.cuda.device(dev):
+        w = _weights(mod)
+        Ep, Fp = w["Ep"], w["Fp"]
+        nct = (V + 127) // 128
+        sos_p = split(sos.contiguous(), ld=Ep)
+        tf_p = split(target_feats.contiguous(), ld=Fp)
+        P_tf = torch.empty(R, E, device=dev)
+        gemm(R, E, [(tf_p, Fp // 32)], w["Wtf"], bias=w["b_td"], C=P_tf)
+        local_c = local.contiguous()
+        loc_p = split(local_c.view(R * L, F_), ld=Fp)
+        mapped = torch.empty(R * L, H, device=dev)
+        gemm(R * L, H, [(loc_p, Fp // 32)], w["Wm"], C=mapped)
+        h1 = torch.zeros(2, R, H, device=dev)
+        h2 = torch.zeros(2, R, H, device=dev)
+        h1p = [Planes(R, H, dev, zero=True), Planes(R, H, dev)]
+        h2p = [Planes(R, H, dev, zero=True), Planes(R, H, dev)]
+        x1p, x2p = Planes(R, Ep, dev), Planes(R, Ep, dev)
+        attp = Planes(R, Fp, dev, zero=Fp != F_)
+        qh = torch.empty(R, H, device=dev)
+        keys = torch.empty(R, nct, dtype=torch.int64, device=dev)
+        cap = torch.empty(T, R, V, device=dev)
+        alpha = torch.empty(T, R, L, device=dev)
+        st = _C.stream_ptr()
+        cur = 0
+        for t in range(T):
+            nxt = cur ^ 1
+            word = (sos_p, Ep // 32, rows_per_scene) if t == 0 else (w["emb"], Ep // 32)
+            gemm(R, E, [word, (h2p[cur], H // 32)], w["W1"], add=P_tf, relu=True, P=x1p,
+                 tokkeys=None if t == 0 else keys)
+            gemm(R, H, [(x1p, Ep // 32), (h1p[cur], H // 32)], w["Wg1"], bias=w["bg1"], gru=True,
+                 hprev=h1[cur], C=h1[nxt], P=h1p[nxt])
+            gemm(R, H, [(h1p[nxt], H // 32)], w["Wq"], C=qh)
+            if _C.TIMER.enabled:      # one pass over mapped + local features
+                _C.TIMER.alg_bytes = 4 * (R * L * (H + F_ + 1) + R * (H + F_))
+            _C.call("s2c_attn_local_fwd_planes", R, L, H, F_, mapped.data_ptr(), qh.data_ptr(), H,
+                    w["wa"].data_ptr(), 0.0, None, local_c.data_ptr(), alpha[t].data_ptr(), None,
+                    F_, attp.ptr(), attp.pstride, Fp, st)
+            gemm(R, E, [(attp, Fp // 32), (h1p[nxt], H // 32)], w["W5"], bias=w["b_lang"],
+                 relu=True, P=x2p)
+            gemm(R, H, [(x2p, Ep // 32), (h2p[cur], H // 32)], w["Wg2"], bias=w["bg2"], gru=True,
+                 hprev=h2[cur], C=h2[nxt], P=h2p[nxt])
+            gemm(R, V, [(h2p[nxt], H // 32)], w["Wc"], bias=w["b_cls"], C=cap[t], amax=keys)
+            cur = nxt
+    return cap, alpha

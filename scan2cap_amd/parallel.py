@@ -37,13 +37,21 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # ranks of THIS node (torch.distributed.run exports LOCAL_WORLD_SIZE; a multi-node job with
+    # fewer than 8 GPUs per node is as valid as 8 ranks on one node)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "0")) or world
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if world > 1 and ndev and local_world > ndev:
+        # several ranks share a device (the gloo rehearsal): two persistent decoder kernels of
+        # different processes could each hold part of the CUs and wait for the rest
+        from .models import decoder_fused
+        decoder_fused.set_persist(False)
     if world > 1 and not dist.is_initialized():
         backend = dist_backend(backend)
-        if backend == "nccl" and torch.cuda.is_available() \
-                and torch.cuda.device_count() < min(world, 8):
-            raise RuntimeError("RCCL needs one GPU per rank (%d ranks, %d visible GPUs); set "
-                             "S2C_DIST_BACKEND=gloo to run several ranks on one GPU"
-                             % (world, torch.cuda.device_count()))
+        if backend == "nccl" and ndev and ndev < local_world:
+            raise RuntimeError("RCCL needs one GPU per rank (%d ranks on this node, %d visible "
+                               "GPUs); set S2C_DIST_BACKEND=gloo to run several ranks on one GPU"
+                               % (local_world, ndev))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

@@ -117,3 +117,68 @@ def scene_labels(xyz, num_boxes=32, seed=42, num_class=18, mean_size_arr=None):
                 nvotes[i] += 1
             out["vote_label_mask"][b, ids] = 1
     return out
+
+
+# ---- synthetic ScanNet-like scenes (the layout of the reference's preprocessed files) ----
+# instances: nyu40 ids incl. wall(1) / floor(2) / ceiling(22), which carry neither
+# votes nor boxes (lib/dataset.py:29, batch_load_scannet_data.py:42)
+_SEM_POOL = [5, 5, 7, 4, 3, 39, 1, 2, 14, 33, 22, 24, 8, 40, 6, 12]
+_OBJ_CLASS_IDS = {3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 23, 24,
+                  25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40}
+
+
+def make_scene(seed, num_vertices, multiview_width=0, num_instances=14):
+    """One seeded scene as data/scannet/load_scannet_data.py:97-152 stores it:
+    `mesh_vertices` (Nv,9) f32 = xyz rgb normal, `instance_labels` / `semantic_labels` (Nv)
+    uint32, `instance_bboxes` (nb,8) f64 = centre, size, nyu40 id, object id [, `multiview`
+    (Nv,W) f32].  Shared by bench.py --feed builder, smoke() and the scene-builder tests."""
+    g = np.random.Generator(np.random.PCG64(seed))
+    f32 = np.float32
+    sem_of = np.array([_SEM_POOL[i % len(_SEM_POOL)] for i in range(num_instances)])
+    centre = g.uniform([-3, -3, 0.2], [3, 3, 2.2], size=(num_instances, 3))
+    extent = g.uniform(0.15, 0.6, size=(num_instances, 3))
+    owner = g.integers(-3, num_instances, size=num_vertices)          # <0: unannotated
+    xyz = g.uniform([-3.5, -3.5, 0.0], [3.5, 3.5, 2.6], size=(num_vertices, 3))
+    has = owner >= 0
+    xyz[has] = centre[owner[has]] + g.uniform(-1, 1, size=(has.sum(), 3)) * extent[owner[has]]
+    rgb = g.integers(0, 256, size=(num_vertices, 3)).astype(np.float64)
+    nrm = g.normal(size=(num_vertices, 3))
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    verts = np.concatenate([xyz, rgb, nrm], 1).astype(f32)
+    ins = np.where(has, owner + 1, 0).astype(np.uint32)
+    sem = np.where(has, sem_of[np.maximum(owner, 0)], 0).astype(np.uint32)
+    boxes = []
+    for i in range(num_instances):
+        rows = np.where(ins == i + 1)[0]
+        if len(rows) == 0 or int(sem_of[i]) not in _OBJ_CLASS_IDS:
+            continue
+        p = verts[rows, :3].astype(np.float64)
+        lo, hi = p.min(0), p.max(0)
+        boxes.append(np.concatenate([(lo + hi) / 2, hi - lo, [sem_of[i], i]]))
+    scene = {"mesh_vertices": verts, "instance_labels": ins, "semantic_labels": sem,
+             "instance_bboxes": np.asarray(boxes, np.float64)}
+    if multiview_width:
+        scene["multiview"] = np.maximum(
+            g.normal(size=(num_vertices, multiview_width)) * 0.5, 0).astype(f32)
+    return scene
+
+
+def aim_reference_boxes_at_proposals(model, dd, proposal=0):
+    """At random init no proposal overlaps the synthetic ground-truth box of a scene by
+    IoU >= 0.25, so `good_bbox_masks` is all False, the caption loss is exactly 0
+    (lib/loss_helper.py:189-230 masks it) and every gradient of the captioner and the relation
+    graph is exactly 0.  Point each scene's described box (`ref_box_corner_label`) at the box
+    the model itself predicts for one proposal: IoU = 1, the caption loss and its backward
+    through decoder, attention and EdgeConv are live.  Returns the updated batch dict (the
+    model's weights / BN statistics are left untouched)."""
+    import torch
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    was_training = model.training
+    with torch.no_grad():
+        out = model(dict(dd), use_tf=True, is_eval=False)
+    model.load_state_dict(state)
+    model.train(was_training)
+    dd = dict(dd)
+    dd["ref_box_corner_label"] = out["bbox_corner"][:, proposal].detach().to(
+        dd["ref_box_corner_label"].dtype).clone()
+    return dd

@@ -154,24 +154,7 @@ def forced_vote_sampling(model, inds):
         del sa.forward
 
 
-def aim_reference_boxes_at_proposals(model, dd):
-    """At random init no proposal overlaps the synthetic ground-truth box of a scene by
-    IoU >= 0.25, so `good_bbox_masks` is all False, the caption loss is exactly 0
-    (lib/loss_helper.py:189-230 masks it) and every gradient of the captioner and the relation
-    graph is exactly 0 -- a comparison of zeros.  Point each scene's described box
-    (`ref_box_corner_label`) at the box the model itself predicts for proposal 0: IoU = 1,
-    the caption loss and its backward through decoder, attention and EdgeConv are live.
-    Returns the updated batch dict (the model's weights / BN statistics are left untouched)."""
-    state = {k: v.clone() for k, v in model.state_dict().items()}
-    was_training = model.training
-    with torch.no_grad():
-        out = model(dict(dd), use_tf=True, is_eval=False)
-    model.load_state_dict(state)
-    model.train(was_training)
-    dd = dict(dd)
-    dd["ref_box_corner_label"] = out["bbox_corner"][:, 0].detach().to(
-        dd["ref_box_corner_label"].dtype).clone()
-    return dd
+from scan2cap_amd.synthetic import aim_reference_boxes_at_proposals  # noqa: E402,F401
 
 
 ULP_NOISE = 1.0e-7      # relative, rms: about one float32 rounding error per value

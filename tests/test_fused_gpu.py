@@ -472,8 +472,8 @@ def test_eval_greedy_decode_fused_step_matches_step_loop():
     outs = {}
     old = (cm.FUSE_EVAL_STEP, cm.SPLIT_EVAL_MIN_ROWS)
     try:
-        for flag in (False, True, "split"):
-            cm.FUSE_EVAL_STEP = bool(flag)
+        for flag in (False, True, "split", "planes"):
+            cm.FUSE_EVAL_STEP = "planes" if flag == "planes" else bool(flag)
             # "split": the GEMMs of the step as bf16x3-plane library GEMMs (normally only
             # from 4096 rows up)
             cm.SPLIT_EVAL_MIN_ROWS = 1 if flag == "split" else 1 << 30
@@ -486,6 +486,13 @@ def test_eval_greedy_decode_fused_step_matches_step_loop():
     assert torch.equal(s_["lang_cap"].argmax(-1), b["lang_cap"].argmax(-1))
     assert _rel(s_["lang_cap"], b["lang_cap"]) < 1e-4
     assert _rel(s_["topdown_attn"], b["topdown_attn"]) < 1e-4
+    # the default: every product of the step on the planes GEMMs (greedy_fused.py)
+    p_, b = outs["planes"], outs[False]
+    assert p_["lang_cap"].shape == b["lang_cap"].shape == (B, K, 7, V)
+    assert torch.equal(p_["lang_cap"].argmax(-1), b["lang_cap"].argmax(-1))
+    assert _rel(p_["lang_cap"], b["lang_cap"]) < 1e-4
+    assert _rel(p_["topdown_attn"], b["topdown_attn"]) < 1e-4
+    assert torch.equal(p_["valid_masks"], b["valid_masks"])
     a, b = outs[True], outs[False]
     assert a["lang_cap"].shape == b["lang_cap"].shape == (B, K, 7, V)
     assert torch.equal(a["lang_cap"].argmax(-1), b["lang_cap"].argmax(-1))

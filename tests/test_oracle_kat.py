@@ -317,6 +317,33 @@ def test_persistent_decoder_argument_structs_match_the_header():
     assert ok(8, 10, 512, 300, 128, 63) == 0      # more than 62 steps
 
 
+def test_planes_gemm_argument_structs_match_the_header():
+    """ctypes mirrors of s2c_planes_seg / s2c_planes_gemm_args (models/greedy_fused.py): size as
+    compiled, members in header order; invalid arguments are refused before any launch."""
+    import ctypes
+    from scan2cap_amd import _C
+    from scan2cap_amd.models import greedy_fused as gf
+    lib = _C.load()
+    lib.s2c_planes_args_sizeof.argtypes = [ctypes.c_int]
+    lib.s2c_planes_args_sizeof.restype = ctypes.c_longlong
+    assert lib.s2c_planes_args_sizeof(0) == ctypes.sizeof(gf._GemmArgs)
+    assert lib.s2c_planes_args_sizeof(1) == ctypes.sizeof(gf._Seg)
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "s2c_fused.h")).read(), flags=re.S)
+    for cname, mirror in (("s2c_planes_seg", gf._Seg), ("s2c_planes_gemm_args", gf._GemmArgs)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), txt, flags=re.S).group(1)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            decl = re.sub(r"^(const\s+)?(unsigned\s+)?(long\s+long|float|int|short|s2c_planes_seg)\b",
+                          "", decl)
+            names += [re.sub(r"[\s\*]|\[\d+\]", "", n) for n in decl.split(",")]
+        assert names == [f[0] for f in mirror._fields_], (cname, names)
+    a = gf._GemmArgs()
+    assert lib.s2c_planes_gemm(ctypes.byref(a), None) == -1          # M = 0, no operand
+
+
 def test_streaming_gemm_dispatch_table():
     """Which layer shapes the streaming kernel of csrc/s2c_gemm2.hip takes is host logic (LDS
     budget: W planes + one LDS-DMA ring per wave): pinned here without a GPU."""

@@ -1,0 +1,140 @@
+"""csrc/s2c_planes.hip (the greedy decoder's bf16x3-plane MFMA GEMMs, models/greedy_fused.py)
+against float64 products of the same operands: plane split, generic epilogue (bias, row addend,
+ReLU, fp32 + plane outputs, arg-max keys), gathered / two-segment A operands, the GRU-cell epilogue
+against torch.nn.GRUCell (models/caption_module.py:254,263), and the greedy feedback through the keys
+(caption_module.py:559-566)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
+
+
+def _planes_sum(p):
+    return p.t.float().sum(0)
+
+
+def test_planes_split_reconstructs_fp32_and_pads_with_zeros():
+    from scan2cap_amd.models import greedy_fused as gf
+    torch.manual_seed(0)
+    x = torch.randn(37, 300, device="cuda") * torch.logspace(-3, 3, 300, device="cuda")
+    xs = torch.zeros(37, 333, device="cuda")
+    xs[:, :300] = x                                       # a strided source (row stride 333)
+    for src in (x, xs[:, :300]):
+        p = gf.split(src, rows_out=64, ld=320)
+        t = p.t.float()
+        hi = src.bfloat16().float()
+        assert torch.equal(t[0, :37, :300], hi)           # round-to-nearest-even, like torch
+        mid = (src - hi).bfloat16().float()
+        assert torch.equal(t[1, :37, :300], mid)
+        assert torch.equal(t[2, :37, :300], ((src - hi) - mid).bfloat16().float())
+        assert float(t[:, 37:].abs().max()) == 0 and float(t[:, :, 300:].abs().max()) == 0
+        err = (t.sum(0)[:37, :300].double() - src.double()).abs() / src.abs().double().clamp(min=1e-30)
+        assert float(err.max()) < 2.0 ** -22
+
+
+@pytest.mark.parametrize("M,N,K0,K1,gather", [
+    (300, 300, 300, 96, True),        # ragged rows / columns, gathered first segment
+    (128, 128, 64, 0, False),         # exactly one tile, one segment
+    (1000, 520, 128, 512, False),     # several row and column tiles (XCD map), two segments
+    (77, 3500, 512, 0, False),        # the classifier's width
+])
+def test_planes_gemm_generic_epilogue_matches_float64(M, N, K0, K1, gather):
+    from scan2cap_amd.models import greedy_fused as gf
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    rnd = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    src_rows = 50 if gather else M
+    A0 = rnd(src_rows, K0)
+    rowmap = torch.randint(0, src_rows, (M,), device="cuda", generator=g, dtype=torch.int32) \
+        if gather else None
+    A1 = rnd(M, K1) if K1 else None
+    K0p, K1p = gf._up(K0, 32), gf._up(K1, 32)
+    W = torch.zeros(N, K0p + K1p, device="cuda")
+    W[:, :K0] = rnd(N, K0) / K0 ** 0.5
+    if K1:
+        W[:, K0p:K0p + K1] = rnd(N, K1) / K1 ** 0.5
+    bias, add = rnd(N), rnd(M, N)
+    segs = [(gf.split(A0, ld=K0p), K0p // 32, rowmap)]
+    if K1:
+        segs.append((gf.split(A1, ld=K1p), K1p // 32))
+    Wp = gf.split(W, rows_out=gf._up(N, 128))
+    C = torch.full((M, N), float("nan"), device="cuda")
+    P = gf.Planes(M, gf._up(N, 32), "cuda")
+    P.t.fill_(float("nan"))
+    nct = (N + 127) // 128
+    keys = torch.zeros(M, nct, dtype=torch.int64, device="cuda")
+    gf.gemm(M, N, segs, Wp, bias=bias, add=add, relu=True, C=C, P=P, amax=keys)
+    a0 = A0[rowmap.long()] if gather else A0
+    want = a0.double() @ W[:, :K0].double().t() + bias.double() + add.double()
+    if K1:
+        want = want + A1.double() @ W[:, K0p:K0p + K1].double().t()
+    want = want.clamp(min=0)
+    assert _rel(C, want) < 2e-6
+    ps = _planes_sum(P)
+    assert torch.equal(ps[:, :N], C)                      # hi + mid + lo of an fp32 value is exact
+    assert float(ps[:, N:].abs().max()) == 0 if P.ld > N else True
+    # keys: the first maximum of every row over the columns of each 128-wide tile
+    k = keys.cpu().numpy().astype(np.uint64)
+    col = (np.uint64(0xFFFFFFFF) - (k & np.uint64(0xFFFFFFFF))).astype(np.int64)
+    Cc = C.cpu().numpy()
+    for ct in range(nct):
+        blk = Cc[:, 128 * ct:128 * (ct + 1)]
+        assert np.array_equal(col[:, ct], 128 * ct + blk.argmax(1))
+    assert np.array_equal(col[np.arange(M), k.argmax(1)], Cc.argmax(1))     # == torch.argmax
+    # no bias / add / ReLU, fp32 output only
+    C2 = torch.empty(M, N, device="cuda")
+    gf.gemm(M, N, segs, Wp, C=C2)
+    want2 = a0.double() @ W[:, :K0].double().t()
+    if K1:
+        want2 = want2 + A1.double() @ W[:, K0p:K0p + K1].double().t()
+    assert _rel(C2, want2) < 2e-6
+
+
+@pytest.mark.parametrize("M,E,H", [(200, 300, 512), (128, 64, 32), (333, 300, 96)])
+def test_planes_gemm_gru_epilogue_matches_grucell(M, E, H):
+    from scan2cap_amd.models import greedy_fused as gf
+    torch.manual_seed(M)
+    cell = torch.nn.GRUCell(E, H).cuda()
+    x, h = torch.randn(M, E, device="cuda"), torch.randn(M, H, device="cuda")
+    Ep = gf._up(E, 32)
+    Wg, bg = gf.pack_gru(cell, Ep)
+    hn = torch.empty(M, H, device="cuda")
+    hp = gf.Planes(M, H, "cuda")
+    gf.gemm(M, H, [(gf.split(x, ld=Ep), Ep // 32), (gf.split(h), H // 32)], Wg, bias=bg,
+            gru=True, hprev=h, C=hn, P=hp)
+    with torch.no_grad():
+        want = cell.double()(x.double(), h.double())
+    assert _rel(hn, want) < 2e-6
+    assert torch.equal(_planes_sum(hp), hn)
+
+
+def test_greedy_feedback_through_the_argmax_keys():
+    """G7 leaves keys, the next G1 gathers the embedding rows of the arg-max tokens."""
+    from scan2cap_amd.models import greedy_fused as gf
+    torch.manual_seed(3)
+    M, V, H, E = 260, 700, 64, 300
+    h = torch.randn(M, H, device="cuda")
+    Wc = torch.randn(V, H, device="cuda")
+    logits = torch.empty(M, V, device="cuda")
+    keys = torch.empty(M, (V + 127) // 128, dtype=torch.int64, device="cuda")
+    gf.gemm(M, V, [(gf.split(h), H // 32)], gf.split(Wc, rows_out=gf._up(V, 128)), C=logits,
+            amax=keys)
+    tok = logits.argmax(-1)
+    table = torch.randn(V, E, device="cuda")
+    Ep = gf._up(E, 32)
+    W = torch.zeros(E, Ep, device="cuda")
+    W[:, :E] = torch.eye(E, device="cuda")
+    out = torch.empty(M, E, device="cuda")
+    gf.gemm(M, E, [(gf.split(table, ld=Ep), Ep // 32)], gf.split(W, rows_out=gf._up(E, 128)),
+            C=out, tokkeys=keys)
+    assert torch.equal(out, table[tok])                   # identity weights: the gathered rows
+    # rowdiv: row r reads source row r / 13 (the scene's first word for all of its proposals)
+    src = torch.randn(M // 13 + 1, E, device="cuda")
+    gf.gemm(M, E, [(gf.split(src, ld=Ep), Ep // 32, 13)], gf.split(W, rows_out=gf._up(E, 128)),
+            C=out)
+    assert torch.equal(out, src[torch.arange(M, device="cuda") // 13])
