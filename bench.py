@@ -600,6 +600,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
     rank, world, local_rank = init_from_env()
     assert world == args.gpus, "--gpus must match the launched world size"
+    if os.environ.get("S2C_BENCH_FAIL_RANK") == str(rank) and world > 1:
+        # fault injection for tests/test_bench_launch_gpu.py: this rank dies after the rendezvous;
+        # the launcher must take the other ranks down and return its exit code
+        os._exit(17)
     # one GPU per rank; several ranks share a device only under S2C_DIST_BACKEND=gloo (the
     # one-GPU rehearsal of the N>1 path)
     dev_index = local_rank % torch.cuda.device_count()

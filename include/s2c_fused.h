@@ -453,11 +453,13 @@ int s2c_attn_local_fwd(int R, int L, int H, int F, const float *mapped, const fl
                        int ldq, const float *wa, float ba, const float *valid,
                        const float *feats, float *alpha, float *att, int lda, void *stream);
 /* the same, additionally (att may be NULL) writing att as bf16x3 planes (3 x R x ldp, plane stride
- * pstride elements): the operand format of s2c_planes_gemm below */
+ * pstride elements; tiled: the TILED layout, rows allocated up to a multiple of 32): the operand
+ * format of s2c_planes_gemm below */
 int s2c_attn_local_fwd_planes(int R, int L, int H, int F, const float *mapped, const float *q,
                               int ldq, const float *wa, float ba, const float *valid,
                               const float *feats, float *alpha, float *att, int lda,
-                              unsigned short *planes, long long pstride, int ldp, void *stream);
+                              unsigned short *planes, long long pstride, int ldp, int tiled,
+                              void *stream);
 
 /* ---------------------------------------------------------------------------
  * Detection loss of get_scene_cap_loss (lib/loss_helper.py:24-187, :381-491;
@@ -677,25 +679,33 @@ int s2c_multi_rowsum(const s2c_rowsum_args *a, void *stream);
  * row-major with row stride ld (a multiple of 32 >= K, zero beyond K), plane j at p + j * pstride;
  * Y = A W^T is formed from the six plane products with i + j <= 2 in an fp32 accumulator
  * (the arithmetic of the rows GEMMs in s2c_gemm.hip).  A = up to two K segments side by side
- * ([x | h]: nothing is concatenated); segment 0 may be gathered by a row map. */
+ * ([x | h]: nothing is concatenated); segment 0 may be gathered by a row map.
+ * TILED planes (what the kernel streams fastest; W always, activations where no row map applies): the
+ * matrix (rows a multiple of 32 -- allocate up to the next multiple of 128 for an A operand --, ld a
+ * multiple of 16) as blocks of 32 rows x 16 columns = 1 KB ordered [row block][column block]; inside a
+ * block row r32 sits at 32 r32 bytes with its two 16-byte halves swapped where (r32 >> 3) & 1 -- the image
+ * one LDS-DMA instruction lands in LDS: element (r, k) at
+ *   ((r >> 5) (ld >> 4) + (k >> 4)) 512 + ((r & 31) 2 + (((k >> 3) & 1) ^ (((r & 31) >> 3) & 1))) 8 + (k & 7). */
 typedef struct s2c_planes_seg {
   const unsigned short *p;      /* plane 0 */
   long long pstride;            /* elements from one plane to the next */
   int ld;                       /* row stride in elements, a multiple of 8 */
   int kc;                       /* number of 32-column chunks of this segment */
   const int *rowmap;            /* NULL, or: output row r reads source row rowmap[r] */
-  int rowdiv, pad_;             /* > 0 (and rowmap NULL): output row r reads source row r / rowdiv */
+  int rowdiv;                   /* > 0 (and rowmap NULL): output row r reads source row r / rowdiv */
+  int tiled;                    /* 0: row-major planes; 1: TILED planes (below) -- no row map then */
 } s2c_planes_seg;
 
 typedef struct s2c_planes_gemm_args {
   int M, N;                     /* output rows; output columns (gru: hidden units, a multiple of 32) */
-  int gru, relu, nseg, pad0_;
+  int gru, relu, nseg;
+  int dbg;                      /* 0 (timing experiments: 1 = no products, 2 = no DMA) */
   s2c_planes_seg seg[2];
   /* greedy feedback: NULL, or (M x ntokkeys) arg-max keys as the `amax` output below leaves them;
    * segment 0 then reads source row = the column of the row's largest key (first maximum) */
   const unsigned long long *tokkeys;
   int ntokkeys, ldw;
-  /* W planes: ceil(N / 128) * 128 rows (gru: 4 N rows) x ldw, ldw = 32 * (seg[0].kc + seg[1].kc);
+  /* W planes, TILED: ceil(N / 128) * 128 rows (gru: 4 N rows) x ldw, ldw = 32 * (seg[0].kc + seg[1].kc);
    * gru: rows 128 c .. 128 c + 127 = [r | z | n_i | n_h] of units 32 c .. 32 c + 31, the n_i rows
    * zero in segment 1's columns and the n_h rows zero in segment 0's (those products are skipped) */
   const unsigned short *W;
@@ -709,14 +719,18 @@ typedef struct s2c_planes_gemm_args {
                                    out = n + z (hprev - n) (ATen's fused GRU cell) */
   unsigned long long *amax;     /* NULL or (M x namax): per 128-column tile the key of the row's maximum:
                                    (order-preserving bits of the value) << 32 | (2^32 - 1 - column) */
-  int ldadd, ldc, ldp, ldh, namax, pad1_;
+  int ldadd, ldc, ldp, ldh, namax;
+  int ptiled;                   /* P is written TILED */
+  int big_ok, pad_;             /* every tiled operand and W are allocated to multiples of 256 rows (W: 256
+                                   rows per 64 gru units): the 256 x 256 tile kernel may be used */
 } s2c_planes_gemm_args;
 int s2c_planes_gemm(const s2c_planes_gemm_args *a, void *stream);
+void s2c_planes_set_big(int mode);   /* 256 x 256 tiles: -1 by grid size (default), 0 never, 1 whenever big_ok */
 long long s2c_planes_args_sizeof(int which);   /* 0: s2c_planes_gemm_args, 1: s2c_planes_seg */
 /* planes of an fp32 matrix: X (rows_in x K, row stride ldx) -> P (3 x rows_out x ldp) bf16, zero in
  * rows >= rows_in and columns >= K; ldp a multiple of 8 */
 int s2c_planes_split(long long rows_in, int K, const float *X, long long ldx, long long rows_out,
-                     int ldp, unsigned short *P, long long pstride, void *stream);
+                     int ldp, unsigned short *P, long long pstride, int tiled, void *stream);
 
 #ifdef __cplusplus
 }

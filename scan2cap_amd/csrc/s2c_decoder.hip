@@ -805,7 +805,7 @@ __global__ __launch_bounds__(256) void attn_local_kernel(
     const float *__restrict__ q, int ldq, const float *__restrict__ wa, float ba,
     const float *__restrict__ valid, const float *__restrict__ feats,
     float *__restrict__ alpha, float *__restrict__ att, int lda,
-    unsigned short *__restrict__ planes, long long pstride, int ldp) {
+    unsigned short *__restrict__ planes, long long pstride, int ldp, int tiled) {
   constexpr int LM = LT > 0 ? LT : AL_MAXL;
   const int L = LT > 0 ? LT : Lrt;
   const int lane = threadIdx.x & 63;
@@ -867,7 +867,12 @@ __global__ __launch_bounds__(256) void attn_local_kernel(
       const float r1 = a - (float)h;
       const __bf16 m = (__bf16)r1;
       const __bf16 lo = (__bf16)(r1 - (float)m);
-      unsigned short *pp = planes + (size_t)r * ldp + f;
+      // (tiled: the 32-row x 16-column block layout of include/s2c_fused.h)
+      const int r32 = r & 31;
+      unsigned short *pp = planes + (tiled
+          ? ((size_t)(r >> 5) * (ldp >> 4) + (f >> 4)) * 512 +
+                ((r32 * 2 + (((f >> 3) & 1) ^ ((r32 >> 3) & 1))) << 3) + (f & 7)
+          : (size_t)r * ldp + f);
       pp[0] = __builtin_bit_cast(unsigned short, h);
       pp[pstride] = __builtin_bit_cast(unsigned short, m);
       pp[2 * pstride] = __builtin_bit_cast(unsigned short, lo);
@@ -1054,18 +1059,19 @@ extern "C" int s2c_attn_bwd_x2(int R, int K, int H, int F, int E, const float *d
 static int attn_local_launch(int R, int L, int H, int F, const float *mapped, const float *q,
                              int ldq, const float *wa, float ba, const float *valid,
                              const float *feats, float *alpha, float *att, int lda,
-                             unsigned short *planes, long long pstride, int ldp, void *stream) {
+                             unsigned short *planes, long long pstride, int ldp, int tiled,
+                             void *stream) {
   if (R <= 0 || L <= 0 || L > AL_MAXL || (H & 3) || (ldq & 3) || F <= 0 || !mapped || !q ||
       !wa || !feats || !alpha || (!att && !planes))
     return -1;
   if (L == 10)       // CONF default num_locals (scripts/train.py:332)
     hipLaunchKernelGGL(attn_local_kernel<10>, dim3((R + 3) / 4), dim3(256), 0,
                        (hipStream_t)stream, R, L, H, F, mapped, q, ldq, wa, ba, valid, feats,
-                       alpha, att, lda, planes, pstride, ldp);
+                       alpha, att, lda, planes, pstride, ldp, tiled);
   else
     hipLaunchKernelGGL(attn_local_kernel<0>, dim3((R + 3) / 4), dim3(256), 0,
                        (hipStream_t)stream, R, L, H, F, mapped, q, ldq, wa, ba, valid, feats,
-                       alpha, att, lda, planes, pstride, ldp);
+                       alpha, att, lda, planes, pstride, ldp, tiled);
   return chk("attn_local_fwd");
 }
 
@@ -1074,17 +1080,17 @@ extern "C" int s2c_attn_local_fwd(int R, int L, int H, int F, const float *mappe
                                   const float *valid, const float *feats, float *alpha,
                                   float *att, int lda, void *stream) {
   return attn_local_launch(R, L, H, F, mapped, q, ldq, wa, ba, valid, feats, alpha, att, lda,
-                           nullptr, 0, 0, stream);
+                           nullptr, 0, 0, 0, stream);
 }
 
 extern "C" int s2c_attn_local_fwd_planes(int R, int L, int H, int F, const float *mapped,
                                          const float *q, int ldq, const float *wa, float ba,
                                          const float *valid, const float *feats, float *alpha,
                                          float *att, int lda, unsigned short *planes,
-                                         long long pstride, int ldp, void *stream) {
-  if (planes == nullptr || ldp < F) return -1;
+                                         long long pstride, int ldp, int tiled, void *stream) {
+  if (planes == nullptr || ldp < F || (tiled && (ldp & 15))) return -1;
   return attn_local_launch(R, L, H, F, mapped, q, ldq, wa, ba, valid, feats, alpha, att, lda,
-                           planes, pstride, ldp, stream);
+                           planes, pstride, ldp, tiled, stream);
 }
 
 extern "C" int s2c_split_bf16x3(long long M, int K, const float *A, long long lda,

@@ -12,14 +12,18 @@
 // pure matrix-core loop: 12 `ds_read_b128` feed 24 MFMAs (the three planes of an A / W fragment
 // pair serve six products), no VALU work between them.
 //
-// Tile.  Workgroup = 4 waves on 128 rows x 128 columns, wave w = rows 32 w .. 32 w + 31 x all 128
+// Tile.  Workgroup = 128 rows x 128 columns; a wave = rows 32 w .. 32 w + 31 x all 128
 // columns (4 accumulator tiles of 32 x 32): the four gate pre-activations (r, z, n_i, n_h) of
 // a GRU unit then sit in the SAME lane and register of the four tiles and the GRU cell is the
 // GEMM's epilogue.  K walks in chunks of 32; a chunk of both operands (3 planes x 128 rows x 64 B
 // x 2 = 48 KB) is fetched by LDS-DMA (`global_load_lds_dwordx4`, no VGPR staging), rows of 64 B
 // with the 16-byte slot XOR-swizzled by (row >> 2) & 3 on the SOURCE address (the DMA writes
-// lane-linear), which makes the one-row-per-lane fragment reads conflict-free.  Single-buffered:
-// three workgroups per CU (145 KB of LDS, <= 168 VGPRs) overlap one's DMA with another's MFMAs.
+// lane-linear), which makes the one-row-per-lane fragment reads conflict-free.  The chunks go
+// through a ring of THREE stages (144 KB: one workgroup per CU) requested two chunks ahead, counted
+// with `s_waitcnt vmcnt(N)` and ONE raw `s_barrier` per chunk: the matrix pipe of every SIMD runs
+// back to back while 96 KB per CU are in flight.  (First version: one stage, three workgroups per
+// CU covering each other's DMA latency -- 0.36 of the bf16 roof on the classifier, 0.05-0.16 on
+// the narrow products whose grid does not fill the chip three times; tools/bench_planes.py.)
 // Workgroup ids are XCD-aware: the 8 row tiles r = x, x + 8, ... of XCD x walk the column tiles
 // together, so both operand tiles of a workgroup are L2 hits for all but the first toucher.
 //
@@ -37,6 +41,8 @@
 #include "../../include/s2c_fused.h"
 
 #include <stdio.h>
+#include <stdlib.h>
+#include <type_traits>
 
 using namespace s2c;
 
@@ -46,12 +52,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int PG_BM = 128, PG_BN = 128, PG_BK = 32;
-constexpr unsigned PG_PLANE_BYTES = 128 * 64;                 // one plane of one operand tile
-constexpr unsigned PG_W_BASE = 3 * PG_PLANE_BYTES;            // A planes, then W planes
-constexpr unsigned PG_TOK_BASE = 6 * PG_PLANE_BYTES;          // 128 ints: resolved row map
-constexpr unsigned PG_LDS_BYTES = PG_TOK_BASE + 128 * 4;
 
 __device__ __forceinline__ void pg_glds16(const void *gsrc, unsigned lds_dst) {
   unsigned keep;
@@ -87,257 +87,439 @@ __device__ __forceinline__ u64 pg_key(float v, int col) {
   return ((u64)o << 32) | (u64)(0xFFFFFFFFu - (u32)col);
 }
 
-__device__ __forceinline__ float pg_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+// TILED plane layout: a matrix is stored as blocks of 32 rows x 16 k = 1 KB, each block the exact
+// lane-linear image one LDS-DMA instruction lands in LDS (row r32 at 32 r32 bytes, its two 16-byte
+// halves swapped where (r32 >> 3) & 1), blocks ordered [row block][k block].  A DMA piece is then
+// 8 full cache lines instead of 32 half-used ones: the DMA path pays per line it touches (the
+// loop without products, classifier shape at R = 8192: 80 us with 64-byte row pieces, 137 us with
+// 32-byte ones, both from row-major planes).
+__device__ __forceinline__ long long pg_tiled_off(long long r, int k, int ld) {
+  const int r32 = (int)(r & 31);
+  return ((r >> 5) * (ld >> 4) + (k >> 4)) * 512 +
+         ((r32 * 2 + (((k >> 3) & 1) ^ ((r32 >> 3) & 1))) << 3) + (k & 7);
+}
 
-// GRU = true: N = hidden units; column tile c = units 32 c .. 32 c + 31 as the four 32-column
-// groups [r | z | n_i | n_h] (W rows 128 c ..), segment 0 = the cell's input x (groups r, z, n_i
-// multiply), segment 1 = the previous hidden state (groups r, z, n_h).
-template <bool GRU>
-__global__ __launch_bounds__(256, 3) void planes_gemm_kernel(s2c_planes_gemm_args a) {
+__device__ __forceinline__ float pg_fast_sigmoid(float x) {   // hardware exp2 / rcp: ~2e-7 absolute
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
+__device__ __forceinline__ float pg_fast_tanh(float x) {
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x * 2.8853900817779268f) + 1.0f);
+}
+
+// Geometry of a workgroup: WM = 4 row groups x WN column halves of waves; a wave = RT row tiles of
+// 32 x 4 column tiles of 32 (its 128 columns: the four gate groups of 32 GRU units).
+//   small (RT 1, WN 1): 4 waves, 128 x 128, stage 24 KB, two workgroups per CU
+//   big   (RT 2, WN 2): 8 waves, 256 x 256, stage 48 KB, one workgroup per CU
+// Either way a chunk of 16 k is (4 RT + 4 WN) blocks of 32 rows per operand plane = ONE LDS-DMA
+// instruction per wave, operand and plane (6 per wave and chunk).
+template <int RT, int WN>
+struct PgGeo {
+  static constexpr int WM = 4, NW = WM * WN;
+  static constexpr int BM = 32 * RT * WM, BN = 128 * WN;
+  static constexpr int ABLK = RT * WM, WBLK = 4 * WN;            // 32-row blocks per operand
+  static constexpr unsigned A_PLANE = 1024u * ABLK, W_PLANE = 1024u * WBLK;
+  static constexpr unsigned W_BASE = 3 * A_PLANE;
+  static constexpr unsigned STAGE = 3 * (A_PLANE + W_PLANE);
+  static constexpr unsigned TOK_BASE = 3 * STAGE;               // BM ints: resolved row map
+  static constexpr unsigned LDS = TOK_BASE + 4 * BM;
+};
+
+// one k-step of 16 of the staged chunk for the accumulator tiles in MASK (compile-time: straight-
+// line code, the W fragments of the next tile are requested before the products of this one)
+// `dma(k)`, k = 0..5, requests the wave's k-th LDS-DMA piece of the chunk two ahead: the pieces are
+// spread over the products (two per accumulator-tile group) instead of issued as one burst -- an
+// LDS-DMA instruction holds the wave's issue slot for ~110 cycles, and a burst of six at the top of
+// the chunk in BOTH waves of a SIMD left the matrix pipe idle for a third of the 256 x 256 loop.
+template <int MASK, int RT, unsigned A_PLANE, unsigned W_PLANE, typename DMA>
+__device__ __forceinline__ void pg_kstep(f32x16 (&acc)[RT][4], const unsigned char *stage,
+                                         unsigned fa_off, unsigned fw_off, DMA dma) {
+  bf16x8 fa[RT][3], fb[2][3];
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+      fa[i][pl] = *reinterpret_cast<const bf16x8 *>(stage + fa_off + pl * A_PLANE + i * 1024u);
+  constexpr int first = (MASK & 1) ? 0 : (MASK & 2) ? 1 : (MASK & 4) ? 2 : 3;
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl)
+    fb[0][pl] = *reinterpret_cast<const bf16x8 *>(stage + fw_off + pl * W_PLANE + first * 1024u);
+  constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+  int cur = 0, piece = 0;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    if (!((MASK >> nt) & 1)) continue;
+    int nxt = -1;
+#pragma unroll
+    for (int m = 3; m > nt; --m) if ((MASK >> m) & 1) nxt = m;
+    if (nxt >= 0) {
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        fb[cur ^ 1][pl] = *reinterpret_cast<const bf16x8 *>(stage + fw_off + pl * W_PLANE + nxt * 1024u);
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+#pragma unroll
+      for (int i = 0; i < RT; ++i)
+        acc[i][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][TA[q]], fb[cur][TB[q]], acc[i][nt], 0, 0, 0);
+      if (q == 1 || q == 3) {
+        __builtin_amdgcn_sched_barrier(0);
+        dma(piece++);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    cur ^= 1;
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k)
+    if (k >= piece) dma(k);
+}
+
+// GRU = true: N = hidden units; a wave's 128 columns = units 32 c .. 32 c + 31 as the four
+// 32-column groups [r | z | n_i | n_h] (W rows 128 c ..), segment 0 = the cell's input x (groups r,
+// z, n_i multiply), segment 1 = the previous hidden state (groups r, z, n_h).
+//
+// What shaped it (classifier shape R = 8192 x 512 -> 3500, tools/bench_planes.py + S2C_PLANES_DBG):
+// the LDS-DMA path delivers ~35 B/clk/CU whatever the layout of the source (row-major 64-byte or
+// 32-byte row pieces, or the tiled 1 KB blocks: ~110 cycles of a SIMD per instruction), i.e.
+// ~20 TB/s chip-wide, and a 128 x 128 tile needs 1 byte per 128 flop -- exactly the ratio of the
+// bf16 roof to that rate: DMA and MFMA time are equal (~75 us each) and every 128 x 128 variant
+// landed at 195-257 us (one 32-k stage x 3 workgroups per CU: 195; 3-stage ring, 1 workgroup per
+// CU: 257, nothing overlapped; the same as 8 waves = 2 k-halves per row group: 226; 3-stage ring
+// of 16-k chunks, 2 workgroups per CU: 233).  Hence the 256 x 256 tile (half the bytes per flop,
+// two waves per SIMD: one's DMA issue and fragment reads under the other's MFMAs) wherever the
+// grid still fills the chip, and the 128 x 128 tile with two workgroups per CU elsewhere.
+template <bool GRU, int RT, int WN>
+__global__ __launch_bounds__(64 * 4 * WN, WN == 1 ? 2 : 1) void planes_gemm_kernel(s2c_planes_gemm_args a) {
+  typedef PgGeo<RT, WN> G;
   extern __shared__ __attribute__((aligned(16))) unsigned char pg_smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 31, lk = lane >> 5;
   const int M = a.M, N = a.N;
 
   // ---- XCD-aware tile id: XCD x owns row tiles x, x + 8, ... and walks the column tiles ----
-  const int nrt = (M + PG_BM - 1) / PG_BM;
-  const int nct = GRU ? (N + 31) / 32 : (N + PG_BN - 1) / PG_BN;
-  const int RT = (nrt + 7) >> 3;
+  const int nrt = (M + G::BM - 1) / G::BM;
+  const int nct = GRU ? (N + 32 * WN - 1) / (32 * WN) : (N + G::BN - 1) / G::BN;
+  const int RTX = (nrt + 7) >> 3;
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-  const int ct = idx / RT, rt = (idx % RT) * 8 + xcd;
+  const int ct = idx / RTX, rt = (idx % RTX) * 8 + xcd;
   if (rt >= nrt || ct >= nct) return;
-  const int m0 = rt * PG_BM;
-  const int cbase = GRU ? ct * 32 : ct * PG_BN;       // first output column (GRU: first unit)
-  const long long wrow0 = (long long)ct * PG_BN;      // first W row of the tile
+  const int m0 = rt * G::BM;
+  // first output column of the WAVE (GRU: its first unit), first W row of the workgroup
+  const int cbase = GRU ? (ct * WN + wn) * 32 : ct * G::BN + 128 * wn;
+  const long long wrow0 = (long long)ct * G::BN;
 
-  // live 32-column groups (generic: those that start below N rounded up to 32)
+  // live 32-column groups of the wave (generic: those that start below N rounded up to 32)
   int live = 0xF;
   if (!GRU) {
     live = 0;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
       if (cbase + 32 * nt < ((N + 31) & ~31)) live |= 1 << nt;
+  } else if (cbase >= N) {
+    live = 0;
   }
 
   const unsigned lds0 = (unsigned)(size_t)pg_smem;
-  int *s_tok = reinterpret_cast<int *>(pg_smem + PG_TOK_BASE);
+  int *s_tok = reinterpret_cast<int *>(pg_smem + G::TOK_BASE);
 
   // ---- row map of segment 0 from the classifier's arg-max keys (greedy feedback) ----------
   if (a.tokkeys != nullptr) {
-    if (tid < PG_BM) {
-      const int row = m0 + tid < M ? m0 + tid : M - 1;
+    for (int t = tid; t < G::BM; t += 64 * G::NW) {
+      const int row = m0 + t < M ? m0 + t : M - 1;
       const u64 *kp = a.tokkeys + (long long)row * a.ntokkeys;
       u64 best = 0;
       for (int j = 0; j < a.ntokkeys; ++j) { const u64 k = kp[j]; best = k > best ? k : best; }
-      s_tok[tid] = (int)(0xFFFFFFFFu - (u32)best);
+      s_tok[t] = (int)(0xFFFFFFFFu - (u32)best);
     }
     __syncthreads();
   }
 
-  // ---- staging map: wave w fetches tile rows 32 w .. 32 w + 31 of both operands -------------
-  // piece j = 16 rows x 64 B = one LDS-DMA instruction per plane; lane -> (row lane >> 2, slot
-  // lane & 3), the slot holds source chunk slot ^ ((row >> 2) & 3)
-  const int sr = lane >> 2, sslot = lane & 3;
-  long long aoff[2][2];          // [segment][piece]: element offset of (source row, chunk col)
-  int scol[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int rr = 32 * wave + 16 * j + sr;
-    scol[j] = 8 * (sslot ^ ((rr >> 2) & 3));
+  // ---- staging map: wave w fetches 32-row block w of both operands (of RT WM resp. 4 WN) -----
+  // a block = 32 rows x 32 B (16 k) = one LDS-DMA instruction per plane; lane -> (row lane >> 1,
+  // 16-byte slot lane & 1), the slot holds source half slot ^ ((row >> 3) & 1): the one-row-per-
+  // lane fragment reads (ds_read_b128, 16 lanes per LDS cycle) then touch every bank once.  Tiled
+  // planes (include/s2c_fused.h) hold exactly this image: the DMA is a linear 1 KB copy.
+  const int kc0 = 2 * a.seg[0].kc, kct = kc0 + (a.nseg > 1 ? 2 * a.seg[1].kc : 0);   // chunks of 16 k
+  const bool stage_a = wave < G::ABLK, stage_wb = wave < G::WBLK;
+  long long aoff0, aoff1, woff;      // element offsets of the wave's first piece of a segment
+  int astep0 = 16, astep1 = 16;      // ... and from one 16-k chunk to the next
+  {
+    const int rr = 32 * wave + (lane >> 1);            // tile row of this lane's piece
+    const int scol = 8 * ((lane & 1) ^ ((rr >> 3) & 1));
     const int row = m0 + rr < M ? m0 + rr : M - 1;
+    const long long rb = (m0 >> 5) + wave;             // the wave's 32-row block of A
+    long long src = row;
+    if (a.tokkeys != nullptr) src = s_tok[stage_a ? rr : 0];
+    else if (a.seg[0].rowmap != nullptr) src = a.seg[0].rowmap[row];
+    else if (a.seg[0].rowdiv > 0) src = row / a.seg[0].rowdiv;
+    aoff0 = src * a.seg[0].ld + scol;
+    if (a.seg[0].tiled) { aoff0 = rb * (a.seg[0].ld >> 4) * 512 + lane * 8; astep0 = 512; }
+    src = row;
+    aoff1 = 0;
+    if (a.nseg > 1) {
+      if (a.seg[1].rowmap != nullptr) src = a.seg[1].rowmap[row];
+      else if (a.seg[1].rowdiv > 0) src = row / a.seg[1].rowdiv;
+      aoff1 = src * a.seg[1].ld + scol;
+      if (a.seg[1].tiled) { aoff1 = rb * (a.seg[1].ld >> 4) * 512 + lane * 8; astep1 = 512; }
+    }
+    woff = ((wrow0 >> 5) + wave) * (long long)(a.ldw >> 4) * 512 + lane * 8;     // W: always tiled
+  }
+  const unsigned short *p0 = a.seg[0].p, *p1 = a.seg[1].p;
+  const long long ps0 = a.seg[0].pstride, ps1 = a.seg[1].pstride;
+  const unsigned piece_off = (unsigned)wave * 1024u;
+
+  f32x16 acc[RT][4];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      long long src = row;
-      if (s < a.nseg) {
-        const s2c_planes_seg &sg = a.seg[s];
-        if (s == 0 && a.tokkeys != nullptr) src = s_tok[rr];
-        else if (sg.rowmap != nullptr) src = sg.rowmap[row];
-        else if (sg.rowdiv > 0) src = row / sg.rowdiv;
-        aoff[s][j] = src * sg.ld + scol[j];
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][nt][e] = 0.f;
+
+  // fragment addresses: row li of the wave's A blocks RT wm + i / of W block 4 wn + nt, 16-byte
+  // slot lk ^ f
+  const unsigned slot = ((unsigned)lk ^ (unsigned)((li >> 3) & 1)) * 16u;
+  const unsigned fa_off = (unsigned)(RT * wm) * 1024u + (unsigned)li * 32u + slot;
+  const unsigned fw_off = G::W_BASE + (unsigned)(4 * wn) * 1024u + (unsigned)li * 32u + slot;
+
+  // ---- K loop: a ring of three stages filled by LDS-DMA two chunks ahead ---------------------
+  // chunk g lives in stage g % 3.  Iteration c: wait until this wave's pieces of chunk c have
+  // landed (only the pieces of chunk c + 1 may still be in flight), ONE barrier (everybody's
+  // pieces landed; everybody is done reading stage (c + 2) % 3 = the stage of chunk c - 1),
+  // request chunk c + 2, multiply chunk c.  The barrier is the raw instruction: a
+  // __syncthreads() would also wait for the DMA just issued.
+  const int dbg = a.dbg;       // bench only: bit 0 = no MFMA, bit 1 = no DMA
+  // W blocks whose products are skipped are not fetched either (GRU: n_h in segment 0, n_i in 1)
+  auto chunk_wmask = [&](int g) { return GRU ? (g < kc0 ? 0x7 : 0xB) : 0xF; };
+  // the (up to) six pieces of chunk g: 0..2 the A block's planes, 3..5 the W block's
+  const unsigned short *dma_a = nullptr, *dma_w = nullptr;
+  long long dma_pst = 0;
+  unsigned dma_dst = 0;
+  auto prep = [&](int g, unsigned stage_base) -> int {       // returns the DMA count of the chunk
+    dma_a = dma_w = nullptr;
+    if (g >= kct || (dbg & 2)) return 0;
+    const bool s1 = g >= kc0;
+    const int lc = s1 ? g - kc0 : g;
+    dma_pst = s1 ? ps1 : ps0;
+    dma_dst = stage_base + piece_off;
+    int n = 0;
+    if (stage_a) {
+      dma_a = s1 ? p1 + aoff1 + (long long)astep1 * lc : p0 + aoff0 + (long long)astep0 * lc;
+      n += 3;
+    }
+    if (stage_wb && ((chunk_wmask(g) >> (wave & 3)) & 1)) {
+      dma_w = a.W + woff + 512ll * g;
+      n += 3;
+    }
+    return n;
+  };
+  auto piece = [&](int k) {
+    if (k < 3) {
+      if (dma_a != nullptr) pg_glds16(dma_a + k * dma_pst, dma_dst + k * G::A_PLANE);
+    } else if (k < 6 && dma_w != nullptr) {
+      pg_glds16(dma_w + (k - 3) * a.wpstride, dma_dst + G::W_BASE + (k - 3) * G::W_PLANE);
+    }
+  };
+  auto issue = [&](int g, unsigned stage_base) -> int {
+    const int n = prep(g, stage_base);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) piece(k);
+    return n;
+  };
+  int n_next;
+  issue(0, lds0);                                               // chunk 0 -> stage 0
+  n_next = issue(1, lds0 + G::STAGE);                           // chunk 1 -> stage 1
+  unsigned st_c = 0, st_n2 = 2;                                 // stage of chunk c / of chunk c + 2
+  // the chunk loop with the set of live accumulator tiles as a compile-time constant (as a run-
+  // time test inside the loop every tile's products sat in their own basic block: no fragment
+  // read ahead of a product, and the accumulators were copied between the blocks' registers)
+  auto run = [&](auto mask_c, int c_begin, int c_end) {
+    constexpr int MASK = decltype(mask_c)::value;
+    for (int c = c_begin; c < c_end; ++c) {
+      if (n_next == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (n_next == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      n_next = prep(c + 2, lds0 + st_n2 * G::STAGE);
+      if (MASK != 0 && !(dbg & 1)) {
+        pg_kstep<MASK == 0 ? 1 : MASK, RT, G::A_PLANE, G::W_PLANE>(acc, pg_smem + st_c * G::STAGE, fa_off,
+                                                                   fw_off, piece);
       } else {
-        aoff[s][j] = 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) piece(k);
       }
+      st_c = st_c == 2 ? 0 : st_c + 1;
+      st_n2 = st_n2 == 2 ? 0 : st_n2 + 1;
     }
-  }
-  long long woff[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-    woff[j] = (wrow0 + 32 * wave + 16 * j + sr) * (long long)a.ldw + scol[j];
-
-  f32x16 acc[4];
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
-
-  // fragment addresses: row li of the wave's A rows / of W group nt, 16-byte slot (2 s + lk) ^ f
-  const unsigned fsw = (unsigned)((li >> 2) & 3);
-  const unsigned fa_base = lds0 + (unsigned)(32 * wave + li) * 64u;
-  const unsigned fw_base = lds0 + PG_W_BASE + (unsigned)li * 64u;
-
-  int wchunk = 0;                                   // chunk index along W's K
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {                     // (unrolled: aoff[s] stays in registers)
-    if (s >= a.nseg) break;
-    const s2c_planes_seg sg = a.seg[s];
-    const int mask = GRU ? (s == 0 ? 0x7 : 0xB) : live;
-    const bool stage_w = (mask >> wave) & 1;
-    for (int c = 0; c < sg.kc; ++c, ++wchunk) {
-      // ---- fetch the chunk ----
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const unsigned short *ap = sg.p + aoff[s][j] + 32 * c;
-        const unsigned dst = lds0 + (unsigned)(32 * wave + 16 * j) * 64u;
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          pg_glds16(ap + pl * sg.pstride, dst + pl * PG_PLANE_BYTES);
-        if (stage_w) {
-          const unsigned short *wp = a.W + woff[j] + 32 * wchunk;
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl)
-            pg_glds16(wp + pl * a.wpstride, dst + PG_W_BASE + pl * PG_PLANE_BYTES);
-        }
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      // ---- 2 k-steps of 16: 3 A fragments, per live group 3 W fragments and 6 products ----
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const unsigned slot = ((unsigned)(2 * ks + lk) ^ fsw) * 16u;
-        bf16x8 fa[3];
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          fa[pl] = *reinterpret_cast<const bf16x8 *>(
-              pg_smem + (fa_base - lds0) + pl * PG_PLANE_BYTES + slot);
-        constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          if (!((mask >> nt) & 1)) continue;
-          bf16x8 fb[3];
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl)
-            fb[pl] = *reinterpret_cast<const bf16x8 *>(
-                pg_smem + (fw_base - lds0) + pl * PG_PLANE_BYTES + (unsigned)nt * 2048u + slot);
-#pragma unroll
-          for (int q = 0; q < 6; ++q)
-            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[TA[q]], fb[TB[q]], acc[nt], 0, 0, 0);
-        }
-      }
-      __syncthreads();                               // the tiles are overwritten next
+  };
+  if (GRU) {
+    if (live) {
+      run(std::integral_constant<int, 0x7>(), 0, kc0);
+      run(std::integral_constant<int, 0xB>(), kc0, kct);
+    } else {
+      run(std::integral_constant<int, 0>(), 0, kct);
     }
+  } else if (live == 0xF) {
+    run(std::integral_constant<int, 0xF>(), 0, kct);
+  } else if (live == 0x7) {
+    run(std::integral_constant<int, 0x7>(), 0, kct);
+  } else if (live == 0x3) {
+    run(std::integral_constant<int, 0x3>(), 0, kct);
+  } else if (live == 0x1) {
+    run(std::integral_constant<int, 0x1>(), 0, kct);
+  } else {
+    run(std::integral_constant<int, 0>(), 0, kct);             // a wave beyond N: DMA and barriers only
   }
+  __syncthreads();                                   // the staging tiles are dead from here on
+  if (live == 0) return;
 
   // ------------------------------------------------------------------------------------------
   // epilogue.  C/D layout of 32x32: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5).
-  // Through a wave-private 32 x 32 fp32 patch (the staging tiles are dead: every wave passed the
-  // barrier above) each lane gets 8 consecutive columns of rows (lane >> 2) and (lane >> 2) + 16.
+  // Through a wave-private 32 x 32 fp32 patch (the staging tiles are dead) each lane gets 8
+  // consecutive columns of rows (lane >> 2), (lane >> 2) + 16.
   float *patch = reinterpret_cast<float *>(pg_smem) + wave * 1024;
   const int prow = lane >> 2, pcol = 8 * (lane & 3);
+  const int mrow0 = m0 + 32 * RT * wm;                 // first row of the wave
 
   if (GRU) {
     const int u = cbase + li;
     const bool uok = u < N;
     const float br = uok ? a.bias[u] : 0.f, bz = uok ? a.bias[N + u] : 0.f;
     const float bni = uok ? a.bias[2 * N + u] : 0.f, bnh = uok ? a.bias[3 * N + u] : 0.f;
-    float hp[16];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int row = m0 + 32 * wave + (e & 3) + 8 * (e >> 2) + 4 * lk;
-      hp[e] = (row < M && uok) ? a.hprev[(long long)row * a.ldh + u] : 0.f;
-    }
+    for (int i = 0; i < RT; ++i) {
+      float hp[16];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const float r = pg_sigmoid(acc[0][e] + br);
-      const float z = pg_sigmoid(acc[1][e] + bz);
-      const float n = tanhf((acc[2][e] + bni) + r * (acc[3][e] + bnh));
-      acc[0][e] = n + z * (hp[e] - n);
+      for (int e = 0; e < 16; ++e) {
+        const int row = mrow0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lk;
+        hp[e] = (row < M && uok) ? a.hprev[(long long)row * a.ldh + u] : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float r = pg_fast_sigmoid(acc[i][0][e] + br);
+        const float z = pg_fast_sigmoid(acc[i][1][e] + bz);
+        const float n = pg_fast_tanh((acc[i][2][e] + bni) + r * (acc[i][3][e] + bnh));
+        acc[i][0][e] = n + z * (hp[e] - n);
+      }
     }
   }
 
-  u64 best[2] = {0, 0};
+  // bias of all live tiles requested before the first patch round trip (a load per tile inside
+  // the loop below was a chain of L2 latencies)
+  float bv[GRU ? 1 : 4][8];
+  if (!GRU) {
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) {
-    if (GRU ? nt > 0 : !((live >> nt) & 1)) continue;
+    for (int nt = 0; nt < 4; ++nt) {
+      const int col0 = cbase + 32 * nt + pcol;
 #pragma unroll
-    for (int e = 0; e < 16; ++e)
-      patch[((e & 3) + 8 * (e >> 2) + 4 * lk) * 32 + li] = acc[nt][e];
-    __builtin_amdgcn_wave_barrier();
-    const int col0 = cbase + 32 * nt + pcol;        // first of the lane's 8 columns
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int row = m0 + 32 * wave + prow + 16 * p;
-      const float4 v0 = *reinterpret_cast<const float4 *>(patch + (prow + 16 * p) * 32 + pcol);
-      const float4 v1 = *reinterpret_cast<const float4 *>(patch + (prow + 16 * p) * 32 + pcol + 4);
-      float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-      if (row >= M) continue;
-      if (!GRU) {
-        const bool full = col0 + 8 <= N;
-        if (a.bias != nullptr) {
-          if (full) {
-            const float4 b0 = *reinterpret_cast<const float4 *>(a.bias + col0);
-            const float4 b1 = *reinterpret_cast<const float4 *>(a.bias + col0 + 4);
-            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-            v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-          } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) if (col0 + i < N) v[i] += a.bias[col0 + i];
-          }
-        }
-        if (a.add != nullptr) {
-          const float *ad = a.add + (long long)row * a.ldadd + col0;
-          if (full && (a.ldadd & 3) == 0) {
-            const float4 b0 = *reinterpret_cast<const float4 *>(ad);
-            const float4 b1 = *reinterpret_cast<const float4 *>(ad + 4);
-            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-            v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-          } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) if (col0 + i < N) v[i] += ad[i];
-          }
-        }
-        if (a.relu) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) if (col0 + i >= N) v[i] = 0.f;   // plane padding stays finite
-        if (a.amax != nullptr) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i)
-            if (col0 + i < N) { const u64 k = pg_key(v[i], col0 + i); best[p] = k > best[p] ? k : best[p]; }
-        }
-      }
-      if (a.C != nullptr) {
-        float *cp = a.C + (long long)row * a.ldc + col0;
-        if (col0 + 8 <= N && (a.ldc & 3) == 0) {
-          *reinterpret_cast<float4 *>(cp) = make_float4(v[0], v[1], v[2], v[3]);
-          *reinterpret_cast<float4 *>(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      for (int i = 0; i < 8; ++i) bv[nt][i] = 0.f;
+      if (a.bias != nullptr && ((live >> nt) & 1)) {
+        if (col0 + 8 <= N) {
+          const float4 b0 = *reinterpret_cast<const float4 *>(a.bias + col0);
+          const float4 b1 = *reinterpret_cast<const float4 *>(a.bias + col0 + 4);
+          bv[nt][0] = b0.x; bv[nt][1] = b0.y; bv[nt][2] = b0.z; bv[nt][3] = b0.w;
+          bv[nt][4] = b1.x; bv[nt][5] = b1.y; bv[nt][6] = b1.z; bv[nt][7] = b1.w;
         } else {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) if (col0 + i < N) cp[i] = v[i];
+          for (int i = 0; i < 8; ++i) if (col0 + i < N) bv[nt][i] = a.bias[col0 + i];
         }
       }
-      if (a.P != nullptr && col0 < a.ldp) {          // ldp: a multiple of 32 >= N
-        uint4 h, m, l;
-        pg_split8(v, h, m, l);
-        unsigned short *pp = a.P + (long long)row * a.ldp + col0;
-        *reinterpret_cast<uint4 *>(pp) = h;
-        *reinterpret_cast<uint4 *>(pp + a.ppstride) = m;
-        *reinterpret_cast<uint4 *>(pp + 2 * a.ppstride) = l;
-      }
     }
-    __builtin_amdgcn_wave_barrier();
   }
-  if (!GRU && a.amax != nullptr) {
-    // a row's 128 columns sit in the 4 lanes of a quad: fold, lane 0 of the quad writes
+
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      u64 k = best[p];
-      k = umax64(k, dpp_mov_u64<DPP_QUAD_1032>(k));
-      k = umax64(k, dpp_mov_u64<DPP_QUAD_2301>(k));
-      const int row = m0 + 32 * wave + prow + 16 * p;
-      if ((lane & 3) == 0 && row < M) a.amax[(long long)row * a.namax + ct] = k;
+  for (int i = 0; i < RT; ++i) {
+    u64 best[2] = {0, 0};
+    // the row addends of this row tile, all live column tiles at once
+    float av[GRU ? 1 : 4][GRU ? 1 : 2][8];
+    if (!GRU) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const int col0 = cbase + 32 * nt + pcol;
+          const int row = mrow0 + 32 * i + prow + 16 * p;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) av[nt][p][q] = 0.f;
+          if (a.add != nullptr && ((live >> nt) & 1)) {
+            const float *ad = a.add + (long long)(row < M ? row : M - 1) * a.ldadd + col0;
+            if (col0 + 8 <= N && (a.ldadd & 3) == 0) {
+              const float4 b0 = *reinterpret_cast<const float4 *>(ad);
+              const float4 b1 = *reinterpret_cast<const float4 *>(ad + 4);
+              av[nt][p][0] = b0.x; av[nt][p][1] = b0.y; av[nt][p][2] = b0.z; av[nt][p][3] = b0.w;
+              av[nt][p][4] = b1.x; av[nt][p][5] = b1.y; av[nt][p][6] = b1.z; av[nt][p][7] = b1.w;
+            } else {
+#pragma unroll
+              for (int q = 0; q < 8; ++q) if (col0 + q < N) av[nt][p][q] = ad[q];
+            }
+          }
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      if (GRU ? nt > 0 : !((live >> nt) & 1)) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        patch[((e & 3) + 8 * (e >> 2) + 4 * lk) * 32 + li] = acc[i][nt][e];
+      __builtin_amdgcn_wave_barrier();
+      const int col0 = cbase + 32 * nt + pcol;        // first of the lane's 8 columns
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int row = mrow0 + 32 * i + prow + 16 * p;
+        const float4 v0 = *reinterpret_cast<const float4 *>(patch + (prow + 16 * p) * 32 + pcol);
+        const float4 v1 = *reinterpret_cast<const float4 *>(patch + (prow + 16 * p) * 32 + pcol + 4);
+        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        if (row >= M) continue;
+        if (!GRU) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] = (v[q] + bv[GRU ? 0 : nt][q]) + av[GRU ? 0 : nt][GRU ? 0 : p][q];
+          if (a.relu) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) if (col0 + q >= N) v[q] = 0.f;   // plane padding stays finite
+          if (a.amax != nullptr) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+              if (col0 + q < N) { const u64 k = pg_key(v[q], col0 + q); best[p] = k > best[p] ? k : best[p]; }
+          }
+        }
+        if (a.C != nullptr) {
+          float *cp = a.C + (long long)row * a.ldc + col0;
+          if (col0 + 8 <= N && (a.ldc & 3) == 0) {
+            *reinterpret_cast<float4 *>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4 *>(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+          } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) if (col0 + q < N) cp[q] = v[q];
+          }
+        }
+        if (a.P != nullptr && col0 < a.ldp) {          // ldp: a multiple of 32 >= N
+          uint4 h, m, l;
+          pg_split8(v, h, m, l);
+          unsigned short *pp = a.P + (a.ptiled ? pg_tiled_off(row, col0, a.ldp) : (long long)row * a.ldp + col0);
+          *reinterpret_cast<uint4 *>(pp) = h;
+          *reinterpret_cast<uint4 *>(pp + a.ppstride) = m;
+          *reinterpret_cast<uint4 *>(pp + 2 * a.ppstride) = l;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (!GRU && a.amax != nullptr) {
+      // a row's 128 columns of this wave sit in the 4 lanes of a quad: fold, lane 0 of the quad
+      // writes the key of 128-column tile cbase / 128
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        u64 k = best[p];
+        k = umax64(k, dpp_mov_u64<DPP_QUAD_1032>(k));
+        k = umax64(k, dpp_mov_u64<DPP_QUAD_2301>(k));
+        const int row = mrow0 + 32 * i + prow + 16 * p;
+        if ((lane & 3) == 0 && row < M) a.amax[(long long)row * a.namax + (cbase >> 7)] = k;
+      }
     }
   }
 }
@@ -345,7 +527,7 @@ __global__ __launch_bounds__(256, 3) void planes_gemm_kernel(s2c_planes_gemm_arg
 // fp32 (rows_in x K, row stride ldx) -> planes (3 x rows_out x ldp) bf16, zero beyond the matrix
 __global__ __launch_bounds__(256) void planes_split_kernel(
     long long rows_in, int K, const float *__restrict__ X, long long ldx, long long rows_out,
-    int ldp, unsigned short *__restrict__ P, long long pstride) {
+    int ldp, unsigned short *__restrict__ P, long long pstride, int tiled) {
   const int per_row = ldp >> 3;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= rows_out * per_row) return;
@@ -368,7 +550,7 @@ __global__ __launch_bounds__(256) void planes_split_kernel(
   }
   uint4 h, m, l;
   pg_split8(v, h, m, l);
-  unsigned short *pp = P + r * ldp + k;
+  unsigned short *pp = P + (tiled ? pg_tiled_off(r, k, ldp) : r * ldp + k);
   *reinterpret_cast<uint4 *>(pp) = h;
   *reinterpret_cast<uint4 *>(pp + pstride) = m;
   *reinterpret_cast<uint4 *>(pp + 2 * pstride) = l;
@@ -383,22 +565,26 @@ int pg_chk(const char *k) {
   return 0;
 }
 
-template <bool GRU>
+template <bool GRU, int RT, int WN>
 int pg_launch(const s2c_planes_gemm_args &a, hipStream_t st) {
+  typedef PgGeo<RT, WN> G;
   static int attr_state[64];                   // per device: 0 unknown, 1 ok, -1 refused
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
   if (attr_state[dev] == 0)
-    attr_state[dev] = hipFuncSetAttribute((const void *)planes_gemm_kernel<GRU>,
+    attr_state[dev] = hipFuncSetAttribute((const void *)planes_gemm_kernel<GRU, RT, WN>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)PG_LDS_BYTES) == hipSuccess ? 1 : -1;
+                                          (int)G::LDS) == hipSuccess ? 1 : -1;
   if (attr_state[dev] < 0) return -3;
-  const int nrt = (a.M + PG_BM - 1) / PG_BM;
-  const int nct = GRU ? (a.N + 31) / 32 : (a.N + PG_BN - 1) / PG_BN;
-  const int RT = (nrt + 7) / 8;
-  hipLaunchKernelGGL(planes_gemm_kernel<GRU>, dim3(8 * RT * nct), dim3(256), PG_LDS_BYTES, st, a);
+  const int nrt = (a.M + G::BM - 1) / G::BM;
+  const int nct = GRU ? (a.N + 32 * WN - 1) / (32 * WN) : (a.N + G::BN - 1) / G::BN;
+  const int RTX = (nrt + 7) / 8;
+  hipLaunchKernelGGL((planes_gemm_kernel<GRU, RT, WN>), dim3(8 * RTX * nct), dim3(64 * G::NW), G::LDS,
+                     st, a);
   return pg_chk("planes_gemm");
 }
+
+int g_pg_big = -1;       // S2C_PLANES_BIG: -1 auto, 0 never, 1 always (where the operands allow)
 
 }  // namespace
 
@@ -406,27 +592,48 @@ extern "C" int s2c_planes_gemm(const s2c_planes_gemm_args *a, void *stream) {
   if (a == nullptr || a->M <= 0 || a->N <= 0 || a->nseg < 1 || a->nseg > 2 || a->W == nullptr ||
       (a->ldw & 31))
     return -1;
-  for (int s = 0; s < a->nseg; ++s)
-    if (a->seg[s].p == nullptr || a->seg[s].kc <= 0 || (a->seg[s].ld & 7)) return -1;
+  for (int s = 0; s < a->nseg; ++s) {
+    const s2c_planes_seg &g = a->seg[s];
+    if (g.p == nullptr || g.kc <= 0 || (g.ld & 7)) return -1;
+    // a tiled segment is read block-wise: no row map, whole 16-k blocks
+    if (g.tiled && ((g.ld & 15) || g.rowmap != nullptr || g.rowdiv > 0 ||
+                    (s == 0 && a->tokkeys != nullptr)))
+      return -1;
+  }
   if (a->P != nullptr && ((a->ldp & 31) || a->ldp < a->N)) return -1;
   if (a->tokkeys != nullptr && a->ntokkeys <= 0) return -1;
+  if (g_pg_big == -1) {
+    const char *e = getenv("S2C_PLANES_BIG");
+    g_pg_big = e ? atoi(e) + 2 : 1;                // 1 auto, 2 never, 3 always
+  }
+  // 256 x 256 tiles where their grid still covers the chip (>= 192 workgroups); they read whole
+  // 256-row / 256-column groups of blocks: the caller allocates operands to multiples of 256
+  // (a->big_ok) -- models/greedy_fused.py does
+  const long long tiles_big = (long long)((a->M + 255) / 256) *
+                              (a->gru ? (a->N + 63) / 64 : (a->N + 255) / 256);
+  const bool big = a->big_ok && (g_pg_big == 3 || (g_pg_big == 1 && tiles_big >= 192));
   if (a->gru) {
     if (a->nseg != 2 || a->bias == nullptr || a->hprev == nullptr || (a->N & 31)) return -1;
-    return pg_launch<true>(*a, (hipStream_t)stream);
+    return big ? pg_launch<true, 2, 2>(*a, (hipStream_t)stream)
+               : pg_launch<true, 1, 1>(*a, (hipStream_t)stream);
   }
-  if (a->amax != nullptr && a->namax < (a->N + PG_BN - 1) / PG_BN) return -1;
-  return pg_launch<false>(*a, (hipStream_t)stream);
+  if (a->amax != nullptr && a->namax < (a->N + 127) / 128) return -1;
+  return big ? pg_launch<false, 2, 2>(*a, (hipStream_t)stream)
+             : pg_launch<false, 1, 1>(*a, (hipStream_t)stream);
 }
+
+// -1: by grid size (default), 0: never, 1: wherever the operands allow -- the 256 x 256 tile kernel
+extern "C" void s2c_planes_set_big(int mode) { g_pg_big = mode < 0 ? 1 : (mode == 0 ? 2 : 3); }
 
 extern "C" int s2c_planes_split(long long rows_in, int K, const float *X, long long ldx,
                                 long long rows_out, int ldp, unsigned short *P,
-                                long long pstride, void *stream) {
+                                long long pstride, int tiled, void *stream) {
   if (rows_out <= 0 || rows_in < 0 || rows_in > rows_out || K < 0 || (ldp & 7) || ldp < K ||
-      P == nullptr || (rows_in > 0 && X == nullptr))
+      P == nullptr || (rows_in > 0 && X == nullptr) || (tiled && ((rows_out & 31) || (ldp & 15))))
     return -1;
   const long long n = rows_out * (ldp >> 3);
   hipLaunchKernelGGL(planes_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, rows_in, K, X, ldx, rows_out, ldp, P, pstride);
+                     (hipStream_t)stream, rows_in, K, X, ldx, rows_out, ldp, P, pstride, tiled);
   return pg_chk("planes_split");
 }
 

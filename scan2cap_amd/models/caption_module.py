@@ -415,8 +415,12 @@ class TopDownSceneCaptionModule(nn.Module):
                                  dim=-1)[0]
             # relation t of target k lands on its t-th adjacency neighbour; add it
             # wherever that neighbour is one of the attended objects
-            hit = (att_ids.unsqueeze(-1) == nbr.unsqueeze(-2)).to(rel.dtype)  # (B,K,La,Ln)
-            local = local + torch.matmul(hit, rel)
+            # (the adjacency ids of a row are distinct: at most ONE relation lands on an attended
+            # object -- a gather, not the (La x Ln) x (Ln x F) product per row)
+            hit = att_ids.unsqueeze(-1) == nbr.unsqueeze(-2)                  # (B,K,La,Ln)
+            pos = hit.to(torch.uint8).argmax(-1)                              # (B,K,La)
+            add = torch.gather(rel, 2, pos.unsqueeze(-1).expand(B, K, L, F_))
+            local = local + add * hit.any(-1).unsqueeze(-1).to(rel.dtype)
         local = local.reshape(R, L, F_)
         T = max_len - 1
         ids = att_ids.reshape(R, L)

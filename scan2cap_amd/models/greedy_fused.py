@@ -25,22 +25,34 @@ _I, _P, _LL = ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong
 class _Seg(ctypes.Structure):
     """include/s2c_fused.h: s2c_planes_seg"""
     _fields_ = [("p", _P), ("pstride", _LL), ("ld", _I), ("kc", _I), ("rowmap", _P),
-                ("rowdiv", _I), ("pad_", _I)]
+                ("rowdiv", _I), ("tiled", _I)]
 
 
 class _GemmArgs(ctypes.Structure):
     """include/s2c_fused.h: s2c_planes_gemm_args"""
-    _fields_ = [("M", _I), ("N", _I), ("gru", _I), ("relu", _I), ("nseg", _I), ("pad0_", _I),
+    _fields_ = [("M", _I), ("N", _I), ("gru", _I), ("relu", _I), ("nseg", _I), ("dbg", _I),
                 ("seg", _Seg * 2), ("tokkeys", _P), ("ntokkeys", _I), ("ldw", _I), ("W", _P),
                 ("wpstride", _LL), ("bias", _P), ("add", _P), ("C", _P), ("P", _P),
                 ("ppstride", _LL), ("hprev", _P), ("amax", _P), ("ldadd", _I), ("ldc", _I),
-                ("ldp", _I), ("ldh", _I), ("namax", _I), ("pad1_", _I)]
+                ("ldp", _I), ("ldh", _I), ("namax", _I), ("ptiled", _I), ("big_ok", _I),
+                ("pad_", _I)]
 
 
 _C.register("s2c_planes_gemm", [_P, _P])
-_C.register("s2c_planes_split", [_LL, _I, _P, _LL, _LL, _I, _P, _LL, _P])
+_C.register("s2c_planes_split", [_LL, _I, _P, _LL, _LL, _I, _P, _LL, _I, _P])
 _C.register("s2c_attn_local_fwd_planes", [_I, _I, _I, _I, _P, _P, _I, _P, ctypes.c_float, _P, _P,
-                                          _P, _P, _I, _P, _LL, _I, _P])
+                                          _P, _P, _I, _P, _LL, _I, _I, _P])
+
+
+DEBUG = 0      # tools/bench_planes.py: 1 = no products, 2 = no DMA (timing experiments only)
+
+
+def set_big(mode):
+    """256 x 256 tiles: -1 = where the grid still covers the chip (default), 0 never, 1 always."""
+    lib = _C.load()
+    lib.s2c_planes_set_big.argtypes = [_I]
+    lib.s2c_planes_set_big.restype = None
+    lib.s2c_planes_set_big(int(mode))
 
 
 def _up(n, m):
@@ -48,19 +60,34 @@ def _up(n, m):
 
 
 class Planes(object):
-    """bf16x3 planes of a (rows x K) matrix: tensor t (3, rows_alloc, ld) bf16."""
+    """bf16x3 planes of a (rows x K) matrix: tensor t (3, rows_alloc, ld) bf16.  tiled (default):
+    the 32-row x 16-column block layout the kernel streams (include/s2c_fused.h), rows allocated
+    up to a multiple of 256 (the big tile reads whole 256-row groups); tiled=False: row-major, for operands gathered through a row map."""
 
-    def __init__(self, rows, ld, device, zero=False):
-        self.rows, self.ld = rows, ld
-        self.t = (torch.zeros if zero else torch.empty)((3, rows, ld), dtype=torch.bfloat16,
-                                                        device=device)
-        self.pstride = rows * ld
+    def __init__(self, rows, ld, device, zero=False, tiled=True):
+        self.rows, self.ld, self.tiled = rows, ld, tiled
+        self.rows_alloc = _up(rows, 256) if tiled else rows
+        assert ld % (16 if tiled else 8) == 0
+        self.t = (torch.zeros if zero else torch.empty)((3, self.rows_alloc, ld),
+                                                        dtype=torch.bfloat16, device=device)
+        self.pstride = self.rows_alloc * ld
 
     def ptr(self):
         return self.t.data_ptr()
 
+    def dense(self):
+        """(3, rows, ld) row-major view / copy of the planes (tests)."""
+        if not self.tiled:
+            return self.t[:, :self.rows]
+        t = self.t.view(3, self.rows_alloc // 32, self.ld // 16, 32, 2, 8)
+        r8 = (torch.arange(32, device=t.device) >> 3) & 1
+        # slot s of row r32 holds half s ^ r8: undo the swap
+        sw = torch.where(r8.view(32, 1, 1).bool(), t.flip(4), t)
+        out = sw.permute(0, 1, 3, 2, 4, 5).reshape(3, self.rows_alloc, self.ld)
+        return out[:, :self.rows]
 
-def split(x, rows_out=None, ld=None):
+
+def split(x, rows_out=None, ld=None, tiled=True):
     """fp32 (rows, K) [unit column stride] -> Planes, zero padded to (rows_out, ld)."""
     assert x.dim() == 2 and x.dtype == torch.float32 and x.is_cuda
     if x.stride(1) != 1:
@@ -68,10 +95,10 @@ def split(x, rows_out=None, ld=None):
     rows, K = x.shape
     rows_out = rows if rows_out is None else rows_out
     ld = _up(K, 32) if ld is None else ld
-    out = Planes(rows_out, ld, x.device)
+    out = Planes(rows_out, ld, x.device, tiled=tiled)
     with torch.cuda.device(x.device):
-        _C.call("s2c_planes_split", rows, K, x.data_ptr(), x.stride(0), rows_out, ld, out.ptr(),
-                out.pstride, _C.stream_ptr())
+        _C.call("s2c_planes_split", rows, K, x.data_ptr(), x.stride(0), out.rows_alloc, ld,
+                out.ptr(), out.pstride, int(tiled), _C.stream_ptr())
     return out
 
 
@@ -79,12 +106,18 @@ def gemm(M, N, segs, W, bias=None, add=None, relu=False, C=None, P=None, gru=Fal
          amax=None, tokkeys=None):
     """One s2c_planes_gemm launch.  segs: list of (Planes, kc[, rowmap tensor | rowdiv int])."""
     a = _GemmArgs()
-    a.M, a.N, a.gru, a.relu, a.nseg = M, N, int(gru), int(relu), len(segs)
+    a.M, a.N, a.gru, a.relu, a.nseg, a.dbg = M, N, int(gru), int(relu), len(segs), DEBUG
     kct = 0
+    big_ok = True
     for i, sg in enumerate(segs):
         pl, kc = sg[0], sg[1]
         a.seg[i].p, a.seg[i].pstride, a.seg[i].ld, a.seg[i].kc = pl.ptr(), pl.pstride, pl.ld, kc
+        a.seg[i].tiled = int(pl.tiled)
         assert 32 * kc <= pl.ld
+        mapped = (len(sg) > 2 and sg[2] is not None) or (i == 0 and tokkeys is not None)
+        assert not (pl.tiled and mapped), "a gathered operand must be row-major planes"
+        assert mapped or pl.rows >= M
+        big_ok = big_ok and (mapped or pl.rows_alloc >= _up(M, 256))
         if len(sg) > 2 and sg[2] is not None:
             if torch.is_tensor(sg[2]):
                 assert sg[2].dtype == torch.int32 and sg[2].is_contiguous()
@@ -93,8 +126,9 @@ def gemm(M, N, segs, W, bias=None, add=None, relu=False, C=None, P=None, gru=Fal
                 a.seg[i].rowdiv = int(sg[2])
         kct += kc
     assert W.ld == 32 * kct, (W.ld, kct)
-    assert W.rows >= (4 * N if gru else _up(N, 128))
+    assert W.tiled and W.rows_alloc >= (4 * N if gru else _up(N, 128))
     a.W, a.wpstride, a.ldw = W.ptr(), W.pstride, W.ld
+    a.big_ok = int(big_ok and W.rows_alloc >= (_up(N, 64) * 4 if gru else _up(N, 256)))
     if tokkeys is not None:
         a.tokkeys, a.ntokkeys = tokkeys.data_ptr(), tokkeys.shape[1]
     if bias is not None:
@@ -107,7 +141,8 @@ def gemm(M, N, segs, W, bias=None, add=None, relu=False, C=None, P=None, gru=Fal
         assert C.stride(1) == 1 and C.dtype == torch.float32
         a.C, a.ldc = C.data_ptr(), C.stride(0)
     if P is not None:
-        a.P, a.ppstride, a.ldp = P.ptr(), P.pstride, P.ld
+        a.P, a.ppstride, a.ldp, a.ptiled = P.ptr(), P.pstride, P.ld, int(P.tiled)
+        assert P.rows >= M
     if hprev is not None:
         a.hprev, a.ldh = hprev.data_ptr(), hprev.stride(0)
     if amax is not None:
@@ -183,7 +218,7 @@ def _weights(mod):
         V = mod.classifier.weight.shape[0]
         w["Wc"] = split(mod.classifier.weight.detach(), rows_out=_up(V, 128))
         w["b_cls"] = mod.classifier.bias.detach().contiguous()
-        w["emb"] = split(mod._emb_table.detach(), ld=Ep)
+        w["emb"] = split(mod._emb_table.detach(), ld=Ep, tiled=False)     # gathered by token
     _WEIGHTS[id(mod)] = (key, w)
     return w
 
@@ -199,7 +234,7 @@ def decode(mod, sos, rows_per_scene, target_feats, local, T):
         w = _weights(mod)
         Ep, Fp = w["Ep"], w["Fp"]
         nct = (V + 127) // 128
-        sos_p = split(sos.contiguous(), ld=Ep)
+        sos_p = split(sos.contiguous(), ld=Ep, tiled=False)             # gathered: row r / K
         tf_p = split(target_feats.contiguous(), ld=Fp)
         P_tf = torch.empty(R, E, device=dev)
         gemm(R, E, [(tf_p, Fp // 32)], w["Wtf"], bias=w["b_td"], C=P_tf)
@@ -231,7 +266,7 @@ def decode(mod, sos, rows_per_scene, target_feats, local, T):
                 _C.TIMER.alg_bytes = 4 * (R * L * (H + F_ + 1) + R * (H + F_))
             _C.call("s2c_attn_local_fwd_planes", R, L, H, F_, mapped.data_ptr(), qh.data_ptr(), H,
                     w["wa"].data_ptr(), 0.0, None, local_c.data_ptr(), alpha[t].data_ptr(), None,
-                    F_, attp.ptr(), attp.pstride, Fp, st)
+                    F_, attp.ptr(), attp.pstride, Fp, int(attp.tiled), st)
             gemm(R, E, [(attp, Fp // 32), (h1p[nxt], H // 32)], w["W5"], bias=w["b_lang"],
                  relu=True, P=x2p)
             gemm(R, H, [(x2p, Ep // 32), (h2p[cur], H // 32)], w["Wg2"], bias=w["bg2"], gru=True,

@@ -51,6 +51,43 @@ def test_bench_self_launches_two_ranks_on_one_gpu():
     assert "cpu_baseline" not in line                            # rank 0, N == 1 only
 
 
+def test_bench_self_launches_eight_ranks_on_one_gpu():
+    """The driver's `python bench.py --gpus 8` end to end on the one leased GPU (gloo, the small
+    cfg1 workload): eight ranks rendezvous on their own port, every rank is seen by the collective,
+    only rank 0 prints, the OpenMP pools are divided between the ranks, and bucket 0's timing
+    against the detector's backward graph is reported."""
+    env = dict(os.environ, S2C_DIST_BACKEND="gloo", S2C_BENCH_WINDOWS="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "OMP_NUM_THREADS"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8",
+                          "--workload", "cfg1", "--steps", "2", "--warmup", "1"], env=env,
+                         capture_output=True, text=True, timeout=1500)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line (rank 0): %d" % len(lines)
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["config"]["parallelism"] == "dp8"
+    assert line["config"]["global_batch"] == 8 * line["config"]["scenes_per_gpu"]
+    d = line["ddp"]
+    assert d["ranks_seen"] == 8 and d["world_size"] == 8 and d["backend"] == "gloo"
+    assert isinstance(d["bucket0_hidden"], bool)
+    assert d["stage2_graph_ms"] > 0 and len(d["allreduce_alone_ms"]) == 2
+    assert np.isfinite(line["value"]) and line["value"] > 0
+
+
+def test_a_dying_rank_takes_the_launch_down():
+    """bench.py's launcher: a rank that exits non-zero after the rendezvous terminates the other
+    ranks (which would otherwise wait in a collective for ever) and its code is returned."""
+    env = dict(os.environ, S2C_DIST_BACKEND="gloo", S2C_BENCH_FAIL_RANK="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2",
+                          "--workload", "cfg1", "--steps", "1", "--warmup", "1"], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 17, (res.returncode, res.stderr[-2000:])
+    assert not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+
+
 def _rank_main(rank, world, port, out_path):
     """One rank of the two-graph step (what bench.py's `replay` does), small shapes."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),

@@ -16,7 +16,16 @@ def _rel(a, b):
 
 
 def _planes_sum(p):
-    return p.t.float().sum(0)
+    return p.dense().float().sum(0)
+
+
+@pytest.fixture(params=[0, 1], ids=["tile128", "tile256"])
+def tile(request):
+    """Both tile geometries of the kernel (the 256 x 256 one is chosen by grid size otherwise)."""
+    from scan2cap_amd.models import greedy_fused as gf
+    gf.set_big(request.param)
+    yield request.param
+    gf.set_big(-1)
 
 
 def test_planes_split_reconstructs_fp32_and_pads_with_zeros():
@@ -25,9 +34,16 @@ def test_planes_split_reconstructs_fp32_and_pads_with_zeros():
     x = torch.randn(37, 300, device="cuda") * torch.logspace(-3, 3, 300, device="cuda")
     xs = torch.zeros(37, 333, device="cuda")
     xs[:, :300] = x                                       # a strided source (row stride 333)
-    for src in (x, xs[:, :300]):
-        p = gf.split(src, rows_out=64, ld=320)
-        t = p.t.float()
+    for src, tiled in ((x, False), (xs[:, :300], False), (x, True), (xs[:, :300], True)):
+        p = gf.split(src, rows_out=64, ld=320, tiled=tiled)
+        t = p.dense().float()
+        assert t.shape == (3, 64, 320)
+        if tiled:       # element (r, k) sits where include/s2c_fused.h says
+            raw = p.t.view(3, -1).float()
+            for r, k in ((0, 0), (9, 5), (9, 13), (36, 299), (31, 17), (24, 8)):
+                off = ((r >> 5) * 20 + (k >> 4)) * 512 + \
+                    (((r & 31) * 2 + (((k >> 3) & 1) ^ (((r & 31) >> 3) & 1))) << 3) + (k & 7)
+                assert float(raw[0, off]) == float(src[r, k].bfloat16().float())
         hi = src.bfloat16().float()
         assert torch.equal(t[0, :37, :300], hi)           # round-to-nearest-even, like torch
         mid = (src - hi).bfloat16().float()
@@ -44,7 +60,7 @@ def test_planes_split_reconstructs_fp32_and_pads_with_zeros():
     (1000, 520, 128, 512, False),     # several row and column tiles (XCD map), two segments
     (77, 3500, 512, 0, False),        # the classifier's width
 ])
-def test_planes_gemm_generic_epilogue_matches_float64(M, N, K0, K1, gather):
+def test_planes_gemm_generic_epilogue_matches_float64(M, N, K0, K1, gather, tile):
     from scan2cap_amd.models import greedy_fused as gf
     g = torch.Generator(device="cuda").manual_seed(M + N)
     rnd = lambda *s: torch.randn(*s, device="cuda", generator=g)
@@ -59,10 +75,10 @@ def test_planes_gemm_generic_epilogue_matches_float64(M, N, K0, K1, gather):
     if K1:
         W[:, K0p:K0p + K1] = rnd(N, K1) / K1 ** 0.5
     bias, add = rnd(N), rnd(M, N)
-    segs = [(gf.split(A0, ld=K0p), K0p // 32, rowmap)]
+    segs = [(gf.split(A0, ld=K0p, tiled=not gather), K0p // 32, rowmap)]
     if K1:
         segs.append((gf.split(A1, ld=K1p), K1p // 32))
-    Wp = gf.split(W, rows_out=gf._up(N, 128))
+    Wp = gf.split(W, rows_out=gf._up(N, 256))
     C = torch.full((M, N), float("nan"), device="cuda")
     P = gf.Planes(M, gf._up(N, 32), "cuda")
     P.t.fill_(float("nan"))
@@ -96,7 +112,7 @@ def test_planes_gemm_generic_epilogue_matches_float64(M, N, K0, K1, gather):
 
 
 @pytest.mark.parametrize("M,E,H", [(200, 300, 512), (128, 64, 32), (333, 300, 96)])
-def test_planes_gemm_gru_epilogue_matches_grucell(M, E, H):
+def test_planes_gemm_gru_epilogue_matches_grucell(M, E, H, tile):
     from scan2cap_amd.models import greedy_fused as gf
     torch.manual_seed(M)
     cell = torch.nn.GRUCell(E, H).cuda()
@@ -113,7 +129,7 @@ def test_planes_gemm_gru_epilogue_matches_grucell(M, E, H):
     assert torch.equal(_planes_sum(hp), hn)
 
 
-def test_greedy_feedback_through_the_argmax_keys():
+def test_greedy_feedback_through_the_argmax_keys(tile):
     """G7 leaves keys, the next G1 gathers the embedding rows of the arg-max tokens."""
     from scan2cap_amd.models import greedy_fused as gf
     torch.manual_seed(3)
@@ -130,11 +146,11 @@ def test_greedy_feedback_through_the_argmax_keys():
     W = torch.zeros(E, Ep, device="cuda")
     W[:, :E] = torch.eye(E, device="cuda")
     out = torch.empty(M, E, device="cuda")
-    gf.gemm(M, E, [(gf.split(table, ld=Ep), Ep // 32)], gf.split(W, rows_out=gf._up(E, 128)),
-            C=out, tokkeys=keys)
+    gf.gemm(M, E, [(gf.split(table, ld=Ep, tiled=False), Ep // 32)],
+            gf.split(W, rows_out=gf._up(E, 128)), C=out, tokkeys=keys)
     assert torch.equal(out, table[tok])                   # identity weights: the gathered rows
     # rowdiv: row r reads source row r / 13 (the scene's first word for all of its proposals)
     src = torch.randn(M // 13 + 1, E, device="cuda")
-    gf.gemm(M, E, [(gf.split(src, ld=Ep), Ep // 32, 13)], gf.split(W, rows_out=gf._up(E, 128)),
-            C=out)
+    gf.gemm(M, E, [(gf.split(src, ld=Ep, tiled=False), Ep // 32, 13)],
+            gf.split(W, rows_out=gf._up(E, 128)), C=out)
     assert torch.equal(out, src[torch.arange(M, device="cuda") // 13])

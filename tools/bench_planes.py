@@ -25,6 +25,8 @@ def timed(fn, reps=20):
 
 def main():
     Rs = [int(a) for a in sys.argv[1:]] or [2048, 8192]
+    dbg = int(os.environ.get("S2C_PLANES_DBG", "0"))     # bit 0: no MFMA, bit 1: no DMA (timing only)
+    gf.DEBUG = dbg
     E, H, F, V = 300, 512, 128, 3500
     Ep = 320
     dev = "cuda"

@@ -1,4 +1,4 @@
-"""Which GEMMs of the cfg3 train step still go to the library (torch.mm / addmm / bmm / matmul /
+"""Which GEMMs of the cfg3 train step (or, with an argument, of another workload's forward) still go to the library (torch.mm / addmm / bmm / matmul /
 F.linear -> hipBLASLt), with shapes, call sites and HIP-event times (eager step)."""
 import collections, os, sys, traceback
 import numpy as np, torch
@@ -7,7 +7,8 @@ sys.path.insert(0, ROOT)
 from tests import test_configs_gpu as T
 from scan2cap_amd.loss_helper import get_scene_cap_loss
 
-bench, wl, model, dd, batch, msa, dev = T._setup("cfg3")
+WL = sys.argv[1] if len(sys.argv) > 1 else "cfg3"     # cfg3 (train step) | cfg2 | cfg3e | cfg5 (forward)
+bench, wl, model, dd, batch, msa, dev = T._setup(WL)
 cfg = bench.LossConfig(msa)
 log = []
 names = ["mm", "addmm", "bmm", "matmul", "baddbmm"]
@@ -38,6 +39,10 @@ for n in names:
 torch.nn.functional.linear = wrap("linear", orig_lin)
 
 def step():
+    if not wl["train"]:
+        with torch.no_grad():
+            model(dict(dd), use_tf=False, is_eval=True)
+        return
     model.zero_grad(set_to_none=True)
     d = model(dict(dd), use_tf=True, is_eval=False)
     d = get_scene_cap_loss(d, dev, cfg, None, detection=True, caption=True, orientation=False, distance=False)
