@@ -909,10 +909,33 @@ def _eval_fusable(specs, params, pool_ns):
         W = params[pi]
         pi += 1 + (1 if sp.has_bias else 0) + (2 if sp.bn is not None else 0)
         bn = sp.bn
-        if (sp.has_bias or bn is None or bn.training or bn.running_mean is None
-                or W.stride(1) != 1):
+        if (bn is not None and (bn.training or bn.running_mean is None)) or W.stride(1) != 1:
             return False
     return True
+
+
+def _plain_stack(specs):
+    """every layer = conv (no bias) + frozen BN: what the one-kernel inference stage takes"""
+    return all(sp.bn is not None and not sp.has_bias for sp in specs)
+
+
+_EVAL_CONST = {}
+
+
+def _eval_affine(sp, bias, gamma, beta, Cout, dev):
+    """(gamma, beta, mean, var, eps) for the GEMM's inference epilogue out = relu?(acc * sc + sh),
+    sc = gamma / sqrt(var + eps), sh = beta - mean * sc.  A bias in front of a frozen BatchNorm
+    moves its mean (BN(y + b) = (y - (mean - b)) sc + beta); a layer without BatchNorm is the
+    identity affine (gamma = var = 1, eps = 0: sc = 1 exactly) with beta = bias."""
+    bn = sp.bn
+    if bn is not None:
+        mean = bn.running_mean if bias is None else bn.running_mean - bias
+        return gamma, beta, mean, bn.running_var, float(bn.eps)
+    key = (dev, Cout)
+    if key not in _EVAL_CONST:
+        _EVAL_CONST[key] = (torch.ones(Cout, device=dev), torch.zeros(Cout, device=dev))
+    ones, zeros = _EVAL_CONST[key]
+    return ones, (bias if bias is not None else zeros), zeros, ones, 0.0
 
 
 class _EvalLayer(ctypes.Structure):
@@ -933,7 +956,7 @@ def _eval_stage_fused(gather, M, dev, specs, pool_ns, params):
     """-> pooled (M / pool_ns, N3) tensor, or None when the fused kernel does not take the stage."""
     g = gather
     if not (FUSE_EVAL_STAGE and g is not None and len(specs) == 3 and pool_ns == g.ns
-            and all(sp.relu for sp in specs) and (g.m * g.ns) % 32 == 0):
+            and _plain_stack(specs) and all(sp.relu for sp in specs) and (g.m * g.ns) % 32 == 0):
         return None
     Ws = [params[3 * l] for l in range(3)]
     if [W.shape[1] for W in Ws] != [3 + g.C, Ws[0].shape[0], Ws[1].shape[0]]:
@@ -975,9 +998,14 @@ def _eval_stack(X, gather, M, dev, specs, pool_ns, params):
         return fused_out
     A, pi, nl = X, 0, len(specs)
     for li, sp in enumerate(specs):
-        W, gamma, beta = params[pi], params[pi + 1], params[pi + 2]
-        pi += 3
-        bn, Cout = sp.bn, W.shape[0]
+        W = params[pi]; pi += 1
+        bias = gamma = beta = None
+        if sp.has_bias:
+            bias = params[pi]; pi += 1
+        if sp.bn is not None:
+            gamma, beta = params[pi], params[pi + 1]; pi += 2
+        Cout = W.shape[0]
+        gamma, beta, mean, var, eps = _eval_affine(sp, bias, gamma, beta, Cout, dev)
         pn = pool_ns if li == nl - 1 else 0
         out = torch.empty((M // pn if pn else M, Cout), device=dev)
         if gather is not None and li == 0:
@@ -985,8 +1013,7 @@ def _eval_stack(X, gather, M, dev, specs, pool_ns, params):
             _call("s2c_sa_gather_gemm_bn_eval", out, g.B, g.N, g.m, g.ns, g.C, g.frs, g.fbs,
                   g.radius, g.normalize, g.xyz.data_ptr(), g.new_xyz.data_ptr(),
                   _ptr(g.feats), g.idx.data_ptr(), Cout, W.data_ptr(), W.stride(0),
-                  _ptr(gamma), _ptr(beta), bn.running_mean.data_ptr(),
-                  bn.running_var.data_ptr(), float(bn.eps), int(sp.relu), pn,
+                  _ptr(gamma), _ptr(beta), mean.data_ptr(), var.data_ptr(), eps, int(sp.relu), pn,
                   out.data_ptr(), Cout,
                   alg_bytes=4 * (min(g.B * g.N, M) * (3 + g.C) + M + out.numel()),
                   alg_flops=2 * M * (3 + g.C) * Cout)
@@ -995,9 +1022,8 @@ def _eval_stack(X, gather, M, dev, specs, pool_ns, params):
                 A = A.contiguous()
             K_in = A.shape[1]
             _call("s2c_rows_gemm_bn_eval", out, M, Cout, K_in, A.data_ptr(), A.stride(0),
-                  W.data_ptr(), W.stride(0), _ptr(gamma), _ptr(beta),
-                  bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.eps),
-                  int(sp.relu), pn, out.data_ptr(), Cout,
+                  W.data_ptr(), W.stride(0), _ptr(gamma), _ptr(beta), mean.data_ptr(),
+                  var.data_ptr(), eps, int(sp.relu), pn, out.data_ptr(), Cout,
                   alg_bytes=4 * (M * K_in + out.numel()), alg_flops=2 * M * K_in * Cout)
         A = out
     return A
