@@ -110,9 +110,13 @@ __device__ __forceinline__ float pg_fast_tanh(float x) {
 // 32 x 4 column tiles of 32 (its 128 columns: the four gate groups of 32 GRU units).
 //   small (RT 1, WN 1): 4 waves, 128 x 128, stage 24 KB, two workgroups per CU
 //   big   (RT 2, WN 2): 8 waves, 256 x 256, stage 48 KB, one workgroup per CU
+// ST = stages of the LDS-DMA ring = 3.  (A lone 128 x 128 workgroup on its CU -- grids of <= 256
+// tiles -- takes 0.85 us per 16-k chunk, twice its MFMA time; a SIX-stage ring, five chunks in
+// flight, was measured and is 15-25 % SLOWER: what a lone wave per SIMD pays is the serial issue of
+// its six DMA pieces (~110 cycles each) in front of its 24 MFMAs, not the DMA latency.)
 // Either way a chunk of 16 k is (4 RT + 4 WN) blocks of 32 rows per operand plane = ONE LDS-DMA
 // instruction per wave, operand and plane (6 per wave and chunk).
-template <int RT, int WN>
+template <int RT, int WN, int ST>
 struct PgGeo {
   static constexpr int WM = 4, NW = WM * WN;
   static constexpr int BM = 32 * RT * WM, BN = 128 * WN;
@@ -120,7 +124,7 @@ struct PgGeo {
   static constexpr unsigned A_PLANE = 1024u * ABLK, W_PLANE = 1024u * WBLK;
   static constexpr unsigned W_BASE = 3 * A_PLANE;
   static constexpr unsigned STAGE = 3 * (A_PLANE + W_PLANE);
-  static constexpr unsigned TOK_BASE = 3 * STAGE;               // BM ints: resolved row map
+  static constexpr unsigned TOK_BASE = ST * STAGE;              // BM ints: resolved row map
   static constexpr unsigned LDS = TOK_BASE + 4 * BM;
 };
 
@@ -188,9 +192,10 @@ __device__ __forceinline__ void pg_kstep(f32x16 (&acc)[RT][4], const unsigned ch
 // of 16-k chunks, 2 workgroups per CU: 233).  Hence the 256 x 256 tile (half the bytes per flop,
 // two waves per SIMD: one's DMA issue and fragment reads under the other's MFMAs) wherever the
 // grid still fills the chip, and the 128 x 128 tile with two workgroups per CU elsewhere.
-template <bool GRU, int RT, int WN>
-__global__ __launch_bounds__(64 * 4 * WN, WN == 1 ? 2 : 1) void planes_gemm_kernel(s2c_planes_gemm_args a) {
-  typedef PgGeo<RT, WN> G;
+template <bool GRU, int RT, int WN, int ST>
+__global__ __launch_bounds__(64 * 4 * WN, (WN == 1 && ST == 3) ? 2 : 1) void planes_gemm_kernel(s2c_planes_gemm_args a) {
+  typedef PgGeo<RT, WN, ST> G;
+  constexpr int D = ST - 1;                     // chunks requested ahead of the one being multiplied
   extern __shared__ __attribute__((aligned(16))) unsigned char pg_smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -328,22 +333,44 @@ __global__ __launch_bounds__(64 * 4 * WN, WN == 1 ? 2 : 1) void planes_gemm_kern
     for (int k = 0; k < 6; ++k) piece(k);
     return n;
   };
-  int n_next;
-  issue(0, lds0);                                               // chunk 0 -> stage 0
-  n_next = issue(1, lds0 + G::STAGE);                           // chunk 1 -> stage 1
-  unsigned st_c = 0, st_n2 = 2;                                 // stage of chunk c / of chunk c + 2
+  // pieces this wave requests for chunk g (the vmcnt bookkeeping below must match `prep`)
+  auto nof = [&](int g) -> int {
+    if (g >= kct || (dbg & 2)) return 0;
+    return (stage_a ? 3 : 0) + ((stage_wb && ((chunk_wmask(g) >> (wave & 3)) & 1)) ? 3 : 0);
+  };
+  // chunk g lives in stage g % ST; chunks 0 .. D - 1 are requested up front
+#pragma unroll
+  for (int g = 0; g < D; ++g) issue(g, lds0 + g * G::STAGE);
+  // `allowed` = pieces of the chunks c + 1 .. c + D - 1: what may still be in flight when chunk c
+  // is needed (LDS-DMA completes in order)
+  int allowed = 0;
+#pragma unroll
+  for (int g = 1; g < D; ++g) allowed += nof(g);
+  unsigned st_c = 0, st_p = ST - 1;                             // stage of chunk c / of chunk c - 1
   // the chunk loop with the set of live accumulator tiles as a compile-time constant (as a run-
   // time test inside the loop every tile's products sat in their own basic block: no fragment
   // read ahead of a product, and the accumulators were copied between the blocks' registers)
   auto run = [&](auto mask_c, int c_begin, int c_end) {
     constexpr int MASK = decltype(mask_c)::value;
     for (int c = c_begin; c < c_end; ++c) {
-      if (n_next == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else if (n_next == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      switch (allowed / 3) {       // s_waitcnt takes an immediate
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(27)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(30)" ::: "memory"); break;   // ST <= 7
+      }
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      n_next = prep(c + 2, lds0 + st_n2 * G::STAGE);
+      // chunk c + D goes where chunk c - 1 was: everybody is past the barrier, i.e. done with it
+      prep(c + D, lds0 + st_p * G::STAGE);
+      allowed += nof(c + D) - nof(c + 1);
       if (MASK != 0 && !(dbg & 1)) {
         pg_kstep<MASK == 0 ? 1 : MASK, RT, G::A_PLANE, G::W_PLANE>(acc, pg_smem + st_c * G::STAGE, fa_off,
                                                                    fw_off, piece);
@@ -351,8 +378,8 @@ __global__ __launch_bounds__(64 * 4 * WN, WN == 1 ? 2 : 1) void planes_gemm_kern
 #pragma unroll
         for (int k = 0; k < 6; ++k) piece(k);
       }
-      st_c = st_c == 2 ? 0 : st_c + 1;
-      st_n2 = st_n2 == 2 ? 0 : st_n2 + 1;
+      st_p = st_c;
+      st_c = st_c == ST - 1 ? 0 : st_c + 1;
     }
   };
   if (GRU) {
@@ -565,21 +592,21 @@ int pg_chk(const char *k) {
   return 0;
 }
 
-template <bool GRU, int RT, int WN>
+template <bool GRU, int RT, int WN, int ST>
 int pg_launch(const s2c_planes_gemm_args &a, hipStream_t st) {
-  typedef PgGeo<RT, WN> G;
+  typedef PgGeo<RT, WN, ST> G;
   static int attr_state[64];                   // per device: 0 unknown, 1 ok, -1 refused
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
   if (attr_state[dev] == 0)
-    attr_state[dev] = hipFuncSetAttribute((const void *)planes_gemm_kernel<GRU, RT, WN>,
+    attr_state[dev] = hipFuncSetAttribute((const void *)planes_gemm_kernel<GRU, RT, WN, ST>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)G::LDS) == hipSuccess ? 1 : -1;
   if (attr_state[dev] < 0) return -3;
   const int nrt = (a.M + G::BM - 1) / G::BM;
   const int nct = GRU ? (a.N + 32 * WN - 1) / (32 * WN) : (a.N + G::BN - 1) / G::BN;
   const int RTX = (nrt + 7) / 8;
-  hipLaunchKernelGGL((planes_gemm_kernel<GRU, RT, WN>), dim3(8 * RTX * nct), dim3(64 * G::NW), G::LDS,
+  hipLaunchKernelGGL((planes_gemm_kernel<GRU, RT, WN, ST>), dim3(8 * RTX * nct), dim3(64 * G::NW), G::LDS,
                      st, a);
   return pg_chk("planes_gemm");
 }
@@ -614,17 +641,16 @@ extern "C" int s2c_planes_gemm(const s2c_planes_gemm_args *a, void *stream) {
   const bool big = a->big_ok && (g_pg_big == 3 || (g_pg_big == 1 && tiles_big >= 192));
   if (a->gru) {
     if (a->nseg != 2 || a->bias == nullptr || a->hprev == nullptr || (a->N & 31)) return -1;
-    return big ? pg_launch<true, 2, 2>(*a, (hipStream_t)stream)
-               : pg_launch<true, 1, 1>(*a, (hipStream_t)stream);
+    return big ? pg_launch<true, 2, 2, 3>(*a, (hipStream_t)stream)
+               : pg_launch<true, 1, 1, 3>(*a, (hipStream_t)stream);
   }
   if (a->amax != nullptr && a->namax < (a->N + 127) / 128) return -1;
-  return big ? pg_launch<false, 2, 2>(*a, (hipStream_t)stream)
-             : pg_launch<false, 1, 1>(*a, (hipStream_t)stream);
+  return big ? pg_launch<false, 2, 2, 3>(*a, (hipStream_t)stream)
+             : pg_launch<false, 1, 1, 3>(*a, (hipStream_t)stream);
 }
 
 // -1: by grid size (default), 0: never, 1: wherever the operands allow -- the 256 x 256 tile kernel
 extern "C" void s2c_planes_set_big(int mode) { g_pg_big = mode < 0 ? 1 : (mode == 0 ? 2 : 3); }
-
 extern "C" int s2c_planes_split(long long rows_in, int K, const float *X, long long ldx,
                                 long long rows_out, int ldp, unsigned short *P,
                                 long long pstride, int tiled, void *stream) {
