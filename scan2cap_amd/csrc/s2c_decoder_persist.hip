@@ -722,7 +722,10 @@ __global__ __launch_bounds__(PTc, 2) void decoder_fwd_persist_kernel(s2c_dec_fwd
   __syncthreads();
   if (tid == 0 && s_dead) {                    // loud without a host check: the last hidden state
     __hip_atomic_store(a.fail, 1u, __ATOMIC_RELAXED, S2C_AG);      // turns NaN, and with it the loss
-    a.H2[(size_t)T * R * H] = __builtin_nanf("");
+    // an element this workgroup OWNS (row 0 of its first hidden unit; its own last store precedes the
+    // barrier above, nobody else writes it): a NaN in somebody else's element could be overwritten by
+    // its owner's ordinary store afterwards
+    a.H2[(size_t)T * R * H + (u0 < H ? u0 : 0)] = __builtin_nanf("");
   }
   // ---- advance the nonce once every workgroup has read it -----------------------------------
   if (w == 0 && tid == 0) {
@@ -1243,7 +1246,8 @@ __global__ __launch_bounds__(PT, 2) void decoder_bwd_persist_kernel(s2c_dec_bwd_
   __syncthreads();
   if (tid == 0 && s_dead) {                    // loud without a host check: a NaN gradient
     __hip_atomic_store(a.fail, 1u, __ATOMIC_RELAXED, S2C_AG);
-    a.dwa_rows[0] = __builtin_nanf("");
+    // in an element this workgroup owns where it owns one (stored above, before the barrier)
+    a.dwa_rows[(row4 < R && hs0 < H) ? (size_t)row4 * H + hs0 : 0] = __builtin_nanf("");
   }
   if (w == 0 && tid == 0) {
     int spins = 0;

@@ -84,3 +84,27 @@ extern "C" int s2c_probe_copy(int mode, long long M, const float *A, float *Y, i
   }
   return (int)hipGetLastError();
 }
+
+
+// A kernel that just HOLDS compute units: `blocks` workgroups of `threads` threads, each requesting
+// `lds_bytes` of LDS (one per CU above 80 KB), spin for `cycles` shader-clock cycles.  For the test
+// that provokes the persistent decoder's give-up path (tests/test_fused_gpu.py): with part of the
+// chip held, some of its workgroups cannot become resident and the resident ones poll in vain.
+namespace {
+__global__ void probe_hog_kernel(long long cycles, int *sink) {
+  extern __shared__ int hog_lds[];
+  const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+  while ((long long)__builtin_amdgcn_s_memtime() - t0 < cycles) __builtin_amdgcn_s_sleep(64);
+  if (cycles < 0) sink[0] = hog_lds[threadIdx.x];       // never: keeps the LDS request alive
+}
+}  // namespace
+
+extern "C" int s2c_probe_hog(int blocks, int threads, int lds_bytes, long long cycles, void *stream) {
+  if (blocks <= 0 || threads <= 0 || threads > 1024 || lds_bytes < 0 || lds_bytes > 160 * 1024) return -1;
+  if (hipFuncSetAttribute((const void *)probe_hog_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                          lds_bytes) != hipSuccess)
+    return -3;
+  hipLaunchKernelGGL(probe_hog_kernel, dim3(blocks), dim3(threads), lds_bytes, (hipStream_t)stream,
+                     cycles, (int *)nullptr);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}

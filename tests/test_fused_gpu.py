@@ -168,6 +168,59 @@ def test_persistent_decoder_forward_on_the_256_workgroup_grid():
     assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+_GIVE_UP_CHILD = r"""
+import ctypes, sys, time
+import numpy as np, torch
+from scan2cap_amd import _C
+from scan2cap_amd.models import decoder_fused
+from scan2cap_amd.models.caption_module import TopDownSceneCaptionModule
+R, K, H, E, F, T, V = 8, 10, 512, 300, 128, 9, 40
+words = ["w%d" % i for i in range(V)]
+vocab = {"word2idx": {w: i for i, w in enumerate(words)}, "idx2word": {str(i): w for i, w in enumerate(words)}}
+emb = {w: np.random.randn(E).astype(np.float32) for w in words}
+torch.manual_seed(0)
+mod = TopDownSceneCaptionModule(vocab, emb, E, F, H, K, num_locals=K).cuda()
+we = torch.randn(R, 32, E, device="cuda") * 0.3
+obj, tgt = torch.randn(R, K, F, device="cuda") * 0.5, torch.randn(R, F, device="cuda") * 0.5
+masks = torch.ones(R, K, device="cuda")
+assert decoder_fused._plib().s2c_decoder_fwd_persist_supported(R, K, H, E, F, T) == 1
+with torch.no_grad():
+    ok, _ = decoder_fused.decode(mod, we, tgt, obj, masks, T)
+torch.cuda.synchronize()
+assert torch.isfinite(ok).all() and not decoder_fused.persist_failed()
+lib = _C.load()
+lib.s2c_probe_hog.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p]
+lib.s2c_probe_hog.restype = ctypes.c_int
+side = torch.cuda.Stream()
+# 224 of the 256 compute units held for ~3 s (1024 threads + 150 KB of LDS each: nothing fits beside)
+assert lib.s2c_probe_hog(224, 1024, 150 * 1024, 6_000_000_000, side.cuda_stream) == 0
+time.sleep(0.3)
+t0 = time.time()
+with torch.no_grad():
+    bad, _ = decoder_fused.decode(mod, we, tgt, obj, masks, T)
+torch.cuda.synchronize()
+print("decode beside the hog: %.2f s" % (time.time() - t0))
+assert decoder_fused.persist_failed(), "the persistent kernel did not report its give-up"
+assert not torch.isfinite(bad).all(), "no NaN in the logits of a launch that gave up"
+print("GAVE-UP-LOUDLY")
+"""
+
+
+def test_persistent_decoder_gives_up_loudly_when_compute_units_are_held():
+    """The persistent decoder kernels need all of their workgroups co-resident; they are ordinary
+    launches, so a kernel of ANOTHER stream holding compute units can strand part of the grid.  The
+    contract: the resident workgroups give up after 2^20 polls (~1 s), the launch raises its flag
+    (`decoder_fused.persist_failed()`) and poisons the output with a NaN -- a result that says so,
+    never a hung GPU.  Provoked here for real: csrc/s2c_probe.hip's hog kernel holds 224 of 256
+    CUs on a second stream while the decoder is launched (own process: the scratch of a failed
+    launch is not reused)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-c", _GIVE_UP_CHILD], capture_output=True, text=True,
+                       timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "GAVE-UP-LOUDLY" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 @pytest.mark.parametrize("R,K,H,E,F,T", [(8, 10, 512, 300, 128, 9), (5, 7, 256, 128, 64, 6),
                                          (3, 4, 128, 64, 32, 5), (8, 16, 384, 256, 128, 3),
                                          (1, 1, 512, 300, 128, 31), (2, 32, 128, 512, 256, 2),

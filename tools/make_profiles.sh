@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates the judged profile set of a round on the GPU box (run through gpurun from the
 # repo root): tools/make_profiles.sh r02   -> gpurun_out/<round>/...  (copy into profiles/)
-R=${1:-r03}
+R=${1:-r04}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$R
 mkdir -p $OUT
@@ -23,5 +23,14 @@ python $ROOT/tools/pmc_sq_summary.py $(ls /tmp/p_sq/*counter_collection.csv | he
 S2C_DIST_BACKEND=gloo python $ROOT/bench.py --gpus 2 --no-cpu-baseline > $OUT/${R}_bench_2ranks_gloo_1gpu.json 2> $OUT/bench_2ranks.err
 for w in cfg2 cfg5 cfg3e; do
   python $ROOT/bench.py --workload $w --no-cpu-baseline --no-fed > $OUT/${R}_bench_$w.json 2> $OUT/bench_$w.err
+  # per-kernel table of the same workload, launched eagerly (kernel names inside a hipGraph replay
+  # are not attributed): what runs in the forward + greedy decode, and that no library GEMM does
+  rm -rf /tmp/pe_$w && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pe_$w -o s -- python $ROOT/bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline --no-graph --no-fed > $OUT/pe_$w.log 2>&1
+  cp /tmp/pe_$w/s_kernel_stats.csv $OUT/${R}_${w}_eager_kernel_stats.csv
+done
+# the reference's own training batch sizes (README.md:145: 12; slurm/train.job:24: 16): the persistent
+# decoder kernels take up to 8 rows, beyond that the launch chain runs
+for b in 12 16; do
+  python $ROOT/bench.py --batch $b --no-cpu-baseline --no-fed > $OUT/${R}_bench_cfg3_batch$b.json 2> $OUT/bench_b$b.err
 done
 ls -la $OUT
