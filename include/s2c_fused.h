@@ -721,8 +721,13 @@ typedef struct s2c_planes_gemm_args {
                                    (order-preserving bits of the value) << 32 | (2^32 - 1 - column) */
   int ldadd, ldc, ldp, ldh, namax;
   int ptiled;                   /* P is written TILED */
-  int big_ok, pad_;             /* every tiled operand and W are allocated to multiples of 256 rows (W: 256
+  int big_ok;                   /* every tiled operand and W are allocated to multiples of 256 rows (W: 256
                                    rows per 64 gru units): the 256 x 256 tile kernel may be used */
+  /* two outputs side by side (one pass over A for two consumers).  nsplit > 0 (a multiple of 128; not
+   * gru): W rows [0, nsplit) produce C -- n1 <= nsplit valid columns, `bias`, `amax`, `P` -- and W rows
+   * [nsplit, N) produce C2 (N - nsplit columns, row stride ldc2), to which `add` (not to C) is added */
+  int nsplit, n1, ldc2;
+  float *C2;
 } s2c_planes_gemm_args;
 int s2c_planes_gemm(const s2c_planes_gemm_args *a, void *stream);
 void s2c_planes_set_big(int mode);   /* 256 x 256 tiles: -1 by grid size (default), 0 never, 1 whenever big_ok */

@@ -215,13 +215,25 @@ __global__ __launch_bounds__(64 * 4 * WN, (WN == 1 && ST == 3) ? 2 : 1) void pla
   const int cbase = GRU ? (ct * WN + wn) * 32 : ct * G::BN + 128 * wn;
   const long long wrow0 = (long long)ct * G::BN;
 
-  // live 32-column groups of the wave (generic: those that start below N rounded up to 32)
+  // two outputs side by side (nsplit > 0): W rows [0, nsplit) -> C (n1 valid columns, bias, arg-max
+  // keys, planes), W rows [nsplit, N) -> C2 (N - nsplit columns, row addend `add`)
+  const bool part2 = !GRU && a.nsplit > 0 && cbase >= a.nsplit;
+  const int obase = part2 ? cbase - a.nsplit : cbase;         // the wave's first OUTPUT column
+  const int NV = GRU ? N : (part2 ? N - a.nsplit : (a.nsplit > 0 ? a.n1 : N));   // valid output columns
+  float *const Cp = part2 ? a.C2 : a.C;
+  const int ldcp = part2 ? a.ldc2 : a.ldc;
+  const float *const biasp = part2 ? nullptr : a.bias;
+  const float *const addp = (a.nsplit > 0 && !part2) ? nullptr : a.add;
+  unsigned long long *const amaxp = part2 ? nullptr : a.amax;
+  unsigned short *const Pp = part2 ? nullptr : a.P;
+
+  // live 32-column groups of the wave (generic: those that start below NV rounded up to 32)
   int live = 0xF;
   if (!GRU) {
     live = 0;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
-      if (cbase + 32 * nt < ((N + 31) & ~31)) live |= 1 << nt;
+      if (obase + 32 * nt < ((NV + 31) & ~31)) live |= 1 << nt;
   } else if (cbase >= N) {
     live = 0;
   }
@@ -440,18 +452,18 @@ __global__ __launch_bounds__(64 * 4 * WN, (WN == 1 && ST == 3) ? 2 : 1) void pla
   if (!GRU) {
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-      const int col0 = cbase + 32 * nt + pcol;
+      const int col0 = obase + 32 * nt + pcol;
 #pragma unroll
       for (int i = 0; i < 8; ++i) bv[nt][i] = 0.f;
-      if (a.bias != nullptr && ((live >> nt) & 1)) {
-        if (col0 + 8 <= N) {
-          const float4 b0 = *reinterpret_cast<const float4 *>(a.bias + col0);
-          const float4 b1 = *reinterpret_cast<const float4 *>(a.bias + col0 + 4);
+      if (biasp != nullptr && ((live >> nt) & 1)) {
+        if (col0 + 8 <= NV) {
+          const float4 b0 = *reinterpret_cast<const float4 *>(biasp + col0);
+          const float4 b1 = *reinterpret_cast<const float4 *>(biasp + col0 + 4);
           bv[nt][0] = b0.x; bv[nt][1] = b0.y; bv[nt][2] = b0.z; bv[nt][3] = b0.w;
           bv[nt][4] = b1.x; bv[nt][5] = b1.y; bv[nt][6] = b1.z; bv[nt][7] = b1.w;
         } else {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) if (col0 + i < N) bv[nt][i] = a.bias[col0 + i];
+          for (int i = 0; i < 8; ++i) if (col0 + i < NV) bv[nt][i] = biasp[col0 + i];
         }
       }
     }
@@ -467,20 +479,20 @@ __global__ __launch_bounds__(64 * 4 * WN, (WN == 1 && ST == 3) ? 2 : 1) void pla
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-          const int col0 = cbase + 32 * nt + pcol;
+          const int col0 = obase + 32 * nt + pcol;
           const int row = mrow0 + 32 * i + prow + 16 * p;
 #pragma unroll
           for (int q = 0; q < 8; ++q) av[nt][p][q] = 0.f;
-          if (a.add != nullptr && ((live >> nt) & 1)) {
-            const float *ad = a.add + (long long)(row < M ? row : M - 1) * a.ldadd + col0;
-            if (col0 + 8 <= N && (a.ldadd & 3) == 0) {
+          if (addp != nullptr && ((live >> nt) & 1)) {
+            const float *ad = addp + (long long)(row < M ? row : M - 1) * a.ldadd + col0;
+            if (col0 + 8 <= NV && (a.ldadd & 3) == 0) {
               const float4 b0 = *reinterpret_cast<const float4 *>(ad);
               const float4 b1 = *reinterpret_cast<const float4 *>(ad + 4);
               av[nt][p][0] = b0.x; av[nt][p][1] = b0.y; av[nt][p][2] = b0.z; av[nt][p][3] = b0.w;
               av[nt][p][4] = b1.x; av[nt][p][5] = b1.y; av[nt][p][6] = b1.z; av[nt][p][7] = b1.w;
             } else {
 #pragma unroll
-              for (int q = 0; q < 8; ++q) if (col0 + q < N) av[nt][p][q] = ad[q];
+              for (int q = 0; q < 8; ++q) if (col0 + q < NV) av[nt][p][q] = ad[q];
             }
           }
         }
@@ -492,7 +504,7 @@ __global__ __launch_bounds__(64 * 4 * WN, (WN == 1 && ST == 3) ? 2 : 1) void pla
       for (int e = 0; e < 16; ++e)
         patch[((e & 3) + 8 * (e >> 2) + 4 * lk) * 32 + li] = acc[i][nt][e];
       __builtin_amdgcn_wave_barrier();
-      const int col0 = cbase + 32 * nt + pcol;        // first of the lane's 8 columns
+      const int col0 = obase + 32 * nt + pcol;        // first of the lane's 8 columns
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
         const int row = mrow0 + 32 * i + prow + 16 * p;
@@ -508,27 +520,27 @@ __global__ __launch_bounds__(64 * 4 * WN, (WN == 1 && ST == 3) ? 2 : 1) void pla
             for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
           }
 #pragma unroll
-          for (int q = 0; q < 8; ++q) if (col0 + q >= N) v[q] = 0.f;   // plane padding stays finite
-          if (a.amax != nullptr) {
+          for (int q = 0; q < 8; ++q) if (col0 + q >= NV) v[q] = 0.f;   // plane padding stays finite
+          if (amaxp != nullptr) {
 #pragma unroll
             for (int q = 0; q < 8; ++q)
-              if (col0 + q < N) { const u64 k = pg_key(v[q], col0 + q); best[p] = k > best[p] ? k : best[p]; }
+              if (col0 + q < NV) { const u64 k = pg_key(v[q], col0 + q); best[p] = k > best[p] ? k : best[p]; }
           }
         }
-        if (a.C != nullptr) {
-          float *cp = a.C + (long long)row * a.ldc + col0;
-          if (col0 + 8 <= N && (a.ldc & 3) == 0) {
+        if (Cp != nullptr) {
+          float *cp = Cp + (long long)row * ldcp + col0;
+          if (col0 + 8 <= NV && (ldcp & 3) == 0) {
             *reinterpret_cast<float4 *>(cp) = make_float4(v[0], v[1], v[2], v[3]);
             *reinterpret_cast<float4 *>(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
           } else {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) if (col0 + q < N) cp[q] = v[q];
+            for (int q = 0; q < 8; ++q) if (col0 + q < NV) cp[q] = v[q];
           }
         }
-        if (a.P != nullptr && col0 < a.ldp) {          // ldp: a multiple of 32 >= N
+        if (Pp != nullptr && col0 < a.ldp) {          // ldp: a multiple of 32 >= NV
           uint4 h, m, l;
           pg_split8(v, h, m, l);
-          unsigned short *pp = a.P + (a.ptiled ? pg_tiled_off(row, col0, a.ldp) : (long long)row * a.ldp + col0);
+          unsigned short *pp = Pp + (a.ptiled ? pg_tiled_off(row, col0, a.ldp) : (long long)row * a.ldp + col0);
           *reinterpret_cast<uint4 *>(pp) = h;
           *reinterpret_cast<uint4 *>(pp + a.ppstride) = m;
           *reinterpret_cast<uint4 *>(pp + 2 * a.ppstride) = l;
@@ -536,7 +548,7 @@ __global__ __launch_bounds__(64 * 4 * WN, (WN == 1 && ST == 3) ? 2 : 1) void pla
       }
       __builtin_amdgcn_wave_barrier();
     }
-    if (!GRU && a.amax != nullptr) {
+    if (!GRU && amaxp != nullptr) {
       // a row's 128 columns of this wave sit in the 4 lanes of a quad: fold, lane 0 of the quad
       // writes the key of 128-column tile cbase / 128
 #pragma unroll
@@ -545,7 +557,7 @@ __global__ __launch_bounds__(64 * 4 * WN, (WN == 1 && ST == 3) ? 2 : 1) void pla
         k = umax64(k, dpp_mov_u64<DPP_QUAD_1032>(k));
         k = umax64(k, dpp_mov_u64<DPP_QUAD_2301>(k));
         const int row = mrow0 + 32 * i + prow + 16 * p;
-        if ((lane & 3) == 0 && row < M) a.amax[(long long)row * a.namax + (cbase >> 7)] = k;
+        if ((lane & 3) == 0 && row < M) amaxp[(long long)row * a.namax + (cbase >> 7)] = k;
       }
     }
   }
@@ -627,7 +639,11 @@ extern "C" int s2c_planes_gemm(const s2c_planes_gemm_args *a, void *stream) {
                     (s == 0 && a->tokkeys != nullptr)))
       return -1;
   }
-  if (a->P != nullptr && ((a->ldp & 31) || a->ldp < a->N)) return -1;
+  if (a->nsplit != 0 && (a->gru || (a->nsplit & 127) || a->nsplit >= a->N || a->n1 <= 0 ||
+                         a->n1 > a->nsplit || a->C2 == nullptr))
+    return -1;
+  const int nfirst = a->nsplit ? a->n1 : a->N;               // columns of the first output
+  if (a->P != nullptr && ((a->ldp & 31) || a->ldp < nfirst)) return -1;
   if (a->tokkeys != nullptr && a->ntokkeys <= 0) return -1;
   if (g_pg_big == -1) {
     const char *e = getenv("S2C_PLANES_BIG");
@@ -644,7 +660,7 @@ extern "C" int s2c_planes_gemm(const s2c_planes_gemm_args *a, void *stream) {
     return big ? pg_launch<true, 2, 2, 3>(*a, (hipStream_t)stream)
                : pg_launch<true, 1, 1, 3>(*a, (hipStream_t)stream);
   }
-  if (a->amax != nullptr && a->namax < (a->N + 127) / 128) return -1;
+  if (a->amax != nullptr && a->namax < (nfirst + 127) / 128) return -1;
   return big ? pg_launch<false, 2, 2, 3>(*a, (hipStream_t)stream)
              : pg_launch<false, 1, 1, 3>(*a, (hipStream_t)stream);
 }

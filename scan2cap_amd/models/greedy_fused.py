@@ -1,13 +1,14 @@
 """Greedy decode of every proposal (models/caption_module.py:502-592) on the hand-written planes
 GEMMs of csrc/s2c_planes.hip: per token SEVEN launches for all R = B*K rows --
 
-    G1  x1 = relu(W_td[:, :E] emb[token] + W_td[:, E:E+H] h2 + P_tf)      (caption_module.py:252-253)
+    G1  x1 = relu(W_td[:, :E] emb[token] + t1)                              (caption_module.py:252-253)
     G2  h1 = GRUCell_1(x1, h1)         gates, biases and the cell in the GEMM's epilogue   (:254)
-    G3  q  = map_hidd(h1)                                                                   (:257)
+    G3  [q | l1] = [map_hidd ; W_lang[:, F:]] h1          one pass over h1 for both         (:257, :262)
     ATT alpha, att = local attention over the L gathered objects (csrc/s2c_decoder.hip)  (:257-261)
-    G5  x2 = relu(W_lang[:, :F] att + W_lang[:, F:] h1 + b)                                  (:262)
+    G5  x2 = relu(W_lang[:, :F] att + l1 + b)                                                (:262)
     G6  h2 = GRUCell_2(x2, h2)                                                               (:263)
-    G7  logits = classifier(h2) written in place + per-row arg-max keys            (:553, :559-566)
+    G7  [logits | t1] = [classifier ; W_td[:, E:E+H]] h2 (+ P_tf): logits written in place, per-row
+        arg-max keys, and the next token's map_topdown h2 block                (:553, :559-566, :252)
 
 -- every product formed from bf16x3 planes (fp32-accurate, see the kernel), every activation
 leaving its producer already split, the greedy feedback `embeddings[argmax]` resolved by G1's
@@ -35,7 +36,7 @@ class _GemmArgs(ctypes.Structure):
                 ("wpstride", _LL), ("bias", _P), ("add", _P), ("C", _P), ("P", _P),
                 ("ppstride", _LL), ("hprev", _P), ("amax", _P), ("ldadd", _I), ("ldc", _I),
                 ("ldp", _I), ("ldh", _I), ("namax", _I), ("ptiled", _I), ("big_ok", _I),
-                ("pad_", _I)]
+                ("nsplit", _I), ("n1", _I), ("ldc2", _I), ("C2", _P)]
 
 
 _C.register("s2c_planes_gemm", [_P, _P])
@@ -103,8 +104,10 @@ def split(x, rows_out=None, ld=None, tiled=True):
 
 
 def gemm(M, N, segs, W, bias=None, add=None, relu=False, C=None, P=None, gru=False, hprev=None,
-         amax=None, tokkeys=None):
-    """One s2c_planes_gemm launch.  segs: list of (Planes, kc[, rowmap tensor | rowdiv int])."""
+         amax=None, tokkeys=None, split=None):
+    """One s2c_planes_gemm launch.  segs: list of (Planes, kc[, rowmap tensor | rowdiv int]).
+    split = (nsplit, n1, C2): two outputs side by side -- W rows [0, nsplit) -> C (n1 valid columns;
+    bias, amax, P), W rows [nsplit, N) -> C2 (+ add)."""
     a = _GemmArgs()
     a.M, a.N, a.gru, a.relu, a.nseg, a.dbg = M, N, int(gru), int(relu), len(segs), DEBUG
     kct = 0
@@ -147,6 +150,10 @@ def gemm(M, N, segs, W, bias=None, add=None, relu=False, C=None, P=None, gru=Fal
         a.hprev, a.ldh = hprev.data_ptr(), hprev.stride(0)
     if amax is not None:
         a.amax, a.namax = amax.data_ptr(), amax.shape[1]
+    if split is not None:
+        a.nsplit, a.n1 = int(split[0]), int(split[1])
+        assert split[2].stride(1) == 1 and split[2].dtype == torch.float32
+        a.C2, a.ldc2 = split[2].data_ptr(), split[2].stride(0)
     if _C.TIMER.enabled:
         k = 32 * kct
         cols = 3 * N if gru else N
@@ -199,24 +206,28 @@ def _weights(mod):
     dev = ps[0].device
     with torch.no_grad():
         W_td = mod.map_topdown[0].weight.detach()
-        W1 = torch.zeros(E, Ep + H, device=dev)
-        W1[:, :E], W1[:, Ep:] = W_td[:, :E], W_td[:, E:E + H]
         W_lang = mod.map_lang[0].weight.detach()
-        W5 = torch.zeros(E, Fp + H, device=dev)
-        W5[:, :F_], W5[:, Fp:] = W_lang[:, :F_], W_lang[:, F_:]
-        w = {"Ep": Ep, "Fp": Fp}
-        w["W1"] = split(W1, rows_out=_up(E, 128))
+        V = mod.classifier.weight.shape[0]
+        VS, HS = _up(V, 128), _up(H, 128)
+        w = {"Ep": Ep, "Fp": Fp, "VS": VS, "HS": HS}
+        # every product that reads h2 in ONE pass over its planes, likewise h1 (two outputs side by
+        # side, s2c_planes_gemm `nsplit`): [classifier ; map_topdown's h2 block], [map_hidd ; map_lang's
+        # h1 block] -- the word / attention products keep only their own short K
+        w["W1x"] = split(W_td[:, :E], rows_out=_up(E, 128), ld=Ep)
+        Wc2 = torch.zeros(VS + E, H, device=dev)
+        Wc2[:V], Wc2[VS:] = mod.classifier.weight.detach(), W_td[:, E:E + H]
+        w["Wc2"] = split(Wc2, rows_out=_up(VS + E, 128))
+        Wq2 = torch.zeros(HS + E, H, device=dev)
+        Wq2[:H], Wq2[HS:] = mod.map_hidd.weight.detach(), W_lang[:, F_:]
+        w["Wq2"] = split(Wq2, rows_out=_up(HS + E, 128))
+        w["W5a"] = split(W_lang[:, :F_], rows_out=_up(E, 128), ld=Fp)
         w["Wtf"] = split(W_td[:, E + H:], rows_out=_up(E, 128), ld=Fp)
         w["b_td"] = mod.map_topdown[0].bias.detach().contiguous()
         w["Wg1"], w["bg1"] = pack_gru(mod.recurrent_cell_1, Ep)
         w["Wm"] = split(mod.map_feat.weight.detach(), rows_out=_up(H, 128), ld=Fp)
-        w["Wq"] = split(mod.map_hidd.weight.detach(), rows_out=_up(H, 128))
         w["wa"] = mod.attend.weight.detach().reshape(-1).contiguous()
-        w["W5"] = split(W5, rows_out=_up(E, 128))
         w["b_lang"] = mod.map_lang[0].bias.detach().contiguous()
         w["Wg2"], w["bg2"] = pack_gru(mod.recurrent_cell_2, Ep)
-        V = mod.classifier.weight.shape[0]
-        w["Wc"] = split(mod.classifier.weight.detach(), rows_out=_up(V, 128))
         w["b_cls"] = mod.classifier.bias.detach().contiguous()
         w["emb"] = split(mod._emb_table.detach(), ld=Ep, tiled=False)     # gathered by token
     _WEIGHTS[id(mod)] = (key, w)
@@ -233,7 +244,8 @@ def decode(mod, sos, rows_per_scene, target_feats, local, T):
     with torch.cuda.device(dev):
         w = _weights(mod)
         Ep, Fp = w["Ep"], w["Fp"]
-        nct = (V + 127) // 128
+        VS, HS = w["VS"], w["HS"]
+        nct = VS // 128
         sos_p = split(sos.contiguous(), ld=Ep, tiled=False)             # gathered: row r / K
         tf_p = split(target_feats.contiguous(), ld=Fp)
         P_tf = torch.empty(R, E, device=dev)
@@ -249,6 +261,8 @@ def decode(mod, sos, rows_per_scene, target_feats, local, T):
         x1p, x2p = Planes(R, Ep, dev), Planes(R, Ep, dev)
         attp = Planes(R, Fp, dev, zero=Fp != F_)
         qh = torch.empty(R, H, device=dev)
+        t1 = P_tf.clone()       # map_topdown's h2 block + target block + bias: h2 = 0 before the first word
+        l1 = torch.empty(R, E, device=dev)                              # map_lang's h1 block
         keys = torch.empty(R, nct, dtype=torch.int64, device=dev)
         cap = torch.empty(T, R, V, device=dev)
         alpha = torch.empty(T, R, L, device=dev)
@@ -257,20 +271,20 @@ def decode(mod, sos, rows_per_scene, target_feats, local, T):
         for t in range(T):
             nxt = cur ^ 1
             word = (sos_p, Ep // 32, rows_per_scene) if t == 0 else (w["emb"], Ep // 32)
-            gemm(R, E, [word, (h2p[cur], H // 32)], w["W1"], add=P_tf, relu=True, P=x1p,
+            gemm(R, E, [word], w["W1x"], add=t1, relu=True, P=x1p,
                  tokkeys=None if t == 0 else keys)
             gemm(R, H, [(x1p, Ep // 32), (h1p[cur], H // 32)], w["Wg1"], bias=w["bg1"], gru=True,
                  hprev=h1[cur], C=h1[nxt], P=h1p[nxt])
-            gemm(R, H, [(h1p[nxt], H // 32)], w["Wq"], C=qh)
+            gemm(R, HS + E, [(h1p[nxt], H // 32)], w["Wq2"], C=qh, split=(HS, H, l1))
             if _C.TIMER.enabled:      # one pass over mapped + local features
                 _C.TIMER.alg_bytes = 4 * (R * L * (H + F_ + 1) + R * (H + F_))
             _C.call("s2c_attn_local_fwd_planes", R, L, H, F_, mapped.data_ptr(), qh.data_ptr(), H,
                     w["wa"].data_ptr(), 0.0, None, local_c.data_ptr(), alpha[t].data_ptr(), None,
                     F_, attp.ptr(), attp.pstride, Fp, int(attp.tiled), st)
-            gemm(R, E, [(attp, Fp // 32), (h1p[nxt], H // 32)], w["W5"], bias=w["b_lang"],
-                 relu=True, P=x2p)
+            gemm(R, E, [(attp, Fp // 32)], w["W5a"], bias=w["b_lang"], add=l1, relu=True, P=x2p)
             gemm(R, H, [(x2p, Ep // 32), (h2p[cur], H // 32)], w["Wg2"], bias=w["bg2"], gru=True,
                  hprev=h2[cur], C=h2[nxt], P=h2p[nxt])
-            gemm(R, V, [(h2p[nxt], H // 32)], w["Wc"], bias=w["b_cls"], C=cap[t], amax=keys)
+            gemm(R, VS + E, [(h2p[nxt], H // 32)], w["Wc2"], bias=w["b_cls"], C=cap[t], amax=keys,
+                 split=(VS, V, t1), add=P_tf)
             cur = nxt
     return cap, alpha

@@ -154,3 +154,27 @@ def test_greedy_feedback_through_the_argmax_keys(tile):
     gf.gemm(M, E, [(gf.split(src, ld=Ep, tiled=False), Ep // 32, 13)],
             gf.split(W, rows_out=gf._up(E, 128)), C=out)
     assert torch.equal(out, src[torch.arange(M, device="cuda") // 13])
+
+
+def test_planes_gemm_two_outputs_side_by_side(tile):
+    """`nsplit`: W rows [0, nsplit) -> C (n1 valid columns; bias, arg-max keys), rows [nsplit, N) -> C2
+    (+ row addend): the classifier and map_topdown's h2 block in one pass over h2 (greedy_fused G7)."""
+    from scan2cap_amd.models import greedy_fused as gf
+    torch.manual_seed(11)
+    M, K, n1, n2 = 300, 96, 700, 300
+    ns = gf._up(n1, 128)
+    A = torch.randn(M, K, device="cuda")
+    W1, W2 = torch.randn(n1, K, device="cuda"), torch.randn(n2, K, device="cuda")
+    W = torch.zeros(ns + n2, K, device="cuda")
+    W[:n1], W[ns:] = W1, W2
+    bias, add = torch.randn(n1, device="cuda"), torch.randn(M, n2, device="cuda")
+    C = torch.full((M, n1), float("nan"), device="cuda")
+    C2 = torch.full((M, n2), float("nan"), device="cuda")
+    keys = torch.zeros(M, ns // 128, dtype=torch.int64, device="cuda")
+    gf.gemm(M, ns + n2, [(gf.split(A), K // 32)], gf.split(W, rows_out=gf._up(ns + n2, 256)),
+            bias=bias, add=add, C=C, amax=keys, split=(ns, n1, C2))
+    assert _rel(C, A.double() @ W1.double().t() + bias.double()) < 2e-6
+    assert _rel(C2, A.double() @ W2.double().t() + add.double()) < 2e-6
+    k = keys.cpu().numpy().astype(np.uint64)
+    col = (np.uint64(0xFFFFFFFF) - (k & np.uint64(0xFFFFFFFF))).astype(np.int64)
+    assert np.array_equal(col[np.arange(M), k.argmax(1)], C.cpu().numpy().argmax(1))
