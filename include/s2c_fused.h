@@ -737,6 +737,34 @@ long long s2c_planes_args_sizeof(int which);   /* 0: s2c_planes_gemm_args, 1: s2
 int s2c_planes_split(long long rows_in, int K, const float *X, long long ldx, long long rows_out,
                      int ldp, unsigned short *P, long long pstride, int tiled, void *stream);
 
+
+/* ---- many SMALL fp32 GEMMs in one launch (csrc/s2c_mgemm.hip) ---------------------------------
+ * The hoisted, recurrence-free products of the teacher-forced caption decoder
+ * (models/caption_module.py:252, 275, 472 and their backward): C_j = A_j B_j (+ bias_j) (+ C_j),
+ * M_j x K_j by K_j x N_j, exact fp32 FMA chains in k order.  Operands are addressed through index maps
+ * (element offsets, < 2^31): ix(i, {div, hi, lo}) = div > 0 ? (i / div) hi + (i % div) lo : i lo;
+ * A(m, k) = A[ix(m, am) + ix(k, ak)], B(k, n) = B[ix(k, bk) + ix(n, bn)], C(m, n) = C[ix(m, cm) + n]. */
+typedef struct s2c_mgemm_axis { int div, hi, lo; } s2c_mgemm_axis;
+typedef struct s2c_mgemm_job {
+  const float *A, *B;
+  float *C;
+  const float *bias;            /* NULL or (N): added to every row */
+  int M, N, K;
+  s2c_mgemm_axis am, ak, bk, bn, cm;
+  int accumulate;               /* 1: C += A B (+ bias) */
+  int ksplit;                   /* > 1: the reduction in ksplit ranges, added into C with float atomics
+                                   (C zeroed by the caller, or holding what is to be accumulated to) */
+  int tile0, pad_;              /* tile0: filled in by s2c_mgemm */
+} s2c_mgemm_job;
+#define S2C_MGEMM_MAX_JOBS 32
+typedef struct s2c_mgemm_args {
+  int n_jobs, pad_;
+  s2c_mgemm_job job[S2C_MGEMM_MAX_JOBS];
+} s2c_mgemm_args;
+/* jobs of one call must not depend on each other's outputs */
+int s2c_mgemm(const s2c_mgemm_args *a, void *stream);
+long long s2c_mgemm_args_sizeof(void);
+
 #ifdef __cplusplus
 }
 #endif

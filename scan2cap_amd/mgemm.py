@@ -1,0 +1,83 @@
+"""Many small fp32 GEMMs in one launch (csrc/s2c_mgemm.hip): the hoisted, recurrence-free products
+of the teacher-forced caption decoder (models/decoder_fused.py).  Operands are described by index
+maps, not copied: a transposed weight, a column block of a larger matrix or the (t, r) / (r, t) row
+orders of the decoder's tensors are strides."""
+import ctypes
+
+import torch
+
+from . import _C
+
+_I, _P = ctypes.c_int, ctypes.c_void_p
+MAX_JOBS = 32
+
+
+class _Axis(ctypes.Structure):
+    """include/s2c_fused.h: s2c_mgemm_axis"""
+    _fields_ = [("div", _I), ("hi", _I), ("lo", _I)]
+
+
+class _Job(ctypes.Structure):
+    """include/s2c_fused.h: s2c_mgemm_job"""
+    _fields_ = [("A", _P), ("B", _P), ("C", _P), ("bias", _P), ("M", _I), ("N", _I), ("K", _I),
+                ("am", _Axis), ("ak", _Axis), ("bk", _Axis), ("bn", _Axis), ("cm", _Axis),
+                ("accumulate", _I), ("ksplit", _I), ("tile0", _I), ("pad_", _I)]
+
+
+class _Args(ctypes.Structure):
+    """include/s2c_fused.h: s2c_mgemm_args"""
+    _fields_ = [("n_jobs", _I), ("pad_", _I), ("job", _Job * MAX_JOBS)]
+
+
+_C.register("s2c_mgemm", [_P, _P])
+
+
+def ax(lo, div=0, hi=0):
+    """index i -> offset: i * lo, or (two tensor dims walked major-first) (i // div) * hi + (i % div) * lo"""
+    return (int(div), int(hi), int(lo))
+
+
+class Job(object):
+    """C (M x N; element (m, n) at C[ix(m, cm) + n]) = A B (+ bias) (+ C): A(m, k) at
+    A[ix(m, am) + ix(k, ak)], B(k, n) at B[ix(k, bk) + ix(n, bn)]; A, B, C: tensors whose
+    data_ptr() is the origin."""
+
+    def __init__(self, M, N, K, A, am, ak, B, bk, bn, C, cm, bias=None, accumulate=False, ksplit=0):
+        for t in (A, B, C):
+            assert t.dtype == torch.float32 and t.is_cuda
+        self.dims, self.t = (M, N, K), (A, B, C, bias)
+        self.axes = (am, ak, bk, bn, cm)
+        self.accumulate, self.ksplit = int(accumulate), int(ksplit)
+
+
+def mm(A, B, C, bias=None, accumulate=False, ksplit=0):
+    """C = A @ B for 2-D VIEWS (any strides; C with unit column stride)."""
+    M, K = A.shape
+    K2, N = B.shape
+    assert K == K2 and C.shape == (M, N) and C.stride(1) == 1
+    return Job(M, N, K, A, ax(A.stride(0)), ax(A.stride(1)), B, ax(B.stride(0)), ax(B.stride(1)),
+               C, ax(C.stride(0)), bias, accumulate, ksplit)
+
+
+def launch(jobs):
+    """All jobs in one launch (MAX_JOBS per launch).  They must not read each other's outputs."""
+    for i in range(0, len(jobs), MAX_JOBS):
+        chunk = jobs[i:i + MAX_JOBS]
+        a = _Args()
+        a.n_jobs = len(chunk)
+        flops = 0.0
+        for j, jb in enumerate(chunk):
+            d = a.job[j]
+            d.M, d.N, d.K = jb.dims
+            A, B, C, bias = jb.t
+            d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), C.data_ptr()
+            d.bias = bias.data_ptr() if bias is not None else None
+            for name, v in zip(("am", "ak", "bk", "bn", "cm"), jb.axes):
+                x = getattr(d, name)
+                x.div, x.hi, x.lo = v
+            d.accumulate, d.ksplit = jb.accumulate, jb.ksplit
+            flops += 2.0 * d.M * d.N * d.K
+        if _C.TIMER.enabled:
+            _C.TIMER.alg_flops = flops
+        with torch.cuda.device(chunk[0].t[2].device):
+            _C.call("s2c_mgemm", ctypes.byref(a), _C.stream_ptr())

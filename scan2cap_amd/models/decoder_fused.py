@@ -104,6 +104,13 @@ _C.register("s2c_attn_bwd_x2", [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, 
                                 _P, _I, _P, _P])
 
 
+# The hoisted products (in front of / behind the step loop, and every weight gradient) as a few
+# multi-job launches of csrc/s2c_mgemm.hip instead of ~26 library GEMM calls of 6-48 us each;
+# S2C_MGEMM=0: torch.mm / matmul / bmm (hipBLASLt), the reference formulation the tests compare with
+from .. import mgemm as _mg
+USE_MGEMM = _os.environ.get("S2C_MGEMM", "1") != "0"
+
+
 # The whole forward recurrence as ONE persistent kernel (csrc/s2c_decoder_persist.hip): 128
 # co-resident workgroups exchange the per-step vectors as tagged values instead of meeting at
 # 5 T launch boundaries.  S2C_DECODER_PERSIST=0 (or set_persist(False)): the launch chain.
@@ -288,9 +295,17 @@ class TopDownDecode(Function):
         mask = masks.to(torch.float32).contiguous()
         with torch.cuda.device(dev):
             # ---- hoisted, recurrence-free GEMMs -----------------------------
-            Pw = torch.matmul(words, W_td[:, :E].t())               # (R,T,E)
-            Ptf = torch.addmm(b_td, tf, W_td[:, E + H:].t())        # (R,E)
-            M = torch.matmul(O, W_f.t())                            # (R,K,H)
+            if USE_MGEMM:
+                Pw = torch.empty(R, T, E, device=dev)
+                Ptf = torch.empty(R, E, device=dev)
+                M = torch.empty(R, K, H, device=dev)
+                _mg.launch([_mg.mm(words.view(R * T, E), W_td[:, :E].t(), Pw.view(R * T, E)),
+                            _mg.mm(tf, W_td[:, E + H:].t(), Ptf, bias=b_td),
+                            _mg.mm(O.view(R * K, F), W_f.t(), M.view(R * K, H))])
+            else:
+                Pw = torch.matmul(words, W_td[:, :E].t())               # (R,T,E)
+                Ptf = torch.addmm(b_td, tf, W_td[:, E + H:].t())        # (R,E)
+                M = torch.matmul(O, W_f.t())                            # (R,K,H)
             Wqh = torch.cat([W_h, W_lang[:, F:]], 0).contiguous()   # (H+E, H)
             wa = w_a.reshape(-1).contiguous()
             z = lambda *s: torch.zeros(*s, device=dev)
@@ -367,8 +382,17 @@ class TopDownDecode(Function):
                       _p(b_hh2), _p(X2[t]), E, _p(H2[t]), _p(H2[t + 1]),
                       _p(S2[0][t]), _p(S2[1][t]), _p(S2[2][t]), _p(S2[3][t]),
                       alg_bytes=4 * (3 * H * (E + H) + R * (E + 6 * H)))
-            H2n = H2[1:].permute(1, 0, 2).contiguous()              # (R,T,H)
-            logits = torch.addmm(b_cls, H2n.view(R * T, H), W_cls.t()).view(R, T, -1)
+            RH = R * H
+            if USE_MGEMM:
+                # rows (r, t) of the logits read H2[t + 1, r] in place: no (R,T,H) copy
+                H2n = None
+                V = W_cls.shape[0]
+                logits = torch.empty(R, T, V, device=dev)
+                _mg.launch([_mg.Job(R * T, V, H, H2[1:], _mg.ax(RH, div=T, hi=H), _mg.ax(1),
+                                    W_cls, _mg.ax(1), _mg.ax(H), logits, _mg.ax(V), bias=b_cls)])
+            else:
+                H2n = H2[1:].permute(1, 0, 2).contiguous()              # (R,T,H)
+                logits = torch.addmm(b_cls, H2n.view(R * T, H), W_cls.t()).view(R, T, -1)
             attn = ALPHA.permute(1, 2, 0).contiguous()              # (R,K,T)
         if any(ctx.needs_input_grad):
             ctx.save_for_backward(*params)
@@ -388,8 +412,21 @@ class TopDownDecode(Function):
         dev = dlogits.device
         with torch.cuda.device(dev):
             dl = dlogits.contiguous().view(R * T, -1)
-            dW_cls = torch.mm(dl.t(), H2n.view(R * T, H))
-            dH2 = torch.mm(dl, W_cls).view(R, T, H).permute(1, 0, 2).contiguous()
+            V, RH = dl.shape[1], R * H
+            pre_jobs = []
+            if USE_MGEMM:
+                dW_cls = torch.empty(V, H, device=dev)
+                dH2 = torch.zeros(T, R, H, device=dev)          # k ranges add into it
+                h2rows = _mg.ax(RH, div=T, hi=H)                # index (r, t) -> H2[t + 1, r] / dH2[t, r]
+                pre_jobs = [_mg.Job(V, H, R * T, dl, _mg.ax(1), _mg.ax(V), H2[1:], h2rows, _mg.ax(1),
+                                    dW_cls, _mg.ax(H)),
+                            _mg.Job(R * T, H, V, dl, _mg.ax(V), _mg.ax(1), W_cls, _mg.ax(H), _mg.ax(1),
+                                    dH2, h2rows, ksplit=16)]
+            else:
+                if H2n is None:
+                    H2n = H2[1:].permute(1, 0, 2).contiguous()
+                dW_cls = torch.mm(dl.t(), H2n.view(R * T, H))
+                dH2 = torch.mm(dl, W_cls).view(R, T, H).permute(1, 0, 2).contiguous()
             # transposed weights (the same small_linear kernel serves W^T products) and the
             # zeroed accumulators: one batched launch (s2c_batch_prep) instead of ten
             e = lambda *s: torch.empty(*s, device=dev)
@@ -416,11 +453,21 @@ class TopDownDecode(Function):
             WT_hl = torch.cat([WT_h, WT_lang[F:]], 1) if fuse_bwd else None     # (H, H + E)
             DQc = None if fuse_bwd else e(T, R, H)
             dh2_direct, dh1_direct = e(R, H), e(R, H)
+            if pre_jobs and not persist:
+                _mg.launch(pre_jobs)
+                pre_jobs = []
             if persist:
                 # the whole recurrence in one kernel (csrc/s2c_decoder_persist.hip); the attention
                 # backward's datt only enters through <da2, P_k> and <da2, Latt_t>
-                P = torch.matmul(O, W_lang[:, :F].t()).contiguous()          # (R,K,E)
-                Latt = torch.matmul(ATT, W_lang[:, :F].t()).contiguous()     # (T,R,E)
+                if USE_MGEMM:
+                    P, Latt = e(R, K, E), e(T, R, E)
+                    pre_jobs += [_mg.mm(O.view(R * K, F), W_lang[:, :F].t(), P.view(R * K, E)),
+                                 _mg.mm(ATT.view(T * R, F), W_lang[:, :F].t(), Latt.view(T * R, E))]
+                    _mg.launch(pre_jobs)
+                    pre_jobs = []
+                else:
+                    P = torch.matmul(O, W_lang[:, :F].t()).contiguous()          # (R,K,E)
+                    Latt = torch.matmul(ATT, W_lang[:, :F].t()).contiguous()     # (T,R,E)
                 xbuf, ctl = _persist_scratch(dev, H, E, bwd=True)
                 a = _DecBwdArgs()
                 a.R, a.K, a.H, a.E, a.T = R, K, H, E, T
@@ -488,33 +535,86 @@ class TopDownDecode(Function):
             (db_cls, DA1s, db_td, db_ih1, db_hh1, db_lang, db_ih2, db_hh2, dwa) = \
                 fused.row_sums([dl, DA1.view(T, R * E), da1, gi1, gh1, da2, gi2, gh2, dwa_rows])
             DA1s = DA1s.view(R, E)
-            # no recurrence through these two: hoisted out of the time loop
-            dtf = torch.mm(DA1s, W_td[:, E + H:])                             # (R,F)
-            # datt of every step (no recurrence through it): the not-fused path has it in DV
-            DATT = (torch.matmul(da2, WT_lang[:F].t()).view(T, R, F) if fuse_bwd else DV[:, :, :F])
-            dO = torch.bmm(ALPHA.permute(1, 2, 0), DATT.permute(1, 0, 2))
-            # ---- every weight gradient: one stacked GEMM each ------------------
-            # (column blocks written in place by the GEMMs: `out=` on a row-strided view is a
-            # plain ldc for the library -- no temporaries, no copy kernels)
-            dW_td = torch.empty_like(W_td)
-            torch.mm(da1.t(), words.permute(1, 0, 2).reshape(TR, E), out=dW_td[:, :E])
-            torch.mm(da1.t(), H2[:-1].reshape(TR, H), out=dW_td[:, E:E + H])
-            torch.mm(DA1s.t(), tf, out=dW_td[:, E + H:])
-            dW_ih1 = torch.mm(gi1.t(), X1.view(TR, E))
-            dW_hh1 = torch.mm(gh1.t(), H1[:-1].reshape(TR, H))
-            h1n = H1[1:].reshape(TR, H)
-            dW_h = torch.mm(dq_all.t(), h1n)
-            dW_lang = torch.empty_like(W_lang)
-            torch.mm(da2.t(), ATT.view(TR, F), out=dW_lang[:, :F])
-            torch.mm(da2.t(), h1n, out=dW_lang[:, F:])
-            dW_ih2 = torch.mm(gi2.t(), X2.view(TR, E))
-            dW_hh2 = torch.mm(gh2.t(), H2[:-1].reshape(TR, H))
-            dMf = dM.view(R * K, H)
-            dW_f = torch.mm(dMf.t(), O.view(R * K, F))
-            dO = dO + torch.mm(dMf, W_f).view(R, K, F)
-            dwords = None
-            if ctx.words_need_grad:
-                dwords = torch.matmul(DA1.permute(1, 0, 2), W_td[:, :E])
+            if USE_MGEMM:
+                # ---- stage 1: everything that depends on the recurrence only (one launch) -------
+                dtf = e(R, F)
+                dW_td, dW_lang = torch.empty_like(W_td), torch.empty_like(W_lang)
+                dW_ih1, dW_hh1 = torch.empty_like(W_ih1), torch.empty_like(W_hh1)
+                dW_ih2, dW_hh2 = torch.empty_like(W_ih2), torch.empty_like(W_hh2)
+                dW_h, dW_f = torch.empty_like(W_h), torch.empty_like(W_f)
+                dO = e(R, K, F)
+                dMf = dM.view(R * K, H)
+                ldtd, ldlang = W_td.stride(0), W_lang.stride(0)
+
+                def wgrad(G, ldg, n_out, X, xrows, xcols, C, ldc_):
+                    """C (n_out x xcols) = G^T X over the TR rows: G (TR x n_out, row stride ldg) in
+                    (t, r) order, X rows addressed by `xrows` in the same order"""
+                    return _mg.Job(n_out, xcols, TR, G, _mg.ax(1), _mg.ax(ldg), X, xrows, _mg.ax(1),
+                                   C, _mg.ax(ldc_))
+                tr_rows = lambda ld: _mg.ax(ld)                        # (T,R,.) tensors: row t R + r
+                words_rows = _mg.ax(T * E, div=R, hi=E)                # words (R,T,E): index (t, r)
+                jobs = [
+                    # dtf = DA1s W_td[:, E+H:]
+                    _mg.mm(DA1s, W_td[:, E + H:], dtf),
+                    # dW_td column blocks: words | h2 (previous step) | target features
+                    wgrad(da1, E, E, words, words_rows, E, dW_td, ldtd),
+                    wgrad(da1, E, E, H2, tr_rows(H), H, dW_td[:, E:], ldtd),
+                    _mg.mm(DA1s.t(), tf, dW_td[:, E + H:]),
+                    wgrad(gi1, 3 * H, 3 * H, X1, tr_rows(E), E, dW_ih1, E),
+                    wgrad(gh1, 3 * H, 3 * H, H1, tr_rows(H), H, dW_hh1, H),
+                    wgrad(dq_all, dq_all.stride(0), H, H1[1:], tr_rows(H), H, dW_h, H),
+                    wgrad(da2, da2.stride(0), E, ATT, tr_rows(F), F, dW_lang, ldlang),
+                    wgrad(da2, da2.stride(0), E, H1[1:], tr_rows(H), H, dW_lang[:, F:], ldlang),
+                    wgrad(gi2, 3 * H, 3 * H, X2, tr_rows(E), E, dW_ih2, E),
+                    wgrad(gh2, 3 * H, 3 * H, H2, tr_rows(H), H, dW_hh2, H),
+                    # dW_f = dM^T O ; the map_feat part of dO = dM W_f
+                    _mg.mm(dMf.t(), O.view(R * K, F), dW_f),
+                    _mg.mm(dMf, W_f, dO.view(R * K, F)),
+                ]
+                if fuse_bwd:
+                    DATT = e(T, R, F)
+                    jobs.append(_mg.mm(da2, W_lang[:, :F], DATT.view(TR, F)))
+                else:
+                    DATT = DV[:, :, :F]
+                dwords = None
+                if ctx.words_need_grad:
+                    dwords = e(R, T, E)         # rows (r, t) <- DA1 (T,R,E) rows (t, r)
+                    jobs.append(_mg.Job(R * T, E, E, DA1, _mg.ax(R * E, div=T, hi=E), _mg.ax(1),
+                                        W_td, _mg.ax(ldtd), _mg.ax(1), dwords, _mg.ax(E)))
+                _mg.launch(jobs)
+                # ---- stage 2: dO += sum_t alpha_t (x) datt_t, per batch row (reads DATT) ---------
+                ldatt_t = DATT.stride(0)
+                _mg.launch([_mg.Job(K, F, T, ALPHA[:, r], _mg.ax(1), _mg.ax(R * K),
+                                    DATT[:, r], _mg.ax(ldatt_t), _mg.ax(1), dO[r], _mg.ax(F),
+                                    accumulate=True) for r in range(R)])
+            else:
+                # no recurrence through these two: hoisted out of the time loop
+                dtf = torch.mm(DA1s, W_td[:, E + H:])                             # (R,F)
+                # datt of every step (no recurrence through it): the not-fused path has it in DV
+                DATT = (torch.matmul(da2, WT_lang[:F].t()).view(T, R, F) if fuse_bwd else DV[:, :, :F])
+                dO = torch.bmm(ALPHA.permute(1, 2, 0), DATT.permute(1, 0, 2))
+                # ---- every weight gradient: one stacked GEMM each ------------------
+                # (column blocks written in place by the GEMMs: `out=` on a row-strided view is a
+                # plain ldc for the library -- no temporaries, no copy kernels)
+                dW_td = torch.empty_like(W_td)
+                torch.mm(da1.t(), words.permute(1, 0, 2).reshape(TR, E), out=dW_td[:, :E])
+                torch.mm(da1.t(), H2[:-1].reshape(TR, H), out=dW_td[:, E:E + H])
+                torch.mm(DA1s.t(), tf, out=dW_td[:, E + H:])
+                dW_ih1 = torch.mm(gi1.t(), X1.view(TR, E))
+                dW_hh1 = torch.mm(gh1.t(), H1[:-1].reshape(TR, H))
+                h1n = H1[1:].reshape(TR, H)
+                dW_h = torch.mm(dq_all.t(), h1n)
+                dW_lang = torch.empty_like(W_lang)
+                torch.mm(da2.t(), ATT.view(TR, F), out=dW_lang[:, :F])
+                torch.mm(da2.t(), h1n, out=dW_lang[:, F:])
+                dW_ih2 = torch.mm(gi2.t(), X2.view(TR, E))
+                dW_hh2 = torch.mm(gh2.t(), H2[:-1].reshape(TR, H))
+                dMf = dM.view(R * K, H)
+                dW_f = torch.mm(dMf.t(), O.view(R * K, F))
+                dO = dO + torch.mm(dMf, W_f).view(R, K, F)
+                dwords = None
+                if ctx.words_need_grad:
+                    dwords = torch.matmul(DA1.permute(1, 0, 2), W_td[:, :E])
         ctx.stash = None
         return (dwords, dtf, dO, None, None, dW_td, db_td, dW_ih1, dW_hh1, db_ih1,
                 db_hh1, dW_f, dW_h, dwa.view_as(w_a), dW_lang, db_lang, dW_ih2, dW_hh2,

@@ -344,6 +344,16 @@ def test_planes_gemm_argument_structs_match_the_header():
     assert lib.s2c_planes_gemm(ctypes.byref(a), None) == -1          # M = 0, no operand
 
 
+def test_mgemm_argument_structs_match_the_header():
+    import ctypes
+    from scan2cap_amd import _C, mgemm
+    lib = _C.load()
+    lib.s2c_mgemm_args_sizeof.restype = ctypes.c_longlong
+    assert lib.s2c_mgemm_args_sizeof() == ctypes.sizeof(mgemm._Args) <= 4096     # a kernel argument
+    a = mgemm._Args()
+    assert lib.s2c_mgemm(ctypes.byref(a), None) == -1                            # no jobs
+
+
 def test_streaming_gemm_dispatch_table():
     """Which layer shapes the streaming kernel of csrc/s2c_gemm2.hip takes is host logic (LDS
     budget: W planes + one LDS-DMA ring per wave): pinned here without a GPU."""
