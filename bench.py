@@ -106,6 +106,9 @@ KERNELS_OF = {
     "s2c_attn_x2_fwd": ("attn_x2_kernel",),
     "s2c_decoder_fwd_persist": ("decoder_fwd_persist_kernel",),
     "s2c_decoder_bwd_persist": ("decoder_bwd_persist_kernel",),
+    "s2c_planes_gemm": ("planes_gemm_kernel",),
+    "s2c_mgemm": ("mgemm_kernel",),
+    "s2c_attn_local_fwd_planes": ("attn_local_kernel",),
     "s2c_ball_query": ("ball_query_kernel",),
     "s2c_ball_query_grid": ("bq_grid_build_kernel", "ball_query_grid_kernel"),
     "s2c_furthest_point_sampling_bucketed": ("fps_bucket_kernel",),
@@ -482,6 +485,23 @@ def family_roofline(table_k, ms_per_step):
                                         "rows_gemm_c64_kernel", "rows_gemm_kernel")),
             "parts": {k["kernel"]: {"ms_per_step": k["ms_per_step"], "alg_GBps": k["alg_GBps"],
                                     "avg_launch_us": k["avg_us"]} for k in parts}}
+
+
+def decode_roofline(table_k, ms_per_step):
+    """Greedy decoding (cfg3e / cfg5): the planes GEMMs of csrc/s2c_planes.hip taken together -- every
+    product of the token loop -- against the bf16 matrix roof (6 plane products per fp32 product),
+    with the PMC matrix-pipe busy fraction where the committed SQ summary has the kernel."""
+    parts = [k for k in table_k if k["kernel"] == "s2c_planes_gemm"]
+    if not parts:
+        return None
+    k = parts[0]
+    return {"kernel": "s2c_planes_gemm", "bound": "mfma", "achieved": k["alg_TFLOPs"],
+            "peak": MFMA_GEMM_PEAK_TF, "unit": "TFLOP/s", "frac": k["alg_TFLOPs"] / MFMA_GEMM_PEAK_TF,
+            "note": "fp32-equivalent FLOPs of every product (K as padded to 32); peak = bf16 MFMA "
+                    "peak / 6 (bf16x3 plane products)",
+            "ms_per_step": k["ms_per_step"], "share_of_step": k["ms_per_step"] / ms_per_step,
+            "launches_per_step": k["calls_per_step"], "avg_launch_us": k["avg_us"],
+            "mfma_busy": pmc_mfma_busy(("planes_gemm_kernel",))}
 
 
 def self_launch(n):
@@ -1028,6 +1048,7 @@ def main():
             "roofline_main_stream": roof_main,
             "roofline_named": named_roofline(table_k),
             "roofline_gemm": roof_gemm,
+            "roofline_decode": decode_roofline(table_k, ms_per_step),
             "fed": fed,
             "ddp": ddp_info,
             "kernels": table_k[:10],

@@ -155,8 +155,8 @@ def gemm(M, N, segs, W, bias=None, add=None, relu=False, C=None, P=None, gru=Fal
         assert split[2].stride(1) == 1 and split[2].dtype == torch.float32
         a.C2, a.ldc2 = split[2].data_ptr(), split[2].stride(0)
     if _C.TIMER.enabled:
-        k = 32 * kct
-        cols = 3 * N if gru else N
+        k = 32 * kct                                   # (K as padded to whole chunks)
+        cols = 3 * N if gru else (split[1] + N - split[0] if split is not None else N)
         _C.TIMER.alg_flops = 2.0 * M * cols * k
         _C.TIMER.alg_bytes = 6 * (M * k + (4 * N if gru else N) * k) + 4 * M * N
     _C.call("s2c_planes_gemm", ctypes.byref(a), _C.stream_ptr())

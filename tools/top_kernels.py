@@ -16,7 +16,8 @@ CATS = [
     ("geometry: ball query / 3-NN", ("ball_query", "three_nn")),
     ("decoder kernels", ("small_linear", "gru_", "attn_", "decoder_fwd_persist", "decoder_bwd_persist")),
     ("BN stats/apply/pool (fwd+bwd)", ("bn_", "col_stats", "pool_bwd")),
-    ("hand MFMA GEMM", ("rows_gemm", "rows_stream_gemm", "dw_x3", "sa_fused_eval")),
+    ("hand MFMA GEMM", ("rows_gemm", "rows_stream_gemm", "dw_x3", "sa_fused_eval", "planes_gemm")),
+    ("hand fp32 multi-GEMM", ("mgemm_kernel",)),
     ("gather/scatter rows, interpolate", ("sa_gather", "sa_scatter", "three_interpolate", "gather_points", "group_points")),
     ("library GEMM (Tensile)", ("Cijk_",)),
     ("torch elementwise/reduce/copy/fill", ("elementwise", "reduce_kernel", "FillFunctor", "copyBuffer", "fillBuffer", "CatArray", "scatter_gather", "index", "sort", "topk", "gatherTopK", "bitonic", "radix", "softmax", "log_softmax", "nll", "cunn_", "arange", "masked", "where", "clamp", "argmax", "compare", "bucketize")),
