@@ -109,6 +109,11 @@ HAND_DA_GEMM = _os.environ.get("S2C_HAND_DA", "1") != "0"
 HAND_DW_GEMM = _os.environ.get("S2C_HAND_DW", "1") != "0"
 
 
+# forward of the layers that carry a bias (EdgeConv, the voting module's convs, the proposal head's
+# last conv) on the hand GEMM instead of torch.addmm (S2C_BIAS_BY_HAND=0: the library)
+BIAS_LAYERS_BY_HAND = _os.environ.get("S2C_BIAS_BY_HAND", "1") != "0"
+
+
 # S2C_HAND_EVERYWHERE=1: no library GEMM anywhere in the layer-stack backward (costs ~0.5 ms
 # of the 11.5 ms cfg3 step).  Default: each hand-written kernel where it is at least as fast
 # as hipBLASLt on MI355X (tools/bench_bwd.py, us, apply pass + library vs fused / hand):
@@ -491,9 +496,15 @@ class _MLPRows(Function):
                     "BatchNorm(momentum=None) (cumulative moving average) is not "
                     "implemented on the rows path; use a float momentum")
             from_gather = gather is not None and li == 0
+            # (A bias in front of a train-mode BatchNorm cancels in the normalised output; running the
+            # GEMM without it -- statistics out of the epilogue, momentum * bias added back to the
+            # running mean -- was built and withdrawn: time-neutral, and the differently rounded
+            # pre-activations flip a ReLU mask of the voting module against float64,
+            # tests/test_modules_cfg3_gpu.py.)
             gemm_stats = (USE_MFMA_GEMM and train_stats and bias is None
                           and W.stride(1) == 1
                           and (from_gather or deferred is not None or A.stride(1) == 1))
+            pre_activated = False
             if from_gather:
                 assert bias is None and W.stride(1) == 1
                 g = gather
@@ -595,6 +606,21 @@ class _MLPRows(Function):
                       W.data_ptr(), W.stride(0), None, None, Y.data_ptr(), Cout,
                       gpart.data_ptr(), alg_bytes=4 * (M * K_in + M * Cout),
                       alg_flops=2 * M * K_in * Cout)
+            elif (BIAS_LAYERS_BY_HAND and USE_MFMA_GEMM and bn is None and A.is_cuda
+                  and A.dtype == torch.float32 and W.stride(1) == 1 and _gemm_split_on()):
+                # BatchNorm-free layer (EdgeConv's linear layers, vgen.conv3, the proposal head's
+                # last conv): bias (+ ReLU) in the hand GEMM's affine epilogue with identity scale;
+                # what is kept for the backward's ReLU mask is the activation (a > 0 <=> y > 0)
+                if A.stride(1) != 1:
+                    A = A.contiguous()
+                g_, b_, m_, v_, eps_ = _eval_affine(sp, bias, None, None, Cout, dev)
+                K_in = A.shape[1]
+                Y = torch.empty((M, Cout), device=dev)
+                _call("s2c_rows_gemm_bn_eval", Y, M, Cout, K_in, A.data_ptr(), A.stride(0),
+                      W.data_ptr(), W.stride(0), _ptr(g_), _ptr(b_), m_.data_ptr(), v_.data_ptr(),
+                      eps_, int(sp.relu), 0, Y.data_ptr(), Cout,
+                      alg_bytes=4 * (M * K_in + M * Cout), alg_flops=2 * M * K_in * Cout)
+                pre_activated = True
             else:
                 Y = torch.addmm(bias, A, W.t()) if bias is not None else torch.mm(A, W.t())
             rec = {"A_in": None if from_gather else A, "W": W,
@@ -670,7 +696,7 @@ class _MLPRows(Function):
             else:
                 if sp.relu:
                     rec.update(Y=Y, relu=True)
-                    A = torch.relu(Y)
+                    A = Y if pre_activated else torch.relu(Y)
                 else:
                     A = Y
                 out = A
