@@ -967,6 +967,7 @@ def main():
             # scenes/s standalone), whatever was freed in between
             import subprocess
             torch.cuda.synchronize()
+            decoder_fused.release_device_locks()     # the child runs the persistent decoder kernels
             cmd = [sys.executable, os.path.abspath(__file__), "--feed", "builder", "--no-fed",
                    "--no-cpu-baseline", "--workload", args.workload, "--steps", str(args.steps),
                    "--warmup", str(args.warmup), "--feed-scenes", str(args.feed_scenes)]

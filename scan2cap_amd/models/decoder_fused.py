@@ -219,6 +219,19 @@ def persist_allowed(dev):
     return got is not False
 
 
+def release_device_locks():
+    """Give the per-device locks back (a process that is done with its persistent launches and
+    hands the device to a child: bench.py's builder-fed run).  The next persistent launch of this
+    process takes them again."""
+    for index, f in list(_DEVICE_LOCKS.items()):
+        if f not in (True, False):
+            try:
+                f.close()
+            except Exception:
+                pass
+        del _DEVICE_LOCKS[index]
+
+
 _LAST_STREAM = {}       # scratch key -> the stream of its previous launch
 
 

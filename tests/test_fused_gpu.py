@@ -160,7 +160,8 @@ def test_persistent_decoder_forward_on_the_256_workgroup_grid():
     below in a child process with S2C_DECODER_PERSIST_GRID=256."""
     import subprocess
     import sys
-    env = dict(os.environ, S2C_DECODER_PERSIST_GRID="256")
+    # (the parent may hold the device's persistent-kernel lock; it is idle while the child runs)
+    env = dict(os.environ, S2C_DECODER_PERSIST_GRID="256", S2C_PERSIST_LOCK="0")
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", os.path.abspath(__file__), "-k",
                         "test_persistent_decoder_forward and 8-10-512-300-128-9"],
                        env=env, capture_output=True, text=True, timeout=600,
@@ -169,7 +170,8 @@ def test_persistent_decoder_forward_on_the_256_workgroup_grid():
 
 
 _GIVE_UP_CHILD = r"""
-import ctypes, sys, time
+import ctypes, os, sys, time
+os.environ["S2C_PERSIST_LOCK"] = "0"     # the parent test process may hold the device's lock (idle)
 import numpy as np, torch
 from scan2cap_amd import _C
 from scan2cap_amd.models import decoder_fused
