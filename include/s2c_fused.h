@@ -765,6 +765,28 @@ typedef struct s2c_mgemm_args {
 int s2c_mgemm(const s2c_mgemm_args *a, void *stream);
 long long s2c_mgemm_args_sizeof(void);
 
+
+/* ---- tall weight gradients on the fp32 matrix cores (csrc/s2c_dw32.hip) ------------------------
+ * part (slabs x C x K) = per-slab partial sums of dW[c, k] = sum_m dY[m, c] X[m, k] (add them up with
+ * s2c_multi_colsum); slabs = s2c_weight_grad_f32_slabs(M, C, K) (-1: shape not taken, more than 12
+ * blocks of 64 x 64).  X: dense (M x K, row stride ldx, any alignment), or -- g != NULL -- the gathered
+ * operand of a set-abstraction stage's first layer, read in place (K = 3 + feature channels):
+ *   X[(b, j, s), :] = [ (xyz[b, idx] - new_xyz[b, j]) (/ radius if normalize) | feats[b, idx, :] ]
+ * (the arithmetic of s2c_sa_gather_rows).  Exact fp32 products in row order. */
+typedef struct s2c_dw_gather {
+  const float *xyz;        /* (b, n, 3) */
+  const float *new_xyz;    /* (b, m, 3) */
+  const float *feats;      /* point-major, row stride frs, scene stride fbs (floats) */
+  const int *idx;          /* (b, m, ns): one entry per row of X */
+  long long frs, fbs;
+  int n, m, ns, normalize;
+  float radius;
+  int pad_;
+} s2c_dw_gather;
+int s2c_weight_grad_f32_slabs(long long M, int C, int K);
+int s2c_weight_grad_f32(long long M, int C, int K, const float *dY, long long ldy, const float *X,
+                        long long ldx, const s2c_dw_gather *g, float *part, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -731,10 +731,16 @@ class _MLPRows(Function):
             lazy_dw = False
             fused_dA = None
             pre, prestats = prestats, None
+            gather_dw = False
             if A_in is None:
                 if gather.needs_grad or not SCATTER_DW:
-                    # first layer of a gather-fused stack: rebuild its operand now
-                    A_in = gather.materialise()
+                    if (USE_DW32 and BATCH_PARTIAL_SUMS and gather.rows >= DW32_MIN_ROWS
+                            and _dw32_slabs(gather.rows, W.shape[0], 3 + gather.C) > 0):
+                        # first layer of a gather-fused stack: its weight gradient reads the gathered
+                        # operand in place (csrc/s2c_dw32.hip) -- nothing is rebuilt
+                        gather_dw = True
+                    else:
+                        A_in = gather.materialise()
                 else:
                     lazy_dw = True      # dW from point-indexed sums (GatherSpec.weight_grad)
             Cout = W.shape[0]
@@ -859,6 +865,9 @@ class _MLPRows(Function):
                 dY = dA
             if lazy_dw:
                 dW = gather.weight_grad(dY, bn_bwd=lazy_bn if sp.bn is not None else None)
+            elif gather_dw:
+                dW = _weight_grad_f32(dY if dY.stride(1) == 1 else dY.contiguous(), None, pending,
+                                      gather=gather)
             else:
                 dW = _weight_grad(dY, A_in, pending)
             dbias = None
@@ -1197,6 +1206,58 @@ def row_sums(mats):
     return outs
 
 
+class _DwGather(ctypes.Structure):
+    """s2c_dw_gather (include/s2c_fused.h)."""
+    _fields_ = [("xyz", ctypes.c_void_p), ("new_xyz", ctypes.c_void_p), ("feats", ctypes.c_void_p),
+                ("idx", ctypes.c_void_p), ("frs", ctypes.c_longlong), ("fbs", ctypes.c_longlong),
+                ("n", ctypes.c_int), ("m", ctypes.c_int), ("ns", ctypes.c_int),
+                ("normalize", ctypes.c_int), ("radius", ctypes.c_float), ("pad_", ctypes.c_int)]
+
+
+_C.register("s2c_weight_grad_f32", [_L, _I, _I, _P, _L, _P, _L, _P, _P, _P])
+# tall weight gradients on the fp32 matrix cores (csrc/s2c_dw32.hip) instead of the split-K library
+# bmm; first layers of gather stacks read their operand in place (no re-materialised rows).
+# OFF by default: parity-green (tests/test_dw32_gpu.py) but 1.4-2.5x SLOWER than the library's
+# split-K bmm at every shape of the step (tools/bench_dw32.py, DESIGN 4.13) -- S2C_DW32=1 opts in.
+USE_DW32 = _os.environ.get("S2C_DW32", "0") == "1"
+DW32_MIN_ROWS = 32768
+
+
+def _dw32_slabs(M, C, K):
+    lib = _C.load()
+    if not getattr(lib, "_dw32_sized", False):
+        lib.s2c_weight_grad_f32_slabs.restype = _I
+        lib.s2c_weight_grad_f32_slabs.argtypes = [_L, _I, _I]
+        lib._dw32_sized = True
+    return lib.s2c_weight_grad_f32_slabs(M, C, K)
+
+
+def _weight_grad_f32(dY, A, pending, gather=None):
+    """dW (Cout, Cin) = dY^T A as per-slab partials of s2c_weight_grad_f32 (summed by the caller's
+    multi_colsum launch); gather: A is the GatherSpec's operand, read in place.  None: not taken."""
+    M, Cout = dY.shape
+    Cin = (3 + gather.C) if gather is not None else A.shape[1]
+    nslab = _dw32_slabs(M, Cout, Cin)
+    if nslab <= 0:
+        return None
+    dev = dY.device
+    part = torch.empty((nslab, Cout, Cin), dtype=torch.float32, device=dev)
+    dW = torch.empty((Cout, Cin), dtype=torch.float32, device=dev)
+    g = None
+    if gather is not None:
+        g = _DwGather()
+        g.xyz, g.new_xyz = gather.xyz.data_ptr(), gather.new_xyz.data_ptr()
+        g.feats = gather.feats.data_ptr() if gather.feats is not None else None
+        g.idx, g.frs, g.fbs = gather.idx.data_ptr(), gather.frs, gather.fbs
+        g.n, g.m, g.ns, g.normalize, g.radius = gather.N, gather.m, gather.ns, gather.normalize, gather.radius
+    _call("s2c_weight_grad_f32", dW, M, Cout, Cin, dY.data_ptr(), dY.stride(0),
+          A.data_ptr() if gather is None else None, A.stride(0) if gather is None else 0,
+          ctypes.byref(g) if g is not None else None, part.data_ptr(),
+          alg_bytes=4 * M * (Cout + Cin), alg_flops=2 * M * Cout * Cin)
+    pending.append((part, dW))
+    return dW
+
+
 def _weight_grad(dY, A, pending=None):
     """dW (Cout,Cin) = dY^T (Cout,M) @ A (M,Cin) with M up to ~1e6 and a tiny
     output: a plain GEMM call gives the library ONE output tile and a million-deep
@@ -1211,6 +1272,12 @@ def _weight_grad(dY, A, pending=None):
             and dY.stride(1) == 1 and A.stride(1) == 1 and pending is not None
             and BATCH_PARTIAL_SUMS and (HAND_EVERYWHERE or _hand_dw_pays(M, dY.shape[1], A.shape[1]))):
         return _weight_grad_partials(dY, A, pending)
+    if (USE_DW32 and M >= DW32_MIN_ROWS and dY.is_cuda and dY.dtype == torch.float32
+            and A.dtype == torch.float32 and dY.stride(1) == 1 and A.stride(1) == 1
+            and pending is not None and BATCH_PARTIAL_SUMS):
+        dW = _weight_grad_f32(dY, A, pending)
+        if dW is not None:
+            return dW
     # slabs of >= 1024 rows (>= 2048 from 256k rows on), at most 256 of them: measured best
     # trade between the batched GEMM and the partial sum (tools/bench_dw_split.py)
     S, rows = 1, (2048 if M >= 262144 else 1024)
