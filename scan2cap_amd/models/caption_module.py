@@ -418,7 +418,8 @@ class TopDownSceneCaptionModule(nn.Module):
             # (the adjacency ids of a row are distinct: at most ONE relation lands on an attended
             # object -- a gather, not the (La x Ln) x (Ln x F) product per row)
             hit = att_ids.unsqueeze(-1) == nbr.unsqueeze(-2)                  # (B,K,La,Ln)
-            pos = hit.to(torch.uint8).argmax(-1)                              # (B,K,La)
+            # at most one hit per row: its position is the hit-weighted sum of positions
+            pos = (hit * torch.arange(nbr.shape[-1], device=dev)).sum(-1)     # (B,K,La)
             add = torch.gather(rel, 2, pos.unsqueeze(-1).expand(B, K, L, F_))
             local = local + add * hit.any(-1).unsqueeze(-1).to(rel.dtype)
         local = local.reshape(R, L, F_)
