@@ -92,6 +92,8 @@ KERNELS_OF = {
     "s2c_bn_train_stats": ("col_stats_kernel",),
     "s2c_rows_gemm": _GEMM_PLAIN,
     "s2c_sa_gather_gemm": _GEMM_GATHER,
+    "s2c_sa_point_gemm": _GEMM_PLAIN,
+    "s2c_sa_gather_add": ("sa_gather_add_kernel",),
     "s2c_sa_fused_eval": ("sa_fused_eval_kernel",),
     "s2c_sa_gather_rows": ("sa_gather_rows_kernel",),
     "s2c_sa_scatter_rows": ("sa_scatter_rows_kernel",),
@@ -434,6 +436,9 @@ def named_roofline(table_k):
     of both (xyz + centres + idx;  unique source rows + idx + Y)."""
     parts = [k for k in table_k if k["kernel"] in ("s2c_ball_query", "s2c_ball_query_grid",
                                                    "s2c_sa_gather_gemm",
+                                                   # training path (round 4): the first layer in
+                                                   # point space = per-point product + gather-add
+                                                   "s2c_sa_point_gemm", "s2c_sa_gather_add",
                                                    "s2c_sa_gather_gemm_bn_eval",
                                                    "s2c_sa_fused_eval")]
     if not parts:
@@ -454,7 +459,7 @@ def named_roofline(table_k):
                       for k in parts}}
 
 
-GEMM_FAMILY = ("s2c_rows_gemm", "s2c_rows_gemm_bn_relu_side", "s2c_sa_gather_gemm",
+GEMM_FAMILY = ("s2c_rows_gemm", "s2c_rows_gemm_bn_relu_side", "s2c_sa_gather_gemm", "s2c_sa_point_gemm",
                "s2c_bn_bwd_gemm", "s2c_bn_bwd_gemm_next_stats", "s2c_rows_gemm_next_stats",
                "s2c_rows_gemm_bn_eval", "s2c_sa_gather_gemm_bn_eval", "s2c_sa_fused_eval")
 _DECODER_CHAIN = ("s2c_small_linear", "s2c_small_linear_pair", "s2c_gru_fwd", "s2c_attn_fwd",

@@ -40,6 +40,18 @@ int s2c_sa_scatter_rows(int b, int n, int m, int ns, int C, float radius,
                         float *d_feats, float *d_xyz, float *d_new_xyz,
                         void *stream);
 
+/* First layer of a set-abstraction stack in point space (replaces s2c_sa_gather_gemm on the
+ * training path; QueryAndGroup + first Conv2d, pointnet2_utils.py:347-359, pytorch_utils.py:67-120):
+ *   Y[(b,j,s), :] = P[b, idx[b,j,s], :] + W[:, 0:3] ((xyz[b,idx] - new_xyz[b,j]) (/ radius))
+ * with P (b, n, N) = feats W[:, 3:]^T computed per POINT by s2c_rows_gemm (NULL: no features).
+ * N % 4 == 0, N <= 256; W (N x ldw) row-major, its first three columns are used.  partial (may be
+ * NULL): s2c_sa_gather_add_blocks(rows) x 2N column sums / sums of squares for
+ * s2c_bn_finalize_partials. */
+int s2c_sa_gather_add_blocks(long long rows);
+int s2c_sa_gather_add(int b, int n, int m, int ns, int N, float radius, int normalize,
+                      const float *xyz, const float *new_xyz, const float *P, const int *idx,
+                      const float *W, int ldw, float *Y, float *partial, void *stream);
+
 /* For the weight gradient of a gather-fused layer whose inputs need no gradient:
  * Z (b,n,C) = sum of the dY rows (b*m*ns x C) that gathered each point (zeroed by the
  * callee), S (b,m,C) = sum over the ns rows of each centre.  Then

@@ -100,6 +100,7 @@ class KernelTimer(object):
         self.records = {}      # name -> list of (start_event, end_event, alg_bytes)
         self.alg_bytes = 0     # set by the op wrapper right before call()
         self.alg_flops = 0     # ditto (GEMM entry points)
+        self.label = None      # ditto: file the next call under this name instead of the entry point's
 
     def start(self):
         self.records = {}
@@ -157,9 +158,10 @@ def call(name, *args, allow=()):
         s.record()
         rc = getattr(lib, name)(*args)
         e.record()
-        TIMER.records.setdefault(name, []).append((s, e, TIMER.alg_bytes, TIMER.alg_flops))
+        TIMER.records.setdefault(TIMER.label or name, []).append((s, e, TIMER.alg_bytes, TIMER.alg_flops))
         TIMER.alg_bytes = 0
         TIMER.alg_flops = 0
+        TIMER.label = None
     else:
         rc = getattr(lib, name)(*args)
     if rc != 0 and rc not in allow:

@@ -242,7 +242,10 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(
           const float *p = A + row * lda + k;
           if (k + 3 < K) {
             if (avec) v = *reinterpret_cast<const float4 *>(p);
-            else { v.x = p[0]; v.y = p[1]; v.z = p[2]; v.w = p[3]; }
+            else {     // rows of 3 + C floats (the cloud's feature columns): one dword-aligned 16-byte load
+              const F4U q = *reinterpret_cast<const F4U *>(p);
+              v = make_float4(q.x, q.y, q.z, q.w);
+            }
           } else {
             if (k < K) v.x = p[0];
             if (k + 1 < K) v.y = p[1];
@@ -553,7 +556,10 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_x3_kernel(
           const float *p = A + row * lda + k;
           if (k + 3 < K) {
             if (avec) v = *reinterpret_cast<const float4 *>(p);
-            else { v.x = p[0]; v.y = p[1]; v.z = p[2]; v.w = p[3]; }
+            else {     // rows of 3 + C floats (the cloud's feature columns): one dword-aligned 16-byte load
+              const F4U q = *reinterpret_cast<const F4U *>(p);
+              v = make_float4(q.x, q.y, q.z, q.w);
+            }
           } else {
             if (k < K) v.x = p[0];
             if (k + 1 < K) v.y = p[1];

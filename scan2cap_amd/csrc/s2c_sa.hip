@@ -19,6 +19,7 @@
 #include "../../include/s2c_fused.h"
 
 #include <stdio.h>
+#include <stdlib.h>
 
 using namespace s2c;
 
@@ -233,6 +234,143 @@ extern "C" int s2c_sa_scatter_sum_bn_bwd(int b, int n, int m, int ns, int C, con
   hipLaunchKernelGGL(sa_scatter_sum_kernel<true>, dim3((unsigned)(b * m)), dim3(256), 0, st, n,
                      m, ns, C, dA, idx, Z, S, bw);
   return check2("sa_scatter_sum_bn_bwd");
+}
+
+// ---------------------------------------------------------------------------------------
+// First layer of a set-abstraction stack in POINT SPACE.  The layer is linear and the grouping is
+// a gather, so they commute:
+//   Y[(b,j,s), :] = W [ (xyz[b,p] - new_xyz[b,j]) (/r) | feats[b,p,:] ],   p = idx[b,j,s]
+//                 = P[b,p,:] + W_x rel(b,j,s),      P = feats W_f^T   (one row per POINT)
+// (QueryAndGroup + the first Conv2d of the shared MLP: pointnet2_utils.py:347-359,
+// pointnet2_modules.py:251-253, pytorch_utils.py:67-120.)  The feature product runs over the
+// B n points, not over the B m ns gathered rows -- 3.3x fewer rows at SA1 (40000 points, 2048 x
+// 64 samples), 16x / 8x / 8x / 4x at SA2 / SA3 / SA4 / vote aggregation -- on the plain rows GEMM;
+// what is left per gathered row is this kernel: one contiguous N-float row of P (L2-resident:
+// 10 MB per scene at SA1), three FMAs per output for the relative position -- computed from the
+// coordinates exactly as the reference does, no cancellation of absolute positions -- a 16-byte
+// store, and the BatchNorm column sums.  HBM-bound on the Y write.
+//
+// Wave = 64 consecutive rows: lane l first OWNS row l (index, point row, relative position:
+// coalesced loads), then the wave walks its rows G = 64 / LPR at a time, LPR lanes x float4 per
+// row, the owner's values fetched with ds_bpermute; eight steps of P loads in flight per wave.
+struct GatherAddArgs {
+  int n, m, ns, N, ldw, normalize, rpb, has_p;
+  long long rows;
+  float radius;
+  const float *xyz, *new_xyz, *P, *W;
+  const int *idx;
+  float *Y, *partial;
+};
+
+template <int LPR>
+__global__ __launch_bounds__(256) void sa_gather_add_kernel(GatherAddArgs a) {
+  constexpr int G = 64 / LPR, U = 8;
+  __shared__ float s_stat[2][4][4 * LPR];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lc = lane % LPR, lg = lane / LPR;
+  const int c0 = 4 * lc;
+  const bool cok = c0 < a.N;
+  const int c0l = cok ? c0 : 0;
+  float wx[4][3];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) wx[q][d] = a.W[(long long)(c0l + q) * a.ldw + d];
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  const int rpw = a.rpb >> 2;                                   // rows per wave
+  const long long w0 = (long long)blockIdx.x * a.rpb + (long long)wave * rpw;
+  for (int ch = 0; ch < rpw; ch += 64) {
+    const long long r0 = w0 + ch;
+    long long left = a.rows - r0;
+    if (left > rpw - ch) left = rpw - ch;
+    const int nrow = left > 64 ? 64 : (int)left;                // wave-uniform
+    if (nrow <= 0) break;
+    // ---- owner phase: lane l <-> row r0 + l
+    int pr = 0;
+    float rx = 0.f, ry = 0.f, rz = 0.f;
+    {
+      const long long r = r0 + (lane < nrow ? lane : nrow - 1);
+      const long long bj = r / a.ns;
+      const long long b = bj / a.m;
+      pr = (int)(b * a.n + a.idx[r]);
+      const float *x = a.xyz + 3LL * pr, *c = a.new_xyz + 3 * bj;
+      rx = x[0] - c[0]; ry = x[1] - c[1]; rz = x[2] - c[2];
+      if (a.normalize) { rx = rx / a.radius; ry = ry / a.radius; rz = rz / a.radius; }
+    }
+    // ---- the wave's rows, G per step, U steps of loads in flight
+    for (int st0 = 0; st0 < nrow; st0 += G * U) {
+      float4 pv[U];
+      int rr[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int want = st0 + u * G + lg;
+        rr[u] = want < nrow ? want : nrow - 1;                  // clamped: every load is valid
+        pv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.has_p) {
+          const int prr = __shfl(pr, rr[u], 64);
+          pv[u] = *reinterpret_cast<const float4 *>(a.P + (long long)prr * a.N + c0l);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float x = __shfl(rx, rr[u], 64), y = __shfl(ry, rr[u], 64), z = __shfl(rz, rr[u], 64);
+        float o[4] = {pv[u].x, pv[u].y, pv[u].z, pv[u].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          o[q] = __builtin_fmaf(wx[q][2], z, __builtin_fmaf(wx[q][1], y, __builtin_fmaf(wx[q][0], x, o[q])));
+        if (st0 + u * G + lg < nrow && cok) {
+          *reinterpret_cast<float4 *>(a.Y + (r0 + rr[u]) * a.N + c0) = make_float4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { s1[q] += o[q]; s2[q] += o[q] * o[q]; }
+        }
+      }
+    }
+  }
+  if (a.partial == nullptr) return;
+  // ---- column sums: row groups of the wave, the four waves, one partial per workgroup
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) {
+      s1[q] += __shfl_xor(s1[q], off, 64);
+      s2[q] += __shfl_xor(s2[q], off, 64);
+    }
+    if (lg == 0) { s_stat[0][wave][c0 + q] = s1[q]; s_stat[1][wave][c0 + q] = s2[q]; }
+  }
+  __syncthreads();
+  for (int c = tid; c < a.N; c += 256) {
+    float *p = a.partial + (long long)blockIdx.x * 2 * a.N;
+    p[c] = (s_stat[0][0][c] + s_stat[0][1][c]) + (s_stat[0][2][c] + s_stat[0][3][c]);
+    p[a.N + c] = (s_stat[1][0][c] + s_stat[1][1][c]) + (s_stat[1][2][c] + s_stat[1][3][c]);
+  }
+}
+
+static int gather_add_rpb(long long rows) { return rows >= 131072 ? 256 : 64; }
+
+extern "C" int s2c_sa_gather_add_blocks(long long rows) {
+  const int rpb = gather_add_rpb(rows);
+  return (int)((rows + rpb - 1) / rpb);
+}
+
+extern "C" int s2c_sa_gather_add(int b, int n, int m, int ns, int N, float radius, int normalize,
+                                 const float *xyz, const float *new_xyz, const float *P,
+                                 const int *idx, const float *W, int ldw, float *Y,
+                                 float *partial, void *stream) {
+  if (b <= 0 || n <= 0 || m <= 0 || ns <= 0 || N <= 0 || N > 256 || (N & 3) || ldw < 3 || !xyz ||
+      !new_xyz || !idx || !W || !Y || ((uintptr_t)Y & 15) || (P && ((uintptr_t)P & 15)))
+    return fail2("sa_gather_add: sizes / alignment / null pointer");
+  GatherAddArgs a;
+  a.n = n; a.m = m; a.ns = ns; a.N = N; a.ldw = ldw; a.normalize = normalize;
+  a.rows = (long long)b * m * ns;
+  a.rpb = gather_add_rpb(a.rows); a.has_p = P != nullptr;
+  a.radius = radius; a.xyz = xyz; a.new_xyz = new_xyz; a.P = P; a.W = W; a.idx = idx;
+  a.Y = Y; a.partial = partial;
+  const dim3 grid((unsigned)s2c_sa_gather_add_blocks(a.rows));
+  hipStream_t st = (hipStream_t)stream;
+  if (N <= 64) hipLaunchKernelGGL(sa_gather_add_kernel<16>, grid, dim3(256), 0, st, a);
+  else if (N <= 128) hipLaunchKernelGGL(sa_gather_add_kernel<32>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(sa_gather_add_kernel<64>, grid, dim3(256), 0, st, a);
+  return check2("sa_gather_add");
 }
 
 // Feature propagation on point-major rows (PointnetFPModule.forward,

@@ -26,6 +26,7 @@ _I, _L, _P, _F = ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_floa
 _C.register("s2c_sa_gather_rows", [_I, _I, _I, _I, _I, _L, _L, _F, _I, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_sa_scatter_rows", [_I, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_sa_scatter_sum", [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P])
+_C.register("s2c_sa_gather_add", [_I, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P])
 _C.register("s2c_sa_scatter_sum_bn_bwd", [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P])
 _C.register("s2c_fp_interp_rows", [_I, _I, _I, _I, _I, _P, _P, _P, _P, _L, _L, _P, _P])
 _C.register("s2c_fp_interp_rows_grad", [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P])
@@ -51,10 +52,11 @@ def _ptr(t):
     return t.data_ptr() if t is not None else None
 
 
-def _call(name, ref, *args, alg_bytes=0, alg_flops=0):
+def _call(name, ref, *args, alg_bytes=0, alg_flops=0, label=None):
     if _C.TIMER.enabled:
         _C.TIMER.alg_bytes = int(alg_bytes)
         _C.TIMER.alg_flops = int(alg_flops)
+        _C.TIMER.label = label
     with torch.cuda.device(ref.device):
         _C.call(name, *args, _C.stream_ptr())
 
@@ -94,9 +96,31 @@ SCATTER_DW = True
 FUSE_DY_SCATTER = _os.environ.get("S2C_FUSE_DY_SCATTER", "1") != "0"
 
 
+# The first layer of a gather stack in POINT SPACE (csrc/s2c_sa.hip: sa_gather_add): the feature
+# product runs once per point (P = feats W_f^T), the gathered rows are P[idx] + W_x rel; the
+# backward sums dY per point first (Z, S) and multiplies afterwards -- weight AND input gradients
+# from B n point rows instead of B m ns gathered rows.  S2C_POINT_SPACE=0: the round-3 gather GEMM.
+POINT_SPACE = _os.environ.get("S2C_POINT_SPACE", "1") != "0"
+POINT_SPACE_BWD = _os.environ.get("S2C_POINT_SPACE_BWD", "1") != "0"
+# The per-point product P on the exact fp32 matrix instruction (an fp32 FMA chain in k order) instead
+# of the bf16x3 split.  Both are fp32-accurate (rms error against float64 6e-7 vs 5e-7 of |P| ~ 2 on
+# the golden model's own operands, tools/diag_point_space.py), but the c132 golden fixture's backbone
+# gradients sit on a knife edge behind the vote aggregation: with P from the split kernel at any of
+# SA1-SA3 they land 6.5e-2 of scale from the reference's (tolerance 3.7e-2) -- with the exact chain,
+# like the gather GEMM, hipBLASLt and the op-by-op path, 1.3e-2.  Costs 0.04 ms of the cfg3 step.
+# S2C_POINT_GEMM_X3=1: the split kernel.
+POINT_GEMM_EXACT = _os.environ.get("S2C_POINT_GEMM_X3", "0") != "1"
+
+
+def _gather_add_blocks(M):
+    lib = _C.load()
+    lib.s2c_sa_gather_add_blocks.argtypes = [_L]
+    lib.s2c_sa_gather_add_blocks.restype = _I
+    return lib.s2c_sa_gather_add_blocks(M)
+
+
 # Backward of a BN(+ReLU) layer: statistics pass, then ONE kernel that forms dY in the operand
 # load of the input-gradient GEMM dX = dY W (s2c_bn_bwd_gemm) -- no apply pass, no library GEMM
-import os as _os
 # the BN+ReLU pass between two layers folded into the next layer's streaming GEMM (the
 # activated operand leaves as a side output of csrc/s2c_gemm2.hip): S2C_FUSE_BNRELU_GEMM=0 = off
 FUSE_BNRELU_GEMM = _os.environ.get("S2C_FUSE_BNRELU_GEMM", "1") != "0"
@@ -505,7 +529,32 @@ class _MLPRows(Function):
                           and W.stride(1) == 1
                           and (from_gather or deferred is not None or A.stride(1) == 1))
             pre_activated = False
-            if from_gather:
+            point_space = (from_gather and POINT_SPACE and Cout % 4 == 0 and Cout <= 256
+                           and bias is None and W.stride(1) == 1 and gather.feats2d() is not False)
+            if point_space:
+                g = gather
+                P = None
+                if g.C > 0:
+                    f2, Wf = g.feats2d(), W[:, 3:]
+                    P = torch.empty((g.B * g.N, Cout), device=dev)
+                    # (POINT_GEMM_EXACT: see the switch's comment)
+                    prev_split = set_gemm_split(False) if POINT_GEMM_EXACT else None
+                    _call("s2c_rows_gemm", P, g.B * g.N, Cout, g.C, f2.data_ptr(), f2.stride(0),
+                          Wf.data_ptr(), Wf.stride(0), None, None, P.data_ptr(), Cout, None,
+                          # the op's contract (unique source rows + idx + Y) split over the two
+                          # launches; P is an intermediate, not algorithmic traffic
+                          alg_bytes=4 * min(g.B * g.N, M) * g.C, alg_flops=2 * g.B * g.N * g.C * Cout,
+                          label="s2c_sa_point_gemm")
+                    if prev_split is not None:
+                        set_gemm_split(prev_split)
+                nbg = _gather_add_blocks(M)
+                gpart = torch.empty(nbg * 2 * Cout, device=dev) if gemm_stats else None
+                Y = torch.empty((M, Cout), device=dev)
+                _call("s2c_sa_gather_add", Y, g.B, g.N, g.m, g.ns, Cout, g.radius, g.normalize,
+                      g.xyz.data_ptr(), g.new_xyz.data_ptr(), _ptr(P), g.idx.data_ptr(),
+                      W.data_ptr(), W.stride(0), Y.data_ptr(), _ptr(gpart),
+                      alg_bytes=4 * (min(g.B * g.N, M) * 3 + M + M * Cout))
+            elif from_gather:
                 assert bias is None and W.stride(1) == 1
                 g = gather
                 nbg = _gemm_blocks(M, Cout)
@@ -624,7 +673,7 @@ class _MLPRows(Function):
             else:
                 Y = torch.addmm(bias, A, W.t()) if bias is not None else torch.mm(A, W.t())
             rec = {"A_in": None if from_gather else A, "W": W,
-                   "has_bias": bias is not None}
+                   "has_bias": bias is not None, "point_space": point_space}
             last = li == nl - 1
             if bn is not None:
                 scale = torch.empty(Cout, device=dev)
@@ -732,8 +781,11 @@ class _MLPRows(Function):
             fused_dA = None
             pre, prestats = prestats, None
             gather_dw = False
+            point_grads = None
             if A_in is None:
-                if gather.needs_grad or not SCATTER_DW:
+                if POINT_SPACE_BWD and SCATTER_DW and W.shape[0] % 4 == 0:
+                    lazy_dw = True      # weight and input gradients from point-indexed sums
+                elif gather.needs_grad or not SCATTER_DW:
                     if (USE_DW32 and BATCH_PARTIAL_SUMS and gather.rows >= DW32_MIN_ROWS
                             and _dw32_slabs(gather.rows, W.shape[0], 3 + gather.C) > 0):
                         # first layer of a gather-fused stack: its weight gradient reads the gathered
@@ -810,7 +862,8 @@ class _MLPRows(Function):
                           int(rec["frozen"]), partial.data_ptr(), coef.data_ptr(),
                           _ptr(dgamma), _ptr(dbeta), dY.data_ptr(),
                           alg_bytes=4 * (2 * M * Cout + 2 * J * Cout))
-                elif (FUSE_BWD_GEMM and (li > 0 or ctx.x_needs_grad) and W.dtype == torch.float32
+                elif (FUSE_BWD_GEMM and (li > 0 or (ctx.x_needs_grad and not lazy_dw))
+                      and W.dtype == torch.float32
                       and dA.dtype == torch.float32 and dA.stride(1) == 1
                       and dA.stride(0) == Cout and _fused_bwd_pays(M, Cout, W.shape[1])
                       and _gemm_split_on()):
@@ -865,6 +918,8 @@ class _MLPRows(Function):
                 dY = dA
             if lazy_dw:
                 dW = gather.weight_grad(dY, bn_bwd=lazy_bn if sp.bn is not None else None)
+                if gather.needs_grad:
+                    point_grads = gather.input_grads(W)
             elif gather_dw:
                 dW = _weight_grad_f32(dY if dY.stride(1) == 1 else dY.contiguous(), None, pending,
                                       gather=gather)
@@ -877,7 +932,7 @@ class _MLPRows(Function):
                     bias_jobs.append((dY, len(grads)))      # summed after the loop
                 else:
                     dbias = dY.sum(0)
-            need_dA = li > 0 or ctx.x_needs_grad
+            need_dA = li > 0 or (ctx.x_needs_grad and not lazy_dw)
             if not need_dA:
                 dA = None
             elif fused_dA is not None:
@@ -926,7 +981,9 @@ class _MLPRows(Function):
         ctx.saved = None
         d_xyz = d_new = d_feats = None
         if gather is not None:
-            if dA is not None:
+            if point_grads is not None:
+                d_xyz, d_new, d_feats = point_grads
+            elif dA is not None:
                 d_xyz, d_new, d_feats = gather.scatter(dA)
             dA = None
         return (dA, d_xyz, d_new, d_feats, None, None, None) + tuple(flat)
@@ -1313,6 +1370,34 @@ class GatherSpec(object):
         self.rows = self.B * self.m * self.ns
         self.needs_grad = self.need_xyz = self.need_feats = False
 
+    def feats2d(self):
+        """The features as (B n, C) rows with one row stride (a view); None without features,
+        False when the batch stride does not continue the row stride."""
+        f = self.feats
+        if f is None or self.C == 0:
+            return None
+        if f.stride(0) != f.shape[1] * f.stride(1):
+            return False
+        return f.as_strided((self.B * self.N, self.C), (f.stride(1), 1), f.storage_offset())
+
+    def input_grads(self, W):
+        """(d_xyz, d_new_xyz, d_feats) from the point-indexed sums weight_grad() left (Z: per
+        point, S: per centre): the products with W run over B n + B m rows, not over the gathered
+        rows, and nothing is scattered afterwards."""
+        ZS = self._ZS
+        nz = self.B * self.N
+        d_xyz = d_new = d_feats = None
+        if self.need_feats and self.C > 0:
+            d_feats = _input_grad_gemm(ZS[:nz], W[:, 3:]).view(self.B, self.N, self.C)
+        if self.need_xyz:
+            g3 = _input_grad_gemm(ZS, W[:, :3])
+            if self.normalize:
+                g3 = g3 / self.radius
+            d_xyz = g3[:nz].view(self.B, self.N, 3)
+            d_new = (-g3[nz:]).view(self.B, self.m, 3)
+        self._ZS = None
+        return d_xyz, d_new, d_feats
+
     def materialise(self):
         X = torch.empty((self.rows, 3 + self.C), dtype=torch.float32,
                         device=self.xyz.device)
@@ -1332,8 +1417,11 @@ class GatherSpec(object):
         ref = dY if dY is not None else bn_bwd[0]
         dev = ref.device
         Cout = ref.shape[1]
-        Z = torch.empty((self.B, self.N, Cout), device=dev)
-        S = torch.empty((self.B, self.m, Cout), device=dev)
+        # Z and S back to back: input_grads() multiplies both by W_x in one product
+        ZS = torch.empty((self.B * self.N + self.B * self.m, Cout), device=dev)
+        Z = ZS[:self.B * self.N].view(self.B, self.N, Cout)
+        S = ZS[self.B * self.N:].view(self.B, self.m, Cout)
+        self._ZS = ZS
         if bn_bwd is not None and dY is None:
             dA, Y, scale, shift, mean, invstd, coef, relu = bn_bwd
             _call("s2c_sa_scatter_sum_bn_bwd", dA, self.B, self.N, self.m, self.ns, Cout,
@@ -1355,11 +1443,9 @@ class GatherSpec(object):
             dWx = dWx / self.radius
         if self.C == 0:
             return dWx
-        f = self.feats
-        if f.stride(0) == f.shape[1] * f.stride(1):
-            f2 = f.as_strided((self.B * self.N, self.C), (f.stride(1), 1), f.storage_offset())
-        else:
-            f2 = f.reshape(self.B * self.N, self.C)
+        f2 = self.feats2d()
+        if f2 is False:
+            f2 = self.feats.reshape(self.B * self.N, self.C)
         return torch.cat([dWx, _weight_grad(Z2, f2)], 1)
 
     def scatter(self, dX):

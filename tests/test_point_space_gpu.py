@@ -1,0 +1,98 @@
+"""The first layer of a set-abstraction stack in point space (csrc/s2c_sa.hip: sa_gather_add,
+pointnet2/fused.py POINT_SPACE): Y = P[idx] + W_x rel against a float64 evaluation of
+QueryAndGroup + the first 1x1 convolution (pointnet2_utils.py:347-359, pytorch_utils.py:67-120),
+its BatchNorm column sums, and the whole stack (forward, weight / feature / coordinate gradients)
+against the round-3 gather GEMM path."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
+
+
+@pytest.mark.parametrize("B,n,m,ns,C,N,normalize", [
+    (2, 3000, 256, 32, 128, 128, True),      # SA2-like
+    (8, 5000, 260, 64, 132, 64, True),       # SA1-like: 133120 rows -> 256-row workgroups
+    (3, 700, 50, 16, 0, 64, False),          # no features: the relative position only
+    (1, 500, 33, 7, 20, 256, True),          # ragged: 231 rows, 64 lanes per row
+    (2, 900, 61, 16, 64, 36, True),          # 36 columns: 9 of 16 lanes per row
+])
+def test_gather_add_matches_float64_and_leaves_the_column_sums(B, n, m, ns, C, N, normalize):
+    from scan2cap_amd import _C
+    from scan2cap_amd.pointnet2 import fused
+    g = torch.Generator(device="cuda").manual_seed(B * n + N)
+    xyz = torch.rand(B, n, 3, device="cuda", generator=g) * 6 - 3
+    new_xyz = xyz[:, :m].contiguous()
+    feats = torch.randn(B, n, C, device="cuda", generator=g) if C else None
+    idx = torch.randint(0, n, (B, m, ns), device="cuda", generator=g, dtype=torch.int32)
+    W = torch.randn(N, 3 + C, device="cuda", generator=g) / (3 + C) ** 0.5
+    radius = 0.4
+    rows = B * m * ns
+    P = None
+    if C:
+        P = torch.empty(B * n, N, device="cuda")
+        fused._call("s2c_rows_gemm", P, B * n, N, C, feats.data_ptr(), C, W[:, 3:].data_ptr(),
+                    W.stride(0), None, None, P.data_ptr(), N, None)
+    nb = fused._gather_add_blocks(rows)
+    part = torch.full((nb * 2 * N,), float("nan"), device="cuda")
+    Y = torch.full((rows, N), float("nan"), device="cuda")
+    fused._call("s2c_sa_gather_add", Y, B, n, m, ns, N, radius, int(normalize), xyz.data_ptr(),
+                new_xyz.data_ptr(), fused._ptr(P), idx.data_ptr(), W.data_ptr(), W.stride(0),
+                Y.data_ptr(), part.data_ptr())
+    bi = torch.arange(B, device="cuda").view(B, 1, 1).expand(B, m, ns)
+    rel = xyz[bi, idx.long()] - new_xyz.unsqueeze(2)                  # fp32, as the reference
+    if normalize:
+        rel = rel / radius
+    X = rel.double()
+    if C:
+        X = torch.cat([X, feats[bi, idx.long()].double()], -1)
+    want = (X.view(rows, -1) @ W.double().t())
+    assert _rel(Y, want) < 2e-6
+    part = part.view(nb, 2, N).double().sum(0)
+    assert _rel(part[0], Y.double().sum(0)) < 1e-6
+    assert _rel(part[1], (Y.double() ** 2).sum(0)) < 1e-6
+
+
+@pytest.mark.parametrize("input_grad", [True, False])
+@pytest.mark.parametrize("B,N,C,npoint,radius,ns,mlp", [
+    (2, 2048, 128, 1024, 0.4, 32, [128, 128, 256]),
+    (2, 4096, 132, 512, 0.2, 64, [64, 64, 128]),
+])
+def test_point_space_stack_matches_the_gather_gemm_stack(input_grad, B, N, C, npoint, radius, ns, mlp):
+    from scan2cap_amd.pointnet2 import fused
+    from scan2cap_amd.pointnet2.pointnet2_modules import PointnetSAModuleVotes
+    from scan2cap_amd.synthetic import scene_xyz
+    torch.manual_seed(1)
+    sa = PointnetSAModuleVotes(npoint=npoint, radius=radius, nsample=ns, mlp=[C] + mlp,
+                               use_xyz=True, normalize_xyz=True).cuda().train()
+    ref = copy.deepcopy(sa)
+    cloud = torch.cat([torch.from_numpy(scene_xyz(B, N, seed=4)).cuda(),
+                       torch.randn(B, N, C, device="cuda")], -1)      # rows of 3 + C floats
+    outs = []
+    for mod, on in ((sa, True), (ref, False)):
+        fused.POINT_SPACE = on
+        try:
+            pc = cloud.clone()
+            xyz = pc[..., :3].contiguous().requires_grad_(input_grad)
+            feats = pc[..., 3:].requires_grad_(input_grad)            # a strided view, like SA1's
+            nx, nf, ni = mod(xyz, feats.transpose(1, 2))
+            gsum = (nf * torch.linspace(-1, 1, nf.numel(), device="cuda").view_as(nf)).sum()
+            gsum.backward()
+            outs.append((nf.detach(), xyz.grad, feats.grad, [p.grad for p in mod.parameters()],
+                         [b.clone() for b in mod.buffers()]))
+        finally:
+            fused.POINT_SPACE = True
+    a, b = outs
+    assert _rel(a[0], b[0]) < 1e-5
+    if input_grad:
+        assert _rel(a[1], b[1]) < 2e-5 and _rel(a[2], b[2]) < 2e-5
+    for ga, gb in zip(a[3], b[3]):
+        assert _rel(ga, gb) < 2e-5
+    for ba, bb in zip(a[4], b[4]):
+        assert _rel(ba.float(), bb.float()) < 1e-5
