@@ -767,6 +767,7 @@ class _MLPRows(Function):
         dev = dOut.device
         grads = []          # per layer, reversed
         pending = []        # split-K partials of the weight gradients, summed in one launch
+        post = []           # closures that finish a gradient once the partial sums exist
         bias_jobs = []      # (dY, layer slot): bias gradients, summed in one launch
         dA = dOut.contiguous()
         partial = None
@@ -917,7 +918,8 @@ class _MLPRows(Function):
             else:
                 dY = dA
             if lazy_dw:
-                dW = gather.weight_grad(dY, bn_bwd=lazy_bn if sp.bn is not None else None)
+                dW = gather.weight_grad(dY, bn_bwd=lazy_bn if sp.bn is not None else None,
+                                        pending=pending, post=post)
                 if gather.needs_grad:
                     point_grads = gather.input_grads(W)
             elif gather_dw:
@@ -972,6 +974,8 @@ class _MLPRows(Function):
             grads.append(g)
         if pending:
             flush_partial_sums(pending)
+        for fin in post:
+            fin()
         if bias_jobs:
             for (_, slot), db in zip(bias_jobs, row_sums([x for x, _ in bias_jobs])):
                 grads[slot][1] = db
@@ -1409,18 +1413,21 @@ class GatherSpec(object):
                              + self.rows + self.rows * (3 + self.C)))
         return X
 
-    def weight_grad(self, dY, bn_bwd=None):
+    def weight_grad(self, dY, bn_bwd=None, pending=None, post=None):
         """dW (Cout, 3+C) = dY^T G without building G (csrc/s2c_sa.hip:
         sa_scatter_sum): the products run over the B*N points.  bn_bwd = (dA, Y, scale,
         shift, mean, invstd, coef, relu): dY is None and formed on the fly as the
-        BatchNorm(+ReLU) backward of dA (s2c_sa_scatter_sum_bn_bwd)."""
+        BatchNorm(+ReLU) backward of dA (s2c_sa_scatter_sum_bn_bwd).  pending / post: the
+        caller's list of split-K partials (flush_partial_sums) and of closures to run after it --
+        the returned dW is complete once both have run."""
         ref = dY if dY is not None else bn_bwd[0]
         dev = ref.device
         Cout = ref.shape[1]
+        nz = self.B * self.N
         # Z and S back to back: input_grads() multiplies both by W_x in one product
-        ZS = torch.empty((self.B * self.N + self.B * self.m, Cout), device=dev)
-        Z = ZS[:self.B * self.N].view(self.B, self.N, Cout)
-        S = ZS[self.B * self.N:].view(self.B, self.m, Cout)
+        ZS = torch.empty((nz + self.B * self.m, Cout), device=dev)
+        Z = ZS[:nz].view(self.B, self.N, Cout)
+        S = ZS[nz:].view(self.B, self.m, Cout)
         self._ZS = ZS
         if bn_bwd is not None and dY is None:
             dA, Y, scale, shift, mean, invstd, coef, relu = bn_bwd
@@ -1436,17 +1443,38 @@ class GatherSpec(object):
                   dY.data_ptr(), self.idx.data_ptr(), Z.data_ptr(), S.data_ptr(),
                   alg_bytes=4 * (self.rows * (Cout + 1)
                                  + (self.B * self.N + self.B * self.m) * Cout))
-        Z2 = Z.view(self.B * self.N, Cout)
-        dWx = _weight_grad(Z2, self.xyz.view(-1, 3)) - \
-            _weight_grad(S.view(-1, Cout), self.new_xyz.view(-1, 3))
-        if self.normalize:
-            dWx = dWx / self.radius
-        if self.C == 0:
-            return dWx
+        Z2, S2 = ZS[:nz], ZS[nz:]
         f2 = self.feats2d()
         if f2 is False:
-            f2 = self.feats.reshape(self.B * self.N, self.C)
-        return torch.cat([dWx, _weight_grad(Z2, f2)], 1)
+            f2 = self.feats.reshape(nz, self.C)
+        dW = torch.empty((Cout, 3 + self.C), device=dev)
+        # the centres' share of the coordinate columns: - S^T new_xyz
+        dWc = _weight_grad(S2, self.new_xyz.view(-1, 3), pending)
+        if f2 is not None and nz <= 65536:
+            # a small stage: ONE product over the points with [xyz | feats] side by side (the copy
+            # is <= 35 MB), instead of a 3-column product of its own
+            both = _weight_grad(Z2, torch.cat([self.xyz.view(-1, 3), f2], 1), pending)
+            dWp = dWf = None
+        else:
+            both = None
+            dWp = _weight_grad(Z2, self.xyz.view(-1, 3), pending)
+            dWf = _weight_grad(Z2, f2, pending) if f2 is not None else None
+
+        def finish():
+            if both is not None:
+                dW.copy_(both)
+                dW[:, :3] -= dWc
+            else:
+                torch.sub(dWp, dWc, out=dW[:, :3])
+                if dWf is not None:
+                    dW[:, 3:] = dWf
+            if self.normalize:
+                dW[:, :3] /= self.radius
+        if post is not None and pending is not None:
+            post.append(finish)
+        else:
+            finish()
+        return dW
 
     def scatter(self, dX):
         """Row gradients (rows, 3+C) -> d_xyz (B,N,3), d_new_xyz (B,m,3),
