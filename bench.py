@@ -92,7 +92,7 @@ KERNELS_OF = {
     "s2c_bn_train_stats": ("col_stats_kernel",),
     "s2c_rows_gemm": _GEMM_PLAIN,
     "s2c_sa_gather_gemm": _GEMM_GATHER,
-    "s2c_sa_point_gemm": _GEMM_PLAIN,
+    "s2c_sa_point_gemm": ("point_gemm_kernel",),
     "s2c_sa_gather_add": ("sa_gather_add_kernel",),
     "s2c_sa_fused_eval": ("sa_fused_eval_kernel",),
     "s2c_sa_gather_rows": ("sa_gather_rows_kernel",),

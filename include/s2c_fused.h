@@ -52,6 +52,12 @@ int s2c_sa_gather_add(int b, int n, int m, int ns, int N, float radius, int norm
                       const float *xyz, const float *new_xyz, const float *P, const int *idx,
                       const float *W, int ldw, float *Y, float *partial, void *stream);
 
+/* P (M x N, row stride ldp) = A (M x K, row stride lda; rows at any 4-byte address) W^T (W: N x K,
+ * row stride ldw) on the exact fp32 matrix instruction (an fp32 FMA chain over k): the per-point
+ * product in front of s2c_sa_gather_add (csrc/s2c_pgemm.hip). */
+int s2c_point_gemm(long long M, int N, int K, const float *A, long long lda, const float *W,
+                   int ldw, float *P, int ldp, void *stream);
+
 /* For the weight gradient of a gather-fused layer whose inputs need no gradient:
  * Z (b,n,C) = sum of the dY rows (b*m*ns x C) that gathered each point (zeroed by the
  * callee), S (b,m,C) = sum over the ns rows of each centre.  Then

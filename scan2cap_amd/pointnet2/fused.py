@@ -26,6 +26,7 @@ _I, _L, _P, _F = ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_floa
 _C.register("s2c_sa_gather_rows", [_I, _I, _I, _I, _I, _L, _L, _F, _I, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_sa_scatter_rows", [_I, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_sa_scatter_sum", [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P])
+_C.register("s2c_point_gemm", [_L, _I, _I, _P, _L, _P, _I, _P, _I, _P])
 _C.register("s2c_sa_gather_add", [_I, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P])
 _C.register("s2c_sa_scatter_sum_bn_bwd", [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P])
 _C.register("s2c_fp_interp_rows", [_I, _I, _I, _I, _I, _P, _P, _P, _P, _L, _L, _P, _P])
@@ -102,14 +103,18 @@ FUSE_DY_SCATTER = _os.environ.get("S2C_FUSE_DY_SCATTER", "1") != "0"
 # from B n point rows instead of B m ns gathered rows.  S2C_POINT_SPACE=0: the round-3 gather GEMM.
 POINT_SPACE = _os.environ.get("S2C_POINT_SPACE", "1") != "0"
 POINT_SPACE_BWD = _os.environ.get("S2C_POINT_SPACE_BWD", "1") != "0"
-# The per-point product P on the exact fp32 matrix instruction (an fp32 FMA chain in k order) instead
-# of the bf16x3 split.  Both are fp32-accurate (rms error against float64 6e-7 vs 5e-7 of |P| ~ 2 on
-# the golden model's own operands, tools/diag_point_space.py), but the c132 golden fixture's backbone
-# gradients sit on a knife edge behind the vote aggregation: with P from the split kernel at any of
-# SA1-SA3 they land 6.5e-2 of scale from the reference's (tolerance 3.7e-2) -- with the exact chain,
-# like the gather GEMM, hipBLASLt and the op-by-op path, 1.3e-2.  Costs 0.04 ms of the cfg3 step.
-# S2C_POINT_GEMM_X3=1: the split kernel.
+# The per-point product P on the exact fp32 matrix instruction (csrc/s2c_pgemm.hip: an fp32 FMA chain
+# in k order, bit-identical to the tiled kernel's exact path) instead of the bf16x3 split.  Both are
+# fp32-accurate (rms error against float64 6e-7 vs 5e-7 of |P| ~ 2 on the golden model's own operands,
+# tools/diag_point_space.py), but the train-mode gradients of the golden fixtures hang on discrete
+# decisions behind the vote aggregation (ReLU masks / max aggregations a few ulps from a tie, each
+# worth per cents of a small fixture's weight gradients: tools/diag_golden_ab.py): with P from the split
+# kernel at any of SA1-SA3 the c132 backbone gradients land 6.5e-2 of scale from the reference's
+# (tolerance 3.7e-2), with another k order of the exact chain the cfg1 ones 2.5e-2 (3.5e-3) -- with
+# THIS chain, like the gather GEMM, hipBLASLt and the op-by-op path, both fixtures pass.
+# S2C_POINT_GEMM_X3=1: the split kernel; S2C_POINT_GEMM_TILED=1: the tiled kernel's exact path.
 POINT_GEMM_EXACT = _os.environ.get("S2C_POINT_GEMM_X3", "0") != "1"
+POINT_GEMM_TILED = _os.environ.get("S2C_POINT_GEMM_TILED", "0") == "1"   # exact chain on s2c_gemm.hip
 
 
 def _gather_add_blocks(M):
@@ -537,16 +542,23 @@ class _MLPRows(Function):
                 if g.C > 0:
                     f2, Wf = g.feats2d(), W[:, 3:]
                     P = torch.empty((g.B * g.N, Cout), device=dev)
-                    # (POINT_GEMM_EXACT: see the switch's comment)
-                    prev_split = set_gemm_split(False) if POINT_GEMM_EXACT else None
-                    _call("s2c_rows_gemm", P, g.B * g.N, Cout, g.C, f2.data_ptr(), f2.stride(0),
-                          Wf.data_ptr(), Wf.stride(0), None, None, P.data_ptr(), Cout, None,
-                          # the op's contract (unique source rows + idx + Y) split over the two
-                          # launches; P is an intermediate, not algorithmic traffic
-                          alg_bytes=4 * min(g.B * g.N, M) * g.C, alg_flops=2 * g.B * g.N * g.C * Cout,
-                          label="s2c_sa_point_gemm")
-                    if prev_split is not None:
+                    # the op's contract (unique source rows + idx + Y) is split over the two launches;
+                    # P is an intermediate, not algorithmic traffic
+                    pb, pf = 4 * min(g.B * g.N, M) * g.C, 2 * g.B * g.N * g.C * Cout
+                    if POINT_GEMM_EXACT and POINT_GEMM_TILED:
+                        prev_split = set_gemm_split(False)
+                        _call("s2c_rows_gemm", P, g.B * g.N, Cout, g.C, f2.data_ptr(), f2.stride(0),
+                              Wf.data_ptr(), Wf.stride(0), None, None, P.data_ptr(), Cout, None,
+                              alg_bytes=pb, alg_flops=pf, label="s2c_sa_point_gemm")
                         set_gemm_split(prev_split)
+                    elif POINT_GEMM_EXACT:
+                        _call("s2c_point_gemm", P, g.B * g.N, Cout, g.C, f2.data_ptr(), f2.stride(0),
+                              Wf.data_ptr(), Wf.stride(0), P.data_ptr(), Cout,
+                              alg_bytes=pb, alg_flops=pf, label="s2c_sa_point_gemm")
+                    else:
+                        _call("s2c_rows_gemm", P, g.B * g.N, Cout, g.C, f2.data_ptr(), f2.stride(0),
+                              Wf.data_ptr(), Wf.stride(0), None, None, P.data_ptr(), Cout, None,
+                              alg_bytes=pb, alg_flops=pf, label="s2c_sa_point_gemm")
                 nbg = _gather_add_blocks(M)
                 gpart = torch.empty(nbg * 2 * Cout, device=dev) if gemm_stats else None
                 Y = torch.empty((M, Cout), device=dev)

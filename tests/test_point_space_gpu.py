@@ -96,3 +96,36 @@ def test_point_space_stack_matches_the_gather_gemm_stack(input_grad, B, N, C, np
         assert _rel(ga, gb) < 2e-5
     for ba, bb in zip(a[4], b[4]):
         assert _rel(ba.float(), bb.float()) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K,lda,off", [
+    (40000, 64, 132, 135, 3),      # SA1: the cloud's feature columns in place, 128 x 64 tiles
+    (70000, 64, 132, 135, 3),      # >= 512 row tiles
+    (16384, 128, 128, 128, 0),     # SA2: 64 x 64 tiles
+    (70000, 128, 256, 256, 0),     # 128 x 128 tiles
+    (1000, 36, 5, 7, 2),           # ragged everything, K < one group
+    (333, 256, 259, 259, 0),       # K tail of 3, four column tiles
+])
+def test_point_gemm_matches_float64(M, N, K, lda, off):
+    from scan2cap_amd.pointnet2 import fused
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    buf = torch.randn(M, lda, device="cuda", generator=g)
+    A = buf[:, off:off + K]
+    Wb = torch.randn(N, K + 3, device="cuda", generator=g) / K ** 0.5
+    W = Wb[:, 3:]                                             # a column block, like W[:, 3:]
+    P = torch.full((M, N), float("nan"), device="cuda")
+    fused._call("s2c_point_gemm", P, M, N, K, A.data_ptr(), A.stride(0), W.data_ptr(), W.stride(0),
+                P.data_ptr(), N)
+    want = A.double() @ W.double().t()
+    mag = A.double().abs() @ W.double().abs().t()
+    assert float(((P.double() - want).abs() / mag.clamp(min=1e-30)).max()) < 1e-6   # an fp32 chain over K
+    assert _rel(P, want) < 2e-6
+    # the same fp32 chain as the tiled kernel's exact path: bit for bit
+    T = torch.empty_like(P)
+    prev = fused.set_gemm_split(False)
+    try:
+        fused._call("s2c_rows_gemm", T, M, N, K, A.data_ptr(), A.stride(0), W.data_ptr(), W.stride(0),
+                    None, None, T.data_ptr(), N, None)
+    finally:
+        fused.set_gemm_split(prev)
+    assert torch.equal(P, T)
