@@ -54,6 +54,11 @@ def _split_gemm_available():
         try:
             a = torch.zeros(8, 16, dtype=torch.bfloat16, device="cuda")
             torch.mm(a, a.t(), out_dtype=torch.float32)
+            # ... and the exact addmm overload the classifier of the S2C_EVAL_STEP=1 path uses
+            # (bias, bf16 operands, fp32 `out`): a build with mm(out_dtype) but without it must
+            # fall back here, not fail in the step loop
+            torch.addmm(torch.zeros(8, device="cuda"), a, a.t(), out_dtype=torch.float32,
+                        out=torch.empty(8, 8, device="cuda"))
             _split_ok = hasattr(torch.ops.aten, "_thnn_fused_gru_cell")
         except Exception:
             _split_ok = False
