@@ -169,41 +169,63 @@ struct BnBwdCoefs {
   int relu;
 };
 
-template <bool BNBWD>
+template <bool BNBWD, int U>
 __global__ __launch_bounds__(256) void sa_scatter_sum_kernel(
     int n, int m, int ns, int C, const float *__restrict__ dY,
     const int *__restrict__ idx, float *__restrict__ Z, float *__restrict__ S, BnBwdCoefs bw) {
   __shared__ float s_sum[4][1024];
+  __shared__ float s_pad[4][1024];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long bj = blockIdx.x;
   const long long b = bj / m;
+  // A ball with fewer than ns points is padded with its FIRST index (ball_query_gpu.cu:34-41): the
+  // rows of a centre that gathered that point -- row 0 and every pad -- are summed here and leave
+  // as ONE atomic row per channel.  (Synthetic cfg3 scenes: 79 % of SA1's rows, 87 % of SA2's; the
+  // float atomics are what bounds this kernel.)
+  const int p0 = idx[bj * ns];
   for (int c0 = 0; c0 < C; c0 += 64) {
     const int c = c0 + lane;
-    float acc = 0.f;
+    float acc = 0.f, pad = 0.f;
     float sc = 0.f, sh = 0.f, mu = 0.f, is = 0.f, k0 = 0.f, k1 = 0.f, k2 = 0.f;
     if (BNBWD && c < C) {
       sc = bw.scale[c]; sh = bw.shift[c]; mu = bw.mean[c]; is = bw.invstd[c];
       k0 = bw.coef[c]; k1 = bw.coef[C + c]; k2 = bw.coef[2 * C + c];
     }
-    for (int s = wave; s < ns; s += 4) {
-      const long long r = bj * ns + s;
-      const int p = idx[r];
-      if (c < C) {
-        float v = dY[r * C + c];
+    // U rows of the wave in flight (a row per iteration left ONE index load and one row of loads
+    // outstanding per wave: latency-bound at 1.9 TB/s); addresses clamped, every load unconditional
+    const int cl = c < C ? c : C - 1;
+    for (int s0 = wave; s0 < ns; s0 += 4 * U) {
+      int p[U];
+      float g[U], y[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int s = s0 + 4 * u;
+        const long long r = bj * ns + (s < ns ? s : s0);
+        p[u] = idx[r];
+        g[u] = dY[r * C + cl];
+        y[u] = BNBWD ? bw.Y[r * C + cl] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float v = g[u];
         if (BNBWD) {
-          const float y = bw.Y[r * C + c];
-          if (bw.relu && !(y * sc + sh > 0.f)) v = 0.f;
-          v = k0 * (v - k1 - ((y - mu) * is) * k2);
+          if (bw.relu && !(y[u] * sc + sh > 0.f)) v = 0.f;
+          v = k0 * (v - k1 - ((y[u] - mu) * is) * k2);
         }
-        acc += v;
-        atomicAdd(Z + (b * n + p) * (long long)C + c, v);
+        if (c < C && s0 + 4 * u < ns) {
+          acc += v;
+          if (p[u] == p0) pad += v;
+          else atomicAdd(Z + (b * n + p[u]) * (long long)C + c, v);
+        }
       }
     }
-    if (c < C) s_sum[wave][c] = acc;
+    if (c < C) { s_sum[wave][c] = acc; s_pad[wave][c] = pad; }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256)
+  for (int c = threadIdx.x; c < C; c += 256) {
     S[bj * C + c] = (s_sum[0][c] + s_sum[1][c]) + (s_sum[2][c] + s_sum[3][c]);
+    atomicAdd(Z + (b * n + p0) * (long long)C + c, (s_pad[0][c] + s_pad[1][c]) + (s_pad[2][c] + s_pad[3][c]));
+  }
 }
 
 extern "C" int s2c_sa_scatter_sum(int b, int n, int m, int ns, int C, const float *dY,
@@ -213,8 +235,12 @@ extern "C" int s2c_sa_scatter_sum(int b, int n, int m, int ns, int C, const floa
   hipStream_t st = (hipStream_t)stream;
   if (zero_async(Z, sizeof(float) * (size_t)b * n * C, st) != hipSuccess)
     return fail2("memset");
-  hipLaunchKernelGGL(sa_scatter_sum_kernel<false>, dim3((unsigned)(b * m)), dim3(256), 0, st, n,
-                     m, ns, C, dY, idx, Z, S, BnBwdCoefs());
+  if (ns > 32)
+    hipLaunchKernelGGL((sa_scatter_sum_kernel<false, 8>), dim3((unsigned)(b * m)), dim3(256), 0, st, n,
+                       m, ns, C, dY, idx, Z, S, BnBwdCoefs());
+  else
+    hipLaunchKernelGGL((sa_scatter_sum_kernel<false, 4>), dim3((unsigned)(b * m)), dim3(256), 0, st, n,
+                       m, ns, C, dY, idx, Z, S, BnBwdCoefs());
   return check2("sa_scatter_sum");
 }
 
@@ -231,8 +257,12 @@ extern "C" int s2c_sa_scatter_sum_bn_bwd(int b, int n, int m, int ns, int C, con
   if (zero_async(Z, sizeof(float) * (size_t)b * n * C, st) != hipSuccess)
     return fail2("memset");
   BnBwdCoefs bw = {Y, scale, shift, mean, invstd, coef, relu};
-  hipLaunchKernelGGL(sa_scatter_sum_kernel<true>, dim3((unsigned)(b * m)), dim3(256), 0, st, n,
-                     m, ns, C, dA, idx, Z, S, bw);
+  if (ns > 32)
+    hipLaunchKernelGGL((sa_scatter_sum_kernel<true, 8>), dim3((unsigned)(b * m)), dim3(256), 0, st, n,
+                       m, ns, C, dA, idx, Z, S, bw);
+  else
+    hipLaunchKernelGGL((sa_scatter_sum_kernel<true, 4>), dim3((unsigned)(b * m)), dim3(256), 0, st, n,
+                       m, ns, C, dA, idx, Z, S, bw);
   return check2("sa_scatter_sum_bn_bwd");
 }
 
