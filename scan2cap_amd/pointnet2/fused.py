@@ -1459,29 +1459,28 @@ class GatherSpec(object):
         f2 = self.feats2d()
         if f2 is False:
             f2 = self.feats.reshape(nz, self.C)
-        dW = torch.empty((Cout, 3 + self.C), device=dev)
         # the centres' share of the coordinate columns: - S^T new_xyz
         dWc = _weight_grad(S2, self.new_xyz.view(-1, 3), pending)
         if f2 is not None and nz <= 65536:
             # a small stage: ONE product over the points with [xyz | feats] side by side (the copy
-            # is <= 35 MB), instead of a 3-column product of its own
-            both = _weight_grad(Z2, torch.cat([self.xyz.view(-1, 3), f2], 1), pending)
+            # is <= 35 MB), instead of a 3-column product of its own; its output IS dW
+            dW = _weight_grad(Z2, torch.cat([self.xyz.view(-1, 3), f2], 1), pending)
             dWp = dWf = None
         else:
-            both = None
+            dW = torch.empty((Cout, 3 + self.C), device=dev)
             dWp = _weight_grad(Z2, self.xyz.view(-1, 3), pending)
             dWf = _weight_grad(Z2, f2, pending) if f2 is not None else None
 
         def finish():
-            if both is not None:
-                dW.copy_(both)
-                dW[:, :3] -= dWc
+            x3 = dW[:, :3]                       # in-place ops on the view: no copy back
+            if dWp is None:
+                x3.sub_(dWc)
             else:
-                torch.sub(dWp, dWc, out=dW[:, :3])
+                torch.sub(dWp, dWc, out=x3)
                 if dWf is not None:
-                    dW[:, 3:] = dWf
+                    dW[:, 3:].copy_(dWf)
             if self.normalize:
-                dW[:, :3] /= self.radius
+                x3.div_(self.radius)
         if post is not None and pending is not None:
             post.append(finish)
         else:
