@@ -180,12 +180,24 @@ __global__ __launch_bounds__(256) void edge_rows_grad_kernel(
     float *di = dx + bi * F;
     for (int f = lane; f < F; f += 64) {
       float acc = 0.0f;
-      for (int l = 0; l < L; ++l) {
-        const long long e = bi * L + l;
-        const float *g = dR + e * 2 * F;
-        const float a = g[f], d = g[F + f];
-        atomicAdd(dx + (b * K + nbr[e]) * F + f, a - d);
-        acc += d;
+      // five edges of loads in flight (one edge per iteration left two loads and an index
+      // outstanding per wave between atomics: latency-bound)
+      for (int l0 = 0; l0 < L; l0 += 5) {
+        float a[5], d[5];
+        long long to[5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+          const long long e = bi * L + (l0 + u < L ? l0 + u : l0);
+          const float *g = dR + e * 2 * F;
+          a[u] = g[f]; d[u] = g[F + f];
+          to[u] = nbr[e];
+        }
+#pragma unroll
+        for (int u = 0; u < 5; ++u)
+          if (l0 + u < L) {
+            atomicAdd(dx + (b * K + to[u]) * F + f, a[u] - d[u]);
+            acc += d[u];
+          }
       }
       atomicAdd(di + f, acc);
     }
