@@ -297,6 +297,10 @@ int s2c_gemm_set_split(int on);
  * workgroups per CU), 0 = the 32-k-slice kernel (which keeps the BatchNorm-backward prologue of
  * s2c_bn_bwd_gemm either way).  Identical results.  Returns the previous setting. */
 int s2c_gemm_set_c64(int on);
+/* 1 (default; S2C_GEMM_C64_NARROW): that kernel on 128 x 32 workgroup tiles when 128 x 128 ones would
+ * cover the chip once or less (bit-identical values; not for the pooled epilogues); returns the
+ * previous setting */
+int s2c_gemm_set_c64_narrow(int on);
 int s2c_rows_gemm(long long M, int N, int K, const float *A, int lda, const float *W,
                   int ldw, const float *pscale, const float *pshift, float *Y,
                   int ldy, float *partial, void *stream);

@@ -97,13 +97,14 @@ struct BwdArgs {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ void affine_epilogue(const f32x16 (&acc)[2][2], const EpiArgs &ep,
+template <int TM = 2, int TN = 2>
+__device__ __forceinline__ void affine_epilogue(const f32x16 (&acc)[TM][TN], const EpiArgs &ep,
                                                 long long M, int N, long long m0w, int n0w,
                                                 int li, int lk) {
-  // m0w / n0w: first row / column of this wave's 64 x 64 tile
+  // m0w / n0w: first row / column of this wave's (32 TM) x (32 TN) tile (pooling: TM == 2)
   // C/D layout of 32x32: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < TN; ++j) {
     const int col = n0w + j * 32 + li;
     const bool ok = col < N;
     float sc = 0.f, sh = 0.f;
@@ -112,9 +113,9 @@ __device__ __forceinline__ void affine_epilogue(const f32x16 (&acc)[2][2], const
       sc = (ep.gamma ? ep.gamma[col] : 1.0f) * invstd;
       sh = (ep.beta ? ep.beta[col] : 0.0f) - ep.mean[col] * sc;
     }
-    if (ep.pool_ns == 0) {
+    if (ep.pool_ns == 0 || TM != 2) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const long long row = m0w + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
@@ -126,7 +127,7 @@ __device__ __forceinline__ void affine_epilogue(const f32x16 (&acc)[2][2], const
       const int ns = ep.pool_ns;
       float g[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           float v = acc[i][j][e] * sc + sh;
@@ -845,14 +846,23 @@ struct PoolExt {
 constexpr int C64_LD = 68;
 constexpr size_t C64_LDS_BYTES = 2 * 128 * C64_LD * sizeof(float);     // 69632
 
-template <int PRO>
+// Two shapes of the same kernel.  (WM, WN, TM, TN) = (2, 2, 2, 2): workgroup tile 128 x 128, wave
+// 64 x 64 (all epilogues).  (4, 1, 1, 1): workgroup tile 128 x 32, wave 32 x 32 -- for launches whose
+// 128 x 128 tiles would cover the chip once or less: such a launch lasts as long as ONE tile (two
+// 64-k chunks of loads, staging, barriers, 64 four-byte stores per lane), and a quarter of the
+// columns is a quarter of the MFMAs and stores per wave, 10 instead of 16 loads per thread and
+// four times the workgroups.  The 128-row tile -- the statistics partials -- is the same; the
+// pooled epilogues need the 64-row wave tile and stay on the wide shape.  Every output sums the
+// same products in the same order: bit-identical values.
+template <int PRO, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256, 2) void rows_gemm_c64_kernel(
     long long M, int N, int K, const float *__restrict__ A, int lda,
     const float *__restrict__ W, int ldw, const float *__restrict__ pscale,
     const float *__restrict__ pshift, GatherArgs ga, float *__restrict__ Y, int ldy,
     float *__restrict__ partial, EpiArgs ep, float *__restrict__ side, int ld_side,
     NextStats nx, PoolExt px) {
-  constexpr int WM = 2, WN = 2, BN = 128;
+  static_assert(WM * WN == 4 && 32 * TM * WM == 128, "four waves on 128 rows");
+  constexpr int WTM = 32 * TM, WTN = 32 * TN, BN = WTN * WN, NPW = BN / 16;
   extern __shared__ __attribute__((aligned(16))) float c64_smem[];
   __shared__ float s_stat[2][WM][BN];
   float *As = c64_smem, *Ws = c64_smem + 128 * C64_LD;
@@ -861,14 +871,14 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_c64_kernel(
   const int li = lane & 31, lk = lane >> 5;
   // 1-D grid, XCD-aware: workgroup ids that differ by 8 share an XCD (its L2) and start one
   // after the other -- the column blocks of ONE row tile, so that the A tile comes from HBM once
-  const int nby = (N + 127) >> 7;
+  const int nby = (N + BN - 1) / BN;
   const int by = (int)((blockIdx.x >> 3) % nby);
   const long long bx = 8ll * ((blockIdx.x >> 3) / nby) + (blockIdx.x & 7);
   if (bx * 128 >= M) return;
   const long long m0 = bx * 128;
-  const int n0 = by * 128;
+  const int n0 = by * BN;
   const int nchunks = (K + 63) >> 6;
-  const bool live = n0 + 64 * wn < N;               // a wave beyond N multiplies nothing
+  const bool live = n0 + WTN * wn < N;              // a wave beyond N multiplies nothing
   long long *pr = g_prof;
   const bool prof_on = pr != nullptr && (int)bx == g_prof_block && by == 0 && tid == 0;
   int nstamp = 0;
@@ -895,7 +905,7 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_c64_kernel(
     }
   }
 
-  float4 ra[8], rw[8];
+  float4 ra[8], rw[NPW];
   auto issue = [&](int c) {
     const int k = 64 * c + 4 * kq;
 #pragma unroll
@@ -921,16 +931,18 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_c64_kernel(
         const long long rc = row < M ? row : M - 1;   // clamped: loads stay inside the matrix
         ra[i] = mid_load4(A + rc * lda, k, K);
       }
-      const int n = n0 + 16 * i + lr;
-      rw[i] = mid_load4(W + (long long)(n < N ? n : N - 1) * ldw, k, K);
+      if (i < NPW) {
+        const int n = n0 + 16 * i + lr;
+        rw[i < NPW ? i : 0] = mid_load4(W + (long long)(n < N ? n : N - 1) * ldw, k, K);
+      }
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -965,38 +977,39 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_c64_kernel(
       }
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 8; ++i)
       *reinterpret_cast<float4 *>(As + (16 * i + lr) * C64_LD + 4 * kq) = ra[i];
+#pragma unroll
+    for (int i = 0; i < NPW; ++i)
       *reinterpret_cast<float4 *>(Ws + (16 * i + lr) * C64_LD + 4 * kq) = rw[i];
-    }
     if (c + 1 < nchunks) issue(c + 1);               // flies while this chunk is multiplied
     __syncthreads();
     X3_STAMP();                // per chunk: operands landed, staged, barrier
     if (live) {
       const int kleft = K - 64 * c;
       const int nsteps = kleft >= 64 ? 4 : (kleft + 15) >> 4;
-      const float *fa0 = As + (64 * wm + li) * C64_LD + 8 * lk;
-      const float *fw0 = Ws + (64 * wn + li) * C64_LD + 8 * lk;
+      const float *fa0 = As + (WTM * wm + li) * C64_LD + 8 * lk;
+      const float *fw0 = Ws + (WTN * wn + li) * C64_LD + 8 * lk;
       for (int s = 0; s < nsteps; ++s) {
         // (one W fragment at a time: 20 registers less than holding both; every accumulator
         // still receives its six products in the same order)
-        MidPlanes pa[2];
+        MidPlanes pa[TM];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < TM; ++t) {
           const float *fa = fa0 + 32 * t * C64_LD + 16 * s;
           pa[t] = mid_split8(*reinterpret_cast<const float4 *>(fa),
                              *reinterpret_cast<const float4 *>(fa + 4));
         }
         constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < TN; ++j) {
           const float *fw = fw0 + 32 * j * C64_LD + 16 * s;
           const MidPlanes pb = mid_split8(*reinterpret_cast<const float4 *>(fw),
                                           *reinterpret_cast<const float4 *>(fw + 4));
 #pragma unroll
           for (int q = 0; q < 6; ++q)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TM; ++i)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[i].p[TA[q]], pb.p[TB[q]],
                                                                   acc[i][j], 0, 0, 0);
         }
@@ -1007,10 +1020,10 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_c64_kernel(
   }
 
   if (ep.mean != nullptr) {    // inference: BN + ReLU (+ max-pool) leave with the GEMM
-    affine_epilogue(acc, ep, M, N, m0 + wm * 64, n0 + wn * 64, li, lk);
+    affine_epilogue<TM, TN>(acc, ep, M, N, m0 + wm * WTM, n0 + wn * WTN, li, lk);
     return;
   }
-  if (PRO != PRO_GATHER && px.ext != nullptr) {
+  if constexpr (PRO != PRO_GATHER && TM == 2 && TN == 2) if (px.ext != nullptr) {
     // ---- pooled layer: per centre and column the maximum of sign * y and its first row -----
     const int ns = px.ns;
 #pragma unroll
@@ -1073,26 +1086,26 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_c64_kernel(
   // C/D layout of 32x32: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
   const bool next_stats = PRO == PRO_NONE && nx.Y != nullptr;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = n0 + wn * 64 + j * 32 + li;
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn * WTN + j * 32 + li;
     float s1 = 0.f, s2 = 0.f;
     float nsc = 0.f, nsh = 0.f, nmu = 0.f, nis = 0.f;
     if (next_stats && col < N) {
       nsc = nx.scale[col]; nsh = nx.shift[col]; nmu = nx.mean[col]; nis = nx.invstd[col];
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TM; ++i) {
       float ny[PRO == PRO_NONE ? 16 : 1];
       if (next_stats) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const long long row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+          const long long row = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
           ny[PRO == PRO_NONE ? e : 0] = (row < M && col < N) ? nx.Y[row * (long long)N + col] : 0.f;
         }
       }
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const long long row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+        const long long row = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
         const float v = acc[i][j][e];
         if (row < M && col < N) {
           Y[row * ldy + col] = v;
@@ -1113,8 +1126,8 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_c64_kernel(
       s1 += __shfl_xor(s1, 32, 64);
       s2 += __shfl_xor(s2, 32, 64);
       if (lk == 0) {
-        s_stat[0][wm][wn * 64 + j * 32 + li] = s1;
-        s_stat[1][wm][wn * 64 + j * 32 + li] = s2;
+        s_stat[0][wm][wn * WTN + j * 32 + li] = s1;
+        s_stat[1][wm][wn * WTN + j * 32 + li] = s2;
       }
     }
   }
@@ -1149,6 +1162,16 @@ static bool c64_on() {
   return g_c64 != 0;
 }
 
+// S2C_GEMM_C64_NARROW=0 / s2c_gemm_set_c64_narrow(0): always 128 x 128 tiles
+static int g_c64_narrow = -1;
+static bool c64_narrow_on() {
+  if (g_c64_narrow < 0) {
+    const char *e = getenv("S2C_GEMM_C64_NARROW");
+    g_c64_narrow = e ? atoi(e) : 1;
+  }
+  return g_c64_narrow != 0;
+}
+
 template <int PRO>
 int launch_c64(long long M, int N, int K, const float *A, int lda, const float *W, int ldw,
                const float *pscale, const float *pshift, const GatherArgs &ga, float *Y, int ldy,
@@ -1158,17 +1181,30 @@ int launch_c64(long long M, int N, int K, const float *A, int lda, const float *
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
   if (attr_state[dev] == 0)
-    attr_state[dev] = hipFuncSetAttribute((const void *)rows_gemm_c64_kernel<PRO>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)C64_LDS_BYTES) == hipSuccess ? 1 : -1;
+    attr_state[dev] = (hipFuncSetAttribute((const void *)rows_gemm_c64_kernel<PRO, 2, 2, 2, 2>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)C64_LDS_BYTES) == hipSuccess &&
+                       hipFuncSetAttribute((const void *)rows_gemm_c64_kernel<PRO, 4, 1, 1, 1>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)C64_LDS_BYTES) == hipSuccess) ? 1 : -1;
   if (attr_state[dev] < 0) {
     (void)hipGetLastError();
     return -2;                                 // not taken: the 32-k-slice kernel runs instead
   }
-  const long long nbx = (M + 127) / 128, nby = (N + 127) / 128;
+  const long long nbx = (M + 127) / 128;
+  // 128 x 32 tiles while 128 x 128 ones cover the chip once or less (not for the pooled epilogues)
+  const bool narrow = c64_narrow_on() && nbx * ((N + 127) / 128) <= 192 && px.ext == nullptr &&
+                      !(ep.mean != nullptr && ep.pool_ns != 0);
+  const long long nby = narrow ? (N + 31) / 32 : (N + 127) / 128;
   dim3 grid((unsigned)(8 * ((nbx + 7) / 8) * nby));
-  hipLaunchKernelGGL((rows_gemm_c64_kernel<PRO>), grid, dim3(256), C64_LDS_BYTES, st, M, N, K, A,
-                     lda, W, ldw, pscale, pshift, ga, Y, ldy, partial, ep, side, ld_side, nx, px);
+  if (narrow)
+    hipLaunchKernelGGL((rows_gemm_c64_kernel<PRO, 4, 1, 1, 1>), grid, dim3(256),
+                       (128 + 32) * C64_LD * sizeof(float), st, M, N, K, A, lda, W, ldw, pscale,
+                       pshift, ga, Y, ldy, partial, ep, side, ld_side, nx, px);
+  else
+    hipLaunchKernelGGL((rows_gemm_c64_kernel<PRO, 2, 2, 2, 2>), grid, dim3(256), C64_LDS_BYTES, st,
+                       M, N, K, A, lda, W, ldw, pscale, pshift, ga, Y, ldy, partial, ep, side,
+                       ld_side, nx, px);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     fprintf(stderr, "s2c_rows_gemm(c64) launch failed: %s\n", hipGetErrorString(e));
@@ -1434,6 +1470,12 @@ extern "C" int s2c_gemm_set_profile(long long *prof, int block) {
 
 /* 1 (default; environment S2C_GEMM_C64): problems with N > 64 on rows_gemm_c64_kernel (K in
  * 64-chunks of fp32 in LDS), 0: on the 32-k-slice kernel.  Returns the previous setting. */
+extern "C" int s2c_gemm_set_c64_narrow(int on) {
+  const int old = c64_narrow_on() ? 1 : 0;
+  g_c64_narrow = on ? 1 : 0;
+  return old;
+}
+
 extern "C" int s2c_gemm_set_c64(int on) {
   const int old = c64_on() ? 1 : 0;
   g_c64 = on ? 1 : 0;

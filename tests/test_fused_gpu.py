@@ -3,6 +3,7 @@ PyTorch fp32 reference of the same computation: the op-by-op path of the module
 (QueryAndGroup -> Conv2d/BatchNorm2d/ReLU -> max_pool2d, i.e. exactly the
 reference's formulation), forward and backward, train and eval statistics."""
 import copy
+import ctypes
 import os
 
 import numpy as np
@@ -1178,6 +1179,43 @@ def test_chunk64_gemm_matches_fp64_and_the_slice_kernel(M, N, K, lda, pro):
     assert torch.equal(outs[0][0], outs[1][0])
 
 
+@pytest.mark.parametrize("M,N,K,pro", [(16384, 128, 128, 0), (8192, 256, 256, 1), (20480, 256, 128, 0),
+                                       (3000, 200, 131, 1), (32768, 128, 259, 0), (129, 65, 16, 0)])
+def test_chunk64_gemm_narrow_tiles_are_bit_identical(M, N, K, pro):
+    """rows_gemm_c64_kernel on 128 x 32 workgroup tiles (taken when 128 x 128 ones would cover the
+    chip once or less) against the 128 x 128 tiling: values bit for bit, statistics partials to
+    rounding (the four 32-row waves of a tile add up in another order than the two 64-row ones)."""
+    _C, lib = _stream_lib()
+    lib.s2c_gemm_set_c64_narrow.argtypes = [ctypes.c_int]
+    lib.s2c_gemm_set_c64_narrow.restype = ctypes.c_int
+    torch.manual_seed(M % 1000 + N + K)
+    A = torch.randn(M, K, device="cuda")
+    W = torch.randn(N, K, device="cuda") * 0.2
+    sc = (torch.rand(K + 3, device="cuda") + 0.5)[:K].contiguous() if pro else None
+    sh = (torch.randn(K + 3, device="cuda") * 0.3)[:K].contiguous() if pro else None
+    nb = lib.s2c_rows_gemm_blocks(M, N)
+    outs = []
+    for narrow in (1, 0):
+        Y = torch.full((M, N), float("nan"), device="cuda")
+        part = torch.full((nb * 2 * N,), float("nan"), device="cuda")
+        prev = lib.s2c_gemm_set_c64_narrow(narrow)
+        try:
+            _C.call("s2c_rows_gemm", M, N, K, A.data_ptr(), K, W.data_ptr(), K,
+                    sc.data_ptr() if pro else None, sh.data_ptr() if pro else None,
+                    Y.data_ptr(), N, part.data_ptr(), _C.stream_ptr())
+        finally:
+            lib.s2c_gemm_set_c64_narrow(prev)
+        torch.cuda.synchronize()
+        outs.append((Y, part.view(nb, 2, N)))
+    assert torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][1]).all()
+    assert torch.equal(outs[0][0], outs[1][0])
+    pa, pb = outs[0][1].double(), outs[1][1].double()
+    assert float((pa - pb).abs().max()) <= 1e-5 * float(pb.abs().max())
+    Ain = torch.relu(A * sc + sh) if pro else A
+    ref = Ain.double() @ W.double().t()
+    assert float((outs[0][0].double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("M,N,K,relu", [(4160, 128, 256, 1), (33000, 256, 128, 1), (1000, 132, 64, 0)])
 def test_next_layer_statistics_out_of_the_gemm_epilogue(M, N, K, relu):
     """s2c_rows_gemm_next_stats: dX = dY W on the 64-k-chunk kernel whose epilogue also forms the
@@ -1270,7 +1308,10 @@ def test_pooled_extremum_out_of_the_chunk_kernel(M, N, K, ns, pro):
     assert rc == 0
     torch.cuda.synchronize()
     assert torch.equal(Y, Y0)
-    assert torch.equal(p1.view(nb, 2, N), p0.view(nb, 2, N))
+    # (the plain GEMM of a launch this small runs on 128 x 32 tiles: four 32-row waves per tile add
+    # their column sums in another order than the two 64-row waves of the pooled kernel)
+    pa, pb = p1.view(nb, 2, N).double(), p0.view(nb, 2, N).double()
+    assert float((pa - pb).abs().max()) <= 2e-6 * float(pb.abs().max())
     if pro:
         assert torch.equal(side, A)
     Y3 = Y0.view(J, ns, N)
