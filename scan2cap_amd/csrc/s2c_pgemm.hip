@@ -198,12 +198,14 @@ template <int TM, int TN, int WM, int WN, bool ODD>
 int pg_launch_v(const PgArgs &a, hipStream_t st) {
   constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
   constexpr int lds = (BM + BN) * PG_LD * (int)sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_done[64];                 // per device (the attribute is the device's)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!attr_done[dev]) {
     if (hipFuncSetAttribute((const void *)point_gemm_kernel<TM, TN, WM, WN, ODD>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return -1;
-    attr_done = true;
+    attr_done[dev] = true;
   }
   const dim3 grid((unsigned)((a.M + BM - 1) / BM), (unsigned)((a.N + BN - 1) / BN));
   hipLaunchKernelGGL((point_gemm_kernel<TM, TN, WM, WN, ODD>), grid, dim3(256), lds, st, a);
