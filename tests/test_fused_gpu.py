@@ -155,6 +155,20 @@ def test_fused_decoder_matches_torch_loop(K):
         decoder_fused.set_persist(True)
 
 
+@pytest.mark.parametrize("R", [12, 16])
+def test_decoder_at_the_reference_batch_sizes_runs_on_the_launch_chain(R):
+    """README.md:145 trains at batch 12, slurm/train.job:24 at 16: the persistent kernels take at
+    most 8 rows (`s2c_decoder_*_persist_supported` says so), and with everything at its default
+    `decoder_fused.decode` hands these shapes to the launch chain -- same values and gradients as
+    the module's step loop (bench.py --batch 12 / 16 time exactly this)."""
+    from scan2cap_amd.models import decoder_fused
+    lib = decoder_fused._plib()
+    assert lib.s2c_decoder_fwd_persist_supported(R, 10, 512, 300, 128, 30) == 0
+    assert lib.s2c_decoder_fwd_persist_supported(8, 10, 512, 300, 128, 30) == 1
+    _decoder_vs_torch_loop(10, R=R)
+    assert not decoder_fused.persist_failed()
+
+
 def test_persistent_decoder_forward_on_the_256_workgroup_grid():
     """The forward kernel's second grid (256 workgroups x 256 threads, taken when the first one's
     LDS request does not fit) is chosen once per process: run the benchmark-shape case of the test
@@ -316,11 +330,11 @@ def test_persistent_decoder_forward(R, K, H, E, F, T):
             assert _rel(out_g, want) < 2e-5
 
 
-def _decoder_vs_torch_loop(K):
+def _decoder_vs_torch_loop(K, R=8):
     from scan2cap_amd.models import decoder_fused
     from scan2cap_amd.models.caption_module import TopDownSceneCaptionModule
     torch.manual_seed(3)
-    V, R, T = 50, 8, 9
+    V, T = 50, 9
     words = ["w%d" % i for i in range(V)]
     vocab = {"word2idx": {w: i for i, w in enumerate(words)},
              "idx2word": {str(i): w for i, w in enumerate(words)}}
