@@ -428,7 +428,12 @@ def roofline_of(top, ms_per_step, wl):
     return roof
 
 
-def named_roofline(table_k):
+# the FUSED contract of the same five stages (query -> gather -> MLP -> max, nothing
+# materialised: compulsory inputs + pooled outputs + idx), MB per step at the workload's own batch size
+SURVEY_FUSED_MB = {"cfg3": (232.5, 8), "cfg3e": (232.5, 8), "cfg2": (68.7, 8), "cfg5": (813.0, 16), "cfg1": (7.5, 1)}
+
+
+def named_roofline(table_k, workload=None, batch=None):
     """north_star's named target: ball_query + grouping as a fraction of the HBM roof.
     Grouping is fused into the first GEMM of every set-abstraction stage
     (s2c_sa_gather_gemm: the gathered (rows, 3+C) operand is never materialised), so the
@@ -447,9 +452,18 @@ def named_roofline(table_k):
     nbytes = sum(k["alg_bytes_per_launch"] * k["calls_per_step"] for k in parts)
     gbs = nbytes / max(ms, 1e-9) / 1e6
     tflops = sum(k["alg_TFLOPs"] * k["ms_per_step"] for k in parts) / max(ms, 1e-9)
+    survey = None
+    if workload in SURVEY_FUSED_MB:
+        mb, b0 = SURVEY_FUSED_MB[workload]
+        sb = mb * 1e6 * (batch or b0) / b0
+        sg = sb / max(ms, 1e-9) / 1e6
+        survey = {"alg_bytes_per_step": sb, "achieved": sg, "frac": sg / HBM_PEAK_GBS,
+                  "note": "SURVEY.md 8(d) fused contract (nothing between the query and the pooled output "
+                          "counts); `frac` above uses the op contract of the launches that exist: xyz + "
+                          "centres + idx, unique source rows + idx + the first layer's output"}
     return {"kernels": [k["kernel"] for k in parts], "bound": "hbm", "achieved": gbs,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-            "ms_per_step": ms, "alg_bytes_per_step": nbytes,
+            "ms_per_step": ms, "alg_bytes_per_step": nbytes, "survey_fused_contract": survey,
             # the fully fused inference stage (s2c_sa_fused_eval) moves only its compulsory
             # bytes and sits on the matrix pipe instead: the other roof of the same pair
             "other_roof": {"bound": "mfma", "achieved": tflops, "peak": MFMA_GEMM_PEAK_TF,
@@ -1056,7 +1070,7 @@ def main():
                               if wl["train"] else None,
             "roofline": roof,
             "roofline_main_stream": roof_main,
-            "roofline_named": named_roofline(table_k),
+            "roofline_named": named_roofline(table_k, args.workload, B),
             "roofline_gemm": roof_gemm,
             "roofline_decode": decode_roofline(table_k, ms_per_step),
             "fed": fed,
