@@ -809,6 +809,19 @@ int s2c_weight_grad_f32_slabs(long long M, int C, int K);
 int s2c_weight_grad_f32(long long M, int C, int K, const float *dY, long long ldy, const float *X,
                         long long ldx, const s2c_dw_gather *g, float *part, void *stream);
 
+/* ---- tall weight gradients as a streaming kernel (csrc/s2c_dwstream.hip, round 5) ---------------
+ * part (parts x C x N) = per-workgroup partial sums of dW[c, n] = sum_m dY[m, c] A[m, n] (add them up
+ * with s2c_multi_colsum); parts = s2c_weight_grad_stream_parts(...) (0: shape not taken -- C % 64,
+ * ldy % 4, 16-byte aligned dY, more than 8 tiles of 64 x 64, fewer than 1024 rows).  A: any N, rows
+ * dword-aligned (row stride lda >= N: e.g. the (B,N,3+C) cloud's rows or its feature columns, read in
+ * place); A == dY (same strides): the Gram matrix, loaded once.  fp32-accurate bf16x3 MFMA products,
+ * deterministic.  Autograd of lib/pointnet2/pytorch_utils.py:67-120 (the shared MLPs' 1x1 convs). */
+int s2c_weight_grad_stream_parts(long long M, int C, int N, const float *dY, long long ldy,
+                                 const float *A, long long lda);
+int s2c_weight_grad_stream(long long M, int C, int N, const float *dY, long long ldy,
+                           const float *A, long long lda, float *part, void *stream);
+int s2c_weight_grad_stream_set_grid(int workgroups);
+
 #ifdef __cplusplus
 }
 #endif

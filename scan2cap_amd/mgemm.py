@@ -1,5 +1,7 @@
 """Many small fp32 GEMMs in one launch (csrc/s2c_mgemm.hip): the hoisted, recurrence-free products
-of the teacher-forced caption decoder (models/decoder_fused.py).  Operands are described by index
+of the teacher-forced caption decoder (models/decoder_fused.py).  Jobs with ksplit > 1 add their
+k-slices with float atomics: those outputs (the decoder's dH2 with ksplit = 16) differ in the last
+bits from run to run; ksplit <= 1 is deterministic.  Operands are described by index
 maps, not copied: a transposed weight, a column block of a larger matrix or the (t, r) / (r, t) row
 orders of the decoder's tensors are strides."""
 import ctypes
@@ -35,6 +37,16 @@ _C.register("s2c_mgemm", [_P, _P])
 def ax(lo, div=0, hi=0):
     """index i -> offset: i * lo, or (two tensor dims walked major-first) (i // div) * hi + (i % div) * lo"""
     return (int(div), int(hi), int(lo))
+
+
+def _reach(axis, n):
+    """largest offset an index map produces over 0 .. n-1"""
+    div, hi, lo = axis
+    if n <= 0:
+        return 0
+    if div:
+        return ((n - 1) // div) * hi + min(n - 1, div - 1) * lo
+    return (n - 1) * lo
 
 
 class Job(object):
@@ -74,7 +86,14 @@ def launch(jobs):
             d.bias = bias.data_ptr() if bias is not None else None
             for name, v in zip(("am", "ak", "bk", "bn", "cm"), jb.axes):
                 x = getattr(d, name)
+                # 32-bit fields on the device side (include/s2c_fused.h): ctypes would truncate silently
+                assert all(0 <= int(q) < 2 ** 31 for q in v), (name, v)
                 x.div, x.hi, x.lo = v
+            M_, N_, K_ = jb.dims
+            am, ak, bk, bn, cm = jb.axes
+            for what, reach in (("A", _reach(am, M_) + _reach(ak, K_)),
+                                ("B", _reach(bk, K_) + _reach(bn, N_)), ("C", _reach(cm, M_) + N_)):
+                assert reach < 2 ** 31, "s2c_mgemm: operand %s reaches element %d (>= 2^31)" % (what, reach)
             d.accumulate, d.ksplit = jb.accumulate, jb.ksplit
             flops += 2.0 * d.M * d.N * d.K
         if _C.TIMER.enabled:

@@ -39,6 +39,11 @@ class Pointnet2Backbone(nn.Module):
         rows in place."""
         xyz = pc[..., :3].contiguous()
         features = pc[..., 3:].transpose(1, 2) if pc.size(-1) > 3 else None
+        if features is not None and pc.is_contiguous() and pc.dtype == torch.float32:
+            # xyz is a copy of the first three columns of these rows and `features` a view of the
+            # rest: the first layer's weight gradient reads [xyz | features] as ONE operand, the
+            # cloud's own rows (pointnet2/fused.py: GatherSpec.weight_grad)
+            xyz._s2c_cloud = pc
         return xyz, features
 
     def compute_geometry(self, point_clouds):

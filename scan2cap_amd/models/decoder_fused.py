@@ -183,6 +183,8 @@ _DEVICE_LOCKS = {}      # device index -> open file object (lock held) or False 
 
 
 def _device_lock_path(index):
+    """Per-user directory (mode 0700) under the temp dir: another user's lock file of the same
+    name can neither block this process nor be followed through a symlink."""
     try:
         ident = str(torch.cuda.get_device_properties(index).uuid)
     except Exception:
@@ -190,7 +192,19 @@ def _device_lock_path(index):
                                            _os.environ.get("ROCR_VISIBLE_DEVICES", "all")), index)
     ident = "".join(c if c.isalnum() else "_" for c in ident)
     import tempfile
-    return _os.path.join(tempfile.gettempdir(), "s2c_persist_%s.lock" % ident)
+    d = _os.path.join(tempfile.gettempdir(), "s2c-%d" % _os.getuid())
+    _os.makedirs(d, mode=0o700, exist_ok=True)
+    return _os.path.join(d, "persist_%s.lock" % ident)
+
+
+def _open_lock(path):
+    """O_NOFOLLOW (no symlink games in a shared temp dir), O_CLOEXEC (an exec'd child does not
+    inherit the descriptor; forked workers are handled by the at-fork hook below)."""
+    fd = _os.open(path, _os.O_RDWR | _os.O_CREAT | _os.O_NOFOLLOW | _os.O_CLOEXEC, 0o600)
+    return _os.fdopen(fd, "r+")
+
+
+_WARNED_LOCK = []
 
 
 def persist_allowed(dev):
@@ -207,16 +221,38 @@ def persist_allowed(dev):
         else:
             try:
                 import fcntl
-                f = open(_device_lock_path(index), "a+")
+                f = _open_lock(_device_lock_path(index))
                 try:
                     fcntl.flock(f, fcntl.LOCK_EX | fcntl.LOCK_NB)
                     got = f                     # held until the process exits
                 except OSError:
-                    f.close()
-            except Exception:                   # no lock file possible: be conservative
+                    f.close()                   # another process owns the device: launch chain
+            except Exception as e:              # no lock file possible: be conservative, say so once
                 got = False
+                if not _WARNED_LOCK:
+                    _WARNED_LOCK.append(1)
+                    import warnings
+                    warnings.warn("scan2cap_amd: the per-device lock of the persistent decoder "
+                                  "kernels cannot be taken (%r); the decoder runs as a launch "
+                                  "chain in this process" % (e,))
         _DEVICE_LOCKS[index] = got
     return got is not False
+
+
+def _drop_locks_in_child():
+    # a forked child (DataLoader worker) shares the open file description, hence the flock: it must
+    # not keep the device reserved after the parent exits, and must not launch persistently itself
+    for index, f in list(_DEVICE_LOCKS.items()):
+        if f not in (True, False):
+            try:
+                _os.close(f.fileno())
+            except Exception:
+                pass
+        _DEVICE_LOCKS[index] = False
+
+
+if hasattr(_os, "register_at_fork"):
+    _os.register_at_fork(after_in_child=_drop_locks_in_child)
 
 
 def release_device_locks():

@@ -185,22 +185,14 @@ def supported(mod, L):
             and mod.attend.bias is None and mod.map_topdown[0].bias is not None)
 
 
-_WEIGHTS = {}     # id(module) -> (version key, dict of planes)
-
-
 def _weights(mod):
-    """The planes of every weight of the step, split once per weight version (evaluation calls
-    the decoder once per scene batch with frozen weights)."""
-    ps = [mod.map_topdown[0].weight, mod.map_topdown[0].bias, mod.recurrent_cell_1.weight_ih,
-          mod.recurrent_cell_1.weight_hh, mod.recurrent_cell_1.bias_ih, mod.recurrent_cell_1.bias_hh,
-          mod.map_feat.weight, mod.map_hidd.weight, mod.attend.weight, mod.map_lang[0].weight,
-          mod.map_lang[0].bias, mod.recurrent_cell_2.weight_ih, mod.recurrent_cell_2.weight_hh,
-          mod.recurrent_cell_2.bias_ih, mod.recurrent_cell_2.bias_hh, mod.classifier.weight,
-          mod.classifier.bias, mod._emb_table]
-    key = tuple((p.data_ptr(), p._version, p.device) for p in ps)
-    hit = _WEIGHTS.get(id(mod))
-    if hit is not None and hit[0] == key:
-        return hit[1]
+    """The planes of every weight of the step, split on EVERY decode() call: ~20 small launches
+    against 29 x 7 per caption batch.  No cache -- a hipGraph replay of optimizer.step(), writes
+    through `p.data` and EMA swaps change a weight without changing `data_ptr()` or `_version`,
+    and stale planes would decode silently with the old weights
+    (tests/test_planes_gpu.py::test_greedy_decode_sees_weights_changed_in_place).  Inside a
+    captured evaluation step the split launches are part of the graph and re-run per replay."""
+    ps = [mod.map_topdown[0].weight]
     E, H, F_ = mod.emb_size, mod.hidden_size, mod.feat_size
     Ep, Fp = _up(E, 32), _up(F_, 32)
     dev = ps[0].device
@@ -230,7 +222,6 @@ def _weights(mod):
         w["Wg2"], w["bg2"] = pack_gru(mod.recurrent_cell_2, Ep)
         w["b_cls"] = mod.classifier.bias.detach().contiguous()
         w["emb"] = split(mod._emb_table.detach(), ld=Ep, tiled=False)     # gathered by token
-    _WEIGHTS[id(mod)] = (key, w)
     return w
 
 

@@ -39,8 +39,15 @@ def init_from_env(backend=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # ranks of THIS node (torch.distributed.run exports LOCAL_WORLD_SIZE; a multi-node job with
     # fewer than 8 GPUs per node is as valid as 8 ranks on one node)
-    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "0")) or world
     ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "0"))
+    if not local_world:
+        # srun / mpirun with a hand-set RANK / WORLD_SIZE (e.g. 16 ranks on 2 x 8 GPUs) exports no
+        # LOCAL_WORLD_SIZE: assume at most one rank per visible device on this node, and call the
+        # launch over-subscribed only when LOCAL_RANK does not fit the devices
+        local_world = min(world, max(ndev, 1))
+        if ndev and local_rank >= ndev:
+            local_world = local_rank + 1
     if world > 1 and ndev and local_world > ndev:
         # several ranks share a device (the gloo rehearsal): two persistent decoder kernels of
         # different processes could each hold part of the CUs and wait for the rest

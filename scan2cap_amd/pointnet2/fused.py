@@ -1331,6 +1331,43 @@ def _weight_grad_f32(dY, A, pending, gather=None):
     return dW
 
 
+_C.register("s2c_weight_grad_stream", [_L, _I, _I, _P, _L, _P, _L, _P, _P])
+# tall weight gradients on the streaming kernel (csrc/s2c_dwstream.hip): LDS-DMA ring, column reads
+# of the row-major chunks as the transposed MFMA operand, one partial tile per workgroup
+DW_STREAM = _os.environ.get("S2C_DW_STREAM", "1") != "0"
+DW_STREAM_MIN_ROWS = 32768
+
+
+def _dw_stream_parts(M, C, N, dY, A):
+    lib = _C.load()
+    if not getattr(lib, "_dws_sized", False):
+        lib.s2c_weight_grad_stream_parts.restype = _I
+        lib.s2c_weight_grad_stream_parts.argtypes = [_L, _I, _I, _P, _L, _P, _L]
+        lib._dws_sized = True
+    return lib.s2c_weight_grad_stream_parts(M, C, N, dY.data_ptr(), dY.stride(0), A.data_ptr(),
+                                            A.stride(0))
+
+
+def _weight_grad_stream(dY, A, pending):
+    """dW (C, N) = dY^T A as per-workgroup partials of s2c_weight_grad_stream (summed by the
+    caller's multi_colsum launch).  A: (M, N) rows with unit column stride, any row stride (a
+    column block of a wider tensor is read in place).  None: shape not taken."""
+    M, C = dY.shape
+    N = A.shape[1]
+    parts = _dw_stream_parts(M, C, N, dY, A)
+    if parts <= 0:
+        return None
+    dev = dY.device
+    part = torch.empty((parts, C, N), dtype=torch.float32, device=dev)
+    dW = torch.empty((C, N), dtype=torch.float32, device=dev)
+    same = A.data_ptr() == dY.data_ptr() and A.stride(0) == dY.stride(0) and C == N
+    _call("s2c_weight_grad_stream", dW, M, C, N, dY.data_ptr(), dY.stride(0), A.data_ptr(),
+          A.stride(0), part.data_ptr(),
+          alg_bytes=4 * M * (C if same else C + N), alg_flops=2 * M * C * N)
+    pending.append((part, dW))
+    return dW
+
+
 def _weight_grad(dY, A, pending=None):
     """dW (Cout,Cin) = dY^T (Cout,M) @ A (M,Cin) with M up to ~1e6 and a tiny
     output: a plain GEMM call gives the library ONE output tile and a million-deep
@@ -1345,6 +1382,12 @@ def _weight_grad(dY, A, pending=None):
             and dY.stride(1) == 1 and A.stride(1) == 1 and pending is not None
             and BATCH_PARTIAL_SUMS and (HAND_EVERYWHERE or _hand_dw_pays(M, dY.shape[1], A.shape[1]))):
         return _weight_grad_partials(dY, A, pending)
+    if (DW_STREAM and M >= DW_STREAM_MIN_ROWS and dY.is_cuda and dY.dtype == torch.float32
+            and A.dtype == torch.float32 and dY.stride(1) == 1 and A.stride(1) == 1
+            and pending is not None and BATCH_PARTIAL_SUMS):
+        dW = _weight_grad_stream(dY, A, pending)
+        if dW is not None:
+            return dW
     if (USE_DW32 and M >= DW32_MIN_ROWS and dY.is_cuda and dY.dtype == torch.float32
             and A.dtype == torch.float32 and dY.stride(1) == 1 and A.stride(1) == 1
             and pending is not None and BATCH_PARTIAL_SUMS):
@@ -1461,7 +1504,20 @@ class GatherSpec(object):
             f2 = self.feats.reshape(nz, self.C)
         # the centres' share of the coordinate columns: - S^T new_xyz
         dWc = _weight_grad(S2, self.new_xyz.view(-1, 3), pending)
-        if f2 is not None and nz <= 65536:
+        cloud = getattr(self.xyz, "_s2c_cloud", None)
+        rows = None
+        if (DW_STREAM and cloud is not None and f2 is not None and f2 is not False and nz > 65536
+                and cloud.is_contiguous() and cloud.shape[-1] == 3 + self.C
+                and cloud.numel() == nz * (3 + self.C) and f2.stride(0) == 3 + self.C
+                and f2.data_ptr() == cloud.data_ptr() + 12):
+            rows = cloud.view(nz, 3 + self.C)
+        if rows is not None and _dw_stream_parts(nz, Cout, 3 + self.C, Z2, rows) > 0:
+            # the features are the cloud's own columns 3.. and xyz its columns 0..2 (set by the
+            # backbone, models/backbone_module.py): ONE streaming product over the rows as they lie
+            # in memory instead of a 3-column product and a features product
+            dW = _weight_grad(Z2, rows, pending)
+            dWp = dWf = None
+        elif f2 is not None and nz <= 65536:
             # a small stage: ONE product over the points with [xyz | feats] side by side (the copy
             # is <= 35 MB), instead of a 3-column product of its own; its output IS dW
             dW = _weight_grad(Z2, torch.cat([self.xyz.view(-1, 3), f2], 1), pending)
