@@ -458,13 +458,6 @@ int s2c_attn_bwd(int R, int K, int H, int F, const float *datt, int ldd,
                  const float *M, const float *q, int ldq, const float *wa, float *dM,
                  float *dq, float *dwa_rows, void *stream);
 
-/* bf16x3 planes of a row-major fp32 matrix A (M x K, row stride lda) for a library
- * bf16 GEMM: out (M x 6*Kp) bf16, Kp = K rounded up to 8, K-block b of every row holds
- * plane order6[b] (0 hi = bf16(x), 1 mid = bf16(x - hi), 2 lo = bf16(x - hi - mid)),
- * zero padded.  With order (0,0,1,1,0,2) for the activations and (0,1,0,1,2,0) for the
- * weights, A6 W6^T is the fp32-accurate product from ONE bf16 GEMM of depth 6*Kp. */
-int s2c_split_bf16x3(long long M, int K, const float *A, long long lda, void *out,
-                     const int *order6, void *stream);
 
 /* local attention of the greedy decode (caption_module.py:502-592 with num_locals):
  * mapped (R,L,H) = map_feat of the L gathered objects of each row, q (R,H) = map_hidd(h1),
@@ -788,27 +781,6 @@ int s2c_mgemm(const s2c_mgemm_args *a, void *stream);
 long long s2c_mgemm_args_sizeof(void);
 
 
-/* ---- tall weight gradients on the fp32 matrix cores (csrc/s2c_dw32.hip) ------------------------
- * part (slabs x C x K) = per-slab partial sums of dW[c, k] = sum_m dY[m, c] X[m, k] (add them up with
- * s2c_multi_colsum); slabs = s2c_weight_grad_f32_slabs(M, C, K) (-1: shape not taken, more than 12
- * blocks of 64 x 64).  X: dense (M x K, row stride ldx, any alignment), or -- g != NULL -- the gathered
- * operand of a set-abstraction stage's first layer, read in place (K = 3 + feature channels):
- *   X[(b, j, s), :] = [ (xyz[b, idx] - new_xyz[b, j]) (/ radius if normalize) | feats[b, idx, :] ]
- * (the arithmetic of s2c_sa_gather_rows).  Exact fp32 products in row order. */
-typedef struct s2c_dw_gather {
-  const float *xyz;        /* (b, n, 3) */
-  const float *new_xyz;    /* (b, m, 3) */
-  const float *feats;      /* point-major, row stride frs, scene stride fbs (floats) */
-  const int *idx;          /* (b, m, ns): one entry per row of X */
-  long long frs, fbs;
-  int n, m, ns, normalize;
-  float radius;
-  int pad_;
-} s2c_dw_gather;
-int s2c_weight_grad_f32_slabs(long long M, int C, int K);
-int s2c_weight_grad_f32(long long M, int C, int K, const float *dY, long long ldy, const float *X,
-                        long long ldx, const s2c_dw_gather *g, float *part, void *stream);
-
 /* ---- tall weight gradients as a streaming kernel (csrc/s2c_dwstream.hip, round 5) ---------------
  * part (parts x C x N) = per-workgroup partial sums of dW[c, n] = sum_m dY[m, c] A[m, n] (add them up
  * with s2c_multi_colsum); parts = s2c_weight_grad_stream_parts(...) (0: shape not taken -- C % 64,
@@ -821,6 +793,19 @@ int s2c_weight_grad_stream_parts(long long M, int C, int N, const float *dY, lon
 int s2c_weight_grad_stream(long long M, int C, int N, const float *dY, long long ldy,
                            const float *A, long long lda, float *part, void *stream);
 int s2c_weight_grad_stream_set_grid(int workgroups);
+
+/* ---- the small products of the layer stacks (csrc/s2c_sgemm.hip, round 5) --------------------------
+ * Y (M x N, row stride ldy) = A (M x K, row stride lda) B (+ bias[n]):
+ *   b_transposed = 0: B is (K x N) row-major, row stride ldb -- the input gradient dX = dY W with W as
+ *                     stored (no transposed copy);
+ *   b_transposed = 1: B is W (N x K) row-major, Y = A W^T -- the forward of a Conv1d / Linear layer.
+ * 64 x 64 tiles, the four waves of a workgroup split K; fp32-accurate bf16x3 MFMA products.
+ * s2c_small_gemm_supported: 4 <= K <= 1024, (K x N) form: N % 4 == 0, ldb % 4 == 0, B 16-byte aligned.
+ * Autograd / forward of lib/pointnet2/pytorch_utils.py:67-120 at 2048 .. 32768 rows. */
+int s2c_small_gemm_supported(long long M, int N, int K, long long lda, long long ldb, int b_transposed);
+int s2c_small_gemm(long long M, int N, int K, const float *A, long long lda, const float *B,
+                   long long ldb, int b_transposed, const float *bias, float *Y, long long ldy,
+                   void *stream);
 
 #ifdef __cplusplus
 }

@@ -94,5 +94,22 @@ def build(force=False, verbose=False, contract=None):
     return out
 
 
+PROBES_DIR = os.path.join(_HERE, "..", "tools", "probes")
+PROBES_PATH = os.path.join(PROBES_DIR, "libs2c_probes.so")
+
+
+def build_probes(force=False):
+    """tools/probes/s2c_probe.hip -> tools/probes/libs2c_probes.so: streaming-copy probes and the
+    CU-hogging kernel tests/test_fused_gpu.py provokes the persistent decoder's give-up path with.
+    Test / diagnostic code: NOT part of libs2c_hip.so."""
+    src = os.path.join(PROBES_DIR, "s2c_probe.hip")
+    if not force and os.path.exists(PROBES_PATH) and \
+            os.path.getmtime(PROBES_PATH) >= os.path.getmtime(src):
+        return PROBES_PATH
+    subprocess.check_call([os.environ.get("HIPCC", "hipcc")] + HIPCC_FLAGS +
+                          ["-shared", "-o", PROBES_PATH, src])
+    return PROBES_PATH
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))

@@ -880,40 +880,6 @@ __global__ __launch_bounds__(256) void attn_local_kernel(
   }
 }
 
-// ---------------------------------------------------------------------------
-// bf16x3 planes of a row-major fp32 matrix for the library's bf16 GEMM (greedy decode:
-// 8192-row GEMMs that sit on the fp32 MFMA roof).  out (M x 6 Kp) bf16, Kp = K rounded
-// up to 8; the six K-blocks of a row hold the planes order[0..5] (0 hi, 1 mid, 2 lo).
-// With A6 = planes (hi,hi,mid,mid,hi,lo) and W6 = planes (hi,mid,hi,mid,lo,hi),
-// A6 W6^T = the 6 products of the split with i + j <= 2, accumulated in fp32 by ONE
-// bf16 GEMM of depth 6 Kp (16x the fp32 MFMA rate).
-// ---------------------------------------------------------------------------
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-
-__global__ __launch_bounds__(256) void split_bf16x3_kernel(
-    long long M, int K, int Kp, const float *__restrict__ A, long long lda,
-    unsigned *__restrict__ out, int o0, int o1, int o2, int o3, int o4, int o5) {
-  const int Kp2 = Kp >> 1;                       // bf16 pairs per plane block
-  const long long total = M * Kp2;
-  const int order[6] = {o0, o1, o2, o3, o4, o5};
-  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total;
-       e += (long long)gridDim.x * 256) {
-    const long long r = e / Kp2;
-    const int k = (int)(e - r * Kp2) * 2;
-    f32x2_t v = {k < K ? A[r * lda + k] : 0.f, k + 1 < K ? A[r * lda + k + 1] : 0.f};
-    const bf16x2_t h = __builtin_convertvector(v, bf16x2_t);
-    const f32x2_t r1 = v - __builtin_convertvector(h, f32x2_t);
-    const bf16x2_t m = __builtin_convertvector(r1, bf16x2_t);
-    const f32x2_t r2 = r1 - __builtin_convertvector(m, f32x2_t);
-    const bf16x2_t l = __builtin_convertvector(r2, bf16x2_t);
-    const unsigned pl[3] = {__builtin_bit_cast(unsigned, h), __builtin_bit_cast(unsigned, m),
-                            __builtin_bit_cast(unsigned, l)};
-    unsigned *row = out + r * (6LL * Kp2) + (k >> 1);
-#pragma unroll
-    for (int b = 0; b < 6; ++b) row[(long long)b * Kp2] = pl[order[b]];
-  }
-}
 
 }  // namespace
 
@@ -1093,17 +1059,3 @@ extern "C" int s2c_attn_local_fwd_planes(int R, int L, int H, int F, const float
                            planes, pstride, ldp, tiled, stream);
 }
 
-extern "C" int s2c_split_bf16x3(long long M, int K, const float *A, long long lda,
-                                void *out, const int *order6, void *stream) {
-  if (M <= 0 || K <= 0 || !A || !out || !order6 || lda < K) return -1;
-  for (int i = 0; i < 6; ++i)
-    if (order6[i] < 0 || order6[i] > 2) return -1;
-  const int Kp = (K + 7) / 8 * 8;
-  const long long total = M * (Kp / 2);
-  long long blocks = (total + 255) / 256;
-  if (blocks > 256 * 32) blocks = 256 * 32;
-  hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)blocks), dim3(256), 0,
-                     (hipStream_t)stream, M, K, Kp, A, lda, (unsigned *)out, order6[0],
-                     order6[1], order6[2], order6[3], order6[4], order6[5]);
-  return chk("split_bf16x3");
-}

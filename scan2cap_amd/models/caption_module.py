@@ -29,17 +29,12 @@ from . import decoder_fused, greedy_fused
 from .graph_module import query_locals
 
 _I, _F32, _P = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
-_C.register("s2c_attn_local_fwd", [_I, _I, _I, _I, _P, _P, _I, _P, _F32, _P, _P, _P, _P, _I, _P])
-# greedy decode: "planes" (default) = every product of the step on the hand-written bf16x3-plane MFMA
+# greedy decode: True (default) = every product of the step on the hand-written bf16x3-plane MFMA
 # kernels (greedy_fused.py / csrc/s2c_planes.hip: 7 launches per token, no library GEMM, no ATen
-# kernel); True = split-weight step on library GEMMs + one-pass local attention kernel (the
-# round-1..3 path, kept as an A/B reference); False = the module's `_step` loop
-FUSE_EVAL_STEP = {"0": False, "1": True}.get(_os.environ.get("S2C_EVAL_STEP", "planes"), "planes")
-# greedy decode GEMMs (thousands of rows: on the fp32 MFMA roof) as ONE library bf16 GEMM
-# over the bf16x3 planes of both operands (csrc/s2c_decoder.hip: split_bf16x3)
-SPLIT_EVAL_GEMMS = True
-SPLIT_EVAL_MIN_ROWS = 4096     # measured: +5 % at 8192 rows (cfg5), -9 % at 2048 (cfg3e)
-_split_ok = None
+# kernel) where the shapes allow; False = the module's `_step` loop (the reference's formulation,
+# caption_module.py:250-292; what opbyop.py and the parity tests compare against).  (The round-1..3
+# library-GEMM step with split weights, S2C_EVAL_STEP=1, was measured against and removed in round 5.)
+FUSE_EVAL_STEP = True
 
 
 # teacher-forced decoder with num_locals = L: attention over the L gathered objects instead of
@@ -47,44 +42,8 @@ _split_ok = None
 LOCAL_TRAIN_ATTENTION = _os.environ.get("S2C_LOCAL_TRAIN_ATTN", "1") != "0"
 
 
-def _split_gemm_available():
-    """torch.mm(bf16, bf16, out_dtype=float32) and the fused GRU pointwise op exist?"""
-    global _split_ok
-    if _split_ok is None:
-        try:
-            a = torch.zeros(8, 16, dtype=torch.bfloat16, device="cuda")
-            torch.mm(a, a.t(), out_dtype=torch.float32)
-            # ... and the exact addmm overload the classifier of the S2C_EVAL_STEP=1 path uses
-            # (bias, bf16 operands, fp32 `out`): a build with mm(out_dtype) but without it must
-            # fall back here, not fail in the step loop
-            torch.addmm(torch.zeros(8, device="cuda"), a, a.t(), out_dtype=torch.float32,
-                        out=torch.empty(8, 8, device="cuda"))
-            _split_ok = hasattr(torch.ops.aten, "_thnn_fused_gru_cell")
-        except Exception:
-            _split_ok = False
-    return _split_ok
 _C.register("s2c_select_target", [_I, _I, _P, _P, _P, _P, _P])
 USE_SELECT_TARGET_KERNEL = True      # one launch instead of ~15 (csrc/s2c_boxes.hip)
-_C.register("s2c_split_bf16x3", [ctypes.c_longlong, _I, _P, ctypes.c_longlong, _P, _P, _P])
-_ORDER_A = (ctypes.c_int * 6)(0, 0, 1, 1, 0, 2)      # activations: hi hi mid mid hi lo
-_ORDER_W = (ctypes.c_int * 6)(0, 1, 0, 1, 2, 0)      # weights:     hi mid hi mid lo hi
-
-
-def _split6(x, order):
-    """fp32 (M,K) (row stride >= K, unit column stride) -> bf16 (M, 6*Kp) planes."""
-    if x.stride(1) != 1:
-        x = x.contiguous()
-    M, K = x.shape
-    Kp = (K + 7) // 8 * 8
-    out = torch.empty((M, 6 * Kp), dtype=torch.bfloat16, device=x.device)
-    _C.call("s2c_split_bf16x3", M, K, x.data_ptr(), x.stride(0), out.data_ptr(),
-            ctypes.addressof(order), _C.stream_ptr())
-    return out
-
-
-def _mm6(a6, w6):
-    """fp32-accurate a @ w^T from the planes of both (one bf16 GEMM, fp32 accumulate)."""
-    return torch.mm(a6, w6.t(), out_dtype=torch.float32)
 
 
 def select_target(data_dict):
@@ -430,7 +389,7 @@ class TopDownSceneCaptionModule(nn.Module):
         local = local.reshape(R, L, F_)
         T = max_len - 1
         ids = att_ids.reshape(R, L)
-        if (FUSE_EVAL_STEP == "planes" and dev.type == "cuda" and not torch.is_grad_enabled()
+        if (FUSE_EVAL_STEP and dev.type == "cuda" and not torch.is_grad_enabled()
                 and greedy_fused.supported(self, L)):
             cap_buf, alpha = greedy_fused.decode(self, word_embs[:, 0], K,
                                                  obj_feats.reshape(R, F_), local, T)
@@ -452,86 +411,12 @@ class TopDownSceneCaptionModule(nn.Module):
         # 115 MB copy per step at cfg5)
         cap_buf = torch.empty(T, R, self.num_vocabs, device=dev)
         attn = torch.zeros(R, K, T, device=dev)
-        # the fused step calls raw kernels outside autograd: only when nothing can ask
-        # for a gradient (RL / saliency callers with grad enabled take `_step`)
-        fused_step = (FUSE_EVAL_STEP and dev.type == "cuda" and L <= 32
-                      and not torch.is_grad_enabled()
-                      and self.hidden_size % 4 == 0 and self.attend.bias is None)
-        if fused_step:
-            # Same step as `_step`, re-associated so that nothing step-invariant and no
-            # concatenation is recomputed: map_topdown / map_lang are split by column
-            # blocks (the target-feature block is hoisted), and the whole attention
-            # (add, tanh, attend, mask, softmax, weighted sum) is ONE pass over
-            # `mapped` (csrc/s2c_decoder.hip: attn_local_kernel).
-            E, H = self.emb_size, self.hidden_size
-            W_td, b_td = self.map_topdown[0].weight, self.map_topdown[0].bias
-            Wx_t, Wh_t = W_td[:, :E].t(), W_td[:, E:E + H].t()
-            P_tf = torch.addmm(b_td, target_feats, W_td[:, E + H:].t())      # (R,E)
-            W_lang, b_lang = self.map_lang[0].weight, self.map_lang[0].bias
-            Wa_t, Wl_t = W_lang[:, :F_].t(), W_lang[:, F_:].t()
-            wa = self.attend.weight.reshape(-1).contiguous()
-            mapped_c, local_c = mapped.contiguous(), local.contiguous()
-            alpha = torch.empty(R, L, device=dev)
-            att = torch.empty(R, F_, device=dev)
-            split = (SPLIT_EVAL_GEMMS and R >= SPLIT_EVAL_MIN_ROWS
-                     and _split_gemm_available())
-            if split:
-                c1, c2 = self.recurrent_cell_1, self.recurrent_cell_2
-                w6 = {"x": _split6(W_td[:, :E], _ORDER_W), "h": _split6(W_td[:, E:E + H], _ORDER_W),
-                      "ih1": _split6(c1.weight_ih, _ORDER_W), "hh1": _split6(c1.weight_hh, _ORDER_W),
-                      "q": _split6(self.map_hidd.weight, _ORDER_W),
-                      "l": _split6(W_lang[:, F_:], _ORDER_W),
-                      "ih2": _split6(c2.weight_ih, _ORDER_W), "hh2": _split6(c2.weight_hh, _ORDER_W),
-                      # the classifier (R x 512 -> V): the largest GEMM of a step, 276 us in fp32
-                      # at 8192 rows against 220 on the planes, bias included (tools/probe_mm_out.py)
-                      "cls": _split6(self.classifier.weight, _ORDER_W)}
-                gru = torch.ops.aten._thnn_fused_gru_cell
-                h1_6 = _split6(hidden_1, _ORDER_A)
-                h2_6 = _split6(hidden_2, _ORDER_A)
         for t in range(T):
-            if fused_step and split:
-                # every GEMM of the step with K >= 300 on the bf16 pipe; each activation
-                # is split once and shared by the products that read it
-                x1 = (_mm6(_split6(step_input, _ORDER_A), w6["x"]) + P_tf).add_(
-                    _mm6(h2_6, w6["h"])).relu_()
-                hidden_1 = gru(_mm6(_split6(x1, _ORDER_A), w6["ih1"]), _mm6(h1_6, w6["hh1"]),
-                               hidden_1, c1.bias_ih, c1.bias_hh)[0]
-                h1_6 = _split6(hidden_1, _ORDER_A)
-                qh = _mm6(h1_6, w6["q"])
-                if _C.TIMER.enabled:
-                    _C.TIMER.alg_bytes = 4 * (R * L * (H + F_ + 1) + R * (H + F_))
-                _C.call("s2c_attn_local_fwd", R, L, H, F_, mapped_c.data_ptr(),
-                        qh.data_ptr(), H, wa.data_ptr(), 0.0, None, local_c.data_ptr(),
-                        alpha.data_ptr(), att.data_ptr(), F_, _C.stream_ptr())
-                x2 = torch.addmm(b_lang, att, Wa_t).add_(_mm6(h1_6, w6["l"])).relu_()
-                hidden_2 = gru(_mm6(_split6(x2, _ORDER_A), w6["ih2"]), _mm6(h2_6, w6["hh2"]),
-                               hidden_2, c2.bias_ih, c2.bias_hh)[0]
-                h2_6 = _split6(hidden_2, _ORDER_A)
-                m = alpha
-            elif fused_step:
-                x1 = torch.addmm(P_tf, step_input, Wx_t)
-                x1.addmm_(hidden_2, Wh_t).relu_()
-                hidden_1 = self.recurrent_cell_1(x1, hidden_1)
-                qh = self.map_hidd(hidden_1)
-                if _C.TIMER.enabled:      # one pass over mapped + local features
-                    _C.TIMER.alg_bytes = 4 * (R * L * (H + F_ + 1) + R * (H + F_))
-                _C.call("s2c_attn_local_fwd", R, L, H, F_, mapped_c.data_ptr(),
-                        qh.data_ptr(), H, wa.data_ptr(), 0.0, None, local_c.data_ptr(),
-                        alpha.data_ptr(), att.data_ptr(), F_, _C.stream_ptr())
-                x2 = torch.addmm(b_lang, att, Wa_t)
-                x2.addmm_(hidden_1, Wl_t).relu_()
-                hidden_2 = self.recurrent_cell_2(x2, hidden_2)
-                m = alpha
-            else:
-                hidden_1, hidden_2, m = self._step(
-                    step_input, target_feats, local, hidden_1, hidden_2, ones, mapped)
-                m = m.squeeze(-1)
-            if fused_step and split:
-                logits = torch.addmm(self.classifier.bias, h2_6, w6["cls"].t(),
-                                     out_dtype=torch.float32, out=cap_buf[t])   # (R,V)
-            else:
-                logits = torch.addmm(self.classifier.bias, hidden_2, self.classifier.weight.t(),
-                                     out=cap_buf[t])                     # (R,V)
+            hidden_1, hidden_2, m = self._step(
+                step_input, target_feats, local, hidden_1, hidden_2, ones, mapped)
+            m = m.squeeze(-1)
+            logits = torch.addmm(self.classifier.bias, hidden_2, self.classifier.weight.t(),
+                                 out=cap_buf[t])                     # (R,V)
             attn[:, :, t].scatter_(1, ids, m)
             step_input = self._emb_table[logits.argmax(dim=-1)]          # greedy
         data_dict["lang_cap"] = cap_buf.view(T, B, K, -1).permute(1, 2, 0, 3)  # (B,K,T,V)

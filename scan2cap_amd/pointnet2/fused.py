@@ -103,18 +103,14 @@ FUSE_DY_SCATTER = _os.environ.get("S2C_FUSE_DY_SCATTER", "1") != "0"
 # from B n point rows instead of B m ns gathered rows.  S2C_POINT_SPACE=0: the round-3 gather GEMM.
 POINT_SPACE = _os.environ.get("S2C_POINT_SPACE", "1") != "0"
 POINT_SPACE_BWD = _os.environ.get("S2C_POINT_SPACE_BWD", "1") != "0"
-# The per-point product P on the exact fp32 matrix instruction (csrc/s2c_pgemm.hip: an fp32 FMA chain
-# in k order, bit-identical to the tiled kernel's exact path) instead of the bf16x3 split.  Both are
-# fp32-accurate (rms error against float64 6e-7 vs 5e-7 of |P| ~ 2 on the golden model's own operands,
-# tools/diag_point_space.py), but the train-mode gradients of the golden fixtures hang on discrete
-# decisions behind the vote aggregation (ReLU masks / max aggregations a few ulps from a tie, each
-# worth per cents of a small fixture's weight gradients: tools/diag_golden_ab.py): with P from the split
-# kernel at any of SA1-SA3 the c132 backbone gradients land 6.5e-2 of scale from the reference's
-# (tolerance 3.7e-2), with another k order of the exact chain the cfg1 ones 2.5e-2 (3.5e-3) -- with
-# THIS chain, like the gather GEMM, hipBLASLt and the op-by-op path, both fixtures pass.
-# S2C_POINT_GEMM_X3=1: the split kernel; S2C_POINT_GEMM_TILED=1: the tiled kernel's exact path.
-POINT_GEMM_EXACT = _os.environ.get("S2C_POINT_GEMM_X3", "0") != "1"
-POINT_GEMM_TILED = _os.environ.get("S2C_POINT_GEMM_TILED", "0") == "1"   # exact chain on s2c_gemm.hip
+# The per-point product P runs on the exact fp32 matrix instruction (csrc/s2c_pgemm.hip: an fp32 FMA
+# chain in k order, bit-identical to the tiled kernel's exact path), not on the bf16x3 split.  Both
+# are fp32-accurate (rms error against float64 6e-7 vs 5e-7 of |P| ~ 2 on the golden model's own
+# operands), but the train-mode gradients of the golden fixtures hang on discrete decisions behind the
+# vote aggregation (ReLU masks / max aggregations a few ulps from a tie, each worth per cents of a small
+# fixture's weight gradients: tools/diag_golden_ab.py): with P from the split kernel the c132 backbone
+# gradients land 6.5e-2 of scale from the reference's, with another k order of the exact chain the cfg1
+# ones 2.5e-2 -- with THIS chain, like the gather GEMM and the op-by-op path, both fixtures pass.
 
 
 def _gather_add_blocks(M):
@@ -130,32 +126,18 @@ def _gather_add_blocks(M):
 # activated operand leaves as a side output of csrc/s2c_gemm2.hip): S2C_FUSE_BNRELU_GEMM=0 = off
 FUSE_BNRELU_GEMM = _os.environ.get("S2C_FUSE_BNRELU_GEMM", "1") != "0"
 FUSE_BWD_GEMM = _os.environ.get("S2C_FUSE_BWD_GEMM", "1") != "0"
-# input gradients of the remaining layers (pooled / BN-free) through the hand-written GEMM
-# instead of torch.mm (hipBLASLt)
-HAND_DA_GEMM = _os.environ.get("S2C_HAND_DA", "1") != "0"
-# weight gradients through csrc/s2c_dw.hip (slab partials + the multi_colsum launch) instead of
-# a split-K batched library GEMM
-HAND_DW_GEMM = _os.environ.get("S2C_HAND_DW", "1") != "0"
-
-
 # forward of the layers that carry a bias (EdgeConv, the voting module's convs, the proposal head's
 # last conv) on the hand GEMM instead of torch.addmm (S2C_BIAS_BY_HAND=0: the library)
 BIAS_LAYERS_BY_HAND = _os.environ.get("S2C_BIAS_BY_HAND", "1") != "0"
 
 
-# S2C_HAND_EVERYWHERE=1: no library GEMM anywhere in the layer-stack backward (costs ~0.5 ms
-# of the 11.5 ms cfg3 step).  Default: each hand-written kernel where it is at least as fast
-# as hipBLASLt on MI355X (tools/bench_bwd.py, us, apply pass + library vs fused / hand):
-#   (M, C, N) = (1M, 64, 64): 324 vs 244 | (1M, 128, 64): 556 vs 421 | (262144, 128, 128): 168 vs
-#   148 | (65536, 256, 128): 70 vs 58 | (262144, 128, 131): 200 vs 265 (N % 4 != 0: 4-byte
-#   operand loads) | (8192, 256, 256): 21 vs 40 (too few row blocks to fill 256 CUs);
-#   plain dX = dY W: (1M, 64, 64) 155 vs 143, otherwise the library is 3-20 % ahead;
-#   dW = dY^T A: library split-K 120 vs 146 at (1M, 64, 64), hand 25 vs 35 at 8192 rows.
-HAND_EVERYWHERE = _os.environ.get("S2C_HAND_EVERYWHERE", "0") == "1"
-
-
+# Which hand-written kernel takes a backward product (measured on MI355X, tools/bench_bwd.py,
+# tools/bench_dw_mid.py, tools/bench_da_mid.py, tools/bench_dwstream.py, tools/bench_sgemm.py); since
+# round 5 the cfg3 train step makes no library GEMM call at all (tools/lib_gemm_census.py): tall weight
+# gradients on csrc/s2c_dwstream.hip, small products on csrc/s2c_sgemm.hip.  torch.mm / bmm remain only
+# as the fallback for layouts no kernel takes (non-unit column strides, exotic shapes).
 def _fused_bwd_pays(M, C, N):
-    return HAND_EVERYWHERE or (M >= 32768 and N % 4 == 0)
+    return M >= 32768 and N % 4 == 0
 
 
 def _hand_dw_pays(M, C, N):
@@ -178,7 +160,7 @@ def _hand_da_pays(M, C, N):
     W^T copy: (32768,128,128) 21 vs 19 | (32768,128,259) 38 vs 33 | (65536,128,259) 65 vs 55 |
     (65536,256,128) 43 vs 40 | (262144,256,128) 149 vs 140 | (262144,128,131) 124 vs 127; below
     32768 rows hipBLASLt is ahead inside a replayed graph: (8192,256,256) 13 vs 20)."""
-    return HAND_EVERYWHERE or (M >= 262144 and N <= 64) or (M >= 32768 and N > 64)
+    return (M >= 262144 and N <= 64) or (M >= 32768 and N > 64)
 
 
 def _gemm_split_on():
@@ -188,6 +170,44 @@ def _gemm_split_on():
     on = lib.s2c_gemm_set_split(1)
     lib.s2c_gemm_set_split(on)
     return bool(on)
+
+
+_C.register("s2c_small_gemm", [_L, _I, _I, _P, _L, _P, _L, _I, _P, _P, _L, _P])
+# the small products of the layer stacks (2048 .. 32768 rows) on csrc/s2c_sgemm.hip instead of
+# torch.mm / torch.addmm: dX = dY W reads W as stored (no transposed copy), y = x W^T + b
+SMALL_GEMM = _os.environ.get("S2C_SMALL_GEMM", "1") != "0"
+
+
+def _small_gemm_ok(M, N, K, lda, ldb, transposed):
+    lib = _C.load()
+    if not getattr(lib, "_sg_sized", False):
+        lib.s2c_small_gemm_supported.restype = _I
+        lib.s2c_small_gemm_supported.argtypes = [_L, _I, _I, _L, _L, _I]
+        lib._sg_sized = True
+    return bool(lib.s2c_small_gemm_supported(M, N, K, lda, ldb, int(transposed)))
+
+
+def small_gemm(A, B, transposed, bias=None):
+    """Y = A @ B (B: (K, N)) or A @ B^T (transposed: B is (N, K)) (+ bias) on s2c_small_gemm; None when
+    the shape / layout is not taken (the caller falls back)."""
+    if not (SMALL_GEMM and A.is_cuda and A.dtype == torch.float32 and B.dtype == torch.float32
+            and A.dim() == 2 and B.dim() == 2 and A.stride(1) == 1 and B.stride(1) == 1):
+        return None
+    M, K = A.shape
+    N = B.shape[0] if transposed else B.shape[1]
+    if (B.shape[1] if transposed else B.shape[0]) != K or M == 0:
+        return None
+    if not _small_gemm_ok(M, N, K, A.stride(0), B.stride(0), transposed):
+        return None
+    if A.data_ptr() % 4 or B.data_ptr() % (4 if transposed else 16):
+        return None
+    if bias is not None and not (bias.is_contiguous() and bias.dtype == torch.float32):
+        return None
+    Y = torch.empty((M, N), device=A.device)
+    _call("s2c_small_gemm", Y, M, N, K, A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0),
+          int(transposed), _ptr(bias), Y.data_ptr(), N,
+          alg_bytes=4 * (M * K + K * N + M * N), alg_flops=2 * M * N * K)
+    return Y
 
 
 def _input_grad_gemm(dY, W):
@@ -545,20 +565,9 @@ class _MLPRows(Function):
                     # the op's contract (unique source rows + idx + Y) is split over the two launches;
                     # P is an intermediate, not algorithmic traffic
                     pb, pf = 4 * min(g.B * g.N, M) * g.C, 2 * g.B * g.N * g.C * Cout
-                    if POINT_GEMM_EXACT and POINT_GEMM_TILED:
-                        prev_split = set_gemm_split(False)
-                        _call("s2c_rows_gemm", P, g.B * g.N, Cout, g.C, f2.data_ptr(), f2.stride(0),
-                              Wf.data_ptr(), Wf.stride(0), None, None, P.data_ptr(), Cout, None,
-                              alg_bytes=pb, alg_flops=pf, label="s2c_sa_point_gemm")
-                        set_gemm_split(prev_split)
-                    elif POINT_GEMM_EXACT:
-                        _call("s2c_point_gemm", P, g.B * g.N, Cout, g.C, f2.data_ptr(), f2.stride(0),
-                              Wf.data_ptr(), Wf.stride(0), P.data_ptr(), Cout,
-                              alg_bytes=pb, alg_flops=pf, label="s2c_sa_point_gemm")
-                    else:
-                        _call("s2c_rows_gemm", P, g.B * g.N, Cout, g.C, f2.data_ptr(), f2.stride(0),
-                              Wf.data_ptr(), Wf.stride(0), None, None, P.data_ptr(), Cout, None,
-                              alg_bytes=pb, alg_flops=pf, label="s2c_sa_point_gemm")
+                    _call("s2c_point_gemm", P, g.B * g.N, Cout, g.C, f2.data_ptr(), f2.stride(0),
+                          Wf.data_ptr(), Wf.stride(0), P.data_ptr(), Cout,
+                          alg_bytes=pb, alg_flops=pf, label="s2c_sa_point_gemm")
                 nbg = _gather_add_blocks(M)
                 gpart = torch.empty(nbg * 2 * Cout, device=dev) if gemm_stats else None
                 Y = torch.empty((M, Cout), device=dev)
@@ -683,7 +692,9 @@ class _MLPRows(Function):
                       alg_bytes=4 * (M * K_in + M * Cout), alg_flops=2 * M * K_in * Cout)
                 pre_activated = True
             else:
-                Y = torch.addmm(bias, A, W.t()) if bias is not None else torch.mm(A, W.t())
+                Y = small_gemm(A, W, True, bias)
+                if Y is None:
+                    Y = torch.addmm(bias, A, W.t()) if bias is not None else torch.mm(A, W.t())
             rec = {"A_in": None if from_gather else A, "W": W,
                    "has_bias": bias is not None, "point_space": point_space}
             last = li == nl - 1
@@ -793,19 +804,12 @@ class _MLPRows(Function):
             lazy_dw = False
             fused_dA = None
             pre, prestats = prestats, None
-            gather_dw = False
             point_grads = None
             if A_in is None:
                 if POINT_SPACE_BWD and SCATTER_DW and W.shape[0] % 4 == 0:
                     lazy_dw = True      # weight and input gradients from point-indexed sums
                 elif gather.needs_grad or not SCATTER_DW:
-                    if (USE_DW32 and BATCH_PARTIAL_SUMS and gather.rows >= DW32_MIN_ROWS
-                            and _dw32_slabs(gather.rows, W.shape[0], 3 + gather.C) > 0):
-                        # first layer of a gather-fused stack: its weight gradient reads the gathered
-                        # operand in place (csrc/s2c_dw32.hip) -- nothing is rebuilt
-                        gather_dw = True
-                    else:
-                        A_in = gather.materialise()
+                    A_in = gather.materialise()
                 else:
                     lazy_dw = True      # dW from point-indexed sums (GatherSpec.weight_grad)
             Cout = W.shape[0]
@@ -934,9 +938,6 @@ class _MLPRows(Function):
                                         pending=pending, post=post)
                 if gather.needs_grad:
                     point_grads = gather.input_grads(W)
-            elif gather_dw:
-                dW = _weight_grad_f32(dY if dY.stride(1) == 1 else dY.contiguous(), None, pending,
-                                      gather=gather)
             else:
                 dW = _weight_grad(dY, A_in, pending)
             dbias = None
@@ -951,7 +952,7 @@ class _MLPRows(Function):
                 dA = None
             elif fused_dA is not None:
                 dA = fused_dA
-            elif (HAND_DA_GEMM and dY.is_cuda and dY.dtype == torch.float32
+            elif (dY.is_cuda and dY.dtype == torch.float32
                   and W.dtype == torch.float32 and dY.stride(1) == 1
                   and _hand_da_pays(M, Cout, W.shape[1])):
                 Cin = W.shape[1]
@@ -977,7 +978,9 @@ class _MLPRows(Function):
                 if dA is None:
                     dA = _input_grad_gemm(dY, W)
             else:
-                dA = torch.mm(dY, W)
+                dA = small_gemm(dY, W, False)
+                if dA is None:
+                    dA = torch.mm(dY, W)
             g = [dW]
             if rec["has_bias"]:
                 g.append(dbias)
@@ -1279,58 +1282,6 @@ def row_sums(mats):
     return outs
 
 
-class _DwGather(ctypes.Structure):
-    """s2c_dw_gather (include/s2c_fused.h)."""
-    _fields_ = [("xyz", ctypes.c_void_p), ("new_xyz", ctypes.c_void_p), ("feats", ctypes.c_void_p),
-                ("idx", ctypes.c_void_p), ("frs", ctypes.c_longlong), ("fbs", ctypes.c_longlong),
-                ("n", ctypes.c_int), ("m", ctypes.c_int), ("ns", ctypes.c_int),
-                ("normalize", ctypes.c_int), ("radius", ctypes.c_float), ("pad_", ctypes.c_int)]
-
-
-_C.register("s2c_weight_grad_f32", [_L, _I, _I, _P, _L, _P, _L, _P, _P, _P])
-# tall weight gradients on the fp32 matrix cores (csrc/s2c_dw32.hip) instead of the split-K library
-# bmm; first layers of gather stacks read their operand in place (no re-materialised rows).
-# OFF by default: parity-green (tests/test_dw32_gpu.py) but 1.4-2.5x SLOWER than the library's
-# split-K bmm at every shape of the step (tools/bench_dw32.py, DESIGN 4.13) -- S2C_DW32=1 opts in.
-USE_DW32 = _os.environ.get("S2C_DW32", "0") == "1"
-DW32_MIN_ROWS = 32768
-
-
-def _dw32_slabs(M, C, K):
-    lib = _C.load()
-    if not getattr(lib, "_dw32_sized", False):
-        lib.s2c_weight_grad_f32_slabs.restype = _I
-        lib.s2c_weight_grad_f32_slabs.argtypes = [_L, _I, _I]
-        lib._dw32_sized = True
-    return lib.s2c_weight_grad_f32_slabs(M, C, K)
-
-
-def _weight_grad_f32(dY, A, pending, gather=None):
-    """dW (Cout, Cin) = dY^T A as per-slab partials of s2c_weight_grad_f32 (summed by the caller's
-    multi_colsum launch); gather: A is the GatherSpec's operand, read in place.  None: not taken."""
-    M, Cout = dY.shape
-    Cin = (3 + gather.C) if gather is not None else A.shape[1]
-    nslab = _dw32_slabs(M, Cout, Cin)
-    if nslab <= 0:
-        return None
-    dev = dY.device
-    part = torch.empty((nslab, Cout, Cin), dtype=torch.float32, device=dev)
-    dW = torch.empty((Cout, Cin), dtype=torch.float32, device=dev)
-    g = None
-    if gather is not None:
-        g = _DwGather()
-        g.xyz, g.new_xyz = gather.xyz.data_ptr(), gather.new_xyz.data_ptr()
-        g.feats = gather.feats.data_ptr() if gather.feats is not None else None
-        g.idx, g.frs, g.fbs = gather.idx.data_ptr(), gather.frs, gather.fbs
-        g.n, g.m, g.ns, g.normalize, g.radius = gather.N, gather.m, gather.ns, gather.normalize, gather.radius
-    _call("s2c_weight_grad_f32", dW, M, Cout, Cin, dY.data_ptr(), dY.stride(0),
-          A.data_ptr() if gather is None else None, A.stride(0) if gather is None else 0,
-          ctypes.byref(g) if g is not None else None, part.data_ptr(),
-          alg_bytes=4 * M * (Cout + Cin), alg_flops=2 * M * Cout * Cin)
-    pending.append((part, dW))
-    return dW
-
-
 _C.register("s2c_weight_grad_stream", [_L, _I, _I, _P, _L, _P, _L, _P, _P])
 # tall weight gradients on the streaming kernel (csrc/s2c_dwstream.hip): LDS-DMA ring, column reads
 # of the row-major chunks as the transposed MFMA operand, one partial tile per workgroup
@@ -1378,20 +1329,14 @@ def _weight_grad(dY, A, pending=None):
     if (USE_DW_KERNEL and dY.is_cuda and M >= DW_KERNEL_MIN_ROWS and dY.dtype == torch.float32
             and A.dtype == torch.float32 and dY.stride(1) == 1 and A.stride(1) == 1):
         return weight_grad_kernel(dY, A)
-    if (HAND_DW_GEMM and dY.is_cuda and dY.dtype == torch.float32 and A.dtype == torch.float32
+    if (dY.is_cuda and dY.dtype == torch.float32 and A.dtype == torch.float32
             and dY.stride(1) == 1 and A.stride(1) == 1 and pending is not None
-            and BATCH_PARTIAL_SUMS and (HAND_EVERYWHERE or _hand_dw_pays(M, dY.shape[1], A.shape[1]))):
+            and BATCH_PARTIAL_SUMS and _hand_dw_pays(M, dY.shape[1], A.shape[1])):
         return _weight_grad_partials(dY, A, pending)
     if (DW_STREAM and M >= DW_STREAM_MIN_ROWS and dY.is_cuda and dY.dtype == torch.float32
             and A.dtype == torch.float32 and dY.stride(1) == 1 and A.stride(1) == 1
             and pending is not None and BATCH_PARTIAL_SUMS):
         dW = _weight_grad_stream(dY, A, pending)
-        if dW is not None:
-            return dW
-    if (USE_DW32 and M >= DW32_MIN_ROWS and dY.is_cuda and dY.dtype == torch.float32
-            and A.dtype == torch.float32 and dY.stride(1) == 1 and A.stride(1) == 1
-            and pending is not None and BATCH_PARTIAL_SUMS):
-        dW = _weight_grad_f32(dY, A, pending)
         if dW is not None:
             return dW
     # slabs of >= 1024 rows (>= 2048 from 256k rows on), at most 256 of them: measured best

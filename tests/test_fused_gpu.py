@@ -205,7 +205,8 @@ with torch.no_grad():
     ok, _ = decoder_fused.decode(mod, we, tgt, obj, masks, T)
 torch.cuda.synchronize()
 assert torch.isfinite(ok).all() and not decoder_fused.persist_failed()
-lib = _C.load()
+from scan2cap_amd import build as _b
+lib = ctypes.CDLL(_b.build_probes())
 lib.s2c_probe_hog.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p]
 lib.s2c_probe_hog.restype = ctypes.c_int
 side = torch.cuda.Stream()
@@ -228,7 +229,7 @@ def test_persistent_decoder_gives_up_loudly_when_compute_units_are_held():
     launches, so a kernel of ANOTHER stream holding compute units can strand part of the grid.  The
     contract: the resident workgroups give up after 2^20 polls (~1 s), the launch raises its flag
     (`decoder_fused.persist_failed()`) and poisons the output with a NaN -- a result that says so,
-    never a hung GPU.  Provoked here for real: csrc/s2c_probe.hip's hog kernel holds 224 of 256
+    never a hung GPU.  Provoked here for real: tools/probes/s2c_probe.hip's hog kernel holds 224 of 256
     CUs on a second stream while the decoder is launched (own process: the scratch of a failed
     launch is not reused)."""
     import subprocess
@@ -519,10 +520,11 @@ def test_fp_module_point_major_matches_channel_major():
 
 
 def test_eval_greedy_decode_fused_step_matches_step_loop():
-    """Greedy decode of every proposal (caption_module.py:502-592): the split-weight step
-    with the one-pass local-attention kernel vs the module's plain `_step` loop.  Before
-    the first word where two logits tie to < 1e-5 the argmax sequences must agree, so the
-    whole (B,K,T,V) output must match."""
+    """Greedy decode of every proposal (caption_module.py:502-592): the planes GEMMs of
+    greedy_fused.py vs the module's plain `_step` loop.  Before the first word where two logits tie
+    to < 1e-5 the argmax sequences must agree, so the whole (B,K,T,V) output must match.  Then the
+    weights are changed IN PLACE through `.data` (no version bump, as a replayed optimizer graph or
+    an EMA swap does): the next decode must see them (the planes are split per call, no cache)."""
     from scan2cap_amd.models import caption_module as cm
     from scan2cap_amd.box_util import get_3d_box_batch
     torch.manual_seed(5)
@@ -541,36 +543,35 @@ def test_eval_greedy_decode_fused_step_matches_step_loop():
         "bbox_feature": (torch.randn(B, K, 128, generator=g) * 0.5).cuda(),
         "lang_feat": (torch.randn(B, 32, 300, generator=g) * 0.3).cuda(),
     }
-    outs = {}
-    old = (cm.FUSE_EVAL_STEP, cm.SPLIT_EVAL_MIN_ROWS)
-    try:
-        for flag in (False, True, "split", "planes"):
-            cm.FUSE_EVAL_STEP = "planes" if flag == "planes" else bool(flag)
-            # "split": the GEMMs of the step as bf16x3-plane library GEMMs (normally only
-            # from 4096 rows up)
-            cm.SPLIT_EVAL_MIN_ROWS = 1 if flag == "split" else 1 << 30
-            with torch.no_grad():
-                outs[flag] = mod(dict(dd), use_tf=False, is_eval=True, max_len=8)
-    finally:
-        cm.FUSE_EVAL_STEP, cm.SPLIT_EVAL_MIN_ROWS = old
-    assert cm._split_gemm_available()
-    s_, b = outs["split"], outs[False]
-    assert torch.equal(s_["lang_cap"].argmax(-1), b["lang_cap"].argmax(-1))
-    assert _rel(s_["lang_cap"], b["lang_cap"]) < 1e-4
-    assert _rel(s_["topdown_attn"], b["topdown_attn"]) < 1e-4
-    # the default: every product of the step on the planes GEMMs (greedy_fused.py)
-    p_, b = outs["planes"], outs[False]
-    assert p_["lang_cap"].shape == b["lang_cap"].shape == (B, K, 7, V)
-    assert torch.equal(p_["lang_cap"].argmax(-1), b["lang_cap"].argmax(-1))
-    assert _rel(p_["lang_cap"], b["lang_cap"]) < 1e-4
-    assert _rel(p_["topdown_attn"], b["topdown_attn"]) < 1e-4
-    assert torch.equal(p_["valid_masks"], b["valid_masks"])
-    a, b = outs[True], outs[False]
-    assert a["lang_cap"].shape == b["lang_cap"].shape == (B, K, 7, V)
-    assert torch.equal(a["lang_cap"].argmax(-1), b["lang_cap"].argmax(-1))
-    assert _rel(a["lang_cap"], b["lang_cap"]) < 1e-4
-    assert _rel(a["topdown_attn"], b["topdown_attn"]) < 1e-4
-    assert torch.equal(a["valid_masks"], b["valid_masks"])
+
+    def both():
+        outs = {}
+        old = cm.FUSE_EVAL_STEP
+        try:
+            for flag in (False, True):
+                cm.FUSE_EVAL_STEP = flag
+                with torch.no_grad():
+                    outs[flag] = mod(dict(dd), use_tf=False, is_eval=True, max_len=8)
+        finally:
+            cm.FUSE_EVAL_STEP = old
+        return outs[True], outs[False]
+
+    def check(p_, b):
+        assert p_["lang_cap"].shape == b["lang_cap"].shape == (B, K, 7, V)
+        assert torch.equal(p_["lang_cap"].argmax(-1), b["lang_cap"].argmax(-1))
+        assert _rel(p_["lang_cap"], b["lang_cap"]) < 1e-4
+        assert _rel(p_["topdown_attn"], b["topdown_attn"]) < 1e-4
+        assert torch.equal(p_["valid_masks"], b["valid_masks"])
+    p0, b0 = both()
+    check(p0, b0)
+    with torch.no_grad():
+        versions = [p._version for p in mod.parameters()]
+        for prm in mod.parameters():
+            prm.data.mul_(0.9).add_(torch.randn_like(prm.data) * 0.02)
+        assert [p._version for p in mod.parameters()] == versions      # invisible to a version key
+    p1, b1 = both()
+    check(p1, b1)
+    assert _rel(p1["lang_cap"], p0["lang_cap"]) > 1e-3                  # the weights did change
 
 
 def test_device_prefetcher_delivers_identical_batches():

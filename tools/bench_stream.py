@@ -1,11 +1,12 @@
-"""Streaming-copy probes (csrc/s2c_probe.hip): the bandwidth ceiling of a (M x 64) fp32
+"""Streaming-copy probes (tools/probes/s2c_probe.hip): the bandwidth ceiling of a (M x 64) fp32
 row pass with plain loads vs a wave-private LDS-DMA ring."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from scan2cap_amd import _C
 from tools.bench_ops import timeit
-lib = _C.load()
+from scan2cap_amd import build as _b
+lib = ctypes.CDLL(_b.build_probes())
 _I, _L, _P = ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p
 lib.s2c_probe_copy.argtypes = [_I, _L, _P, _P, _I, _I, _P]
 M = 1048576

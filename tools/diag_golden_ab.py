@@ -20,14 +20,11 @@ def _bwd_rec(ctx, dOut):
     SAVED.setdefault(CUR[0], []).append((recs, dOut.detach().clone()))
     return _bwd(ctx, dOut)
 fused._MLPRows.backward = staticmethod(_bwd_rec)
-FLAGS = {"S2C_POINT_SPACE": "POINT_SPACE", "S2C_POINT_GEMM_TILED": "POINT_GEMM_TILED",
-         "S2C_POINT_GEMM_X3": None}
+FLAGS = {"S2C_POINT_SPACE": "POINT_SPACE"}    # (the S2C_POINT_GEMM_* variants were dropped in round 5)
 res = []
 for i, env in enumerate(envs):
     CUR[0] = i
     fused.POINT_SPACE = env.get("S2C_POINT_SPACE", "1") != "0"
-    fused.POINT_GEMM_TILED = env.get("S2C_POINT_GEMM_TILED", "0") == "1"
-    fused.POINT_GEMM_EXACT = env.get("S2C_POINT_GEMM_X3", "0") != "1"
     model, sd = build_model("cuda", name)
     model.train(); model.zero_grad()
     with gc.forced_vote_sampling(model, torch.from_numpy(ref["train/aggregated_vote_inds"])):

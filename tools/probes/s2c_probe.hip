@@ -2,7 +2,7 @@
 // over (M x 64) fp32 rows can reach on this chip with (0) plain dwordx4 loads/stores and
 // (1) a wave-private ring of LDS-DMA loads (global_load_lds_dwordx4, no VGPR staging).
 // Not on the product path.
-#include "s2c_common.h"
+#include "../../scan2cap_amd/csrc/s2c_common.h"
 
 namespace {
 
