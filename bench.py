@@ -110,6 +110,10 @@ KERNELS_OF = {
     "s2c_decoder_bwd_persist": ("decoder_bwd_persist_kernel",),
     "s2c_planes_gemm": ("planes_gemm_kernel",),
     "s2c_mgemm": ("mgemm_kernel",),
+    "s2c_weight_grad": ("dw_x3_kernel",),
+    "s2c_weight_grad_multi": ("dw_x3_multi_kernel",),
+    "s2c_weight_grad_stream": ("dw_private_kernel",),
+    "s2c_small_gemm": ("sgemm_kernel",),
     "s2c_attn_local_fwd_planes": ("attn_local_kernel",),
     "s2c_ball_query": ("ball_query_kernel",),
     "s2c_ball_query_grid": ("bq_grid_build_kernel", "ball_query_grid_kernel"),
@@ -226,7 +230,7 @@ def build_model(wl, vocabulary, embeddings, msa):
     return CapNet(num_class=18, vocabulary=vocabulary, embeddings=embeddings,
                   num_heading_bin=1, num_size_cluster=18, mean_size_arr=msa,
                   input_feature_dim=wl["C"], num_proposal=wl["K"],
-                  num_locals=10 if cap else -1,
+                  num_locals=wl.get("num_locals", 10) if cap else -1,
                   no_caption=not cap, use_topdown=True,
                   query_mode="corner", graph_mode="edge_conv",
                   num_graph_steps=2 if cap else 0,
@@ -475,7 +479,9 @@ def named_roofline(table_k, workload=None, batch=None):
 
 GEMM_FAMILY = ("s2c_rows_gemm", "s2c_rows_gemm_bn_relu_side", "s2c_sa_gather_gemm", "s2c_sa_point_gemm",
                "s2c_bn_bwd_gemm", "s2c_bn_bwd_gemm_next_stats", "s2c_rows_gemm_next_stats",
-               "s2c_rows_gemm_bn_eval", "s2c_sa_gather_gemm_bn_eval", "s2c_sa_fused_eval")
+               "s2c_rows_gemm_bn_eval", "s2c_sa_gather_gemm_bn_eval", "s2c_sa_fused_eval",
+               # round 5: the backward products that were library GEMMs until then
+               "s2c_weight_grad", "s2c_weight_grad_multi", "s2c_weight_grad_stream", "s2c_small_gemm")
 _DECODER_CHAIN = ("s2c_small_linear", "s2c_small_linear_pair", "s2c_gru_fwd", "s2c_attn_fwd",
                   "s2c_attn_bwd", "s2c_gru_gates_bwd", "s2c_attn_x2_fwd", "s2c_attn_bwd_x2",
                   "s2c_decoder_fwd_persist", "s2c_decoder_bwd_persist")
@@ -646,6 +652,10 @@ def main():
     ap.add_argument("--batch", type=int, default=0,
                     help="scenes per GPU instead of the workload's (README.md:145 trains at 12, "
                          "slurm/train.job:24 at 16); the headline stays the workload's own B")
+    ap.add_argument("--num-locals", type=int, default=0,
+                    help="attended objects per proposal instead of the workload's 10 (scripts/train.py:322, "
+                         "benchmark/predict.py:249 default to -1 = all K proposals); the headline stays "
+                         "BASELINE's --num_locals 10")
     ap.add_argument("--no-fed", action="store_true",
                     help="skip the second measurement (builder-fed step) of the default run")
     args = ap.parse_args()
@@ -670,6 +680,9 @@ def main():
     #                                                  switched the persistent decoder kernels off)
 
     wl = dict(WORKLOADS[args.workload])
+    if args.num_locals != 0 and args.num_locals != 10:
+        wl["desc"] += " [--num-locals %d: not the BASELINE configuration]" % args.num_locals
+        wl["num_locals"] = args.num_locals
     if args.batch > 0 and args.batch != wl["B"]:
         wl["desc"] = wl["desc"].replace("B=%d" % wl["B"], "B=%d" % args.batch) + \
             " [--batch %d: not the BASELINE batch]" % args.batch

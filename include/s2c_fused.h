@@ -596,6 +596,21 @@ int s2c_weight_grad_slabs(long long M, int Cout, int Cin);
 int s2c_weight_grad(long long M, int Cout, int Cin, const float *dY, long long ldy,
                     const float *A, long long lda, float *dW, int lddw, void *workspace,
                     void *counters, void *stream);
+/* Several independent weight gradients in ONE launch (the layers of a stack).  Job j: partial tiles
+ * into `part` (s2c_weight_grad_slabs(M, Cout, Cin) of them, Cout x Cin each, row stride Cin; one slab:
+ * straight into dW, part may be NULL); the caller adds the slabs up (s2c_multi_colsum). */
+#define S2C_DW_MAX_JOBS 16
+typedef struct s2c_dw_job {
+  const float *dY, *A;
+  float *dW, *part;
+  long long M, ldy, lda;
+  int Cout, Cin, lddw, pad_;
+} s2c_dw_job;
+typedef struct s2c_dw_jobs {
+  int n_jobs, pad_;
+  s2c_dw_job job[S2C_DW_MAX_JOBS];
+} s2c_dw_jobs;
+int s2c_weight_grad_multi(const s2c_dw_jobs *jobs, void *stream);
 
 /* Box bookkeeping of the proposal stage (models/proposal_module.py:80-144,
  * model_util_scannet.py:165-172, utils/box_util.py:360-383) from the head output net

@@ -68,8 +68,8 @@ __device__ __forceinline__ void load8(float (&v)[8], const float *__restrict__ X
   }
 }
 
-__global__ __launch_bounds__(256) void dw_x3_kernel(
-    long long M, int Cout, int Cin, const float *__restrict__ dY, long long ldy,
+__device__ __forceinline__ void dw_x3_body(
+    int bid, long long M, int Cout, int Cin, const float *__restrict__ dY, long long ldy,
     const float *__restrict__ A, long long lda, int rows_per_slab, int nslab, int ntci,
     int ntiles, float *__restrict__ part1, float *__restrict__ part2,
     unsigned *__restrict__ cnt, float *__restrict__ dW, int lddw) {
@@ -77,8 +77,7 @@ __global__ __launch_bounds__(256) void dw_x3_kernel(
   __shared__ unsigned s_ticket;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lk = lane >> 5;
-  // XCD-aware mapping: blocks with equal (blockIdx % 8) share an L2
-  const int bid = blockIdx.x;
+  // XCD-aware mapping: blocks with equal (bid % 8) share an L2
   const int xcd = bid & 7;
   const int t = (bid >> 3) % ntiles;
   const int slab = xcd + 8 * ((bid >> 3) / ntiles);
@@ -234,6 +233,34 @@ __global__ __launch_bounds__(256) void dw_x3_kernel(
   }
 }
 
+__global__ __launch_bounds__(256) void dw_x3_kernel(
+    long long M, int Cout, int Cin, const float *__restrict__ dY, long long ldy,
+    const float *__restrict__ A, long long lda, int rows_per_slab, int nslab, int ntci,
+    int ntiles, float *__restrict__ part1, float *__restrict__ part2,
+    unsigned *__restrict__ cnt, float *__restrict__ dW, int lddw) {
+  dw_x3_body(blockIdx.x, M, Cout, Cin, dY, ldy, A, lda, rows_per_slab, nslab, ntci, ntiles, part1,
+             part2, cnt, dW, lddw);
+}
+
+// Several independent weight gradients in ONE launch (the layers of a stack: 17 us launches that
+// each fill a fraction of the chip): job j owns the blocks [first[j], first[j + 1]); partial tiles
+// only (the caller's multi_colsum launch adds the slabs), one slab: straight into dW.
+struct DwJobPlan { int first, rows_per_slab, nslab, ntci, ntiles; };
+struct DwMulti {
+  s2c_dw_jobs j;
+  DwJobPlan plan[S2C_DW_MAX_JOBS];
+};
+__global__ __launch_bounds__(256) void dw_x3_multi_kernel(DwMulti a) {
+  int j = 0;
+  const int bid = blockIdx.x;
+#pragma unroll 1
+  while (j + 1 < a.j.n_jobs && bid >= a.plan[j + 1].first) ++j;
+  const s2c_dw_job &jb = a.j.job[j];
+  const DwJobPlan &pl = a.plan[j];
+  dw_x3_body(bid - pl.first, jb.M, jb.Cout, jb.Cin, jb.dY, jb.ldy, jb.A, jb.lda, pl.rows_per_slab,
+             pl.nslab, pl.ntci, pl.ntiles, jb.part, nullptr, nullptr, jb.dW, jb.lddw);
+}
+
 int chk6(const char *k) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -301,4 +328,31 @@ extern "C" int s2c_weight_grad(long long M, int Cout, int Cin, const float *dY, 
                      Cin, dY, ldy, A, lda, rps, nslab, (Cin + 63) / 64, nt, part1, part2,
                      (unsigned *)counters, dW, lddw);
   return chk6("weight_grad");
+}
+
+// The weight gradients of several layers in one launch (at most S2C_DW_MAX_JOBS): job j writes
+// s2c_weight_grad_slabs(M, Cout, Cin) partial tiles into job[j].part (one slab: dW itself, part may
+// be NULL); the caller adds the slabs up (s2c_multi_colsum).
+extern "C" int s2c_weight_grad_multi(const s2c_dw_jobs *jobs, void *stream) {
+  if (!jobs || jobs->n_jobs <= 0 || jobs->n_jobs > S2C_DW_MAX_JOBS) return -1;
+  DwMulti a;
+  a.j = *jobs;
+  int first = 0;
+  for (int j = 0; j < jobs->n_jobs; ++j) {
+    const s2c_dw_job &jb = jobs->job[j];
+    if (jb.M <= 0 || jb.Cout <= 0 || jb.Cin <= 0 || !jb.dY || !jb.A || !jb.dW || jb.ldy < jb.Cout ||
+        jb.lda < jb.Cin || jb.lddw < jb.Cin)
+      return -1;
+    int rps, nslab, nt;
+    dw_plan(jb.M, jb.Cout, jb.Cin, &rps, &nslab, &nt);
+    if (nslab > 1 && !jb.part) return -1;
+    a.plan[j].first = first;
+    a.plan[j].rows_per_slab = rps;
+    a.plan[j].nslab = nslab;
+    a.plan[j].ntci = (jb.Cin + 63) / 64;
+    a.plan[j].ntiles = nt;
+    first += 8 * nt * ((nslab + 7) / 8);
+  }
+  hipLaunchKernelGGL(dw_x3_multi_kernel, dim3(first), dim3(256), 0, (hipStream_t)stream, a);
+  return chk6("weight_grad_multi");
 }

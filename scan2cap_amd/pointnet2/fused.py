@@ -1180,6 +1180,38 @@ def weight_grad_kernel(dY, A):
     return dW
 
 
+DW_MAX_JOBS = 16          # S2C_DW_MAX_JOBS (include/s2c_fused.h)
+
+
+class _DwJob(ctypes.Structure):
+    """s2c_dw_job (include/s2c_fused.h)."""
+    _fields_ = [("dY", ctypes.c_void_p), ("A", ctypes.c_void_p), ("dW", ctypes.c_void_p),
+                ("part", ctypes.c_void_p), ("M", ctypes.c_longlong), ("ldy", ctypes.c_longlong),
+                ("lda", ctypes.c_longlong), ("Cout", ctypes.c_int), ("Cin", ctypes.c_int),
+                ("lddw", ctypes.c_int), ("pad_", ctypes.c_int)]
+
+
+class _DwJobs(ctypes.Structure):
+    """s2c_dw_jobs (include/s2c_fused.h)."""
+    _fields_ = [("n_jobs", ctypes.c_int), ("pad_", ctypes.c_int), ("job", _DwJob * DW_MAX_JOBS)]
+
+
+_C.register("s2c_weight_grad_multi", [_P, _P])
+# the slab weight gradients of a layer stack (17 us launches that fill a fraction of the chip each) in
+# ONE multi-job launch at the stack's flush_partial_sums (S2C_DW_MULTI=0: one launch per layer)
+DW_MULTI = _os.environ.get("S2C_DW_MULTI", "1") != "0"
+
+
+class _DeferredDw(object):
+    """An entry of a `pending` list: a slab weight gradient not launched yet (flush_partial_sums
+    launches all of a stack's together, then adds up their slabs with the other partials).  dY and A
+    are kept alive -- and must not be written -- until then."""
+    __slots__ = ("dY", "A", "dW", "part")
+
+    def __init__(self, dY, A, dW, part):
+        self.dY, self.A, self.dW, self.part = dY, A, dW, part
+
+
 def _weight_grad_partials(dY, A, pending):
     """dW = dY^T A: the register-fed MFMA kernel of csrc/s2c_dw.hip writes one partial tile per
     row slab; the caller's single multi_colsum launch adds them (kernel boundary instead of
@@ -1195,12 +1227,32 @@ def _weight_grad_partials(dY, A, pending):
     nslab = lib.s2c_weight_grad_slabs(M, Cout, Cin)
     dW = torch.empty((Cout, Cin), dtype=torch.float32, device=dev)
     part = torch.empty((nslab, Cout, Cin), dtype=torch.float32, device=dev) if nslab > 1 else None
+    if DW_MULTI:
+        pending.append(_DeferredDw(dY, A, dW, part))
+        return dW
     _call("s2c_weight_grad", dW, M, Cout, Cin, dY.data_ptr(), dY.stride(0), A.data_ptr(),
           A.stride(0), dW.data_ptr(), Cin, _ptr(part), None,
           alg_bytes=4 * M * (Cout + Cin), alg_flops=2 * M * Cout * Cin)
     if part is not None:
         pending.append((part, dW))
     return dW
+
+
+def _launch_deferred_dw(jobs):
+    for i in range(0, len(jobs), DW_MAX_JOBS):
+        chunk = jobs[i:i + DW_MAX_JOBS]
+        a = _DwJobs()
+        a.n_jobs = len(chunk)
+        nbytes = flops = 0
+        for j, d in enumerate(chunk):
+            M, Cout = d.dY.shape
+            Cin = d.A.shape[1]
+            a.job[j] = _DwJob(d.dY.data_ptr(), d.A.data_ptr(), d.dW.data_ptr(), _ptr(d.part), M,
+                              d.dY.stride(0), d.A.stride(0), Cout, Cin, Cin, 0)
+            nbytes += 4 * M * (Cout + Cin)
+            flops += 2 * M * Cout * Cin
+        _call("s2c_weight_grad_multi", chunk[0].dW, ctypes.byref(a), alg_bytes=nbytes,
+              alg_flops=flops)
 
 
 COLSUM_MAX_JOBS = 32      # S2C_COLSUM_MAX_JOBS (include/s2c_fused.h)
@@ -1226,7 +1278,13 @@ BATCH_PARTIAL_SUMS = True
 
 
 def flush_partial_sums(pending):
-    """[(part (S,Cout,Cin), dW (Cout,Cin))...] -> every dW filled, COLSUM_MAX_JOBS per launch."""
+    """[(part (S,Cout,Cin), dW (Cout,Cin)) | _DeferredDw ...] -> every dW filled: the deferred slab
+    products in one launch per DW_MAX_JOBS, then the sums, COLSUM_MAX_JOBS per launch."""
+    jobs = [e for e in pending if isinstance(e, _DeferredDw)]
+    if jobs:
+        _launch_deferred_dw(jobs)
+        pending[:] = [(e.part, e.dW) if isinstance(e, _DeferredDw) else e for e in pending
+                      if not (isinstance(e, _DeferredDw) and e.part is None)]
     for i in range(0, len(pending), COLSUM_MAX_JOBS):
         chunk = pending[i:i + COLSUM_MAX_JOBS]
         a = _ColsumArgs()
