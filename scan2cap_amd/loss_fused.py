@@ -116,10 +116,13 @@ class DetectionLoss(Function):
         outs = (t["stats"], t["objectness_label"], t["objectness_mask"],
                 t["object_assignment"])
         ctx.mark_non_differentiable(*outs)
+        ctx.set_materialize_grads(False)     # no zero fills for the non-differentiable outputs
         return (t["stats"][9].clone(),) + outs
 
     @staticmethod
     def backward(ctx, gdet, *_unused):
+        if gdet is None:
+            return (None,) * len(ctx.needs_input_grad)
         t, args, rows = ctx.tensors, ctx.args, ctx.rows
         dev = gdet.device
         gup = gdet.to(torch.float32).contiguous()
@@ -231,10 +234,13 @@ class CaptionLoss(Function):
         ctx.save_for_backward(pred, target, good8, lse, out)
         loss, acc = out[0], out[1]
         ctx.mark_non_differentiable(acc)
+        ctx.set_materialize_grads(False)
         return loss, acc
 
     @staticmethod
     def backward(ctx, g_loss, _g_acc):
+        if g_loss is None:
+            return None, None, None
         pred, target, good8, lse, out = ctx.saved_tensors
         B, T, V = pred.shape
         gup = g_loss.reshape(1).to(torch.float32).contiguous()

@@ -450,10 +450,13 @@ class TopDownDecode(Function):
             ctx.coef = (COEF, S)
             ctx.words_need_grad = ctx.needs_input_grad[0]
         ctx.mark_non_differentiable(attn)
+        ctx.set_materialize_grads(False)
         return logits, attn
 
     @staticmethod
     def backward(ctx, dlogits, _dattn):
+        if dlogits is None:
+            return (None,) * len(ctx.needs_input_grad)
         (W_td, b_td, W_ih1, W_hh1, b_ih1, b_hh1, W_f, W_h, w_a, W_lang, b_lang,
          W_ih2, W_hh2, b_ih2, b_hh2, W_cls, b_cls) = ctx.saved_tensors
         words, tf, O, M, wa, H1, H2, X1, X2, S1, S2, QL, ALPHA, ATT, H2n = ctx.stash

@@ -92,12 +92,17 @@ class _EdgeScatter(torch.autograd.Function):
                     slot8.data_ptr(), out.data_ptr(), msgm.data_ptr(), _C.stream_ptr())
         ctx.save_for_backward(nbr, slot8)
         ctx.dims = (B, K, L, F)
+        ctx.set_materialize_grads(False)     # an unused output's gradient arrives as None, not as a zero fill
         return out, msgm
 
     @staticmethod
     def backward(ctx, d_out, d_msgm):
         nbr, slot8 = ctx.saved_tensors
         B, K, L, F = ctx.dims
+        if d_out is None and d_msgm is None:
+            return None, None, None
+        if d_out is None:
+            d_out = torch.zeros((B, K, F), device=d_msgm.device)
         d_out = d_out.contiguous()
         if d_msgm is not None:
             d_msgm = d_msgm.contiguous()
@@ -319,11 +324,14 @@ class GraphModule(nn.Module):
             feat, message = layer(feat, nbr, slot)
         node_feat = feat
 
-        edge_indices = torch.zeros(B, 2, K * L, device=dev)
-        edge_feats = torch.zeros(B, K, L, self.out_size, device=dev)
-        edge_preds = torch.zeros(B, K * L, self.num_bins + 1, device=dev)
-        num_sources = torch.zeros(B, dtype=torch.long, device=dev)
-        num_targets = torch.zeros(B, dtype=torch.long, device=dev)
+        # the five zero-initialised outputs (graph_module.py:248-252) out of two fills instead of five
+        n_i, n_f, n_p = B * 2 * K * L, B * K * L * self.out_size, B * K * L * (self.num_bins + 1)
+        zf = torch.zeros(n_i + n_f + n_p, device=dev)
+        edge_indices = zf[:n_i].view(B, 2, K * L)
+        edge_feats = zf[n_i:n_i + n_f].view(B, K, L, self.out_size)
+        edge_preds = zf[n_i + n_f:].view(B, K * L, self.num_bins + 1)
+        zl = torch.zeros(2 * B, dtype=torch.long, device=dev)
+        num_sources, num_targets = zl[:B], zl[B:]
 
         if self.return_orientation:
             KL = K * L

@@ -930,7 +930,7 @@ class _MLPRows(Function):
                           partial.data_ptr(), coef.data_ptr(), _ptr(dgamma),
                           _ptr(dbeta), dY.data_ptr(), alg_bytes=4 * 5 * M * Cout)
             elif rec.get("relu"):
-                dY = dA * (rec["Y"] > 0)
+                dY = torch.ops.aten.threshold_backward(dA, rec["Y"], 0.0)     # dA * (Y > 0), one launch
             else:
                 dY = dA
             if lazy_dw:

@@ -28,6 +28,12 @@ class Census(TorchDispatchMode):
                         and "glue_census" not in fr.filename:
                     where = "%s:%d" % (os.path.basename(fr.filename), fr.lineno)
                     break
+            if where == "?":          # issued by the autograd engine itself: name the node it is running
+                try:
+                    node = torch._C._current_autograd_node()
+                    where = "engine:" + (node.name() if node is not None else "-")
+                except Exception:
+                    pass
             big = max([a.numel() for a in args if torch.is_tensor(a)] + [0])
             self.c[(name.replace("aten.", ""), where, big)] += 1
         return func(*args, **(kwargs or {}))
