@@ -154,13 +154,14 @@ def pmc_traffic(entry):
     return total / max(calls, 1)
 
 
-def pmc_mfma_busy(name_parts):
+def pmc_mfma_busy(name_parts, workload="bench"):
     """MFMA-busy fraction (SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024 SIMDs)) of the kernels
     whose names contain one of `name_parts`, time-weighted, from the committed SQ-counter summary
-    (profiles/rNN_pmc_sq_bench.json, newest round; its own rocprofv3 pass: tools/make_profiles.sh).
+    (profiles/rNN_pmc_sq_<workload>.json, newest round -- "bench" = the cfg3 train step, "cfg3e" / "cfg5"
+    = the evaluation workloads; each its own rocprofv3 pass: tools/make_profiles.sh).
     None when not available."""
     import glob
-    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_sq_bench.json")))
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_sq_%s.json" % workload)))
     if not found:
         return None
     try:
@@ -507,12 +508,13 @@ def family_roofline(table_k, ms_per_step):
             # hardware view of the same kernels: matrix-pipe busy cycles (PMC, bf16 pipe:
             # 6 plane products per fp32 product)
             "mfma_busy": pmc_mfma_busy(("rows_stream_gemm_kernel", "rows_gemm_x3_kernel",
-                                        "rows_gemm_c64_kernel", "rows_gemm_kernel")),
+                                        "rows_gemm_c64_kernel", "rows_gemm_kernel", "dw_x3",
+                                        "dw_private_kernel", "sgemm_kernel", "point_gemm_kernel")),
             "parts": {k["kernel"]: {"ms_per_step": k["ms_per_step"], "alg_GBps": k["alg_GBps"],
                                     "avg_launch_us": k["avg_us"]} for k in parts}}
 
 
-def decode_roofline(table_k, ms_per_step):
+def decode_roofline(table_k, ms_per_step, workload="cfg5"):
     """Greedy decoding (cfg3e / cfg5): the planes GEMMs of csrc/s2c_planes.hip taken together -- every
     product of the token loop -- against the bf16 matrix roof (6 plane products per fp32 product),
     with the PMC matrix-pipe busy fraction where the committed SQ summary has the kernel."""
@@ -526,7 +528,7 @@ def decode_roofline(table_k, ms_per_step):
                     "peak / 6 (bf16x3 plane products)",
             "ms_per_step": k["ms_per_step"], "share_of_step": k["ms_per_step"] / ms_per_step,
             "launches_per_step": k["calls_per_step"], "avg_launch_us": k["avg_us"],
-            "mfma_busy": pmc_mfma_busy(("planes_gemm_kernel",))}
+            "mfma_busy": pmc_mfma_busy(("planes_gemm_kernel",), workload)}
 
 
 def self_launch(n):
@@ -1085,7 +1087,7 @@ def main():
             "roofline_main_stream": roof_main,
             "roofline_named": named_roofline(table_k, args.workload, B),
             "roofline_gemm": roof_gemm,
-            "roofline_decode": decode_roofline(table_k, ms_per_step),
+            "roofline_decode": decode_roofline(table_k, ms_per_step, args.workload),
             "fed": fed,
             "ddp": ddp_info,
             "kernels": table_k[:10],

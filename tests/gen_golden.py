@@ -66,6 +66,37 @@ def sensitivity(ref, model, sd, inputs, spec, msa, forced_inds, base):
     return sens
 
 
+def truth64(ref, model, sd, inputs, spec, msa, forced_inds):
+    """The same train step once more in float64 (weights, inputs, every intermediate), the discrete
+    geometry decisions taken on the float32 coordinates as the reference takes them
+    (oracle/torch_ext.py) and the vote sampling forced: `truth/loss/*`, `truth/grad/*`.  The parity
+    tests bound the HIP path's distance to this truth by a multiple of the float32 reference's OWN
+    distance to it -- a measurement of what float32 can deliver per key, instead of a model."""
+    model.load_state_dict(sd)
+    model.double()
+    model.train()
+    model.zero_grad()
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        tin = {k: (v.double() if v.is_floating_point() else v) for k, v in gc.to_torch(inputs).items()}
+        with gc.forced_vote_sampling(model, forced_inds):
+            dd = model(tin, use_tf=True, is_eval=False)
+            dd = ref.loss_helper.get_scene_cap_loss(
+                dd, torch.device("cpu"), gc.LossConfig(msa), None, **gc.LOSS_FLAGS)
+            dd["loss"].backward()
+        out = {}
+        for k in gc.LOSS_KEYS:
+            out["truth/loss/" + k] = np.asarray(dd[k].detach().cpu().numpy(), np.float64)
+        for k, v in gc.extract_grads(model).items():
+            out["truth/grad/" + k] = np.asarray(v, np.float64)
+    finally:
+        torch.set_default_dtype(old)
+        model.float()
+        model.zero_grad()
+    return out
+
+
 def main(name="cfg1"):
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -123,6 +154,14 @@ def main(name="cfg1"):
                        dd["aggregated_vote_inds"].detach().clone(), dict(out))
     for k, v in sens.items():
         out["sens/" + k] = np.asarray(v, np.float64)
+    truth = truth64(ref, model, sd, inputs, spec, msa, dd["aggregated_vote_inds"].detach().clone())
+    out.update(truth)
+
+    def rel(a, b):
+        b = np.asarray(b, np.float64)
+        return float(np.abs(np.asarray(a, np.float64) - b).max() / max(1.0, np.abs(b).max()))
+    far = sorted(((rel(out[k[6:]], v), k[6:]) for k, v in truth.items()), reverse=True)
+    print("float32 reference vs its float64 run, worst keys:", [(round(e, 6), k) for e, k in far[:8]])
     print("conditioning (one-ulp noise per layer), worst keys:",
           sorted(((round(v, 6), k) for k, v in sens.items()), reverse=True)[:8])
     model.load_state_dict(sd)  # reset BN running stats touched by the train pass
