@@ -51,6 +51,14 @@ int s2c_sa_gather_add_blocks(long long rows);
 int s2c_sa_gather_add(int b, int n, int m, int ns, int N, float radius, int normalize,
                       const float *xyz, const float *new_xyz, const float *P, const int *idx,
                       const float *W, int ldw, float *Y, float *partial, void *stream);
+/* Inference: the same pass with the frozen BatchNorm (+ ReLU) behind the layer applied before the store:
+ * Y = relu?(y * sc[c] + sh[c]), sc = gamma / sqrt(var + eps), sh = beta - mean * sc (gamma / beta may be
+ * NULL: 1 / 0) -- the evaluation path's first set-abstraction layer in point space. */
+int s2c_sa_gather_add_eval(int b, int n, int m, int ns, int N, float radius, int normalize,
+                           const float *xyz, const float *new_xyz, const float *P, const int *idx,
+                           const float *W, int ldw, const float *gamma, const float *beta,
+                           const float *mean, const float *var, float eps, int relu, float *Y,
+                           void *stream);
 
 /* P (M x N, row stride ldp) = A (M x K, row stride lda; rows at any 4-byte address) W^T (W: N x K,
  * row stride ldw) on the exact fp32 matrix instruction (an fp32 FMA chain over k): the per-point

@@ -290,6 +290,12 @@ struct GatherAddArgs {
   const float *xyz, *new_xyz, *P, *W;
   const int *idx;
   float *Y, *partial;
+  // inference epilogue (em != nullptr): Y = relu?(y * sc[c] + sh[c]), sc = gamma / sqrt(var + eps),
+  // sh = beta - mean * sc -- the frozen BatchNorm (+ ReLU) behind the first layer
+  // (affine_epilogue of s2c_gemm.hip, the arithmetic of bn_eval_coeffs + bn_relu)
+  const float *eg, *eb, *em, *ev;
+  float eeps;
+  int erelu;
 };
 
 template <int LPR>
@@ -307,6 +313,16 @@ __global__ __launch_bounds__(256) void sa_gather_add_kernel(GatherAddArgs a) {
 #pragma unroll
     for (int d = 0; d < 3; ++d) wx[q][d] = a.W[(long long)(c0l + q) * a.ldw + d];
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool epi = a.em != nullptr;
+  float esc[4] = {1.f, 1.f, 1.f, 1.f}, esh[4] = {0.f, 0.f, 0.f, 0.f};
+  if (epi) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float invstd = 1.0f / sqrtf(a.ev[c0l + q] + a.eeps);
+      esc[q] = (a.eg ? a.eg[c0l + q] : 1.0f) * invstd;
+      esh[q] = (a.eb ? a.eb[c0l + q] : 0.0f) - a.em[c0l + q] * esc[q];
+    }
+  }
   const int rpw = a.rpb >> 2;                                   // rows per wave
   const long long w0 = (long long)blockIdx.x * a.rpb + (long long)wave * rpw;
   for (int ch = 0; ch < rpw; ch += 64) {
@@ -348,6 +364,13 @@ __global__ __launch_bounds__(256) void sa_gather_add_kernel(GatherAddArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           o[q] = __builtin_fmaf(wx[q][2], z, __builtin_fmaf(wx[q][1], y, __builtin_fmaf(wx[q][0], x, o[q])));
+        if (epi) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            o[q] = o[q] * esc[q] + esh[q];
+            if (a.erelu) o[q] = fmaxf(o[q], 0.f);
+          }
+        }
         if (st0 + u * G + lg < nrow && cok) {
           *reinterpret_cast<float4 *>(a.Y + (r0 + rr[u]) * a.N + c0) = make_float4(o[0], o[1], o[2], o[3]);
 #pragma unroll
@@ -382,10 +405,11 @@ extern "C" int s2c_sa_gather_add_blocks(long long rows) {
   return (int)((rows + rpb - 1) / rpb);
 }
 
-extern "C" int s2c_sa_gather_add(int b, int n, int m, int ns, int N, float radius, int normalize,
-                                 const float *xyz, const float *new_xyz, const float *P,
-                                 const int *idx, const float *W, int ldw, float *Y,
-                                 float *partial, void *stream) {
+static int gather_add_launch(int b, int n, int m, int ns, int N, float radius, int normalize,
+                             const float *xyz, const float *new_xyz, const float *P,
+                             const int *idx, const float *W, int ldw, float *Y, float *partial,
+                             const float *eg, const float *eb, const float *em, const float *ev,
+                             float eeps, int erelu, void *stream) {
   if (b <= 0 || n <= 0 || m <= 0 || ns <= 0 || N <= 0 || N > 256 || (N & 3) || ldw < 3 || !xyz ||
       !new_xyz || !idx || !W || !Y || ((uintptr_t)Y & 15) || (P && ((uintptr_t)P & 15)))
     return fail2("sa_gather_add: sizes / alignment / null pointer");
@@ -395,12 +419,34 @@ extern "C" int s2c_sa_gather_add(int b, int n, int m, int ns, int N, float radiu
   a.rpb = gather_add_rpb(a.rows); a.has_p = P != nullptr;
   a.radius = radius; a.xyz = xyz; a.new_xyz = new_xyz; a.P = P; a.W = W; a.idx = idx;
   a.Y = Y; a.partial = partial;
+  a.eg = eg; a.eb = eb; a.em = em; a.ev = ev; a.eeps = eeps; a.erelu = erelu;
   const dim3 grid((unsigned)s2c_sa_gather_add_blocks(a.rows));
   hipStream_t st = (hipStream_t)stream;
   if (N <= 64) hipLaunchKernelGGL(sa_gather_add_kernel<16>, grid, dim3(256), 0, st, a);
   else if (N <= 128) hipLaunchKernelGGL(sa_gather_add_kernel<32>, grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(sa_gather_add_kernel<64>, grid, dim3(256), 0, st, a);
   return check2("sa_gather_add");
+}
+
+extern "C" int s2c_sa_gather_add(int b, int n, int m, int ns, int N, float radius, int normalize,
+                                 const float *xyz, const float *new_xyz, const float *P,
+                                 const int *idx, const float *W, int ldw, float *Y,
+                                 float *partial, void *stream) {
+  return gather_add_launch(b, n, m, ns, N, radius, normalize, xyz, new_xyz, P, idx, W, ldw, Y,
+                           partial, nullptr, nullptr, nullptr, nullptr, 0.f, 0, stream);
+}
+
+// Inference: the first layer in point space with the frozen BatchNorm (+ ReLU) behind it in the
+// same pass: Y = relu?((P[idx] + W_x rel) * sc + sh) (mean / var: the running statistics).
+extern "C" int s2c_sa_gather_add_eval(int b, int n, int m, int ns, int N, float radius,
+                                      int normalize, const float *xyz, const float *new_xyz,
+                                      const float *P, const int *idx, const float *W, int ldw,
+                                      const float *gamma, const float *beta, const float *mean,
+                                      const float *var, float eps, int relu, float *Y,
+                                      void *stream) {
+  if (!mean || !var) return fail2("sa_gather_add_eval: null statistics");
+  return gather_add_launch(b, n, m, ns, N, radius, normalize, xyz, new_xyz, P, idx, W, ldw, Y,
+                           nullptr, gamma, beta, mean, var, eps, relu, stream);
 }
 
 // Feature propagation on point-major rows (PointnetFPModule.forward,

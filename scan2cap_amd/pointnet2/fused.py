@@ -1101,6 +1101,13 @@ def _eval_stage_fused(gather, M, dev, specs, pool_ns, params):
     return out if rc == 0 else None
 
 
+# inference: the first layer of a gather stack in point space too (S2C_EVAL_POINT_SPACE=0: the
+# gather-fused GEMM of rounds 1-4)
+EVAL_POINT_SPACE = _os.environ.get("S2C_EVAL_POINT_SPACE", "1") != "0"
+_C.register("s2c_sa_gather_add_eval", [_I, _I, _I, _I, _I, ctypes.c_float, _I, _P, _P, _P, _P, _P, _I,
+                                       _P, _P, _P, _P, ctypes.c_float, _I, _P, _P])
+
+
 def _eval_stack(X, gather, M, dev, specs, pool_ns, params):
     """Frozen-BN layer stack: one launch per layer, no pre-activation tensor, the last
     layer leaves max-pooled (or the whole stage in one launch: _eval_stage_fused)."""
@@ -1119,7 +1126,27 @@ def _eval_stack(X, gather, M, dev, specs, pool_ns, params):
         gamma, beta, mean, var, eps = _eval_affine(sp, bias, gamma, beta, Cout, dev)
         pn = pool_ns if li == nl - 1 else 0
         out = torch.empty((M // pn if pn else M, Cout), device=dev)
-        if gather is not None and li == 0:
+        if (gather is not None and li == 0 and POINT_SPACE and EVAL_POINT_SPACE and pn == 0
+                and Cout % 4 == 0 and Cout <= 256 and W.stride(1) == 1
+                and gather.feats2d() is not False):
+            # the first layer in point space (as in training, section 4.13): the feature product once
+            # per POINT, then P[idx] + W_x rel with the frozen BatchNorm + ReLU in the same pass -- no
+            # gather-multiply over the B m ns gathered rows
+            g = gather
+            P = None
+            if g.C > 0:
+                f2, Wf = g.feats2d(), W[:, 3:]
+                P = torch.empty((g.B * g.N, Cout), device=dev)
+                _call("s2c_point_gemm", P, g.B * g.N, Cout, g.C, f2.data_ptr(), f2.stride(0),
+                      Wf.data_ptr(), Wf.stride(0), P.data_ptr(), Cout,
+                      alg_bytes=4 * min(g.B * g.N, M) * g.C, alg_flops=2 * g.B * g.N * g.C * Cout,
+                      label="s2c_sa_point_gemm")
+            _call("s2c_sa_gather_add_eval", out, g.B, g.N, g.m, g.ns, Cout, g.radius, g.normalize,
+                  g.xyz.data_ptr(), g.new_xyz.data_ptr(), _ptr(P), g.idx.data_ptr(),
+                  W.data_ptr(), W.stride(0), _ptr(gamma), _ptr(beta), mean.data_ptr(),
+                  var.data_ptr(), eps, int(sp.relu), out.data_ptr(),
+                  alg_bytes=4 * (min(g.B * g.N, M) * 3 + M + M * Cout), label="s2c_sa_gather_add")
+        elif gather is not None and li == 0:
             g = gather
             _call("s2c_sa_gather_gemm_bn_eval", out, g.B, g.N, g.m, g.ns, g.C, g.frs, g.fbs,
                   g.radius, g.normalize, g.xyz.data_ptr(), g.new_xyz.data_ptr(),
