@@ -700,7 +700,7 @@ def main():
     use_graph = not args.no_graph
     # torch's fused multi-tensor Adam: same update as scripts/train.py's optim.Adam, 3
     # launches instead of 17 (S2C_ADAM_FUSED=0: the default foreach implementation)
-    fused_adam = os.environ.get("S2C_ADAM_FUSED", "1") != "0"
+    fused_adam = True
     optimizer = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5,
                                  capturable=use_graph, fused=True if fused_adam else None)
     # S2C_FORCE_DDP=1 exercises the multi-GPU code path (flat gradient bucket,

@@ -300,12 +300,12 @@ int s2c_sa_fused_eval(int b, int n, int m, int ns, int C, long long feat_row_str
  * the previous setting. */
 int s2c_gemm_set_split(int on);
 
-/* problems with N > 64 that the streaming kernel does not take: 1 (default, environment
- * S2C_GEMM_C64) = rows_gemm_c64_kernel (K in 64-chunks of fp32 in LDS, next chunk in flight, two
+/* problems with N > 64 that the streaming kernel does not take: 1 (default)
+ * = rows_gemm_c64_kernel (K in 64-chunks of fp32 in LDS, next chunk in flight, two
  * workgroups per CU), 0 = the 32-k-slice kernel (which keeps the BatchNorm-backward prologue of
  * s2c_bn_bwd_gemm either way).  Identical results.  Returns the previous setting. */
 int s2c_gemm_set_c64(int on);
-/* 1 (default; S2C_GEMM_C64_NARROW): that kernel on 128 x 32 workgroup tiles when 128 x 128 ones would
+/* 1 (default): that kernel on 128 x 32 workgroup tiles when 128 x 128 ones would
  * cover the chip once or less (bit-identical values; not for the pooled epilogues); returns the
  * previous setting */
 int s2c_gemm_set_c64_narrow(int on);
@@ -829,6 +829,23 @@ int s2c_small_gemm_supported(long long M, int N, int K, long long lda, long long
 int s2c_small_gemm(long long M, int N, int K, const float *A, long long lda, const float *B,
                    long long ldb, int b_transposed, const float *bias, float *Y, long long ldy,
                    void *stream);
+/* The general form: operand rows through index maps (index i -> element offset (i / div) * hi + (i % div) * lo;
+ * div == 0: i * lo -- e.g. row (r, t) of a (T, R, .) tensor), three layouts, optional split of K over
+ * workgroups with float atomics into a ZEROED Y (a long reduction behind few tiles; not deterministic):
+ *   form 0: Y = A B,    A (M x K) rows by arow(m), k contiguous;  B (K x N) rows by brow(k), N % 4 == 0
+ *   form 1: Y = A W^T,  A as above;                                W (N x K) rows by brow(n)
+ *   form 2: Y = A^T B,  A (K x M) rows by arow(k), M % 4 == 0;     B (K x N) rows by brow(k)
+ * Y rows by crow(m).  The teacher-forced decoder's classifier products (models/decoder_fused.py). */
+typedef struct s2c_sgemm_map { int div, hi, lo; } s2c_sgemm_map;
+typedef struct s2c_sgemm_args {
+  const float *A, *B, *bias;
+  float *Y;
+  long long M;
+  int N, K, form, ksplit;
+  s2c_sgemm_map arow, brow, crow;
+  int pad_;
+} s2c_sgemm_args;
+int s2c_small_gemm_ex(const s2c_sgemm_args *g, void *stream);
 
 #ifdef __cplusplus
 }

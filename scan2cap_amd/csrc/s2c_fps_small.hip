@@ -448,17 +448,9 @@ static int fps_small_launch(int b, int n, int m, const float *xyz, int *idx, int
   while ((1 << log2bs) < bs) ++log2bs;
   int T = threads;
   if (T == 0) {
-    const char *e = getenv("S2C_FPS_T");
-    if (e) T = atoi(e);
-  }
-  if (T == 0) {
-    // the four-wave kernel with 32-bit reductions up to 2048 points (S2C_FPS_QUAD=0: off)
-    static int quad = -1;
-    if (quad < 0) {
-      const char *q = getenv("S2C_FPS_QUAD");
-      quad = q ? atoi(q) : 1;
-    }
-    if (quad && n <= 2048 && m <= QUAD_MAX_M) {
+    // the four-wave kernel with 32-bit reductions up to 2048 points (an explicit `threads` selects
+    // the register-resident kernel: tests / tools)
+    if (n <= 2048 && m <= QUAD_MAX_M) {
       const int ppt = (n + 255) / 256;
       const bool prof = g_qprof_host;
 #define FPS_QUAD(P_)                                                                          \

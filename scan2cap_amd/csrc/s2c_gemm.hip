@@ -1152,25 +1152,13 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_c64_kernel(
   }
 }
 
-// S2C_GEMM_C64=0: the N > 64 problems stay on the 32-k-slice kernel
-static int g_c64 = -1;
-static bool c64_on() {
-  if (g_c64 < 0) {
-    const char *e = getenv("S2C_GEMM_C64");
-    g_c64 = e ? atoi(e) : 1;
-  }
-  return g_c64 != 0;
-}
+// s2c_gemm_set_c64(0): the N > 64 problems stay on the 32-k-slice kernel (A/B in the tests)
+static int g_c64 = 1;
+static bool c64_on() { return g_c64 != 0; }
 
-// S2C_GEMM_C64_NARROW=0 / s2c_gemm_set_c64_narrow(0): always 128 x 128 tiles
-static int g_c64_narrow = -1;
-static bool c64_narrow_on() {
-  if (g_c64_narrow < 0) {
-    const char *e = getenv("S2C_GEMM_C64_NARROW");
-    g_c64_narrow = e ? atoi(e) : 1;
-  }
-  return g_c64_narrow != 0;
-}
+// s2c_gemm_set_c64_narrow(0): always 128 x 128 tiles
+static int g_c64_narrow = 1;
+static bool c64_narrow_on() { return g_c64_narrow != 0; }
 
 template <int PRO>
 int launch_c64(long long M, int N, int K, const float *A, int lda, const float *W, int ldw,
@@ -1385,14 +1373,10 @@ extern "C" int s2c_sa_gather_gemm(int b, int n, int m, int ns, int C,
   ga.xyz = xyz; ga.new_xyz = new_xyz; ga.feats = feats; ga.idx = idx;
   ga.frs = feat_row_stride; ga.fbs = feat_batch_stride;
   ga.n = n; ga.m = m; ga.ns = ns; ga.radius = radius; ga.normalize = normalize;
-  // wide first layers (N > 64) up to S2C_GATHER_C64_ROWS rows (default 262144: SA2) run on the
+  // wide first layers (N > 64) up to 262144 rows (SA2) run on the
   // 64-k-chunk kernel, not the streaming one (its 4-wave N = 128 configuration keeps 32 KB in
   // flight per CU: 135 vs 122 us at SA2); 0 = the streaming kernel wherever it takes the shape
-  static long long c64_rows = -1;
-  if (c64_rows < 0) {
-    const char *e = getenv("S2C_GATHER_C64_ROWS");
-    c64_rows = e ? atoll(e) : 262144;
-  }
+  const long long c64_rows = 262144;
   if (use_split() && !(N > 64 && M <= c64_rows && c64_on())) {
     const int rc = s2c_sa_gather_stream_gemm(b, n, m, ns, C, feat_row_stride, feat_batch_stride,
                                              radius, normalize, xyz, new_xyz, feats, idx, N, W,
@@ -1468,7 +1452,7 @@ extern "C" int s2c_gemm_set_profile(long long *prof, int block) {
   return 0;
 }
 
-/* 1 (default; environment S2C_GEMM_C64): problems with N > 64 on rows_gemm_c64_kernel (K in
+/* 1 (default): problems with N > 64 on rows_gemm_c64_kernel (K in
  * 64-chunks of fp32 in LDS), 0: on the 32-k-slice kernel.  Returns the previous setting. */
 extern "C" int s2c_gemm_set_c64_narrow(int on) {
   const int old = c64_narrow_on() ? 1 : 0;

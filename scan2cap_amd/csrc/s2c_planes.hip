@@ -623,7 +623,7 @@ int pg_launch(const s2c_planes_gemm_args &a, hipStream_t st) {
   return pg_chk("planes_gemm");
 }
 
-int g_pg_big = -1;       // S2C_PLANES_BIG: -1 auto, 0 never, 1 always (where the operands allow)
+int g_pg_big = -1;       // s2c_planes_set_big: -1 auto, 0 never, 1 always (where the operands allow)
 
 }  // namespace
 
@@ -645,10 +645,7 @@ extern "C" int s2c_planes_gemm(const s2c_planes_gemm_args *a, void *stream) {
   const int nfirst = a->nsplit ? a->n1 : a->N;               // columns of the first output
   if (a->P != nullptr && ((a->ldp & 31) || a->ldp < nfirst)) return -1;
   if (a->tokkeys != nullptr && a->ntokkeys <= 0) return -1;
-  if (g_pg_big == -1) {
-    const char *e = getenv("S2C_PLANES_BIG");
-    g_pg_big = e ? atoi(e) + 2 : 1;                // 1 auto, 2 never, 3 always
-  }
+  if (g_pg_big == -1) g_pg_big = 1;                // 1 auto, 2 never, 3 always (s2c_planes_set_big)
   // 256 x 256 tiles where their grid still covers the chip (>= 192 workgroups); they read whole
   // 256-row / 256-column groups of blocks: the caller allocates operands to multiples of 256
   // (a->big_ok) -- models/greedy_fused.py does

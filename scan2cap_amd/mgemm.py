@@ -100,3 +100,56 @@ def launch(jobs):
             _C.TIMER.alg_flops = flops
         with torch.cuda.device(chunk[0].t[2].device):
             _C.call("s2c_mgemm", ctypes.byref(a), _C.stream_ptr())
+
+
+# ---- the decoder's three classifier products on the matrix cores (csrc/s2c_sgemm.hip) -----------------
+class _SgMap(ctypes.Structure):
+    """include/s2c_fused.h: s2c_sgemm_map"""
+    _fields_ = [("div", _I), ("hi", _I), ("lo", _I)]
+
+
+class _SgArgs(ctypes.Structure):
+    """include/s2c_fused.h: s2c_sgemm_args"""
+    _fields_ = [("A", _P), ("B", _P), ("bias", _P), ("Y", _P), ("M", ctypes.c_longlong), ("N", _I),
+                ("K", _I), ("form", _I), ("ksplit", _I), ("arow", _SgMap), ("brow", _SgMap),
+                ("crow", _SgMap), ("pad_", _I)]
+
+
+_C.register("s2c_small_gemm_ex", [_P, _P])
+NN, NT, TN = 0, 1, 2
+
+
+def mfma(form, M, N, K, A, arow, B, brow, Y, crow, bias=None, ksplit=1):
+    """Y = A B (NN) | A W^T (NT) | A^T B (TN) on s2c_small_gemm_ex (bf16x3 MFMA, fp32-accurate); the
+    row maps are ax(...) triples; A, B, Y: tensors whose data_ptr() is the origin.  ksplit > 1 adds
+    its k-ranges into a ZEROED Y with float atomics (not deterministic, like s2c_mgemm's ksplit).
+    Returns False when the layout is not taken (the caller keeps its s2c_mgemm job)."""
+    for t in (A, B, Y):
+        if not (t.is_cuda and t.dtype == torch.float32):
+            return False
+    if K < 4 or (form != NT and N % 4) or (form == TN and M % 4):
+        return False
+    if A.data_ptr() % (16 if form == TN else 4) or B.data_ptr() % (4 if form == NT else 16):
+        return False
+    if form == TN and (arow[1] % 4 or arow[2] % 4):
+        return False
+    if form != NT and (brow[1] % 4 or brow[2] % 4):
+        return False
+    lim = 2 ** 29
+    if (_reach(arow, K if form == TN else M) + (M if form == TN else K) >= lim
+            or _reach(brow, N if form == NT else K) + (K if form == NT else N) >= lim
+            or _reach(crow, M) + N >= lim):
+        return False
+    a = _SgArgs()
+    a.A, a.B, a.Y = A.data_ptr(), B.data_ptr(), Y.data_ptr()
+    a.bias = bias.data_ptr() if bias is not None else None
+    a.M, a.N, a.K, a.form, a.ksplit = M, N, K, form, int(ksplit)
+    for name, v in (("arow", arow), ("brow", brow), ("crow", crow)):
+        m = getattr(a, name)
+        m.div, m.hi, m.lo = v
+    if _C.TIMER.enabled:
+        _C.TIMER.alg_flops = 2.0 * M * N * K
+        _C.TIMER.alg_bytes = 4 * (M * K + K * N + M * N)
+    with torch.cuda.device(Y.device):
+        _C.call("s2c_small_gemm_ex", ctypes.byref(a), _C.stream_ptr())
+    return True

@@ -38,8 +38,8 @@ FUSE_EVAL_STEP = True
 
 
 # teacher-forced decoder with num_locals = L: attention over the L gathered objects instead of
-# all K with K - L of them masked (S2C_LOCAL_TRAIN_ATTN=0: the dense formulation)
-LOCAL_TRAIN_ATTENTION = _os.environ.get("S2C_LOCAL_TRAIN_ATTN", "1") != "0"
+# all K with K - L of them masked (= False: the dense formulation)
+LOCAL_TRAIN_ATTENTION = True
 
 
 _C.register("s2c_select_target", [_I, _I, _P, _P, _P, _P, _P])

@@ -91,24 +91,26 @@ LOCAL_ATTN_MAX_K = 0
 _C.register("s2c_attn_local_fwd", [_I, _I, _I, _I, _P, _P, _I, _P, ctypes.c_float, _P, _P, _P,
                                    _P, _I, _P])
 # few keys: scores + softmax + weighted sum + the map_lang layer in ONE launch (attn_x2_kernel:
-# 7 -> 5 dependent launches per forward step); S2C_FUSE_ATTN_X2=0: the three launches
+# 7 -> 5 dependent launches per forward step); = False: the three launches
 import os as _os
-FUSE_ATTN_X2 = _os.environ.get("S2C_FUSE_ATTN_X2", "1") != "0"
+FUSE_ATTN_X2 = True
 ATTN_X2_MAX_K = 32
 _C.register("s2c_attn_x2_fwd", [_I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P,
                                 _P, _I, _P, _I, _P])
 # ... and its backward mirror: the transposed map_lang product inside the attention backward
-# (6 -> 5 dependent launches per backward step); S2C_FUSE_ATTN_X2_BWD=0: the two launches
-FUSE_ATTN_X2_BWD = _os.environ.get("S2C_FUSE_ATTN_X2_BWD", "1") != "0"
+# (6 -> 5 dependent launches per backward step); = False: the two launches
+FUSE_ATTN_X2_BWD = True
 _C.register("s2c_attn_bwd_x2", [_I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P,
                                 _P, _I, _P, _P])
 
 
 # The hoisted products (in front of / behind the step loop, and every weight gradient) as a few
 # multi-job launches of csrc/s2c_mgemm.hip instead of ~26 library GEMM calls of 6-48 us each;
-# S2C_MGEMM=0: torch.mm / matmul / bmm (hipBLASLt), the reference formulation the tests compare with
+# = False: torch.mm / matmul / bmm (hipBLASLt), the reference formulation the tests compare with
 from .. import mgemm as _mg
-USE_MGEMM = _os.environ.get("S2C_MGEMM", "1") != "0"
+USE_MGEMM = True
+# the three classifier products of the teacher-forced decoder on s2c_small_gemm_ex (bf16x3 MFMA)
+MFMA_CLASSIFIER = True
 
 
 # The whole forward recurrence as ONE persistent kernel (csrc/s2c_decoder_persist.hip): 128
@@ -138,7 +140,7 @@ _C.register("s2c_decoder_bwd_persist", [_P, _P])
 
 
 _C.register("s2c_decoder_fwd_persist", [_P, _P])
-PERSIST_BACKOFF = int(_os.environ.get("S2C_PERSIST_BACKOFF", "0"))
+PERSIST_BACKOFF = 0
 PROF_BWD = None
 PROF = None     # tools/bench_decoder_persist.py: an int64 tensor (8 * T * 16) of phase stamps
 _XBUF = {}      # (device index, H, E) -> (exchange buffer, [nonce, started]); zeroed once
@@ -437,8 +439,13 @@ class TopDownDecode(Function):
                 H2n = None
                 V = W_cls.shape[0]
                 logits = torch.empty(R, T, V, device=dev)
-                _mg.launch([_mg.Job(R * T, V, H, H2[1:], _mg.ax(RH, div=T, hi=H), _mg.ax(1),
-                                    W_cls, _mg.ax(1), _mg.ax(H), logits, _mg.ax(V), bias=b_cls)])
+                # the classifier (R T x V x H) on the matrix cores (csrc/s2c_sgemm.hip); layouts it does
+                # not take stay on the VALU multi-GEMM
+                if not (MFMA_CLASSIFIER and _mg.mfma(_mg.NT, R * T, V, H, H2[1:],
+                                                     _mg.ax(RH, div=T, hi=H), W_cls, _mg.ax(H),
+                                                     logits, _mg.ax(V), bias=b_cls)):
+                    _mg.launch([_mg.Job(R * T, V, H, H2[1:], _mg.ax(RH, div=T, hi=H), _mg.ax(1),
+                                        W_cls, _mg.ax(1), _mg.ax(H), logits, _mg.ax(V), bias=b_cls)])
             else:
                 H2n = H2[1:].permute(1, 0, 2).contiguous()              # (R,T,H)
                 logits = torch.addmm(b_cls, H2n.view(R * T, H), W_cls.t()).view(R, T, -1)
@@ -470,10 +477,17 @@ class TopDownDecode(Function):
                 dW_cls = torch.empty(V, H, device=dev)
                 dH2 = torch.zeros(T, R, H, device=dev)          # k ranges add into it
                 h2rows = _mg.ax(RH, div=T, hi=H)                # index (r, t) -> H2[t + 1, r] / dH2[t, r]
-                pre_jobs = [_mg.Job(V, H, R * T, dl, _mg.ax(1), _mg.ax(V), H2[1:], h2rows, _mg.ax(1),
-                                    dW_cls, _mg.ax(H)),
-                            _mg.Job(R * T, H, V, dl, _mg.ax(V), _mg.ax(1), W_cls, _mg.ax(H), _mg.ax(1),
-                                    dH2, h2rows, ksplit=16)]
+                pre_jobs = []
+                # dW_cls = dl^T H2 (reduction over the R T rows) and dH2 = dl W_cls (reduction over V,
+                # split over 16 workgroups per tile) on the matrix cores where the layout allows
+                if not (MFMA_CLASSIFIER and _mg.mfma(_mg.TN, V, H, R * T, dl, _mg.ax(V), H2[1:], h2rows,
+                                                     dW_cls, _mg.ax(H))):
+                    pre_jobs.append(_mg.Job(V, H, R * T, dl, _mg.ax(1), _mg.ax(V), H2[1:], h2rows,
+                                            _mg.ax(1), dW_cls, _mg.ax(H)))
+                if not (MFMA_CLASSIFIER and _mg.mfma(_mg.NN, R * T, H, V, dl, _mg.ax(V), W_cls,
+                                                     _mg.ax(H), dH2, h2rows, ksplit=16)):
+                    pre_jobs.append(_mg.Job(R * T, H, V, dl, _mg.ax(V), _mg.ax(1), W_cls, _mg.ax(H),
+                                            _mg.ax(1), dH2, h2rows, ksplit=16))
             else:
                 if H2n is None:
                     H2n = H2[1:].permute(1, 0, 2).contiguous()

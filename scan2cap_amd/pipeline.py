@@ -186,8 +186,11 @@ class GeometrySlots(object):
             lib = _C.load()
             lib.s2c_gemm_set_stream_grid.argtypes = [_ctypes.c_int]
             cus = torch.cuda.get_device_properties(point_clouds.device).multi_processor_count
-            self._old_grid = lib.s2c_gemm_set_stream_grid(
-                max(cus // 4, cus - point_clouds.shape[0] * self.group - int(reserve_cus)))
+            grid = max(cus // 4, cus - point_clouds.shape[0] * self.group - int(reserve_cus))
+            self._old_grid = lib.s2c_gemm_set_stream_grid(grid)
+            # ... and so must the streaming weight-gradient kernel's (csrc/s2c_dwstream.hip)
+            lib.s2c_weight_grad_stream_set_grid.argtypes = [_ctypes.c_int]
+            self._old_dws_grid = lib.s2c_weight_grad_stream_set_grid(grid)
         geo0 = backbone.compute_geometry(point_clouds)
         self._slots = []
         for _ in range(self.depth):
@@ -202,7 +205,14 @@ class GeometrySlots(object):
         if self._old_grid:
             from . import _C
             _C.load().s2c_gemm_set_stream_grid(self._old_grid)
+            _C.load().s2c_weight_grad_stream_set_grid(self._old_dws_grid)
             self._old_grid = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def geometry(self, p):
         return unflatten_geometry(self._slots[p])

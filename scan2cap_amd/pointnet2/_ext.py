@@ -122,7 +122,7 @@ def furthest_point_sampling(points, nsamples, prefix_hint=False, return_fallback
 
 
 FPS_SMALL_THREADS = 0   # 0 = library heuristic (tests sweep 64..1024)
-FPS_PREFIX_VERIFY = os.environ.get("S2C_FPS_PREFIX", "1") != "0"   # honour prefix_hint
+FPS_PREFIX_VERIFY = True   # honour prefix_hint
 FPS_LARGE_IMPL = "cells"   # "cells" (s2c_fps_cells.hip) | "bucket" (s2c_fps_bucket.hip)
 FPS_CELLS_WAVES = 0        # rounds-kernel workgroup in waves: 4 / 8 / 16, 0 = library default
 

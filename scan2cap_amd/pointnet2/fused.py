@@ -93,16 +93,16 @@ USE_MFMA_GEMM = True
 # atomics at SA2 against 91 us of re-materialising + the split-K product; step 9.86 vs 9.84 ms.)
 SCATTER_DW = True
 # the first layer's dY (it has no input gradient to feed) formed inside the point-sum kernel
-# from (dA, Y) instead of written by the BN-backward pass and read back: S2C_FUSE_DY_SCATTER=0 = off
-FUSE_DY_SCATTER = _os.environ.get("S2C_FUSE_DY_SCATTER", "1") != "0"
+# from (dA, Y) instead of written by the BN-backward pass and read back: = False = off
+FUSE_DY_SCATTER = True
 
 
 # The first layer of a gather stack in POINT SPACE (csrc/s2c_sa.hip: sa_gather_add): the feature
 # product runs once per point (P = feats W_f^T), the gathered rows are P[idx] + W_x rel; the
 # backward sums dY per point first (Z, S) and multiplies afterwards -- weight AND input gradients
-# from B n point rows instead of B m ns gathered rows.  S2C_POINT_SPACE=0: the round-3 gather GEMM.
-POINT_SPACE = _os.environ.get("S2C_POINT_SPACE", "1") != "0"
-POINT_SPACE_BWD = _os.environ.get("S2C_POINT_SPACE_BWD", "1") != "0"
+# from B n point rows instead of B m ns gathered rows.  = False: the round-3 gather GEMM.
+POINT_SPACE = True
+POINT_SPACE_BWD = True
 # The per-point product P runs on the exact fp32 matrix instruction (csrc/s2c_pgemm.hip: an fp32 FMA
 # chain in k order, bit-identical to the tiled kernel's exact path), not on the bf16x3 split.  Both
 # are fp32-accurate (rms error against float64 6e-7 vs 5e-7 of |P| ~ 2 on the golden model's own
@@ -123,12 +123,12 @@ def _gather_add_blocks(M):
 # Backward of a BN(+ReLU) layer: statistics pass, then ONE kernel that forms dY in the operand
 # load of the input-gradient GEMM dX = dY W (s2c_bn_bwd_gemm) -- no apply pass, no library GEMM
 # the BN+ReLU pass between two layers folded into the next layer's streaming GEMM (the
-# activated operand leaves as a side output of csrc/s2c_gemm2.hip): S2C_FUSE_BNRELU_GEMM=0 = off
-FUSE_BNRELU_GEMM = _os.environ.get("S2C_FUSE_BNRELU_GEMM", "1") != "0"
-FUSE_BWD_GEMM = _os.environ.get("S2C_FUSE_BWD_GEMM", "1") != "0"
+# activated operand leaves as a side output of csrc/s2c_gemm2.hip): = False = off
+FUSE_BNRELU_GEMM = True
+FUSE_BWD_GEMM = True
 # forward of the layers that carry a bias (EdgeConv, the voting module's convs, the proposal head's
-# last conv) on the hand GEMM instead of torch.addmm (S2C_BIAS_BY_HAND=0: the library)
-BIAS_LAYERS_BY_HAND = _os.environ.get("S2C_BIAS_BY_HAND", "1") != "0"
+# last conv) on the hand GEMM instead of torch.addmm (= False: the library)
+BIAS_LAYERS_BY_HAND = True
 
 
 # Which hand-written kernel takes a backward product (measured on MI355X, tools/bench_bwd.py,
@@ -175,7 +175,7 @@ def _gemm_split_on():
 _C.register("s2c_small_gemm", [_L, _I, _I, _P, _L, _P, _L, _I, _P, _P, _L, _P])
 # the small products of the layer stacks (2048 .. 32768 rows) on csrc/s2c_sgemm.hip instead of
 # torch.mm / torch.addmm: dX = dY W reads W as stored (no transposed copy), y = x W^T + b
-SMALL_GEMM = _os.environ.get("S2C_SMALL_GEMM", "1") != "0"
+SMALL_GEMM = True
 
 
 def _small_gemm_ok(M, N, K, lda, ldb, transposed):
@@ -357,11 +357,11 @@ _C.register("s2c_rows_gemm_next_stats", [_L, _I, _I, _P, _I, _P, _I, _P, _P, _P,
 _C.register("s2c_bn_relu_bwd_apply", [_L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P])
 # the column sums of a layer's BatchNorm backward out of the epilogue of the GEMM that produces
 # its upstream gradient (s2c_bn_bwd_gemm_next_stats) instead of a statistics pass over (dA, Y);
-# S2C_BWD_STATS_IN_GEMM=0: the separate pass
-BWD_STATS_IN_GEMM = _os.environ.get("S2C_BWD_STATS_IN_GEMM", "1") != "0"
+# = False: the separate pass
+BWD_STATS_IN_GEMM = True
 # the extremum a pooled BatchNorm + ReLU layer will select out of the GEMM's epilogue also when Y
-# is materialised (wide layers, 64-k-chunk kernel); S2C_POOL_EXT_IN_GEMM=0: s2c_bn_relu_max over Y
-POOL_EXT_IN_GEMM = _os.environ.get("S2C_POOL_EXT_IN_GEMM", "1") != "0"
+# is materialised (wide layers, 64-k-chunk kernel); = False: s2c_bn_relu_max over Y
+POOL_EXT_IN_GEMM = True
 _C.register("s2c_bn_relu_max_bwd_stats", [_L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P])
 _C.register("s2c_pool_bwd_dk", [_L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_pool_bwd_sp", [_L, _I, _I, _I, _P, _P, _P, _P, _P])
@@ -371,8 +371,8 @@ _C.register("s2c_pool_bwd_input_grad", [_L, _I, _I, _I, _I, _P, _I, _P, _P, _P, 
 
 # The pooled LAST layer of a training stack without its (M x C3) pre-activation / gradient
 # tensors (DESIGN 4.3 "pooled layer algebra"): forward = raw extrema out of the GEMM epilogue,
-# backward = input / weight gradients from the layer's INPUT activation.  S2C_POOL_ALGEBRA=0: off.
-POOL_ALGEBRA = _os.environ.get("S2C_POOL_ALGEBRA", "1") != "0"
+# backward = input / weight gradients from the layer's INPUT activation.  = False: off.
+POOL_ALGEBRA = True
 
 
 def _pool_bwd_takes(M, N, KA, C3):
@@ -1059,8 +1059,8 @@ class _EvalLayer(ctypes.Structure):
 _C.register("s2c_sa_fused_eval", [_I, _I, _I, _I, _I, _L, _L, ctypes.c_float, _I, _P, _P, _P, _P, _P,
                                   _P, _I, _P])
 # the whole inference stage (gather -> 3 layers -> max) in ONE kernel where its weights fit LDS
-# (csrc/s2c_sa_fused.hip: SA1 with few input channels); S2C_FUSE_EVAL_STAGE=0: per-layer kernels
-FUSE_EVAL_STAGE = _os.environ.get("S2C_FUSE_EVAL_STAGE", "1") != "0"
+# (csrc/s2c_sa_fused.hip: SA1 with few input channels); = False: per-layer kernels
+FUSE_EVAL_STAGE = True
 
 
 def _eval_stage_fused(gather, M, dev, specs, pool_ns, params):
@@ -1101,9 +1101,9 @@ def _eval_stage_fused(gather, M, dev, specs, pool_ns, params):
     return out if rc == 0 else None
 
 
-# inference: the first layer of a gather stack in point space too (S2C_EVAL_POINT_SPACE=0: the
+# inference: the first layer of a gather stack in point space too (= False: the
 # gather-fused GEMM of rounds 1-4)
-EVAL_POINT_SPACE = _os.environ.get("S2C_EVAL_POINT_SPACE", "1") != "0"
+EVAL_POINT_SPACE = True
 _C.register("s2c_sa_gather_add_eval", [_I, _I, _I, _I, _I, ctypes.c_float, _I, _P, _P, _P, _P, _P, _I,
                                        _P, _P, _P, _P, ctypes.c_float, _I, _P, _P])
 
@@ -1225,8 +1225,8 @@ class _DwJobs(ctypes.Structure):
 
 _C.register("s2c_weight_grad_multi", [_P, _P])
 # the slab weight gradients of a layer stack (17 us launches that fill a fraction of the chip each) in
-# ONE multi-job launch at the stack's flush_partial_sums (S2C_DW_MULTI=0: one launch per layer)
-DW_MULTI = _os.environ.get("S2C_DW_MULTI", "1") != "0"
+# ONE multi-job launch at the stack's flush_partial_sums (= False: one launch per layer)
+DW_MULTI = True
 
 
 class _DeferredDw(object):
@@ -1370,7 +1370,7 @@ def row_sums(mats):
 _C.register("s2c_weight_grad_stream", [_L, _I, _I, _P, _L, _P, _L, _P, _P])
 # tall weight gradients on the streaming kernel (csrc/s2c_dwstream.hip): LDS-DMA ring, column reads
 # of the row-major chunks as the transposed MFMA operand, one partial tile per workgroup
-DW_STREAM = _os.environ.get("S2C_DW_STREAM", "1") != "0"
+DW_STREAM = True
 DW_STREAM_MIN_ROWS = 32768
 
 

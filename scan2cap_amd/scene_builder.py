@@ -259,7 +259,7 @@ class SceneBatchBuilder(object):
         self.class_of = torch.from_numpy(CLASS_OF_NYU40).to(dev)
         self._staging = {}
         import os
-        self.ring_slots = int(os.environ.get("S2C_FEED_RING", "3"))
+        self.ring_slots = 3
 
     # ---- host: the random numbers, in the reference's order ------------------------
     def draw(self, scene_ids, rng=np.random, device_choices=False):

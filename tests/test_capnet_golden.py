@@ -40,9 +40,12 @@ TOL_DEFAULT = 1e-4
 # reference's train step evaluated in float64 (`truth/<key>`, tests/gen_golden.py: truth64 -- same
 # weights, same discrete geometry decisions, same forced vote sampling).  The float32 reference is
 # itself only an approximation of that truth, off by err_ref(key); the HIP path, another float32
-# evaluation of the same mathematics, must land within K_TRUTH x err_ref(key) (or 1e-4) of the truth.
-# This replaces "how far may a correct implementation be from the reference" (a model: the
-# sensitivity probe above) by "how far is the reference from the right answer" (a measurement).
+# evaluation of the same mathematics, must land within K_TRUTH x max(err_ref(key), sens(key)) (or 1e-4)
+# of the truth: the reference's ONE evaluation can sit closer to the truth than float32 guarantees
+# (cfg1 `vgen.conv3.weight`: 1e-5 where the one-ulp probe moves it by 3e-4), and another summation
+# order of the same kernels -- e.g. another persistent-grid size, which re-orders the BatchNorm
+# partial sums -- lands 2e-4 away; so the measured conditioning is the floor of the bound, and the
+# measured reference error widens it where the reference itself is far off (c132: 2.1e-2).
 K_TRUTH = 3.0
 
 
@@ -95,7 +98,7 @@ class Report(object):
         g = got.detach().cpu().numpy().astype(np.float64).reshape(t.shape)
         e_hip = float(np.abs(g - t).max()) / scale
         e_ref = float(np.abs(np.asarray(ref32, np.float64).reshape(t.shape) - t).max()) / scale
-        bound = max(TOL_DEFAULT, K_TRUTH * e_ref)
+        bound = max(TOL_DEFAULT, K_TRUTH * max(e_ref, self.sens.get(key, 0.0)))
         self.rows.setdefault(key, {}).update({"err_vs_truth": e_hip, "ref_vs_truth": e_ref,
                                               "truth_bound": bound})
         if not e_hip <= bound:

@@ -61,3 +61,41 @@ def test_unsupported_layouts_are_declined():
     assert fused.small_gemm(A, torch.randn(64, 130, device="cuda"), False) is None      # N % 4
     assert fused.small_gemm(A, torch.randn(130, 64, device="cuda"), True) is not None   # any N in the W^T form
     assert fused.small_gemm(A[:, :2], torch.randn(2, 64, device="cuda"), False) is None  # K < 4
+
+
+@pytest.mark.parametrize("R,T,V,H", [(8, 30, 3500, 512), (8, 13, 200, 128), (3, 7, 60, 64), (16, 30, 3500, 512)])
+def test_classifier_products_with_row_maps(R, T, V, H):
+    """The teacher-forced decoder's three classifier products on s2c_small_gemm_ex: rows (r, t) of the
+    logits read H2[t + 1, r] in place (NT, two-level row map), dW_cls = dl^T H2 (TN: reduction over the
+    R T rows), dH2[t, r] = dl W_cls (NN, K = V split over workgroups with float atomics)."""
+    from scan2cap_amd import mgemm as mg
+    torch.manual_seed(R + T + V)
+    H2 = torch.randn(T + 1, R, H, device="cuda")
+    W = torch.randn(V, H, device="cuda") * 0.1
+    b = torch.randn(V, device="cuda")
+    RH = R * H
+    rows = mg.ax(RH, div=T, hi=H)
+    logits = torch.empty(R, T, V, device="cuda")
+    assert mg.mfma(mg.NT, R * T, V, H, H2[1:], rows, W, mg.ax(H), logits, mg.ax(V), bias=b)
+    H2n = H2[1:].permute(1, 0, 2).contiguous().view(R * T, H)
+    want = H2n.double() @ W.double().t() + b.double()
+    assert ((logits.view(R * T, V).double() - want).abs().max() / want.abs().max()).item() < 2e-6
+    dl = torch.randn(R * T, V, device="cuda")
+    dW = torch.empty(V, H, device="cuda")
+    assert mg.mfma(mg.TN, V, H, R * T, dl, mg.ax(V), H2[1:], rows, dW, mg.ax(H))
+    want = dl.double().t() @ H2n.double()
+    assert ((dW.double() - want).abs().max() / want.abs().max()).item() < 2e-6
+    dH2 = torch.zeros(T, R, H, device="cuda")
+    assert mg.mfma(mg.NN, R * T, H, V, dl, mg.ax(V), W, mg.ax(H), dH2, rows, ksplit=16)
+    want = (dl.double() @ W.double()).view(R, T, H).permute(1, 0, 2)
+    assert ((dH2.double() - want).abs().max() / want.abs().max()).item() < 2e-6
+
+
+def test_ex_declines_what_it_cannot_address():
+    from scan2cap_amd import mgemm as mg
+    A = torch.randn(30, 62, device="cuda")            # V = 62: not a multiple of 4
+    B = torch.randn(30, 64, device="cuda")
+    Y = torch.empty(62, 64, device="cuda")
+    assert not mg.mfma(mg.TN, 62, 64, 30, A, mg.ax(62), B, mg.ax(64), Y, mg.ax(64))
+    assert not mg.mfma(mg.NN, 30, 62, 64, B, mg.ax(64), torch.randn(64, 62, device="cuda"), mg.ax(62),
+                       torch.empty(30, 62, device="cuda"), mg.ax(62))
