@@ -234,8 +234,11 @@ def build_model(wl, vocabulary, embeddings, msa):
                   num_locals=wl.get("num_locals", 10) if cap else -1,
                   no_caption=not cap, use_topdown=True,
                   query_mode="corner", graph_mode="edge_conv",
-                  num_graph_steps=2 if cap else 0,
-                  use_relation=cap)
+                  # --num-locals -1 = the reference's DEFAULT command line (scripts/train.py:318-323:
+                  # no --use_relation, --num_graph_steps 0): its relational graph takes a positive
+                  # num_locals only (graph_module.py:216: torch.topk(pc_dist, self.num_locals))
+                  num_graph_steps=2 if cap and wl.get("num_locals", 10) > 0 else 0,
+                  use_relation=cap and wl.get("num_locals", 10) > 0)
 
 
 def make_feeder(wl, dd, depth, msa, device, num_scenes, rank, stream=None):
@@ -683,7 +686,9 @@ def main():
 
     wl = dict(WORKLOADS[args.workload])
     if args.num_locals != 0 and args.num_locals != 10:
-        wl["desc"] += " [--num-locals %d: not the BASELINE configuration]" % args.num_locals
+        wl["desc"] += " [--num-locals %d%s: not the BASELINE configuration]" % (
+            args.num_locals, ", no relational graph (the reference's default command)"
+            if args.num_locals < 0 else "")
         wl["num_locals"] = args.num_locals
     if args.batch > 0 and args.batch != wl["B"]:
         wl["desc"] = wl["desc"].replace("B=%d" % wl["B"], "B=%d" % args.batch) + \

@@ -484,6 +484,17 @@ int s2c_attn_local_fwd_planes(int R, int L, int H, int F, const float *mapped, c
                               unsigned short *planes, long long pstride, int ldp, int tiled,
                               void *stream);
 
+/* Scene-shared attention of the greedy decoder with num_locals = -1 (the reference's default command line;
+ * caption_module.py:270-285 with valid_prop_masks = object_masks, :536): R = B * rows_per_scene query rows,
+ * row r of scene b attends over that scene's K keys.  M (B K, H) = map_feat of the scene's objects,
+ * valid (B, K) 0/1 or NULL, O (B K, F), q (R, H; row stride ldq), wa (H), ba:
+ * alpha (R, K) = softmax_j(wa . tanh(M[b, j] + q[r]) + ba), att (R, F; may be NULL) = sum_j alpha O,
+ * optionally also as bf16x3 planes (as s2c_attn_local_fwd_planes).  K <= 512.  Forward only. */
+int s2c_attn_scene_fwd(int R, int rows_per_scene, int K, int H, int F, const float *M,
+                       const float *valid, const float *O, const float *q, int ldq, const float *wa,
+                       float ba, float *alpha, float *att, int lda, unsigned short *planes,
+                       long long pstride, int ldp, int tiled, void *stream);
+
 /* ---------------------------------------------------------------------------
  * Detection loss of get_scene_cap_loss (lib/loss_helper.py:24-187, :381-491;
  * utils/nn_distance.py:13-59) as 2 forward + 1 backward launches.

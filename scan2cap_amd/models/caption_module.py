@@ -437,6 +437,20 @@ class TopDownSceneCaptionModule(nn.Module):
             valid = object_masks.unsqueeze(1).expand(B, K, K)
         else:
             valid = self._query_locals(data_dict, all_ids, object_masks)   # (B,K,K)
+        if (self.num_locals == -1 and not self.use_relation and FUSE_EVAL_STEP
+                and dev.type == "cuda" and not torch.is_grad_enabled()
+                and greedy_fused.supported(self, K, dense=True)):
+            # the reference's default command line: every proposal attends over ALL proposals of its
+            # scene -- the keys are the scene's objects, shared by its K rows: map_feat once per scene
+            # ((B K, H), not (R, K, H)), one scene-shared attention launch per token
+            # (csrc/s2c_attn_scene.hip), every product on the planes GEMMs (greedy_fused.py)
+            T = max_len - 1
+            cap_buf, alpha = greedy_fused.decode(self, word_embs[:, 0], K, obj_feats.reshape(R, F_),
+                                                 obj_feats, T, scene_valid=object_masks)
+            data_dict["lang_cap"] = cap_buf.view(T, B, K, -1).permute(1, 2, 0, 3)      # (B,K,T,V)
+            data_dict["topdown_attn"] = alpha.view(T, B, K, K).permute(1, 2, 3, 0)    # (B,K,K,T)
+            data_dict["valid_masks"] = valid
+            return data_dict
         if self.use_relation:
             row_feats = self._add_relation_feat(data_dict, obj_feats, all_ids)
         else:

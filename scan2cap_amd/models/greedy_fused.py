@@ -41,6 +41,8 @@ class _GemmArgs(ctypes.Structure):
 
 _C.register("s2c_planes_gemm", [_P, _P])
 _C.register("s2c_planes_split", [_LL, _I, _P, _LL, _LL, _I, _P, _LL, _I, _P])
+_C.register("s2c_attn_scene_fwd", [_I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, ctypes.c_float, _P, _P, _I,
+                                   _P, _LL, _I, _I, _P])
 _C.register("s2c_attn_local_fwd_planes", [_I, _I, _I, _I, _P, _P, _I, _P, ctypes.c_float, _P, _P,
                                           _P, _P, _I, _P, _LL, _I, _I, _P])
 
@@ -180,8 +182,9 @@ def pack_gru(cell, Ep):
     return split(W.contiguous(), rows_out=4 * H), bias
 
 
-def supported(mod, L):
-    return (mod.hidden_size % 32 == 0 and mod.feat_size % 4 == 0 and L <= 32
+def supported(mod, L, dense=False):
+    """L: attended objects per row (num_locals), or -- dense -- the K objects of a scene."""
+    return (mod.hidden_size % 32 == 0 and mod.feat_size % 4 == 0 and L <= (512 if dense else 32)
             and mod.attend.bias is None and mod.map_topdown[0].bias is not None)
 
 
@@ -225,12 +228,21 @@ def _weights(mod):
     return w
 
 
-def decode(mod, sos, rows_per_scene, target_feats, local, T):
+def decode(mod, sos, rows_per_scene, target_feats, local, T, scene_valid=None):
     """sos (B,E): the first input word of every scene (lang_feat[:, 0]); target_feats (R,F);
     local (R,L,F): the attended objects of every row (relation features added).
-    Returns logits (T,R,V) step-major and alpha (T,R,L)."""
+    Returns logits (T,R,V) step-major and alpha (T,R,L).
+    scene_valid (B,K) float 0/1: num_locals = -1 -- every row attends over ALL K objects of its
+    scene; `local` is then the scene's objects (B,K,F) themselves, shared by the scene's rows
+    (s2c_attn_scene_fwd), and alpha is (T,R,K)."""
     dev = local.device
-    R, L, F_ = local.shape
+    dense = scene_valid is not None
+    if dense:
+        Bs, L, F_ = local.shape
+        R = target_feats.shape[0]
+        assert R == Bs * rows_per_scene
+    else:
+        R, L, F_ = local.shape
     E, H, V = mod.emb_size, mod.hidden_size, mod.num_vocabs
     with torch.cuda.device(dev):
         w = _weights(mod)
@@ -242,9 +254,12 @@ def decode(mod, sos, rows_per_scene, target_feats, local, T):
         P_tf = torch.empty(R, E, device=dev)
         gemm(R, E, [(tf_p, Fp // 32)], w["Wtf"], bias=w["b_td"], C=P_tf)
         local_c = local.contiguous()
-        loc_p = split(local_c.view(R * L, F_), ld=Fp)
-        mapped = torch.empty(R * L, H, device=dev)
-        gemm(R * L, H, [(loc_p, Fp // 32)], w["Wm"], C=mapped)
+        NL = local_c.shape[0] * L                       # mapped rows: R L, or B K (scene-shared keys)
+        loc_p = split(local_c.view(NL, F_), ld=Fp)
+        mapped = torch.empty(NL, H, device=dev)
+        gemm(NL, H, [(loc_p, Fp // 32)], w["Wm"], C=mapped)
+        if dense:
+            valid_c = scene_valid.to(torch.float32).contiguous()
         h1 = torch.zeros(2, R, H, device=dev)
         h2 = torch.zeros(2, R, H, device=dev)
         h1p = [Planes(R, H, dev, zero=True), Planes(R, H, dev)]
@@ -267,11 +282,19 @@ def decode(mod, sos, rows_per_scene, target_feats, local, T):
             gemm(R, H, [(x1p, Ep // 32), (h1p[cur], H // 32)], w["Wg1"], bias=w["bg1"], gru=True,
                  hprev=h1[cur], C=h1[nxt], P=h1p[nxt])
             gemm(R, HS + E, [(h1p[nxt], H // 32)], w["Wq2"], C=qh, split=(HS, H, l1))
-            if _C.TIMER.enabled:      # one pass over mapped + local features
-                _C.TIMER.alg_bytes = 4 * (R * L * (H + F_ + 1) + R * (H + F_))
-            _C.call("s2c_attn_local_fwd_planes", R, L, H, F_, mapped.data_ptr(), qh.data_ptr(), H,
-                    w["wa"].data_ptr(), 0.0, None, local_c.data_ptr(), alpha[t].data_ptr(), None,
-                    F_, attp.ptr(), attp.pstride, Fp, int(attp.tiled), st)
+            if dense:
+                if _C.TIMER.enabled:  # the scene's keys once per row block + the rows' q, alpha, att
+                    _C.TIMER.alg_bytes = 4 * (NL * (H + F_) + R * (H + L + F_))
+                _C.call("s2c_attn_scene_fwd", R, rows_per_scene, L, H, F_, mapped.data_ptr(),
+                        valid_c.data_ptr(), local_c.data_ptr(), qh.data_ptr(), H, w["wa"].data_ptr(),
+                        0.0, alpha[t].data_ptr(), None, F_, attp.ptr(), attp.pstride, Fp,
+                        int(attp.tiled), st)
+            else:
+                if _C.TIMER.enabled:      # one pass over mapped + local features
+                    _C.TIMER.alg_bytes = 4 * (R * L * (H + F_ + 1) + R * (H + F_))
+                _C.call("s2c_attn_local_fwd_planes", R, L, H, F_, mapped.data_ptr(), qh.data_ptr(), H,
+                        w["wa"].data_ptr(), 0.0, None, local_c.data_ptr(), alpha[t].data_ptr(), None,
+                        F_, attp.ptr(), attp.pstride, Fp, int(attp.tiled), st)
             gemm(R, E, [(attp, Fp // 32)], w["W5a"], bias=w["b_lang"], add=l1, relu=True, P=x2p)
             gemm(R, H, [(x2p, Ep // 32), (h2p[cur], H // 32)], w["Wg2"], bias=w["bg2"], gru=True,
                  hprev=h2[cur], C=h2[nxt], P=h2p[nxt])

@@ -575,6 +575,47 @@ def test_eval_greedy_decode_fused_step_matches_step_loop():
     assert _rel(p1["lang_cap"], p0["lang_cap"]) > 1e-3                  # the weights did change
 
 
+def test_eval_greedy_decode_all_proposals_matches_step_loop():
+    """num_locals = -1 without the relational graph (the reference's default command line): the
+    scene-shared attention + planes GEMMs (caption_module._forward_scene_batch_dense -> greedy_fused)
+    against the module's `_step` loop -- same tokens, logits and attention maps within 1e-4."""
+    from scan2cap_amd.models import caption_module as cm
+    from scan2cap_amd.box_util import get_3d_box_batch
+    torch.manual_seed(7)
+    V, B, K = 60, 2, 40
+    words = ["w%d" % i for i in range(V)]
+    vocab = {"word2idx": {w: i for i, w in enumerate(words)},
+             "idx2word": {str(i): w for i, w in enumerate(words)}}
+    emb = {w: np.random.randn(300).astype(np.float32) for w in words}
+    mod = cm.TopDownSceneCaptionModule(vocab, emb, 300, 128, 512, K, num_locals=-1).cuda().eval()
+    assert not mod.use_relation
+    g = torch.Generator().manual_seed(3)
+    center = torch.rand(B, K, 3, generator=g, dtype=torch.float64) * 6 - 3
+    size = torch.rand(B, K, 3, generator=g, dtype=torch.float64) * 0.8 + 0.2
+    dd = {
+        "bbox_corner": get_3d_box_batch(size, torch.zeros(B, K, dtype=torch.float64), center).cuda(),
+        "bbox_mask": (torch.rand(B, K, generator=g) < 0.8).long().cuda(),
+        "bbox_feature": (torch.randn(B, K, 128, generator=g) * 0.5).cuda(),
+        "lang_feat": (torch.randn(B, 32, 300, generator=g) * 0.3).cuda(),
+    }
+    outs = {}
+    old = cm.FUSE_EVAL_STEP
+    try:
+        for flag in (False, True):
+            cm.FUSE_EVAL_STEP = flag
+            with torch.no_grad():
+                outs[flag] = mod(dict(dd), use_tf=False, is_eval=True, max_len=8)
+    finally:
+        cm.FUSE_EVAL_STEP = old
+    p_, b = outs[True], outs[False]
+    assert p_["lang_cap"].shape == b["lang_cap"].shape == (B, K, 7, V)
+    assert p_["topdown_attn"].shape == b["topdown_attn"].shape == (B, K, K, 7)
+    assert torch.equal(p_["lang_cap"].argmax(-1), b["lang_cap"].argmax(-1))
+    assert _rel(p_["lang_cap"], b["lang_cap"]) < 1e-4
+    assert _rel(p_["topdown_attn"], b["topdown_attn"]) < 1e-4
+    assert torch.equal(p_["valid_masks"], b["valid_masks"])
+
+
 def test_device_prefetcher_delivers_identical_batches():
     """scan2cap_amd/data_pipeline.py: pinned staging + copy stream; values, order and the
     pass-through of non-tensor entries (solver.py:280-287 moves the same keys)."""

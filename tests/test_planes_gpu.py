@@ -178,3 +178,38 @@ def test_planes_gemm_two_outputs_side_by_side(tile):
     k = keys.cpu().numpy().astype(np.uint64)
     col = (np.uint64(0xFFFFFFFF) - (k & np.uint64(0xFFFFFFFF))).astype(np.int64)
     assert np.array_equal(col[np.arange(M), k.argmax(1)], C.cpu().numpy().argmax(1))
+
+
+@pytest.mark.parametrize("B,rps,K,H,F", [(2, 48, 48, 512, 128), (3, 13, 300, 256, 64), (16, 512, 512, 512, 128),
+                                         (1, 7, 5, 64, 12)])
+def test_scene_shared_attention_matches_float64(B, rps, K, H, F):
+    """s2c_attn_scene_fwd (num_locals = -1: every row attends over all K objects of its scene)
+    against the module's formulation in float64: scores, masked softmax, weighted sum; the bf16x3
+    planes of the attended vector re-assemble to it."""
+    import ctypes
+    from scan2cap_amd import _C
+    from scan2cap_amd.models import greedy_fused as gf
+    torch.manual_seed(B + K + H)
+    R = B * rps
+    M = torch.randn(B * K, H, device="cuda") * 0.7
+    O = torch.randn(B * K, F, device="cuda")
+    q = torch.randn(R, H, device="cuda") * 0.7
+    wa = torch.randn(H, device="cuda") * 0.2
+    valid = (torch.rand(B, K, device="cuda") < 0.8).float()
+    valid[0] = 0 if B > 1 else valid[0]            # a scene without a single valid object: uniform weights
+    alpha = torch.empty(R, K, device="cuda")
+    att = torch.empty(R, F, device="cuda")
+    Fp = (F + 31) // 32 * 32
+    attp = gf.Planes(R, Fp, "cuda", zero=True)
+    _C.call("s2c_attn_scene_fwd", R, rps, K, H, F, M.data_ptr(), valid.data_ptr(), O.data_ptr(),
+            q.data_ptr(), H, wa.data_ptr(), 0.0, alpha.data_ptr(), att.data_ptr(), F, attp.ptr(),
+            attp.pstride, Fp, int(attp.tiled), _C.stream_ptr())
+    Md, Od, qd = M.double().view(B, 1, K, H), O.double().view(B, K, F), q.double().view(B, rps, 1, H)
+    s = (torch.tanh(Md + qd) * wa.double()).sum(-1)                       # (B, rps, K)
+    s = s.masked_fill(valid.view(B, 1, K) == 0, -1e30)
+    a = torch.softmax(s, -1)
+    want = a @ Od                                                            # (B, rps, F)
+    assert (alpha.double().view(B, rps, K) - a).abs().max() < 2e-6
+    assert ((att.double().view(B, rps, F) - want).abs().max() / want.abs().max()) < 2e-6
+    planes = attp.dense().float().sum(0)[:, :F]
+    assert (planes - att).abs().max() < 2e-6 * max(1.0, att.abs().max().item())
