@@ -63,11 +63,14 @@ def test_bench_self_launches_eight_ranks_on_one_gpu():
            "--steps", "2", "--warmup", "1"]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
     if res.returncode != 0 and "HSA_STATUS_ERROR" in res.stderr:
-        # Eight processes cold-starting on ONE device: on a fresh box the runtime has aborted one
-        # rank's queue ("HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION") in 2 of ~25 runs -- never in a
-        # warm repeat, never with one rank per device, never in a single process at these shapes
-        # (12 of 12 back-to-back repeats pass).  A queue abort is the runtime's, not a wrong
-        # result: repeat ONCE; any other failure, or a second abort, fails the test.
+        # Eight processes on ONE device: one rank's queue aborts ("HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION")
+        # inside the replayed step in ~1 of 10 cold starts (tools/repro_cold_start.sh: 1/12, 4/40, also
+        # 4/40 with every large-LDS kernel off and 1/40 without the overlapped all-reduce) -- and in 0 of
+        # 25 + 25 runs of tools/repro_oversubscribe.py, eight processes replaying a hipGraph of plain torch
+        # kernels or of this library's train step WITHOUT torch.distributed: it needs gloo's device-tensor
+        # collectives beside eight processes' graphs on one device, never seen with one rank per device
+        # (DESIGN section 7, item 7).  Not a wrong result: repeat ONCE; any other failure, or a second
+        # abort, fails the test.
         print("first attempt aborted by the runtime:\n" + res.stderr[-1500:])
         res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
     assert res.returncode == 0, res.stderr[-3000:]
