@@ -13,7 +13,8 @@
 // A workgroup = 4 waves x RW rows of one scene.  lane <-> key (64 keys per pass), the hidden index
 // runs inside the lane: no cross-lane reduction per score.  M tiles (64 keys x 64 h) are staged in LDS
 // and shared by the workgroup's rows (the 16 workgroups of a scene re-read them from L2); q and wa
-// are LDS broadcasts.  The kernel is bound by the transcendental rate (2 per element), not by memory.
+// are LDS broadcasts.  The kernel is bound by the transcendental rate, not by memory: the tiles are
+// staged as 2^{c m} and 2^{c q}, so an element costs one reciprocal (see the scores loop).
 // att leaves as fp32 and / or as the bf16x3 planes s2c_planes_gemm consumes (models/greedy_fused.py).
 #include "s2c_common.h"
 #include "../../include/s2c_fused.h"
@@ -59,20 +60,30 @@ __global__ __launch_bounds__(256) void attn_scene_kernel(AsArgs a) {
   const int nrow = a.rps - r0 < RB ? a.rps - r0 : RB;
 
   // ---- scores ---------------------------------------------------------------------------------
+  // tanh(m + q) = 1 - 2 / (e^{2m} e^{2q} + 1): the tiles are staged as E_m = 2^{c m}, E_q = 2^{c q}
+  // (c = 2 log2 e), so an element costs ONE transcendental (the reciprocal) instead of two -- the
+  // kernel is bound by their quarter rate.  Exact as long as neither factor over- or underflows:
+  // a tile with |m| or |q| > 20 (2^{+-58}: the product stays finite, and beyond |x| = 10 tanh is
+  // +-1 in fp32 anyway) is re-staged raw and takes the two-transcendental formula instead.
+  constexpr float C2 = 2.8853900817779268f;
   for (int kb = 0; kb < K; kb += 64) {
     float acc[RW];
 #pragma unroll
     for (int i = 0; i < RW; ++i) acc[i] = 0.f;
     for (int hc = 0; hc < H; hc += 64) {
       __syncthreads();
-      // M tile: 64 keys x 64 h (16 float4 per key): thread -> (key = tid / 4 + 0.., quads)
+      bool big = false;
+      // M tile: 64 keys x 64 h (16 float4 per key): thread -> (key = e / 16, quad = e % 16)
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
-        const int e = tid + 256 * p;               // float4 index: key = e / 16, quad = e % 16
+        const int e = tid + 256 * p;
         const int key = e >> 4, qd = e & 15;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (kb + key < K && hc + 4 * qd < H)
           v = *reinterpret_cast<const float4 *>(Mb + (size_t)(kb + key) * H + hc + 4 * qd);
+        big |= !(fabsf(v.x) <= 20.f && fabsf(v.y) <= 20.f && fabsf(v.z) <= 20.f && fabsf(v.w) <= 20.f);
+        v.x = __builtin_amdgcn_exp2f(v.x * C2); v.y = __builtin_amdgcn_exp2f(v.y * C2);
+        v.z = __builtin_amdgcn_exp2f(v.z * C2); v.w = __builtin_amdgcn_exp2f(v.w * C2);
         *reinterpret_cast<float4 *>(sM + key * AS_LD + 4 * qd) = v;
       }
       for (int e = tid; e < RB * 16; e += 256) {
@@ -80,6 +91,9 @@ __global__ __launch_bounds__(256) void attn_scene_kernel(AsArgs a) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (rr < nrow && hc + 4 * qd < H)
           v = *reinterpret_cast<const float4 *>(a.q + (size_t)(row_base + rr) * a.ldq + hc + 4 * qd);
+        big |= !(fabsf(v.x) <= 20.f && fabsf(v.y) <= 20.f && fabsf(v.z) <= 20.f && fabsf(v.w) <= 20.f);
+        v.x = __builtin_amdgcn_exp2f(v.x * C2); v.y = __builtin_amdgcn_exp2f(v.y * C2);
+        v.z = __builtin_amdgcn_exp2f(v.z * C2); v.w = __builtin_amdgcn_exp2f(v.w * C2);
         *reinterpret_cast<float4 *>(&sQ[rr][4 * qd]) = v;
       }
       if (tid < 16) {
@@ -87,17 +101,52 @@ __global__ __launch_bounds__(256) void attn_scene_kernel(AsArgs a) {
         if (hc + 4 * tid < H) v = *reinterpret_cast<const float4 *>(a.wa + hc + 4 * tid);
         *reinterpret_cast<float4 *>(&sW[4 * tid]) = v;
       }
-      __syncthreads();
+      big = __syncthreads_or(big ? 1 : 0) != 0;
       const float *mrow = sM + lane * AS_LD;
+      if (!big) {
 #pragma unroll 4
-      for (int h = 0; h < 64; h += 4) {
-        const float4 m = *reinterpret_cast<const float4 *>(mrow + h);
-        const float4 w = *reinterpret_cast<const float4 *>(&sW[h]);
+        for (int h = 0; h < 64; h += 4) {
+          const float4 m = *reinterpret_cast<const float4 *>(mrow + h);
+          const float4 w = *reinterpret_cast<const float4 *>(&sW[h]);
 #pragma unroll
-        for (int i = 0; i < RW; ++i) {
-          const float4 qq = *reinterpret_cast<const float4 *>(&sQ[wave * RW + i][h]);
-          acc[i] += w.x * as_tanh(m.x + qq.x) + w.y * as_tanh(m.y + qq.y) +
-                    w.z * as_tanh(m.z + qq.z) + w.w * as_tanh(m.w + qq.w);
+          for (int i = 0; i < RW; ++i) {
+            const float4 qq = *reinterpret_cast<const float4 *>(&sQ[wave * RW + i][h]);
+            const float tx = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_fmaf(m.x, qq.x, 1.0f)), 1.0f);
+            const float ty = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_fmaf(m.y, qq.y, 1.0f)), 1.0f);
+            const float tz = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_fmaf(m.z, qq.z, 1.0f)), 1.0f);
+            const float tw = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_fmaf(m.w, qq.w, 1.0f)), 1.0f);
+            acc[i] += w.x * tx + w.y * ty + w.z * tz + w.w * tw;
+          }
+        }
+      } else {
+        // the rare tile with huge pre-activations: raw values, exact formula
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int e = tid + 256 * p;
+          const int key = e >> 4, qd = e & 15;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (kb + key < K && hc + 4 * qd < H)
+            v = *reinterpret_cast<const float4 *>(Mb + (size_t)(kb + key) * H + hc + 4 * qd);
+          *reinterpret_cast<float4 *>(sM + key * AS_LD + 4 * qd) = v;
+        }
+        for (int e = tid; e < RB * 16; e += 256) {
+          const int rr = e >> 4, qd = e & 15;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (rr < nrow && hc + 4 * qd < H)
+            v = *reinterpret_cast<const float4 *>(a.q + (size_t)(row_base + rr) * a.ldq + hc + 4 * qd);
+          *reinterpret_cast<float4 *>(&sQ[rr][4 * qd]) = v;
+        }
+        __syncthreads();
+        for (int h = 0; h < 64; h += 4) {
+          const float4 m = *reinterpret_cast<const float4 *>(mrow + h);
+          const float4 w = *reinterpret_cast<const float4 *>(&sW[h]);
+#pragma unroll
+          for (int i = 0; i < RW; ++i) {
+            const float4 qq = *reinterpret_cast<const float4 *>(&sQ[wave * RW + i][h]);
+            acc[i] += w.x * as_tanh(m.x + qq.x) + w.y * as_tanh(m.y + qq.y) +
+                      w.z * as_tanh(m.z + qq.z) + w.w * as_tanh(m.w + qq.w);
+          }
         }
       }
     }

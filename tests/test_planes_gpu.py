@@ -197,6 +197,9 @@ def test_scene_shared_attention_matches_float64(B, rps, K, H, F):
     wa = torch.randn(H, device="cuda") * 0.2
     valid = (torch.rand(B, K, device="cuda") < 0.8).float()
     valid[0] = 0 if B > 1 else valid[0]            # a scene without a single valid object: uniform weights
+    if B > 1:                                      # huge pre-activations of opposite sign: the exact fallback tile
+        M[K + 3, 5], q[rps + 1, 5] = 60.0, -57.5
+        M[K + 4, 70 % H], q[rps + 2, 70 % H] = -45.0, 30.0
     alpha = torch.empty(R, K, device="cuda")
     att = torch.empty(R, F, device="cuda")
     Fp = (F + 31) // 32 * 32
