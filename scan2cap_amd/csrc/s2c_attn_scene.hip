@@ -43,9 +43,12 @@ struct AsArgs {
   unsigned short *planes; long long pstride; int ldp, tiled;
 };
 
-template <int RW>
-__global__ __launch_bounds__(256) void attn_scene_kernel(AsArgs a) {
-  constexpr int RB = 4 * RW;                    // rows per workgroup
+// NWV waves x RW rows per workgroup.  (8 x 1 rather than 4 x 2 for the same 8 rows: two waves per SIMD
+// cover each other's reciprocal / LDS latencies -- one wave per SIMD ran at a third of the VALU bound.)
+template <int NWV, int RW>
+__global__ __launch_bounds__(64 * NWV) void attn_scene_kernel(AsArgs a) {
+  constexpr int RB = NWV * RW;                  // rows per workgroup
+  constexpr int NT = 64 * NWV, MP = 1024 / NT;  // threads, M-tile float4 per thread
   __shared__ __attribute__((aligned(16))) float sM[64 * AS_LD];
   __shared__ __attribute__((aligned(16))) float sQ[RB][64];
   __shared__ __attribute__((aligned(16))) float sW[64];
@@ -66,95 +69,104 @@ __global__ __launch_bounds__(256) void attn_scene_kernel(AsArgs a) {
   // a tile with |m| or |q| > 20 (2^{+-58}: the product stays finite, and beyond |x| = 10 tanh is
   // +-1 in fp32 anyway) is re-staged raw and takes the two-transcendental formula instead.
   constexpr float C2 = 2.8853900817779268f;
-  for (int kb = 0; kb < K; kb += 64) {
-    float acc[RW];
+  // tile t = (key block, h chunk); the NEXT tile's global loads are issued into registers before
+  // the current tile is multiplied (the staging latency was exposed: one workgroup per tile loop,
+  // two or three workgroups per CU)
+  const int nhc = (H + 63) >> 6, nkb = (K + 63) >> 6, ntile = nhc * nkb;
+  float4 pm[MP], pq;                             // this thread's pieces of a tile
+  const int q_rr = tid >> 4, q_qd = tid & 15;    // its q piece (threads < RB * 16)
+  auto fetch = [&](int t) {
+    const int kb = (t / nhc) << 6, hc = (t % nhc) << 6;
 #pragma unroll
-    for (int i = 0; i < RW; ++i) acc[i] = 0.f;
-    for (int hc = 0; hc < H; hc += 64) {
-      __syncthreads();
-      bool big = false;
-      // M tile: 64 keys x 64 h (16 float4 per key): thread -> (key = e / 16, quad = e % 16)
+    for (int p = 0; p < MP; ++p) {
+      const int e = tid + NT * p;
+      const int key = e >> 4, qd = e & 15;
+      pm[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (kb + key < K && hc + 4 * qd < H)
+        pm[p] = *reinterpret_cast<const float4 *>(Mb + (size_t)(kb + key) * H + hc + 4 * qd);
+    }
+    pq = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < RB * 16 && q_rr < nrow && hc + 4 * q_qd < H)
+      pq = *reinterpret_cast<const float4 *>(a.q + (size_t)(row_base + q_rr) * a.ldq + hc + 4 * q_qd);
+  };
+  auto far = [](const float4 &v) {
+    return !(fabsf(v.x) <= 20.f && fabsf(v.y) <= 20.f && fabsf(v.z) <= 20.f && fabsf(v.w) <= 20.f);
+  };
+  auto ex = [&](float4 v, bool raw) {
+    if (!raw) {
+      v.x = __builtin_amdgcn_exp2f(v.x * C2); v.y = __builtin_amdgcn_exp2f(v.y * C2);
+      v.z = __builtin_amdgcn_exp2f(v.z * C2); v.w = __builtin_amdgcn_exp2f(v.w * C2);
+    }
+    return v;
+  };
+  auto stage = [&](bool raw) {
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const int e = tid + 256 * p;
-        const int key = e >> 4, qd = e & 15;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (kb + key < K && hc + 4 * qd < H)
-          v = *reinterpret_cast<const float4 *>(Mb + (size_t)(kb + key) * H + hc + 4 * qd);
-        big |= !(fabsf(v.x) <= 20.f && fabsf(v.y) <= 20.f && fabsf(v.z) <= 20.f && fabsf(v.w) <= 20.f);
-        v.x = __builtin_amdgcn_exp2f(v.x * C2); v.y = __builtin_amdgcn_exp2f(v.y * C2);
-        v.z = __builtin_amdgcn_exp2f(v.z * C2); v.w = __builtin_amdgcn_exp2f(v.w * C2);
-        *reinterpret_cast<float4 *>(sM + key * AS_LD + 4 * qd) = v;
-      }
-      for (int e = tid; e < RB * 16; e += 256) {
-        const int rr = e >> 4, qd = e & 15;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (rr < nrow && hc + 4 * qd < H)
-          v = *reinterpret_cast<const float4 *>(a.q + (size_t)(row_base + rr) * a.ldq + hc + 4 * qd);
-        big |= !(fabsf(v.x) <= 20.f && fabsf(v.y) <= 20.f && fabsf(v.z) <= 20.f && fabsf(v.w) <= 20.f);
-        v.x = __builtin_amdgcn_exp2f(v.x * C2); v.y = __builtin_amdgcn_exp2f(v.y * C2);
-        v.z = __builtin_amdgcn_exp2f(v.z * C2); v.w = __builtin_amdgcn_exp2f(v.w * C2);
-        *reinterpret_cast<float4 *>(&sQ[rr][4 * qd]) = v;
-      }
-      if (tid < 16) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);       // wa = 0 beyond H: no contribution
-        if (hc + 4 * tid < H) v = *reinterpret_cast<const float4 *>(a.wa + hc + 4 * tid);
-        *reinterpret_cast<float4 *>(&sW[4 * tid]) = v;
-      }
-      big = __syncthreads_or(big ? 1 : 0) != 0;
-      const float *mrow = sM + lane * AS_LD;
-      if (!big) {
+    for (int p = 0; p < MP; ++p) {
+      const int e = tid + NT * p;
+      *reinterpret_cast<float4 *>(sM + (e >> 4) * AS_LD + 4 * (e & 15)) = ex(pm[p], raw);
+    }
+    if (tid < RB * 16) *reinterpret_cast<float4 *>(&sQ[q_rr][4 * q_qd]) = ex(pq, raw);
+  };
+  float acc[RW];
+  fetch(0);
+  for (int t = 0; t < ntile; ++t) {
+    const int kb = (t / nhc) << 6, hc = (t % nhc) << 6;
+    if (hc == 0) {
+#pragma unroll
+      for (int i = 0; i < RW; ++i) acc[i] = 0.f;
+    }
+    __syncthreads();                             // the previous tile has been multiplied
+    bool big = far(pq);
+#pragma unroll
+    for (int p = 0; p < MP; ++p) big = big || far(pm[p]);
+    stage(false);
+    if (tid < 16) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);       // wa = 0 beyond H: no contribution
+      if (hc + 4 * tid < H) v = *reinterpret_cast<const float4 *>(a.wa + hc + 4 * tid);
+      *reinterpret_cast<float4 *>(&sW[4 * tid]) = v;
+    }
+    big = __syncthreads_or(big ? 1 : 0) != 0;
+    const float *mrow = sM + lane * AS_LD;
+    if (!big) {
+      if (t + 1 < ntile) fetch(t + 1);           // in flight under the products
 #pragma unroll 4
-        for (int h = 0; h < 64; h += 4) {
-          const float4 m = *reinterpret_cast<const float4 *>(mrow + h);
-          const float4 w = *reinterpret_cast<const float4 *>(&sW[h]);
+      for (int h = 0; h < 64; h += 4) {
+        const float4 m = *reinterpret_cast<const float4 *>(mrow + h);
+        const float4 w = *reinterpret_cast<const float4 *>(&sW[h]);
 #pragma unroll
-          for (int i = 0; i < RW; ++i) {
-            const float4 qq = *reinterpret_cast<const float4 *>(&sQ[wave * RW + i][h]);
-            const float tx = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_fmaf(m.x, qq.x, 1.0f)), 1.0f);
-            const float ty = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_fmaf(m.y, qq.y, 1.0f)), 1.0f);
-            const float tz = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_fmaf(m.z, qq.z, 1.0f)), 1.0f);
-            const float tw = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_fmaf(m.w, qq.w, 1.0f)), 1.0f);
-            acc[i] += w.x * tx + w.y * ty + w.z * tz + w.w * tw;
-          }
+        for (int i = 0; i < RW; ++i) {
+          const float4 qq = *reinterpret_cast<const float4 *>(&sQ[wave * RW + i][h]);
+          const float tx = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_fmaf(m.x, qq.x, 1.0f)), 1.0f);
+          const float ty = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_fmaf(m.y, qq.y, 1.0f)), 1.0f);
+          const float tz = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_fmaf(m.z, qq.z, 1.0f)), 1.0f);
+          const float tw = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_fmaf(m.w, qq.w, 1.0f)), 1.0f);
+          acc[i] += w.x * tx + w.y * ty + w.z * tz + w.w * tw;
         }
-      } else {
-        // the rare tile with huge pre-activations: raw values, exact formula
-        __syncthreads();
+      }
+    } else {
+      // the rare tile with huge pre-activations: raw values, the two-transcendental formula
+      __syncthreads();
+      stage(true);
+      __syncthreads();
+      if (t + 1 < ntile) fetch(t + 1);
+      for (int h = 0; h < 64; h += 4) {
+        const float4 m = *reinterpret_cast<const float4 *>(mrow + h);
+        const float4 w = *reinterpret_cast<const float4 *>(&sW[h]);
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          const int e = tid + 256 * p;
-          const int key = e >> 4, qd = e & 15;
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (kb + key < K && hc + 4 * qd < H)
-            v = *reinterpret_cast<const float4 *>(Mb + (size_t)(kb + key) * H + hc + 4 * qd);
-          *reinterpret_cast<float4 *>(sM + key * AS_LD + 4 * qd) = v;
-        }
-        for (int e = tid; e < RB * 16; e += 256) {
-          const int rr = e >> 4, qd = e & 15;
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (rr < nrow && hc + 4 * qd < H)
-            v = *reinterpret_cast<const float4 *>(a.q + (size_t)(row_base + rr) * a.ldq + hc + 4 * qd);
-          *reinterpret_cast<float4 *>(&sQ[rr][4 * qd]) = v;
-        }
-        __syncthreads();
-        for (int h = 0; h < 64; h += 4) {
-          const float4 m = *reinterpret_cast<const float4 *>(mrow + h);
-          const float4 w = *reinterpret_cast<const float4 *>(&sW[h]);
-#pragma unroll
-          for (int i = 0; i < RW; ++i) {
-            const float4 qq = *reinterpret_cast<const float4 *>(&sQ[wave * RW + i][h]);
-            acc[i] += w.x * as_tanh(m.x + qq.x) + w.y * as_tanh(m.y + qq.y) +
-                      w.z * as_tanh(m.z + qq.z) + w.w * as_tanh(m.w + qq.w);
-          }
+        for (int i = 0; i < RW; ++i) {
+          const float4 qq = *reinterpret_cast<const float4 *>(&sQ[wave * RW + i][h]);
+          acc[i] += w.x * as_tanh(m.x + qq.x) + w.y * as_tanh(m.y + qq.y) +
+                    w.z * as_tanh(m.z + qq.z) + w.w * as_tanh(m.w + qq.w);
         }
       }
     }
-    const int key = kb + lane;
-    const bool ok = key < K && (a.valid == nullptr || a.valid[(size_t)b * K + key] != 0.0f);
+    if (hc + 64 >= H) {                          // the key block's scores are complete
+      const int key = kb + lane;
+      const bool ok = key < K && (a.valid == nullptr || a.valid[(size_t)b * K + key] != 0.0f);
 #pragma unroll
-    for (int i = 0; i < RW; ++i)
-      if (key < K) sA[wave * RW + i][key] = ok ? acc[i] + a.ba : -1e30f;
+      for (int i = 0; i < RW; ++i)
+        if (key < K) sA[wave * RW + i][key] = ok ? acc[i] + a.ba : -1e30f;
+    }
   }
   __syncthreads();
 
@@ -191,8 +203,8 @@ __global__ __launch_bounds__(256) void attn_scene_kernel(AsArgs a) {
     float out[RW];
 #pragma unroll
     for (int i = 0; i < RW; ++i) out[i] = 0.f;
-#pragma unroll 4
-    for (int j = 0; j < K; ++j) {
+#pragma unroll 16
+    for (int j = 0; j < K; ++j) {               // 16 L2 round trips in flight
       const float o = fok ? Ob[(size_t)j * a.F + f] : 0.f;
 #pragma unroll
       for (int i = 0; i < RW; ++i) out[i] += sA[wave * RW + i][j] * o;
@@ -244,13 +256,13 @@ extern "C" int s2c_attn_scene_fwd(int R, int rows_per_scene, int K, int H, int F
   a.q = q; a.ldq = ldq; a.wa = wa; a.ba = ba; a.alpha = alpha; a.att = att; a.lda = lda;
   a.planes = planes; a.pstride = pstride; a.ldp = ldp; a.tiled = tiled;
   const int B = R / rows_per_scene;
-  // 8 rows per workgroup while that still gives >= 2 workgroups per CU's worth of work, else 16
+  // 8 rows per workgroup (8 waves x 1) while that gives at most ~2 workgroups per CU, else 16 (8 x 2)
   if (R <= 4096) {
     const int nb = B * ((rows_per_scene + 7) / 8);
-    hipLaunchKernelGGL(attn_scene_kernel<2>, dim3(nb), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((attn_scene_kernel<8, 1>), dim3(nb), dim3(512), 0, (hipStream_t)stream, a);
   } else {
     const int nb = B * ((rows_per_scene + 15) / 16);
-    hipLaunchKernelGGL(attn_scene_kernel<4>, dim3(nb), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((attn_scene_kernel<8, 2>), dim3(nb), dim3(512), 0, (hipStream_t)stream, a);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
