@@ -828,6 +828,24 @@ int s2c_weight_grad_stream(long long M, int C, int N, const float *dY, long long
                            const float *A, long long lda, float *part, void *stream);
 int s2c_weight_grad_stream_set_grid(int workgroups);
 
+/* ---- a 64 -> 64 BatchNorm(+ReLU) layer's backward in one pass (csrc/s2c_bnbwd_fused.hip, round 5) ---
+ * dY = BatchNorm(+ReLU)-backward(dA, Y) (scale .. coef as for s2c_bn_bwd_gemm) is never written:
+ *   dX (M x 64) = dY W                     W (64 x 64) AS STORED (row = output channel, row stride ldw);
+ *   dWpart (parts x 64 x 64): partial sums of dW = dY^T relu?(nY nscale + nshift) -- the layer's input is
+ *                     the previous layer's activation, recomputed from its pre-activation nY (M x 64);
+ *   npartial (parts x 128): [s1 | s2] rows of the previous layer's BatchNorm-backward column sums over
+ *                     (dX, nY), as s2c_bn_bwd_gemm_next_stats leaves them.
+ * parts = s2c_bn_bwd_dx_dw64_parts(M) (0: not taken -- M % 16 != 0 or M < 4096); all row tensors
+ * contiguous (row stride 64), 16-byte aligned.  Replaces s2c_bn_bwd_gemm_next_stats + the dY tensor +
+ * s2c_weight_grad_stream + the forward's activation side output for that layer (SA1's second layer).
+ * Autograd of lib/pointnet2/pytorch_utils.py:67-120 inside pointnet2_modules.py:251-257. */
+int s2c_bn_bwd_dx_dw64_parts(long long M);
+int s2c_bn_bwd_dx_dw64(long long M, const float *dA, const float *Y, const float *scale,
+                       const float *shift, const float *mean, const float *invstd, const float *coef,
+                       int relu, const float *W, int ldw, float *dX, const float *nY,
+                       const float *nscale, const float *nshift, const float *nmean,
+                       const float *ninvstd, int nrelu, float *dWpart, float *npartial, void *stream);
+
 /* ---- the small products of the layer stacks (csrc/s2c_sgemm.hip, round 5) --------------------------
  * Y (M x N, row stride ldy) = A (M x K, row stride lda) B (+ bias[n]):
  *   b_transposed = 0: B is (K x N) row-major, row stride ldb -- the input gradient dX = dY W with W as

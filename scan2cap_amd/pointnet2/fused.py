@@ -351,6 +351,21 @@ _C.register("s2c_pool_select", [_L, _I, _P, _P, _P, _P, _P])
 _C.register("s2c_bn_bwd_gemm_next_stats", [_L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _I,
                                            _P, _P, _P, _P, _P, _I, _P, _P])
 _C.register("s2c_bn_bwd_finalize_partials", [_I, _L, _I, _P, _I, _P, _P, _P, _P, _P, _P])
+_C.register("s2c_bn_bwd_dx_dw64", [_L, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I,
+                                   _P, _P, _P])
+# a 64 -> 64 BatchNorm layer between two others (SA1's second layer): dY never written, dX, dW and the
+# previous layer's column sums in one pass over (dA, Y, the previous layer's Y) -- csrc/s2c_bnbwd_fused.hip;
+# = False: s2c_bn_bwd_gemm_next_stats + the dY tensor + s2c_weight_grad_stream
+FUSE_BWD_DX_DW = True
+
+
+def _bwd_dx_dw_parts(M):
+    lib = _C.load()
+    if not getattr(lib, "_fb_sized", False):
+        lib.s2c_bn_bwd_dx_dw64_parts.restype = _I
+        lib.s2c_bn_bwd_dx_dw64_parts.argtypes = [_L]
+        lib._fb_sized = True
+    return lib.s2c_bn_bwd_dx_dw64_parts(M)
 _C.register("s2c_pool_bwd_input_grad_next_stats", [_L, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _P, _I,
                                                    _P, _P, _P, _P, _P, _I, _P, _P])
 _C.register("s2c_rows_gemm_next_stats", [_L, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P])
@@ -803,6 +818,7 @@ class _MLPRows(Function):
             W, A_in = rec["W"], rec["A_in"]
             lazy_dw = False
             fused_dA = None
+            dW_fused = None
             pre, prestats = prestats, None
             point_grads = None
             if A_in is None:
@@ -887,15 +903,40 @@ class _MLPRows(Function):
                     # statistics, then dY and the input gradient dX = dY W in ONE pass
                     statistics()
                     Cin = W.shape[1]
-                    Wt = W.t().contiguous()
                     fused_dA = torch.empty((M, Cin), device=dev)
                     prev = saved[li - 1] if li > 0 else None
-                    if (BWD_STATS_IN_GEMM and prev is not None and specs[li - 1].bn is not None
-                            and not prev.get("algebra") and prev.get("Y") is not None
-                            and prev["Y"].shape == (M, Cin) and prev["Y"].is_contiguous()
-                            and Cin % 4 == 0):
+                    takes_next = (BWD_STATS_IN_GEMM and prev is not None
+                                  and specs[li - 1].bn is not None
+                                  and not prev.get("algebra") and prev.get("Y") is not None
+                                  and prev["Y"].shape == (M, Cin) and prev["Y"].is_contiguous()
+                                  and Cin % 4 == 0)
+                    fparts = 0
+                    if (FUSE_BWD_DX_DW and takes_next and Cout == 64 and Cin == 64 and not lazy_dw
+                            and not rec["has_bias"] and Y.is_contiguous() and W.stride(1) == 1
+                            and M >= DW_STREAM_MIN_ROWS and pending is not None):
+                        fparts = _bwd_dx_dw_parts(M)
+                    if fparts > 0:
+                        # ... and the weight gradient too: this layer's input is the previous layer's
+                        # activation, recomputed from its pre-activation -- dY is never written
+                        npart = torch.empty(fparts * 2 * Cin, device=dev)
+                        wpart = torch.empty((fparts, Cout, Cin), device=dev)
+                        dW_fused = torch.empty((Cout, Cin), device=dev)
+                        dY = None
+                        _call("s2c_bn_bwd_dx_dw64", Y, M, dA.data_ptr(), Y.data_ptr(),
+                              rec["scale"].data_ptr(), rec["shift"].data_ptr(),
+                              rec["mean"].data_ptr(), rec["invstd"].data_ptr(), coef.data_ptr(),
+                              int(rec["relu"]), W.data_ptr(), W.stride(0), fused_dA.data_ptr(),
+                              prev["Y"].data_ptr(), prev["scale"].data_ptr(),
+                              prev["shift"].data_ptr(), prev["mean"].data_ptr(),
+                              prev["invstd"].data_ptr(), int(prev["relu"]), wpart.data_ptr(),
+                              npart.data_ptr(), alg_bytes=4 * M * (3 * Cout + Cin),
+                              alg_flops=4 * M * Cout * Cin)
+                        pending.append((wpart, dW_fused))
+                        prestats = (npart, fparts)
+                    elif takes_next:
                         # ... and the column sums of the PREVIOUS layer's BatchNorm backward out
                         # of the same GEMM's epilogue (its upstream gradient is this output)
+                        Wt = W.t().contiguous()
                         nbg = _gemm_blocks(M, Cin)
                         npart = torch.empty(nbg * 2 * Cin, device=dev)
                         _call("s2c_bn_bwd_gemm_next_stats", Y, M, Cout, Cin, dA.data_ptr(),
@@ -910,6 +951,7 @@ class _MLPRows(Function):
                               alg_flops=2 * M * Cout * Cin)
                         prestats = (npart, nbg)
                     else:
+                        Wt = W.t().contiguous()
                         _call("s2c_bn_bwd_gemm", Y, M, Cout, Cin, dA.data_ptr(), Y.data_ptr(),
                               rec["scale"].data_ptr(), rec["shift"].data_ptr(),
                               rec["mean"].data_ptr(), rec["invstd"].data_ptr(), coef.data_ptr(),
@@ -938,6 +980,8 @@ class _MLPRows(Function):
                                         pending=pending, post=post)
                 if gather.needs_grad:
                     point_grads = gather.input_grads(W)
+            elif dW_fused is not None:
+                dW = dW_fused
             else:
                 dW = _weight_grad(dY, A_in, pending)
             dbias = None

@@ -1,0 +1,121 @@
+"""A 64 -> 64 BatchNorm(+ReLU) layer's backward in one pass (csrc/s2c_bnbwd_fused.hip: dY never written,
+dX = dY W, dW = dY^T act(previous layer), the previous layer's column sums) against float64 formulas
+and against the three-launch path it replaces (s2c_bn_bwd_gemm_next_stats + dY + s2c_weight_grad_stream).
+Reference: autograd of lib/pointnet2/pytorch_utils.py:67-120 inside pointnet2_modules.py:251-257."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(M, seed, relu, nrelu):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    r = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    d = dict(dA=r(M, 64), Y=r(M, 64) * 1.3 + 0.2, nY=r(M, 64) * 0.8 - 0.1, W=r(64, 64) * 0.2,
+             scale=r(64) * 0.5 + 1.0, shift=r(64) * 0.3, mean=r(64) * 0.2,
+             invstd=r(64).abs() + 0.5, coef=torch.cat([r(64) * 0.5 + 1.0, r(64) * 0.01, r(64) * 0.01]),
+             nscale=r(64) * 0.5 + 1.0, nshift=r(64) * 0.3, nmean=r(64) * 0.2, ninvstd=r(64).abs() + 0.5)
+    d["scale"][3] = -0.7            # a negative BatchNorm weight flips the ReLU mask's sense
+    d["relu"], d["nrelu"] = int(relu), int(nrelu)
+    return d
+
+
+def _run(d):
+    from scan2cap_amd.pointnet2 import fused
+    M = d["dA"].shape[0]
+    parts = fused._bwd_dx_dw_parts(M)
+    assert parts > 0
+    dX = torch.full((M, 64), float("nan"), device="cuda")
+    wpart = torch.full((parts, 64, 64), float("nan"), device="cuda")
+    npart = torch.full((parts, 128), float("nan"), device="cuda")
+    fused._call("s2c_bn_bwd_dx_dw64", dX, M, d["dA"].data_ptr(), d["Y"].data_ptr(),
+                d["scale"].data_ptr(), d["shift"].data_ptr(), d["mean"].data_ptr(),
+                d["invstd"].data_ptr(), d["coef"].data_ptr(), d["relu"], d["W"].data_ptr(),
+                d["W"].stride(0), dX.data_ptr(), d["nY"].data_ptr(), d["nscale"].data_ptr(),
+                d["nshift"].data_ptr(), d["nmean"].data_ptr(), d["ninvstd"].data_ptr(), d["nrelu"],
+                wpart.data_ptr(), npart.data_ptr())
+    return dX, wpart.sum(0), npart.sum(0)
+
+
+def _truth(d):
+    """float64 formulas on the float32 masks (the masks are comparisons of float32 expressions:
+    a float64 mask would differ on knife-edge elements)."""
+    f = lambda k: d[k].double()
+    mask = (d["Y"] * d["scale"] + d["shift"] > 0) if d["relu"] else torch.ones_like(d["Y"], dtype=torch.bool)
+    dz = torch.where(mask, f("dA"), torch.zeros((), dtype=torch.float64, device="cuda"))
+    k0, k1, k2 = f("coef")[:64], f("coef")[64:128], f("coef")[128:]
+    dY = k0 * (dz - k1 - ((f("Y") - f("mean")) * f("invstd")) * k2)
+    dX = dY @ f("W")
+    pre = d["nY"] * d["nscale"] + d["nshift"]                      # float32, as the kernels form it
+    act = (torch.relu(pre) if d["nrelu"] else pre).double()
+    dW = dY.t() @ act
+    nmask = (pre > 0) if d["nrelu"] else torch.ones_like(pre, dtype=torch.bool)
+    # the column sums are over the float32 dX the kernel wrote; its own rounding is checked through dX
+    return dY, dX, dW, nmask
+
+
+@pytest.mark.parametrize("M,relu,nrelu", [(1 << 20, 1, 1), (65536, 1, 1), (4096, 1, 0), (40000 - 40000 % 16, 0, 1),
+                                          (16 * 12345, 1, 1)])
+def test_fused_layer_backward_matches_float64(M, relu, nrelu):
+    d = _inputs(M, 11 + M % 97, relu, nrelu)
+    dX, dW, st = _run(d)
+    dY, tX, tW, nmask = _truth(d)
+    sx = (dY.norm(dim=1)[:, None] * d["W"].double().norm(dim=0)[None, :]).clamp_min(1e-30)
+    ex = ((dX.double() - tX).abs() / sx).max().item()
+    assert ex < 2e-6, ex
+    pre = d["nY"] * d["nscale"] + d["nshift"]
+    act = (torch.relu(pre) if nrelu else pre).double()
+    sw = (dY.norm(dim=0)[:, None] * act.norm(dim=0)[None, :]).clamp_min(1e-30)
+    ew = ((dW.double() - tW).abs() / sw).max().item()
+    assert ew < 2e-6, ew
+    dz = torch.where(nmask, dX.double(), torch.zeros((), dtype=torch.float64, device="cuda"))
+    xhat = (d["nY"].double() - d["nmean"].double()) * d["ninvstd"].double()
+    t1, t2 = dz.sum(0), (dz * xhat).sum(0)
+    n1, n2 = dz.abs().sum(0).clamp_min(1e-30), (dz * xhat).abs().sum(0).clamp_min(1e-30)
+    assert ((st[:64].double() - t1).abs() / n1).max().item() < 2e-6
+    assert ((st[64:].double() - t2).abs() / n2).max().item() < 2e-6
+
+
+def test_fused_layer_backward_agrees_with_the_three_launch_path():
+    """The same layer through s2c_bn_bwd_gemm_next_stats (dY written) + the streaming weight gradient over
+    (dY, the activation tensor): dX to rounding, dW and the column sums to their summation order."""
+    from scan2cap_amd.pointnet2 import fused
+    M = 131072
+    d = _inputs(M, 5, 1, 1)
+    dX, dW, st = _run(d)
+    Wt = d["W"].t().contiguous()
+    dY = torch.empty(M, 64, device="cuda")
+    dX2 = torch.empty(M, 64, device="cuda")
+    nbg = fused._gemm_blocks(M, 64)
+    npart = torch.empty(nbg * 128, device="cuda")
+    fused._call("s2c_bn_bwd_gemm_next_stats", dX2, M, 64, 64, d["dA"].data_ptr(), d["Y"].data_ptr(),
+                d["scale"].data_ptr(), d["shift"].data_ptr(), d["mean"].data_ptr(),
+                d["invstd"].data_ptr(), d["coef"].data_ptr(), 1, Wt.data_ptr(), Wt.stride(0),
+                dY.data_ptr(), dX2.data_ptr(), 64, d["nY"].data_ptr(), d["nscale"].data_ptr(),
+                d["nshift"].data_ptr(), d["nmean"].data_ptr(), d["ninvstd"].data_ptr(), 1,
+                npart.data_ptr())
+    act = torch.relu(d["nY"] * d["nscale"] + d["nshift"])
+    pend = []
+    dW2 = fused._weight_grad_stream(dY, act, pend)
+    fused.flush_partial_sums(pend)
+    assert ((dX - dX2).abs().max() / dX2.abs().max()).item() < 2e-6
+    assert ((dW - dW2).abs().max() / dW2.abs().max()).item() < 2e-6
+    st2 = npart.view(nbg, 128).sum(0)
+    assert ((st - st2).abs().max() / st2.abs().max()).item() < 2e-5
+
+
+def test_fused_layer_backward_is_deterministic_and_declines_ragged_rows():
+    from scan2cap_amd.pointnet2 import fused
+    d = _inputs(65536, 3, 1, 1)
+    a = _run(d)
+    b = _run(d)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert fused._bwd_dx_dw_parts(65536 + 8) == 0
+    assert fused._bwd_dx_dw_parts(1024) == 0
