@@ -515,6 +515,16 @@ def _stream_takes(M, N, K):
     return bool(lib.s2c_rows_stream_supported(M, N, K, 0))
 
 
+def _activation_of(rec):
+    """relu?(Y scale + shift) of a BatchNorm layer's record (s2c_bn_relu): the input of the next layer
+    when the forward did not keep it (act_from_prev)."""
+    Y = rec["Y"]
+    A = torch.empty_like(Y)
+    _call("s2c_bn_relu", Y, Y.shape[0], Y.shape[1], Y.data_ptr(), rec["scale"].data_ptr(),
+          rec["shift"].data_ptr(), A.data_ptr(), int(rec["relu"]), alg_bytes=8 * Y.numel())
+    return A
+
+
 class _MLPRows(Function):
     """forward(X, specs, pool_ns, *params) with params = per layer
     [W (Cout,Cin), bias?, gamma?, beta?].  pool_ns > 0: the last layer's
@@ -560,6 +570,7 @@ class _MLPRows(Function):
                     "BatchNorm(momentum=None) (cumulative moving average) is not "
                     "implemented on the rows path; use a float momentum")
             from_gather = gather is not None and li == 0
+            act_from_prev = False
             # (A bias in front of a train-mode BatchNorm cancels in the normalised output; running the
             # GEMM without it -- statistics out of the epilogue, momentum * bias added back to the
             # running mean -- was built and withdrawn: time-neutral, and the differently rounded
@@ -675,11 +686,20 @@ class _MLPRows(Function):
                 gpart = torch.empty(nbg * 2 * Cout, device=dev)
                 Y = torch.empty((M, Cout), device=dev)
                 K_in = pY.shape[1]
-                A = torch.empty_like(pY)
+                # the activation is kept for this layer's weight gradient -- unless the backward
+                # recomputes it from pY inside its one pass (s2c_bn_bwd_dx_dw64): no side output
+                act_from_prev = bool(
+                    need_grad and FUSE_BWD_DX_DW and FUSE_BWD_GEMM and BWD_STATS_IN_GEMM
+                    and bn is not None and bias is None and Cout == 64 and K_in == 64
+                    and not (li == nl - 1 and pool_ns > 0) and pY.is_contiguous()
+                    and _fused_bwd_pays(M, Cout, K_in) and M >= DW_STREAM_MIN_ROWS
+                    and W.stride(1) == 1 and _gemm_split_on() and _bwd_dx_dw_parts(M) > 0)
+                A = None if act_from_prev else torch.empty_like(pY)
                 _call("s2c_rows_gemm_bn_relu_side", Y, M, Cout, K_in, pY.data_ptr(), pY.stride(0),
-                      pscale.data_ptr(), pshift.data_ptr(), int(prelu), A.data_ptr(), K_in,
+                      pscale.data_ptr(), pshift.data_ptr(), int(prelu), _ptr(A), K_in,
                       W.data_ptr(), W.stride(0), Y.data_ptr(), Cout, gpart.data_ptr(),
-                      alg_bytes=4 * (2 * M * K_in + M * Cout), alg_flops=2 * M * K_in * Cout)
+                      alg_bytes=4 * ((1 if act_from_prev else 2) * M * K_in + M * Cout),
+                      alg_flops=2 * M * K_in * Cout)
             elif gemm_stats:
                 # hand-written f32 MFMA GEMM; BN batch statistics come out of its
                 # epilogue as per-row-block partials (no extra pass over Y)
@@ -711,7 +731,8 @@ class _MLPRows(Function):
                 if Y is None:
                     Y = torch.addmm(bias, A, W.t()) if bias is not None else torch.mm(A, W.t())
             rec = {"A_in": None if from_gather else A, "W": W,
-                   "has_bias": bias is not None, "point_space": point_space}
+                   "has_bias": bias is not None, "point_space": point_space,
+                   "act_from_prev": act_from_prev}
             last = li == nl - 1
             if bn is not None:
                 scale = torch.empty(Cout, device=dev)
@@ -821,7 +842,14 @@ class _MLPRows(Function):
             dW_fused = None
             pre, prestats = prestats, None
             point_grads = None
-            if A_in is None:
+            if rec.get("act_from_prev"):
+                # this layer's input was not kept: it is the previous layer's activation, which the
+                # one-pass kernel recomputes (any other branch below gets it materialised here)
+                if not (FUSE_BWD_DX_DW and FUSE_BWD_GEMM and BWD_STATS_IN_GEMM and _gemm_split_on()
+                        and dA.dtype == torch.float32 and dA.stride(1) == 1
+                        and dA.stride(0) == W.shape[0]):
+                    A_in = _activation_of(saved[li - 1])
+            elif A_in is None:
                 if POINT_SPACE_BWD and SCATTER_DW and W.shape[0] % 4 == 0:
                     lazy_dw = True      # weight and input gradients from point-indexed sums
                 elif gather.needs_grad or not SCATTER_DW:
@@ -829,7 +857,8 @@ class _MLPRows(Function):
                 else:
                     lazy_dw = True      # dW from point-indexed sums (GatherSpec.weight_grad)
             Cout = W.shape[0]
-            M = A_in.shape[0] if A_in is not None else gather.rows
+            M = (A_in.shape[0] if A_in is not None
+                 else rec["Y"].shape[0] if rec.get("act_from_prev") else gather.rows)
             dgamma = dbeta = None
             if rec.get("algebra"):
                 # pooled last layer without Y3 / dY3 (pooled_layer_backward)
@@ -983,6 +1012,8 @@ class _MLPRows(Function):
             elif dW_fused is not None:
                 dW = dW_fused
             else:
+                if A_in is None and rec.get("act_from_prev"):
+                    A_in = _activation_of(saved[li - 1])
                 dW = _weight_grad(dY, A_in, pending)
             dbias = None
             if rec["has_bias"]:

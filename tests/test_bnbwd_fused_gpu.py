@@ -119,3 +119,107 @@ def test_fused_layer_backward_is_deterministic_and_declines_ragged_rows():
         assert torch.equal(x, y)
     assert fused._bwd_dx_dw_parts(65536 + 8) == 0
     assert fused._bwd_dx_dw_parts(1024) == 0
+
+
+def _stack(seed=0, C0=16):
+    torch.manual_seed(seed)
+    convs = [torch.nn.Conv1d(a, b, 1, bias=False).cuda() for a, b in ((C0, 64), (64, 64), (64, 128))]
+    bns = [torch.nn.BatchNorm1d(c).cuda() for c in (64, 64, 128)]
+    for bn in bns:
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.3, 0.3)
+    with torch.no_grad():
+        bns[1].weight[5] = -0.8
+    return convs, bns
+
+
+def _stack_grads(convs, bns, x, gout, pool_ns):
+    from scan2cap_amd.pointnet2 import fused
+    specs = [fused.LayerSpec(False, bn, True) for bn in bns]
+    params = []
+    for c, bn in zip(convs, bns):
+        params += [c.weight.view(c.weight.shape[0], -1), bn.weight, bn.bias]
+    for c, bn in zip(convs, bns):
+        c.weight.grad = bn.weight.grad = bn.bias.grad = None
+    xx = x.detach().clone().requires_grad_(True)
+    out = fused.mlp_rows(xx, specs, params, pool_ns=pool_ns)
+    (out * gout).sum().backward()
+    return out.detach(), xx.grad, [c.weight.grad.clone() for c in convs], \
+        [bn.weight.grad.clone() for bn in bns], [bn.bias.grad.clone() for bn in bns]
+
+
+def _flat(res):
+    out, gx, gw, gg, gb = res
+    return [out, gx] + gw + gg + gb
+
+
+@pytest.mark.parametrize("M,pool_ns", [(65536, 0), (262144, 64), (262144, 0)])
+def test_stack_with_the_one_pass_layer_matches_the_three_launch_stack(M, pool_ns):
+    """A set-abstraction-like stack 16 -> 64 -> 64 -> 128: its middle layer runs on s2c_bn_bwd_dx_dw64 (no
+    dY tensor; from 131072 rows on -- the streaming forward GEMM -- no activation side output in the forward
+    either); every gradient against the same stack with FUSE_BWD_DX_DW off (which the stack tests of
+    tests/test_fused_gpu.py hold against torch; the kernel itself is held against float64 above -- a float64
+    run of the whole stack flips ReLU masks on knife-edge elements and is no reference for per-row gradients)."""
+    import copy
+    from scan2cap_amd.pointnet2 import fused
+    convs, bns = _stack()
+    x = torch.randn(M, 16, device="cuda")
+    rows = M // pool_ns if pool_ns else M
+    gout = torch.randn(rows, 128, device="cuda")
+    state = copy.deepcopy([bn.state_dict() for bn in bns])
+    calls = []
+    real = fused._call
+
+    def spy(name, *a, **k):
+        calls.append(name)
+        return real(name, *a, **k)
+    fused._call = spy
+    try:
+        new = _flat(_stack_grads(convs, bns, x, gout, pool_ns))
+    finally:
+        fused._call = real
+    # (the LAST layer, 64 -> 128, keeps the GEMM with the dY side output when it is not pooled)
+    assert calls.count("s2c_bn_bwd_dx_dw64") == 1
+    assert calls.count("s2c_bn_bwd_gemm_next_stats") == (0 if pool_ns else 1)
+    for bn, st in zip(bns, state):
+        bn.load_state_dict(st)
+    old_flag = fused.FUSE_BWD_DX_DW
+    fused.FUSE_BWD_DX_DW = False
+    try:
+        old = _flat(_stack_grads(convs, bns, x, gout, pool_ns))
+    finally:
+        fused.FUSE_BWD_DX_DW = old_flag
+    for a, b in zip(new, old):
+        assert ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item() < 2e-5
+
+
+def test_activation_not_kept_is_recomputed_when_the_backward_takes_another_path():
+    """The forward skips the activation side output expecting the one-pass backward; if the products are
+    switched to the exact fp32 chain in between, the backward materialises the activation itself."""
+    import copy
+    from scan2cap_amd.pointnet2 import fused
+    M = 65536
+    convs, bns = _stack(3)
+    x = torch.randn(M, 16, device="cuda")
+    gout = torch.randn(M, 128, device="cuda")
+    state = copy.deepcopy([bn.state_dict() for bn in bns])
+    ref = _flat(_stack_grads(convs, bns, x, gout, 0))
+    for bn, st in zip(bns, state):
+        bn.load_state_dict(st)
+    specs = [fused.LayerSpec(False, bn, True) for bn in bns]
+    params = []
+    for c, bn in zip(convs, bns):
+        params += [c.weight.view(c.weight.shape[0], -1), bn.weight, bn.bias]
+        c.weight.grad = bn.weight.grad = bn.bias.grad = None
+    xx = x.clone().requires_grad_(True)
+    out = fused.mlp_rows(xx, specs, params)
+    old_flag = fused.FUSE_BWD_DX_DW
+    fused.FUSE_BWD_DX_DW = False
+    try:
+        (out * gout).sum().backward()
+    finally:
+        fused.FUSE_BWD_DX_DW = old_flag
+    got = [out.detach(), xx.grad] + [c.weight.grad for c in convs] + [b.weight.grad for b in bns] \
+        + [b.bias.grad for b in bns]
+    for a, b in zip(got, ref):
+        assert ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item() < 2e-5
