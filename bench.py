@@ -113,6 +113,7 @@ KERNELS_OF = {
     "s2c_weight_grad": ("dw_x3_kernel",),
     "s2c_weight_grad_multi": ("dw_x3_multi_kernel",),
     "s2c_weight_grad_stream": ("dw_private_kernel",),
+    "s2c_bn_bwd_dx_dw64": ("bn_bwd_dx_dw64_kernel",),
     "s2c_small_gemm": ("sgemm_kernel",),
     "s2c_attn_local_fwd_planes": ("attn_local_kernel",),
     "s2c_ball_query": ("ball_query_kernel",),
@@ -485,7 +486,8 @@ GEMM_FAMILY = ("s2c_rows_gemm", "s2c_rows_gemm_bn_relu_side", "s2c_sa_gather_gem
                "s2c_bn_bwd_gemm", "s2c_bn_bwd_gemm_next_stats", "s2c_rows_gemm_next_stats",
                "s2c_rows_gemm_bn_eval", "s2c_sa_gather_gemm_bn_eval", "s2c_sa_fused_eval",
                # round 5: the backward products that were library GEMMs until then
-               "s2c_weight_grad", "s2c_weight_grad_multi", "s2c_weight_grad_stream", "s2c_small_gemm")
+               "s2c_weight_grad", "s2c_weight_grad_multi", "s2c_weight_grad_stream", "s2c_small_gemm",
+               "s2c_bn_bwd_dx_dw64")
 _DECODER_CHAIN = ("s2c_small_linear", "s2c_small_linear_pair", "s2c_gru_fwd", "s2c_attn_fwd",
                   "s2c_attn_bwd", "s2c_gru_gates_bwd", "s2c_attn_x2_fwd", "s2c_attn_bwd_x2",
                   "s2c_decoder_fwd_persist", "s2c_decoder_bwd_persist")

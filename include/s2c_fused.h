@@ -326,6 +326,14 @@ int s2c_bn_finalize_partials(int nblk, long long M, int C, const float *partial,
                              float *running_var, float *scale, float *shift,
                              float *save_mean, float *save_invstd,
                              long long *num_batches_tracked, void *stream);
+/* ... and Wt (Cin x C, contiguous) = the transpose of the layer's weight W (C x Cin, row stride ldw) out
+ * of the same launch: the operand of the backward's input-gradient GEMMs of the tall layers (a copy
+ * kernel per layer and step otherwise). */
+int s2c_bn_finalize_partials_wt(int nblk, long long M, int C, const float *partial, float eps,
+                                float momentum, const float *gamma, const float *beta,
+                                float *running_mean, float *running_var, float *scale, float *shift,
+                                float *save_mean, float *save_invstd, long long *num_batches_tracked,
+                                const float *W, int ldw, int Cin, float *Wt, void *stream);
 
 /* ---- teacher-forced top-down caption decoder (csrc/s2c_decoder.hip) -------
  * Small-batch (R <= a few dozen rows) building blocks of one recurrent step of

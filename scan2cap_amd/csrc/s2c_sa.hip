@@ -660,8 +660,13 @@ __global__ __launch_bounds__(FIN_BLOCK) void bn_finalize_kernel(
     const float *__restrict__ beta, float *__restrict__ running_mean,
     float *__restrict__ running_var, float *__restrict__ scale,
     float *__restrict__ shift, float *__restrict__ save_mean,
-    float *__restrict__ save_invstd, long long *__restrict__ num_batches_tracked) {
+    float *__restrict__ save_invstd, long long *__restrict__ num_batches_tracked,
+    const float *__restrict__ W, int ldw, int Cin, float *__restrict__ Wt) {
   const int c = blockIdx.x;
+  // Wt != nullptr: the layer's weight (C x Cin) leaves transposed as well (column c of Wt = row c of
+  // W): the backward's input-gradient GEMMs read W^T row-major -- a copy kernel per layer otherwise
+  if (Wt != nullptr)
+    for (int k = threadIdx.x; k < Cin; k += FIN_BLOCK) Wt[(size_t)k * C + c] = W[(size_t)c * ldw + k];
   double s1 = 0.0, s2 = 0.0;
   fin_column_sums(partial, nblk, C, c, s1, s2);
   block_sum2(s1, s2);
@@ -736,7 +741,8 @@ extern "C" int s2c_bn_train_stats(long long M, int C, const float *Y,
                      partial, rpb);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(FIN_BLOCK), 0, st,
                      partial, nb, C, M, eps, momentum, gamma, beta, running_mean,
-                     running_var, scale, shift, save_mean, save_invstd, num_batches_tracked);
+                     running_var, scale, shift, save_mean, save_invstd, num_batches_tracked,
+                     (const float *)nullptr, 0, 0, (float *)nullptr);
   return check2("bn_train_stats");
 }
 
@@ -753,8 +759,27 @@ extern "C" int s2c_bn_finalize_partials(int nblk, long long M, int C,
   if (nblk <= 0 || M <= 0 || C <= 0) return fail2("bn_finalize_partials sizes");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(FIN_BLOCK), 0, (hipStream_t)stream,
                      partial, nblk, C, M, eps, momentum, gamma, beta, running_mean,
-                     running_var, scale, shift, save_mean, save_invstd, num_batches_tracked);
+                     running_var, scale, shift, save_mean, save_invstd, num_batches_tracked,
+                     (const float *)nullptr, 0, 0, (float *)nullptr);
   return check2("bn_finalize_partials");
+}
+
+// ... and Wt (Cin x C, contiguous) = W^T of the layer's weight W (C x Cin, row stride ldw) out of the
+// same launch: what the backward's input-gradient GEMMs of the tall layers read
+extern "C" int s2c_bn_finalize_partials_wt(int nblk, long long M, int C, const float *partial,
+                                           float eps, float momentum, const float *gamma,
+                                           const float *beta, float *running_mean,
+                                           float *running_var, float *scale, float *shift,
+                                           float *save_mean, float *save_invstd,
+                                           long long *num_batches_tracked, const float *W, int ldw,
+                                           int Cin, float *Wt, void *stream) {
+  if (nblk <= 0 || M <= 0 || C <= 0 || !W || !Wt || Cin <= 0 || ldw < Cin)
+    return fail2("bn_finalize_partials_wt sizes");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(FIN_BLOCK), 0, (hipStream_t)stream,
+                     partial, nblk, C, M, eps, momentum, gamma, beta, running_mean,
+                     running_var, scale, shift, save_mean, save_invstd, num_batches_tracked, W, ldw,
+                     Cin, Wt);
+  return check2("bn_finalize_partials_wt");
 }
 
 extern "C" int s2c_bn_eval_coeffs(int C, float eps, const float *gamma,

@@ -43,6 +43,11 @@ _C.register("s2c_rows_gemm", [_L, _I, _I, _P, _I, _P, _I, _P, _P, _P, _I, _P, _P
 _C.register("s2c_sa_gather_gemm", [_I, _I, _I, _I, _I, _L, _L, _F, _I, _P, _P, _P, _P, _I, _P, _I, _P, _I, _P, _P])
 _C.register("s2c_rows_gemm_bn_relu_side", [_L, _I, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P])
 _C.register("s2c_bn_finalize_partials", [_I, _L, _I, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P])
+_C.register("s2c_bn_finalize_partials_wt", [_I, _L, _I, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                            _I, _I, _P, _P])
+# the transposed weight the backward's tall input-gradient GEMMs read (Y = A Wt^T kernels) leaves with the
+# forward's BatchNorm finalize launch of the same layer instead of a copy kernel per layer in the backward
+WT_FROM_FINALIZE = True
 _C.register("s2c_weight_grad", [_L, _I, _I, _P, _L, _P, _L, _P, _I, _P, _P, _P])
 _C.register("s2c_bn_relu_max_bwd", [_L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_bn_relu_bwd_stats", [_L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P])
@@ -210,12 +215,13 @@ def small_gemm(A, B, transposed, bias=None):
     return Y
 
 
-def _input_grad_gemm(dY, W):
+def _input_grad_gemm(dY, W, Wt=None):
     """dX (M, Cin) = dY (M, Cout) @ W (Cout, Cin) on the hand-written rows GEMM
-    (Y = A Wt^T with Wt = W^T)."""
+    (Y = A Wt^T with Wt = W^T; Wt: the forward's copy, if it made one)."""
     M, Cout = dY.shape
     Cin = W.shape[1]
-    Wt = W.t().contiguous()
+    if Wt is None:
+        Wt = W.t().contiguous()
     dX = torch.empty((M, Cin), device=dY.device)
     _call("s2c_rows_gemm", dX, M, Cin, Cout, dY.data_ptr(), dY.stride(0), Wt.data_ptr(),
           Wt.stride(0), None, None, dX.data_ptr(), Cin, None,
@@ -741,11 +747,25 @@ class _MLPRows(Function):
                 invstd = torch.empty(Cout, device=dev)
                 if gemm_stats and gpart is not None:
                     mom = bn.momentum if bn.momentum is not None else 0.0
-                    _call("s2c_bn_finalize_partials", gpart, nbg, M, Cout, gpart.data_ptr(),
-                          float(bn.eps), float(mom), _ptr(gamma), _ptr(beta),
-                          _ptr(bn.running_mean), _ptr(bn.running_var),
-                          scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
-                          invstd.data_ptr(), _ptr(bn.num_batches_tracked))
+                    if (WT_FROM_FINALIZE and need_grad and M >= 32768 and W.stride(1) == 1
+                            and W.dtype == torch.float32 and not from_gather
+                            and not act_from_prev and not (li == nl - 1 and pooled_raw is not None)):
+                        # (layers whose backward multiplies by W^T on the Y = A Wt^T kernels: not the
+                        # first layer of a grouped stack, not the one-pass and the pooled-algebra layers)
+                        Wt = torch.empty((W.shape[1], Cout), device=dev)
+                        rec["Wt"] = Wt
+                        _call("s2c_bn_finalize_partials_wt", gpart, nbg, M, Cout, gpart.data_ptr(),
+                              float(bn.eps), float(mom), _ptr(gamma), _ptr(beta),
+                              _ptr(bn.running_mean), _ptr(bn.running_var),
+                              scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+                              invstd.data_ptr(), _ptr(bn.num_batches_tracked), W.data_ptr(),
+                              W.stride(0), W.shape[1], Wt.data_ptr())
+                    else:
+                        _call("s2c_bn_finalize_partials", gpart, nbg, M, Cout, gpart.data_ptr(),
+                              float(bn.eps), float(mom), _ptr(gamma), _ptr(beta),
+                              _ptr(bn.running_mean), _ptr(bn.running_var),
+                              scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+                              invstd.data_ptr(), _ptr(bn.num_batches_tracked))
                 elif train_stats:
                     nb = _stat_blocks(M)
                     if partial is None or partial.numel() < nb * 2 * Cout:
@@ -965,7 +985,9 @@ class _MLPRows(Function):
                     elif takes_next:
                         # ... and the column sums of the PREVIOUS layer's BatchNorm backward out
                         # of the same GEMM's epilogue (its upstream gradient is this output)
-                        Wt = W.t().contiguous()
+                        Wt = rec.get("Wt")
+                        if Wt is None:
+                            Wt = W.t().contiguous()
                         nbg = _gemm_blocks(M, Cin)
                         npart = torch.empty(nbg * 2 * Cin, device=dev)
                         _call("s2c_bn_bwd_gemm_next_stats", Y, M, Cout, Cin, dA.data_ptr(),
@@ -980,7 +1002,9 @@ class _MLPRows(Function):
                               alg_flops=2 * M * Cout * Cin)
                         prestats = (npart, nbg)
                     else:
-                        Wt = W.t().contiguous()
+                        Wt = rec.get("Wt")
+                        if Wt is None:
+                            Wt = W.t().contiguous()
                         _call("s2c_bn_bwd_gemm", Y, M, Cout, Cin, dA.data_ptr(), Y.data_ptr(),
                               rec["scale"].data_ptr(), rec["shift"].data_ptr(),
                               rec["mean"].data_ptr(), rec["invstd"].data_ptr(), coef.data_ptr(),
@@ -1038,7 +1062,9 @@ class _MLPRows(Function):
                         and prev.get("Y") is not None and prev["Y"].shape == (M, Cin)
                         and prev["Y"].is_contiguous() and Cin % 4 == 0 and _gemm_split_on()):
                     # the previous layer's BN-backward column sums out of this GEMM's epilogue
-                    Wt = W.t().contiguous()
+                    Wt = rec.get("Wt")
+                    if Wt is None:
+                        Wt = W.t().contiguous()
                     nbg = _gemm_blocks(M, Cin)
                     npart = torch.empty(nbg * 2 * Cin, device=dev)
                     dX = torch.empty((M, Cin), device=dev)
@@ -1051,7 +1077,7 @@ class _MLPRows(Function):
                     if rc == 0:
                         dA, prestats = dX, (npart, nbg)
                 if dA is None:
-                    dA = _input_grad_gemm(dY, W)
+                    dA = _input_grad_gemm(dY, W, rec.get("Wt"))
             else:
                 dA = small_gemm(dY, W, False)
                 if dA is None:

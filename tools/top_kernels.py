@@ -15,8 +15,9 @@ CATS = [
     ("geometry: FPS (side stream)", ("fps_",)),
     ("geometry: ball query / 3-NN", ("ball_query", "three_nn")),
     ("decoder kernels", ("small_linear", "gru_", "attn_", "decoder_fwd_persist", "decoder_bwd_persist")),
-    ("BN stats/apply/pool (fwd+bwd)", ("bn_", "col_stats", "pool_bwd")),
-    ("hand MFMA GEMM", ("rows_gemm", "rows_stream_gemm", "dw_x3", "sa_fused_eval", "planes_gemm")),
+    ("BN stats/apply/pool (fwd+bwd)", ("bn_finalize", "bn_bwd_finalize", "bn_bwd_stats", "bn_bwd_apply", "bn_relu", "col_stats", "pool_bwd", "pool_select")),
+    ("hand MFMA GEMM", ("rows_gemm", "rows_stream_gemm", "dw_x3", "sa_fused_eval", "planes_gemm", "dw_private_kernel",
+                        "sgemm_kernel", "point_gemm_kernel", "bn_bwd_dx_dw64")),
     ("hand fp32 multi-GEMM", ("mgemm_kernel",)),
     ("gather/scatter rows, interpolate", ("sa_gather", "sa_scatter", "three_interpolate", "gather_points", "group_points")),
     ("library GEMM (Tensile)", ("Cijk_",)),
