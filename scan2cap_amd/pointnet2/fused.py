@@ -1068,6 +1068,10 @@ class _MLPRows(Function):
                     nbg = _gemm_blocks(M, Cin)
                     npart = torch.empty(nbg * 2 * Cin, device=dev)
                     dX = torch.empty((M, Cin), device=dev)
+                    if _C.TIMER.enabled:
+                        _C.TIMER.alg_bytes = 4 * M * (Cout + 2 * Cin)
+                        _C.TIMER.alg_flops = 2 * M * Cout * Cin
+                        _C.TIMER.label = None
                     rc = _C.call("s2c_rows_gemm_next_stats", M, Cin, Cout, dY.data_ptr(),
                                  dY.stride(0), Wt.data_ptr(), Wt.stride(0), dX.data_ptr(),
                                  prev["Y"].data_ptr(), prev["scale"].data_ptr(),
