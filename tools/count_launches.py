@@ -35,7 +35,7 @@ def sections():
             c = hist.setdefault(k, [0, 0.0]); c[0] += 1; c[1] += e.device_time / 1e3
         HIST[name] = hist
         return r
-    opt.zero_grad(set_to_none=False)
+    opt.zero_grad(set_to_none=True)      # as the bench step: fresh gradient tensors, no accumulate kernels
     run("backbone", lambda: model.backbone_net(dd))
     def vg():
         xyz = dd["fp2_xyz"]; f = dd["fp2_features"]
