@@ -606,6 +606,19 @@ int s2c_edge_scatter_grad(int B, int K, int L, int F, const float *d_out, const 
                           const long long *nbr, const unsigned char *slot, float *d_msg,
                           void *stream);
 
+/* The teacher-forced decoder's inputs in one launch (models/caption_module.py:250-292 with
+ * _add_relation_feat :394-414 restricted to the rows the decoder reads): target_feats (B x F) =
+ * obj[b, tgt[b]], local (B x L x F): local[b, l] = obj[b, id] + sum_t [nbr[b, tgt[b], t] == id]
+ * rel[b, tgt[b], t], id = local_ids[b, l].  obj (B x K x F), rel (B x K x LR x F) or NULL, nbr
+ * (B x K x LR), ids int64 (clamped to 0 .. K-1).  _grad: d_obj (B x K x F) and d_rel (B x K x LR x F,
+ * or NULL) written in full (no zero fill, no atomics: deterministic); d_target may be NULL. */
+int s2c_local_feats(int B, int K, int L, int LR, int F, const float *obj, const float *rel,
+                    const long long *nbr, const long long *tgt, const long long *local_ids,
+                    float *target_feats, float *local, void *stream);
+int s2c_local_feats_grad(int B, int K, int L, int LR, int F, const float *d_target,
+                         const float *d_local, const long long *nbr, const long long *tgt,
+                         const long long *local_ids, float *d_obj, float *d_rel, void *stream);
+
 /* Weight gradient of a rows x channels layer (autograd of the reference's 1x1 convolutions /
  * linears, lib/pointnet2/pytorch_utils.py:11-120): dW (Cout x Cin, row stride lddw) =
  * dY^T A with dY (M x Cout, row stride ldy) and A (M x Cin, row stride lda), fp32-accurate

@@ -319,3 +319,92 @@ extern "C" int s2c_edge_scatter_grad(int B, int K, int L, int F, const float *d_
                      (hipStream_t)stream, K, L, F, d_out, d_msgm, nbr, slot, d_msg, E);
   return chk_graph("edge_scatter_grad");
 }
+
+// ---------------------------------------------------------------------------------------
+// The teacher-forced decoder's inputs in one launch (models/caption_module.py:250-292 with
+// _add_relation_feat :394-414 restricted to the rows the decoder reads): target_feats[b] =
+// obj[b, tgt[b]] and local[b, l] = obj[b, id] + sum_t [nbr[b, tgt[b], t] == id] rel[b, tgt[b], t],
+// id = local_ids[b, l] -- what gather / clone / scatter_add_ / gather over the whole (B, K, F) tensor
+// produced in seven framework launches.  rel == nullptr: no relation rows (use_relation off).
+__global__ __launch_bounds__(256) void local_feats_kernel(
+    int K, int L, int LR, int F, const float *__restrict__ obj, const float *__restrict__ rel,
+    const long long *__restrict__ nbr, const long long *__restrict__ tgt,
+    const long long *__restrict__ local_ids, float *__restrict__ target_feats,
+    float *__restrict__ local) {
+  const int b = blockIdx.x / (L + 1), l = blockIdx.x % (L + 1);
+  long long t0 = tgt[b];
+  t0 = t0 < 0 ? 0 : (t0 >= K ? K - 1 : t0);
+  if (l == L) {
+    for (int f = threadIdx.x; f < F; f += blockDim.x)
+      target_feats[(size_t)b * F + f] = obj[((size_t)b * K + t0) * F + f];
+    return;
+  }
+  long long id = local_ids[(size_t)b * L + l];
+  id = id < 0 ? 0 : (id >= K ? K - 1 : id);
+  for (int f = threadIdx.x; f < F; f += blockDim.x) {
+    float v = obj[((size_t)b * K + id) * F + f];
+    if (rel != nullptr)
+      for (int t = 0; t < LR; ++t)
+        if (nbr[((size_t)b * K + t0) * LR + t] == id) v += rel[(((size_t)b * K + t0) * LR + t) * F + f];
+    local[((size_t)b * L + l) * F + f] = v;
+  }
+}
+
+// gradients of the above, every element of d_obj (B, K, F) and d_rel (B, K, LR, F) written (no zero
+// fill, no atomics): block = one proposal row (b, k)
+__global__ __launch_bounds__(256) void local_feats_grad_kernel(
+    int K, int L, int LR, int F, const float *__restrict__ d_target,
+    const float *__restrict__ d_local, const long long *__restrict__ nbr,
+    const long long *__restrict__ tgt, const long long *__restrict__ local_ids,
+    float *__restrict__ d_obj, float *__restrict__ d_rel) {
+  const int b = blockIdx.x / K, k = blockIdx.x % K;
+  long long t0 = tgt[b];
+  t0 = t0 < 0 ? 0 : (t0 >= K ? K - 1 : t0);
+  for (int f = threadIdx.x; f < F; f += blockDim.x) {
+    float v = 0.f;
+    for (int l = 0; l < L; ++l) {
+      long long id = local_ids[(size_t)b * L + l];
+      id = id < 0 ? 0 : (id >= K ? K - 1 : id);
+      if (id == k) v += d_local[((size_t)b * L + l) * F + f];
+    }
+    if (k == t0 && d_target != nullptr) v += d_target[(size_t)b * F + f];
+    d_obj[((size_t)b * K + k) * F + f] = v;
+    if (d_rel != nullptr)
+      for (int t = 0; t < LR; ++t) {
+        float r = 0.f;
+        if (k == t0) {
+          const long long idt = nbr[((size_t)b * K + t0) * LR + t];
+          for (int l = 0; l < L; ++l) {
+            long long id = local_ids[(size_t)b * L + l];
+            id = id < 0 ? 0 : (id >= K ? K - 1 : id);
+            if (id == idt) r += d_local[((size_t)b * L + l) * F + f];
+          }
+        }
+        d_rel[(((size_t)b * K + k) * LR + t) * F + f] = r;
+      }
+  }
+}
+
+extern "C" int s2c_local_feats(int B, int K, int L, int LR, int F, const float *obj, const float *rel,
+                               const long long *nbr, const long long *tgt,
+                               const long long *local_ids, float *target_feats, float *local,
+                               void *stream) {
+  if (B <= 0 || K <= 0 || L <= 0 || F <= 0 || !obj || !tgt || !local_ids || !target_feats || !local ||
+      (rel && (!nbr || LR <= 0)))
+    return -1;
+  hipLaunchKernelGGL(local_feats_kernel, dim3(B * (L + 1)), dim3(F >= 256 ? 256 : (F + 63) / 64 * 64), 0,
+                     (hipStream_t)stream, K, L, LR, F, obj, rel, nbr, tgt, local_ids, target_feats, local);
+  return chk_graph("local_feats");
+}
+
+extern "C" int s2c_local_feats_grad(int B, int K, int L, int LR, int F, const float *d_target,
+                                    const float *d_local, const long long *nbr, const long long *tgt,
+                                    const long long *local_ids, float *d_obj, float *d_rel,
+                                    void *stream) {
+  if (B <= 0 || K <= 0 || L <= 0 || F <= 0 || !d_local || !tgt || !local_ids || !d_obj ||
+      (d_rel && (!nbr || LR <= 0)))
+    return -1;
+  hipLaunchKernelGGL(local_feats_grad_kernel, dim3(B * K), dim3(F >= 256 ? 256 : (F + 63) / 64 * 64), 0,
+                     (hipStream_t)stream, K, L, LR, F, d_target, d_local, nbr, tgt, local_ids, d_obj, d_rel);
+  return chk_graph("local_feats_grad");
+}

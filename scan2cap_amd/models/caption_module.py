@@ -40,6 +40,64 @@ FUSE_EVAL_STEP = True
 # teacher-forced decoder with num_locals = L: attention over the L gathered objects instead of
 # all K with K - L of them masked (= False: the dense formulation)
 LOCAL_TRAIN_ATTENTION = True
+# the target's and its L local objects' features (relation rows added) in one launch forward and one
+# backward (csrc/s2c_graph.hip: s2c_local_feats) instead of gather / clone / scatter_add_ / gather over the
+# whole (B,K,F) tensor and their autograd nodes (7 + 9 framework launches); False: the torch ops
+FUSE_LOCAL_FEATS = True
+_P_, _I_ = ctypes.c_void_p, ctypes.c_int
+_C.register("s2c_local_feats", [_I_, _I_, _I_, _I_, _I_, _P_, _P_, _P_, _P_, _P_, _P_, _P_, _P_])
+_C.register("s2c_local_feats_grad", [_I_, _I_, _I_, _I_, _I_, _P_, _P_, _P_, _P_, _P_, _P_, _P_, _P_])
+
+
+class _LocalFeats(torch.autograd.Function):
+    """obj (B,K,F), rel (B,K,LR,F) | None, nbr (B,K,LR) int64 | None, target_ids (B,), local_ids (B,L)
+    -> target_feats (B,F) = obj[b, tgt], local (B,L,F) = (obj + relation rows of the target)[b, local_ids]
+    (caption_module.py:250-292, :394-414)."""
+
+    @staticmethod
+    def forward(ctx, obj, rel, nbr, target_ids, local_ids):
+        obj = obj.contiguous()
+        B, K, F_ = obj.shape
+        L = local_ids.shape[1]
+        tgt = target_ids.contiguous().view(B)
+        lid = local_ids.contiguous()
+        if rel is not None:
+            rel, nbr = rel.contiguous(), nbr.contiguous()
+            LR = rel.shape[2]
+        else:
+            LR = 0
+        tf = torch.empty((B, F_), device=obj.device)
+        local = torch.empty((B, L, F_), device=obj.device)
+        with torch.cuda.device(obj.device):
+            _C.call("s2c_local_feats", B, K, L, LR, F_, obj.data_ptr(),
+                    rel.data_ptr() if rel is not None else None,
+                    nbr.data_ptr() if rel is not None else None, tgt.data_ptr(), lid.data_ptr(),
+                    tf.data_ptr(), local.data_ptr(), _C.stream_ptr())
+        ctx.save_for_backward(nbr if rel is not None else tgt, tgt, lid)
+        ctx.dims = (B, K, L, LR, F_)
+        ctx.has_rel = rel is not None
+        ctx.set_materialize_grads(False)
+        return tf, local
+
+    @staticmethod
+    def backward(ctx, d_tf, d_local):
+        nbr, tgt, lid = ctx.saved_tensors
+        B, K, L, LR, F_ = ctx.dims
+        dev = tgt.device
+        if d_local is None:
+            d_local = torch.zeros((B, L, F_), device=dev)
+        d_local = d_local.contiguous()
+        d_tf = d_tf.contiguous() if d_tf is not None else None
+        d_obj = torch.empty((B, K, F_), device=dev)
+        want_rel = ctx.has_rel and ctx.needs_input_grad[1]
+        d_rel = torch.empty((B, K, LR, F_), device=dev) if want_rel else None
+        with torch.cuda.device(dev):
+            _C.call("s2c_local_feats_grad", B, K, L, LR, F_,
+                    d_tf.data_ptr() if d_tf is not None else None, d_local.data_ptr(),
+                    nbr.data_ptr() if ctx.has_rel else None, tgt.data_ptr(), lid.data_ptr(),
+                    d_obj.data_ptr(), d_rel.data_ptr() if d_rel is not None else None,
+                    _C.stream_ptr())
+        return d_obj, d_rel, None, None, None
 
 
 _C.register("s2c_select_target", [_I, _I, _P, _P, _P, _P, _P])
@@ -280,8 +338,6 @@ class TopDownSceneCaptionModule(nn.Module):
             target_ious = torch.ones(B, device=obj_feats.device)
         else:
             target_ids, target_ious = select_target(data_dict)
-        target_feats = torch.gather(
-            obj_feats, 1, target_ids.view(B, 1, 1).expand(B, 1, self.feat_size)).squeeze(1)
         local_ids = None
         if self.num_locals == -1:
             valid_masks = object_masks
@@ -290,9 +346,22 @@ class TopDownSceneCaptionModule(nn.Module):
                 data_dict["bbox_corner"], object_masks, target_ids.view(B, 1),
                 self.num_locals, self.query_mode, True, CONF.TRAIN.OVERLAID_THRESHOLD)
             valid_masks, local_ids = valid_masks.squeeze(1), local_ids.squeeze(1)   # (B,K), (B,L)
-        if self.use_relation:
-            obj_feats = self._add_relation_feat(
-                data_dict, obj_feats, target_ids.view(B, 1)).squeeze(1)
+        fused_local = None
+        if (FUSE_LOCAL_FEATS and local_ids is not None and LOCAL_TRAIN_ATTENTION and obj_feats.is_cuda
+                and obj_feats.dtype == torch.float32
+                and (not self.use_relation or data_dict.get("_adjacent_ids") is not None)
+                and decoder_fused.supported(self.emb_size, self.hidden_size, self.feat_size,
+                                            self.num_proposals)):
+            # the decoder reads the target's row and the L local rows only: one launch
+            target_feats, fused_local = _LocalFeats.apply(
+                obj_feats, data_dict["edge_feature"] if self.use_relation else None,
+                data_dict["_adjacent_ids"] if self.use_relation else None, target_ids, local_ids)
+        else:
+            target_feats = torch.gather(
+                obj_feats, 1, target_ids.view(B, 1, 1).expand(B, 1, self.feat_size)).squeeze(1)
+            if self.use_relation:
+                obj_feats = self._add_relation_feat(
+                    data_dict, obj_feats, target_ids.view(B, 1)).squeeze(1)
 
         if obj_feats.is_cuda and decoder_fused.supported(
                 self.emb_size, self.hidden_size, self.feat_size, self.num_proposals):
@@ -305,8 +374,8 @@ class TopDownSceneCaptionModule(nn.Module):
                 # scores, softmax, their backward), as the greedy decoder above already does;
                 # autograd scatters the local gradient back into the (B,K,F) features.
                 L = local_ids.shape[1]
-                local = torch.gather(obj_feats, 1,
-                                     local_ids.unsqueeze(-1).expand(B, L, self.feat_size))
+                local = fused_local if fused_local is not None else torch.gather(
+                    obj_feats, 1, local_ids.unsqueeze(-1).expand(B, L, self.feat_size))
                 ones = torch.ones(B, L, device=obj_feats.device)
                 lang_cap, attn_l = decoder_fused.decode(
                     self, word_embs, target_feats, local, ones, steps)
