@@ -716,7 +716,11 @@ typedef struct s2c_prep_args {
 int s2c_batch_prep(const s2c_prep_args *a, void *stream);
 
 /* Up to S2C_COLSUM_MAX_JOBS partial-sum jobs in one launch: out[j] (n[j]) = sum over the S[j]
- * slabs of part[j] (S[j] x n[j], dense), fixed order. */
+ * slabs of part[j] (S[j] x n[j], dense), fixed order.  part[j] may be out[j] itself (S = 1).
+ * sub[j] != NULL: out[j] is rows of ncol[j] elements, and the first sub_cols[j] columns of every row r
+ * become (sum - sum over the sub_S[j] slabs of sub[j][s][r][c]) / sub_div[j] (sub_div 0: no division) --
+ * the coordinate columns of a grouped first layer's weight gradient minus the centres' share, over the
+ * radius (pointnet2_utils.py:317-376: grouped_xyz -= new_xyz; /= radius) without launches of its own. */
 #define S2C_COLSUM_MAX_JOBS 32
 typedef struct s2c_colsum_args {
   int n_jobs;
@@ -724,6 +728,9 @@ typedef struct s2c_colsum_args {
   long long n[S2C_COLSUM_MAX_JOBS];
   const float *part[S2C_COLSUM_MAX_JOBS];
   float *out[S2C_COLSUM_MAX_JOBS];
+  const float *sub[S2C_COLSUM_MAX_JOBS];
+  int sub_S[S2C_COLSUM_MAX_JOBS], ncol[S2C_COLSUM_MAX_JOBS], sub_cols[S2C_COLSUM_MAX_JOBS];
+  float sub_div[S2C_COLSUM_MAX_JOBS];
 } s2c_colsum_args;
 int s2c_multi_colsum(const s2c_colsum_args *a, void *stream);
 

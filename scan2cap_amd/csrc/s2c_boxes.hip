@@ -367,8 +367,23 @@ __global__ __launch_bounds__(256) void multi_colsum_kernel(s2c_colsum_args a) {
       }
       s_ph[ph][el] = (s0 + s1) + (s2 + s3);
       __syncthreads();
-      if (ph == 0 && e < n)
-        a.out[j][e] = (s_ph[0][el] + s_ph[1][el]) + (s_ph[2][el] + s_ph[3][el]);
+      if (ph == 0 && e < n) {
+        float tot = (s_ph[0][el] + s_ph[1][el]) + (s_ph[2][el] + s_ph[3][el]);
+        if (a.sub[j] != nullptr) {
+          const int nc = a.ncol[j], sc = a.sub_cols[j];
+          const long long row = e / nc;
+          const int c = (int)(e - row * nc);
+          if (c < sc) {
+            const long long rows = n / nc;
+            const float *q = a.sub[j] + row * sc + c;
+            float t = 0.f;
+            for (int s = 0; s < a.sub_S[j]; ++s) t += q[(long long)s * rows * sc];
+            tot -= t;
+            if (a.sub_div[j] != 0.f) tot /= a.sub_div[j];
+          }
+        }
+        a.out[j][e] = tot;
+      }
       return;
     }
     blk -= nb;
@@ -382,6 +397,9 @@ extern "C" int s2c_multi_colsum(const s2c_colsum_args *a, void *stream) {
   long long blocks = 0;
   for (int j = 0; j < a->n_jobs; ++j) {
     if (!a->part[j] || !a->out[j] || a->S[j] <= 0 || a->n[j] <= 0) return -1;
+    if (a->sub[j] && (a->sub_S[j] <= 0 || a->ncol[j] <= 0 || a->sub_cols[j] <= 0 ||
+                      a->sub_cols[j] > a->ncol[j] || a->n[j] % a->ncol[j] != 0))
+      return -1;
     blocks += (a->n[j] + 63) / 64;
   }
   hipLaunchKernelGGL(multi_colsum_kernel, dim3((unsigned)blocks), dim3(256), 0,

@@ -1395,7 +1395,20 @@ class _ColsumArgs(ctypes.Structure):
     _fields_ = [("n_jobs", ctypes.c_int), ("S", ctypes.c_int * COLSUM_MAX_JOBS),
                 ("n", ctypes.c_longlong * COLSUM_MAX_JOBS),
                 ("part", ctypes.c_void_p * COLSUM_MAX_JOBS),
-                ("out", ctypes.c_void_p * COLSUM_MAX_JOBS)]
+                ("out", ctypes.c_void_p * COLSUM_MAX_JOBS),
+                ("sub", ctypes.c_void_p * COLSUM_MAX_JOBS),
+                ("sub_S", ctypes.c_int * COLSUM_MAX_JOBS), ("ncol", ctypes.c_int * COLSUM_MAX_JOBS),
+                ("sub_cols", ctypes.c_int * COLSUM_MAX_JOBS),
+                ("sub_div", ctypes.c_float * COLSUM_MAX_JOBS)]
+
+
+class _ColsumFix(object):
+    """An entry of a `pending` list: the first `other.shape[1]` columns of dW become (dW - other) / div
+    (div 0: no division) in the partial-sum launch that completes them -- `other` loses its own job."""
+    __slots__ = ("dW", "other", "div")
+
+    def __init__(self, dW, other, div):
+        self.dW, self.other, self.div = dW, other, float(div)
 
 
 _C.register("s2c_multi_colsum", [_P, _P])
@@ -1417,13 +1430,30 @@ def flush_partial_sums(pending):
         _launch_deferred_dw(jobs)
         pending[:] = [(e.part, e.dW) if isinstance(e, _DeferredDw) else e for e in pending
                       if not (isinstance(e, _DeferredDw) and e.part is None)]
-    for i in range(0, len(pending), COLSUM_MAX_JOBS):
-        chunk = pending[i:i + COLSUM_MAX_JOBS]
+    fixes = [e for e in pending if isinstance(e, _ColsumFix)]
+    sums = [e for e in pending if not isinstance(e, _ColsumFix)]
+    fix_of = {}
+    for f in fixes:
+        # the subtrahend's partial table (or, complete already, the tensor itself as one slab) moves into
+        # the minuend's job; a minuend written directly by its product gets a one-slab job of its own
+        k = next((i for i, (_, o) in enumerate(sums) if o is f.other), None)
+        sub = sums.pop(k)[0] if k is not None else f.other.view(1, *f.other.shape)
+        if not any(o is f.dW for _, o in sums):
+            sums.append((f.dW.view(1, *f.dW.shape), f.dW))
+        fix_of[id(f.dW)] = (sub, f)
+    for i in range(0, len(sums), COLSUM_MAX_JOBS):
+        chunk = sums[i:i + COLSUM_MAX_JOBS]
         a = _ColsumArgs()
         a.n_jobs = len(chunk)
         for j, (part, dW) in enumerate(chunk):
             a.S[j], a.n[j] = part.shape[0], dW.numel()
             a.part[j], a.out[j] = part.data_ptr(), dW.data_ptr()
+            fx = fix_of.get(id(dW))
+            if fx is not None:
+                sub, f = fx
+                assert dW.is_contiguous() and sub.is_contiguous() and sub.shape[1] == dW.shape[0]
+                a.sub[j], a.sub_S[j] = sub.data_ptr(), sub.shape[0]
+                a.ncol[j], a.sub_cols[j], a.sub_div[j] = dW.shape[1], sub.shape[2], f.div
         with torch.cuda.device(chunk[0][1].device):
             _C.call("s2c_multi_colsum", ctypes.byref(a), _C.stream_ptr())
     del pending[:]
@@ -1661,6 +1691,12 @@ class GatherSpec(object):
             dW = torch.empty((Cout, 3 + self.C), device=dev)
             dWp = _weight_grad(Z2, self.xyz.view(-1, 3), pending)
             dWf = _weight_grad(Z2, f2, pending) if f2 is not None else None
+
+        if (dWp is None and pending is not None and post is not None and BATCH_PARTIAL_SUMS
+                and dW.is_contiguous() and dWc.is_contiguous()):
+            # (dW[:, :3] - dWc) / radius leaves with the partial-sum launch that completes dW
+            pending.append(_ColsumFix(dW, dWc, self.radius if self.normalize else 0.0))
+            return dW
 
         def finish():
             x3 = dW[:, :3]                       # in-place ops on the view: no copy back
