@@ -15,16 +15,18 @@
 //   * persistent workgroups of 8 waves, every WAVE its own pipeline over 16-row chunks (chunk c to
 //     wave c % (8 grid)): the three row blocks of a chunk land in the wave's private LDS slot by
 //     LDS-DMA (12 x `global_load_lds_dwordx4`, SGPR base + a per-lane offset that never changes, the
-//     16-byte pieces XOR-swizzled by row on the SOURCE address), are read into registers in the four
+//     16-byte pieces XOR-swizzled by row on the SOURCE address), are read into registers in the
 //     layouts the products need, and the slot takes the wave's next chunk while this one is
 //     multiplied -- 8 x 12 KB in flight per CU, no workgroup barrier in the loop;
 //   * dX on v_mfma_f32_16x16x32_bf16 (16 rows x 64 columns, K = the 64 channels; W's bf16x3 planes
 //     resident in LDS in operand order, W read as stored: no transposed copy), dW on
 //     v_mfma_f32_32x32x16_bf16 (K = the chunk's 16 rows: a lane's 8 consecutive-k values are 8 ROWS
 //     of one column, read down the row-major chunk); fp32-accurate bf16x3 products (6 plane products,
-//     truncation split as in s2c_dwstream.hip); dY is formed twice, once per layout (5 VALU
-//     instructions per element against an LDS round trip);
-//   * the dX tile leaves through a wave-private LDS transposer as 256-byte rows (dwordx4 stores);
+//     truncation split as in s2c_dwstream.hip); dY is formed ONCE, in the column layout (a lane = one
+//     channel x 8 rows: its per-channel constants sit in registers), and crosses to dX's row layout
+//     through a wave-private 4 KB LDS transposer (forming it per layout re-read 28 x 16 B of constants
+//     per lane and chunk from LDS: 308 -> 256 us);
+//   * the dX tile leaves through the same transposer as 256-byte rows (dwordx4 stores);
 //   * one (64 x 64) dW partial and one [s1 | s2] row per WORKGROUP (the waves meet in LDS once, at
 //     the end); the caller's s2c_multi_colsum / s2c_bn_bwd_finalize_partials add them up
 //     (kernel-boundary reductions: deterministic).
