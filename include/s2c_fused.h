@@ -855,6 +855,13 @@ int s2c_weight_grad_stream_parts(long long M, int C, int N, const float *dY, lon
 int s2c_weight_grad_stream(long long M, int C, int N, const float *dY, long long ldy,
                            const float *A, long long lda, float *part, void *stream);
 int s2c_weight_grad_stream_set_grid(int workgroups);
+/* ... with the operand relu?(A pscale[n] + pshift[n]) formed on the way: a layer's input activation
+ * recomputed from the previous layer's pre-activation A (the arithmetic of the forward GEMM's
+ * BatchNorm + ReLU prologue), so that the forward writes no activation side output for this product.
+ * Shapes as s2c_weight_grad_stream_parts, except A == dY and single tiles with N <= 16 (-2). */
+int s2c_weight_grad_stream_act(long long M, int C, int N, const float *dY, long long ldy,
+                               const float *A, long long lda, const float *pscale,
+                               const float *pshift, int prelu, float *part, void *stream);
 
 /* ---- a 64 -> 64 BatchNorm(+ReLU) layer's backward in one pass (csrc/s2c_bnbwd_fused.hip, round 5) ---
  * dY = BatchNorm(+ReLU)-backward(dA, Y) (scale .. coef as for s2c_bn_bwd_gemm) is never written:

@@ -63,6 +63,10 @@ struct DwsArgs {
   int slot_bytes;
   long long nd;            // chunks 0 .. nd-1 are filled by DMA, nd .. nchunks-1 by guarded loads
   long long nchunks;       // 16-row chunks
+  // PRO instances: the operand is relu?(A pscale[n] + pshift[n]) -- a layer's input activation recomputed
+  // from the previous layer's pre-activation A (the arithmetic of the forward GEMM's prologue), so that
+  // the forward need not write the activation out for this product alone
+  const float *pscale, *pshift; int prelu;
 };
 
 struct Planes { bf16x8 p[3]; };
@@ -102,7 +106,7 @@ __device__ __forceinline__ void glds16s(const void *sbase, unsigned voff, unsign
                : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 
-template <int NIA, int S>
+template <int NIA, int S, bool PRO = false>
 __global__ __launch_bounds__(512, 1) void dw_private_kernel(DwsArgs p) {
   constexpr int C = 64, NIY = 4, NI = NIY + NIA;
   constexpr int NP = NIA == 1 ? 16 : 64;           // LDS row stride of the A region (floats)
@@ -137,6 +141,16 @@ __global__ __launch_bounds__(512, 1) void dw_private_kernel(DwsArgs p) {
     const int col = q * 4 < ncvp ? q * 4 : 0;     // columns past the operand: any valid address
     offa[j] = (unsigned)(row * (int)p.lda + col) * 4u;
   }
+  // PRO: this lane's two columns of A (li, li + 32 of its tile) and their constants
+  float psc[2] = {0.f, 0.f}, psh[2] = {0.f, 0.f};
+  if (PRO) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = tn * 64 + li + 32 * j;
+      if (col < N) { psc[j] = p.pscale[col]; psh[j] = p.pshift[col]; }
+    }
+  }
+  const int prelu = p.prelu;
   unsigned char *ring = smem + (size_t)wave * S * SLOT;
   const unsigned ring_lds = (unsigned)(size_t)ring;
   auto issue = [&](long long chunk, int slot) {
@@ -194,9 +208,14 @@ __global__ __launch_bounds__(512, 1) void dw_private_kernel(DwsArgs p) {
       }
       if (t >= 6 && t < 22) {
         const int f = (t - 6) >> 2, d = (t - 6) & 3;
-        const float x0 = f == 0 ? va[0][2 * d] : f == 1 ? va[1][2 * d] : f == 2 ? vb[0][2 * d] : vb[1][2 * d];
-        const float x1 = f == 0 ? va[0][2 * d + 1] : f == 1 ? va[1][2 * d + 1]
-                       : f == 2 ? vb[0][2 * d + 1] : vb[1][2 * d + 1];
+        float x0 = f == 0 ? va[0][2 * d] : f == 1 ? va[1][2 * d] : f == 2 ? vb[0][2 * d] : vb[1][2 * d];
+        float x1 = f == 0 ? va[0][2 * d + 1] : f == 1 ? va[1][2 * d + 1]
+                 : f == 2 ? vb[0][2 * d + 1] : vb[1][2 * d + 1];
+        if (PRO && f >= 2) {
+          x0 = x0 * psc[f - 2] + psh[f - 2];
+          x1 = x1 * psc[f - 2] + psh[f - 2];
+          if (prelu) { x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); }
+        }
         unsigned h, m, l;
         split_pair(x0, x1, h, m, l);
         asm volatile("" : "+v"(h), "+v"(m), "+v"(l));    // formed HERE, not sunk behind the MFMAs
@@ -347,11 +366,33 @@ extern "C" int s2c_weight_grad_stream_set_grid(int workgroups) {
   return old;
 }
 
+static int dws_launch(long long M, int C, int N, const float *dY, long long ldy, const float *A,
+                      long long lda, const float *pscale, const float *pshift, int prelu, float *part,
+                      void *stream);
+
 // dW partials: part[grid][C][N], every tile complete (the caller sums over the grid).
 extern "C" int s2c_weight_grad_stream(long long M, int C, int N, const float *dY, long long ldy,
                                       const float *A, long long lda, float *part, void *stream) {
+  return dws_launch(M, C, N, dY, ldy, A, lda, nullptr, nullptr, 0, part, stream);
+}
+
+// The same product with the operand relu?(A pscale[n] + pshift[n]) formed on the way (a layer's input
+// activation from the previous layer's pre-activation A: the forward keeps no copy of it); shapes as
+// s2c_weight_grad_stream_parts says, except A == dY and N <= 16 single tiles (-2).
+extern "C" int s2c_weight_grad_stream_act(long long M, int C, int N, const float *dY, long long ldy,
+                                          const float *A, long long lda, const float *pscale,
+                                          const float *pshift, int prelu, float *part, void *stream) {
+  if (!pscale || !pshift) return -2;
+  return dws_launch(M, C, N, dY, ldy, A, lda, pscale, pshift, prelu, part, stream);
+}
+
+static int dws_launch(long long M, int C, int N, const float *dY, long long ldy, const float *A,
+                      long long lda, const float *pscale, const float *pshift, int prelu, float *part,
+                      void *stream) {
   DwsArgs a;
   if (!part || !dws_plan(M, C, N, dY, ldy, A, lda, &a)) return -2;
+  if (pscale && a.ni != 8) return -2;
+  a.pscale = pscale; a.pshift = pshift; a.prelu = prelu;
   a.part = part;
   const int grid = dws_grid(a);
   static bool attr = false;
@@ -362,6 +403,8 @@ extern "C" int s2c_weight_grad_stream(long long M, int C, int N, const float *dY
         hipFuncSetAttribute((const void *)dw_private_kernel<0, 3>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
         hipFuncSetAttribute((const void *)dw_private_kernel<1, 3>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
+        hipFuncSetAttribute((const void *)dw_private_kernel<4, 2, true>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess) {
       (void)hipGetLastError();
       return -2;
@@ -372,7 +415,9 @@ extern "C" int s2c_weight_grad_stream(long long M, int C, int N, const float *dY
   size_t lds = (size_t)PW * a.S * a.slot_bytes + 1024;
   if (lds < (size_t)PW * 16384) lds = (size_t)PW * 16384;     // the waves' accumulators meet here
   const dim3 blk(64 * PW);
-  if (a.ni == 8)
+  if (a.ni == 8 && pscale)
+    hipLaunchKernelGGL((dw_private_kernel<4, 2, true>), dim3(grid), blk, lds, (hipStream_t)stream, a);
+  else if (a.ni == 8)
     hipLaunchKernelGGL((dw_private_kernel<4, 2>), dim3(grid), blk, lds, (hipStream_t)stream, a);
   else if (a.ni == 4)
     hipLaunchKernelGGL((dw_private_kernel<0, 3>), dim3(grid), blk, lds, (hipStream_t)stream, a);

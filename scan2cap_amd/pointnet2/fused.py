@@ -662,9 +662,11 @@ class _MLPRows(Function):
                 if deferred is not None:
                     pY, pscale, pshift, prelu = deferred
                     deferred = None
-                    A = torch.empty_like(pY)
                     src, K_in = pY, pY.shape[1]
-                    pro = (pscale.data_ptr(), pshift.data_ptr(), int(prelu), A.data_ptr(), K_in)
+                    if need_grad and pY.is_contiguous() and _dw_will_stream(M, Cout, K_in, pY):
+                        act_from_prev = "stream"   # no activation side output (DW_STREAM_ACT)
+                    A = None if act_from_prev else torch.empty_like(pY)
+                    pro = (pscale.data_ptr(), pshift.data_ptr(), int(prelu), _ptr(A), K_in)
                 else:
                     src, K_in = A, A.shape[1]
                     pro = (None, None, 0, None, 0)
@@ -700,6 +702,9 @@ class _MLPRows(Function):
                     and not (li == nl - 1 and pool_ns > 0) and pY.is_contiguous()
                     and _fused_bwd_pays(M, Cout, K_in) and M >= DW_STREAM_MIN_ROWS
                     and W.stride(1) == 1 and _gemm_split_on() and _bwd_dx_dw_parts(M) > 0)
+                if (not act_from_prev and need_grad and bn is not None and pY.is_contiguous()
+                        and _dw_will_stream(M, Cout, K_in, pY)):
+                    act_from_prev = "stream"       # ... or the streaming weight gradient does
                 A = None if act_from_prev else torch.empty_like(pY)
                 _call("s2c_rows_gemm_bn_relu_side", Y, M, Cout, K_in, pY.data_ptr(), pY.stride(0),
                       pscale.data_ptr(), pshift.data_ptr(), int(prelu), _ptr(A), K_in,
@@ -862,7 +867,9 @@ class _MLPRows(Function):
             dW_fused = None
             pre, prestats = prestats, None
             point_grads = None
-            if rec.get("act_from_prev"):
+            if rec.get("act_from_prev") == "stream":
+                pass    # the streaming weight gradient recomputes it (or it is materialised there)
+            elif rec.get("act_from_prev"):
                 # this layer's input was not kept: it is the previous layer's activation, which the
                 # one-pass kernel recomputes (any other branch below gets it materialised here)
                 if not (FUSE_BWD_DX_DW and FUSE_BWD_GEMM and BWD_STATS_IN_GEMM and _gemm_split_on()
@@ -1036,9 +1043,17 @@ class _MLPRows(Function):
             elif dW_fused is not None:
                 dW = dW_fused
             else:
+                dW = None
                 if A_in is None and rec.get("act_from_prev"):
-                    A_in = _activation_of(saved[li - 1])
-                dW = _weight_grad(dY, A_in, pending)
+                    prev = saved[li - 1]
+                    if (rec["act_from_prev"] == "stream" and DW_STREAM and dY.is_cuda
+                            and dY.dtype == torch.float32 and dY.stride(1) == 1):
+                        dW = _weight_grad_stream(dY, prev["Y"], pending,
+                                                 act=(prev["scale"], prev["shift"], prev["relu"]))
+                    if dW is None:
+                        A_in = _activation_of(prev)
+                if dW is None:
+                    dW = _weight_grad(dY, A_in, pending)
             dbias = None
             if rec["has_bias"]:
                 if BATCH_PARTIAL_SUMS and dY.is_cuda and dY.dtype == torch.float32 \
@@ -1412,6 +1427,7 @@ class _ColsumFix(object):
 
 
 _C.register("s2c_multi_colsum", [_P, _P])
+_C.register("s2c_weight_grad_stream_act", [_L, _I, _I, _P, _L, _P, _L, _P, _P, _I, _P, _P])
 BATCH_PARTIAL_SUMS = True
 
 
@@ -1509,34 +1525,59 @@ DW_STREAM = True
 DW_STREAM_MIN_ROWS = 32768
 
 
-def _dw_stream_parts(M, C, N, dY, A):
+def _dw_stream_parts(M, C, N, dY, A, ldy=None, lda=None):
     lib = _C.load()
     if not getattr(lib, "_dws_sized", False):
         lib.s2c_weight_grad_stream_parts.restype = _I
         lib.s2c_weight_grad_stream_parts.argtypes = [_L, _I, _I, _P, _L, _P, _L]
         lib._dws_sized = True
-    return lib.s2c_weight_grad_stream_parts(M, C, N, dY.data_ptr(), dY.stride(0), A.data_ptr(),
-                                            A.stride(0))
+    return lib.s2c_weight_grad_stream_parts(M, C, N, dY.data_ptr(),
+                                            dY.stride(0) if ldy is None else ldy, A.data_ptr(),
+                                            A.stride(0) if lda is None else lda)
 
 
-def _weight_grad_stream(dY, A, pending):
+def _weight_grad_stream(dY, A, pending, act=None):
     """dW (C, N) = dY^T A as per-workgroup partials of s2c_weight_grad_stream (summed by the
     caller's multi_colsum launch).  A: (M, N) rows with unit column stride, any row stride (a
-    column block of a wider tensor is read in place).  None: shape not taken."""
+    column block of a wider tensor is read in place).  act = (scale, shift, relu): the operand is
+    relu?(A scale + shift), formed on the way (s2c_weight_grad_stream_act).  None: shape not taken."""
     M, C = dY.shape
     N = A.shape[1]
     parts = _dw_stream_parts(M, C, N, dY, A)
-    if parts <= 0:
+    if parts <= 0 or (act is not None and (N <= 16 and C == 64)):
         return None
     dev = dY.device
     part = torch.empty((parts, C, N), dtype=torch.float32, device=dev)
     dW = torch.empty((C, N), dtype=torch.float32, device=dev)
     same = A.data_ptr() == dY.data_ptr() and A.stride(0) == dY.stride(0) and C == N
-    _call("s2c_weight_grad_stream", dW, M, C, N, dY.data_ptr(), dY.stride(0), A.data_ptr(),
-          A.stride(0), part.data_ptr(),
-          alg_bytes=4 * M * (C if same else C + N), alg_flops=2 * M * C * N)
+    if act is not None:
+        if same:
+            return None
+        rc = _C.call("s2c_weight_grad_stream_act", M, C, N, dY.data_ptr(), dY.stride(0), A.data_ptr(),
+                     A.stride(0), act[0].data_ptr(), act[1].data_ptr(), int(act[2]), part.data_ptr(),
+                     _C.stream_ptr(), allow=(-2,))
+        if rc != 0:
+            return None
+    else:
+        _call("s2c_weight_grad_stream", dW, M, C, N, dY.data_ptr(), dY.stride(0), A.data_ptr(),
+              A.stride(0), part.data_ptr(),
+              alg_bytes=4 * M * (C if same else C + N), alg_flops=2 * M * C * N)
     pending.append((part, dW))
     return dW
+
+
+# A layer's input activation kept by the forward ONLY for its weight gradient (the side output of the
+# BatchNorm + ReLU prologue GEMMs) is not written where that gradient runs on the streaming kernel: the
+# kernel recomputes it from the previous layer's pre-activation (s2c_weight_grad_stream_act)
+DW_STREAM_ACT = True
+
+
+def _dw_will_stream(M, C, N, ref):
+    """Does _weight_grad send (M, C, N) to the streaming kernel?  (its dispatch, in its order; `ref`: a
+    tensor with the alignment the operands will have)"""
+    return bool(DW_STREAM and DW_STREAM_ACT and BATCH_PARTIAL_SUMS and not USE_DW_KERNEL
+                and not _hand_dw_pays(M, C, N) and M >= DW_STREAM_MIN_ROWS and not (N <= 16 and C == 64)
+                and _dw_stream_parts(M, C, N, ref, ref, ldy=C, lda=N) > 0)
 
 
 def _weight_grad(dY, A, pending=None):

@@ -136,3 +136,78 @@ def test_default_weight_grad_takes_the_streaming_kernel_for_tall_layers():
     finally:
         fused._weight_grad_stream = orig
     assert calls and (dW.double() - dY.double().t() @ A.double()).abs().max() < 1e-2
+
+
+@pytest.mark.parametrize("M,C,N,relu", [(262144, 128, 128, 1), (65536, 256, 128, 1), (131072, 64, 64, 0),
+                                        (32768 + 48, 128, 70, 1), (1 << 20, 64, 64, 1)])
+def test_weight_grad_stream_with_the_activation_formed_on_the_way(M, C, N, relu):
+    """dW = dY^T relu?(P scale + shift) (s2c_weight_grad_stream_act): the operand is the previous layer's
+    pre-activation, the activation is never materialised; against float64 over the float32 activation."""
+    from scan2cap_amd.pointnet2 import fused
+    torch.manual_seed(M % 977 + C + N)
+    dY = torch.randn(M, C, device="cuda")
+    P = torch.randn(M, N, device="cuda") * 0.9 - 0.2
+    scale = torch.randn(N, device="cuda") * 0.5 + 1.0
+    shift = torch.randn(N, device="cuda") * 0.3
+    scale[1] = -0.6
+    pend = []
+    dW = fused._weight_grad_stream(dY, P, pend, act=(scale, shift, relu))
+    assert dW is not None
+    fused.flush_partial_sums(pend)
+    act = P * scale + shift
+    if relu:
+        act = torch.relu(act)
+    want = dY.double().t() @ act.double()
+    sc = (dY.double().norm(dim=0)[:, None] * act.double().norm(dim=0)[None, :]).clamp_min(1e-30)
+    assert ((dW.double() - want).abs() / sc).max().item() < 2e-6
+
+
+def test_stack_without_activation_side_outputs_matches_the_stack_that_keeps_them():
+    """A 16 -> 128 -> 128 -> 256 stack over 262144 rows (SA2's shapes): with DW_STREAM_ACT the forward
+    writes no activation side output for the layers whose weight gradient streams; every output and
+    gradient equals the stack that keeps them."""
+    import copy
+    from scan2cap_amd.pointnet2 import fused
+    torch.manual_seed(4)
+    M = 262144
+    convs = [torch.nn.Conv1d(a, b, 1, bias=False).cuda() for a, b in ((16, 128), (128, 128), (128, 256))]
+    bns = [torch.nn.BatchNorm1d(c).cuda() for c in (128, 128, 256)]
+    x = torch.randn(M, 16, device="cuda")
+    state = copy.deepcopy([bn.state_dict() for bn in bns])
+
+    def run(pool_ns, gout):
+        for bn, st in zip(bns, state):
+            bn.load_state_dict(st)
+        specs = [fused.LayerSpec(False, bn, True) for bn in bns]
+        params = []
+        for c, bn in zip(convs, bns):
+            params += [c.weight.view(c.weight.shape[0], -1), bn.weight, bn.bias]
+            c.weight.grad = bn.weight.grad = bn.bias.grad = None
+        xx = x.clone().requires_grad_(True)
+        out = fused.mlp_rows(xx, specs, params, pool_ns=pool_ns)
+        (out * gout).sum().backward()
+        return [out.detach(), xx.grad] + [c.weight.grad.clone() for c in convs] + \
+            [b.weight.grad.clone() for b in bns] + [b.bias.grad.clone() for b in bns]
+
+    for pool_ns in (0, 32):
+        gout = torch.randn(M // pool_ns if pool_ns else M, 256, device="cuda")
+        seen = []
+        real = fused._weight_grad_stream
+
+        def spy(dY, A, pending, act=None):
+            seen.append(act is not None)
+            return real(dY, A, pending, act=act)
+        fused._weight_grad_stream = spy
+        try:
+            new = run(pool_ns, gout)
+        finally:
+            fused._weight_grad_stream = real
+        assert any(seen), "no weight gradient took the activation-on-the-way kernel"
+        old_flag = fused.DW_STREAM_ACT
+        fused.DW_STREAM_ACT = False
+        try:
+            old = run(pool_ns, gout)
+        finally:
+            fused.DW_STREAM_ACT = old_flag
+        for a, b in zip(new, old):
+            assert ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item() < 2e-5
