@@ -158,6 +158,7 @@ int s2c_pool_bwd_input_grad_next_stats(long long M, int N, int KA, int C3, int n
                                        int ldd, const float *nY, const float *nscale,
                                        const float *nshift, const float *nmean,
                                        const float *ninvstd, int nrelu, float *npartial,
+                                       const float *pscale, const float *pshift, int prelu,
                                        void *stream);
 int s2c_rows_gemm_next_stats(long long M, int N, int K, const float *A, int lda, const float *W,
                              int ldw, float *Y, const float *nY, const float *nscale,
@@ -247,12 +248,17 @@ int s2c_pool_bwd_prep(int C3, int K, const float *coef, const float *mean, const
 int s2c_pool_bwd_final(int C3, int K, const float *partial_sum, const float *gram,
                        const float *W, const float *coef, const float *mean, const float *invstd,
                        float *dW, void *stream);
+/* pscale / pshift (both or NULL) in the three calls below: A is the PREVIOUS layer's pre-activation and the
+ * layer's input relu?(A pscale + pshift) is formed on the way (the forward kept no copy of it);
+ * s2c_pool_bwd_input_grad*: KA <= 64 and ns >= 32 then (-2 otherwise). */
 int s2c_pool_bwd_sp(long long J, int ns, int C3, int K, const float *A, const int *arg,
-                    const float *dk, float *partial, void *stream);
+                    const float *dk, float *partial, const float *pscale, const float *pshift,
+                    int prelu, void *stream);
 int s2c_pool_bwd_supported(long long M, int N, int KA, int C3);   /* 1: the call below takes it */
 int s2c_pool_bwd_input_grad(long long M, int N, int KA, int C3, int ns, const float *A, int lda,
                             const short *arg16, const float *dk, const float *Wcat, int ldw,
-                            const float *cvec, float *dA, int ldd, void *stream);
+                            const float *cvec, float *dA, int ldd, const float *pscale,
+                            const float *pshift, int prelu, void *stream);
 /* workgroups of the streaming kernel's persistent grid (default 240): leave out the CUs held
  * by kernels that run beside it on other streams (one FPS workgroup per scene).  Returns the
  * previous value; workgroups <= 0 only queries. */
@@ -858,7 +864,8 @@ int s2c_weight_grad_stream_set_grid(int workgroups);
 /* ... with the operand relu?(A pscale[n] + pshift[n]) formed on the way: a layer's input activation
  * recomputed from the previous layer's pre-activation A (the arithmetic of the forward GEMM's
  * BatchNorm + ReLU prologue), so that the forward writes no activation side output for this product.
- * Shapes as s2c_weight_grad_stream_parts, except A == dY and single tiles with N <= 16 (-2). */
+ * Shapes as s2c_weight_grad_stream_parts, except single tiles with N <= 16 (-2); A == dY: the Gram matrix
+ * of the activation (both operands transformed). */
 int s2c_weight_grad_stream_act(long long M, int C, int N, const float *dY, long long ldy,
                                const float *A, long long lda, const float *pscale,
                                const float *pshift, int prelu, float *part, void *stream);

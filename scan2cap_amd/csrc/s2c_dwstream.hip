@@ -211,9 +211,9 @@ __global__ __launch_bounds__(512, 1) void dw_private_kernel(DwsArgs p) {
         float x0 = f == 0 ? va[0][2 * d] : f == 1 ? va[1][2 * d] : f == 2 ? vb[0][2 * d] : vb[1][2 * d];
         float x1 = f == 0 ? va[0][2 * d + 1] : f == 1 ? va[1][2 * d + 1]
                  : f == 2 ? vb[0][2 * d + 1] : vb[1][2 * d + 1];
-        if (PRO && f >= 2) {
-          x0 = x0 * psc[f - 2] + psh[f - 2];
-          x1 = x1 * psc[f - 2] + psh[f - 2];
+        if (PRO && (f >= 2 || NIA == 0)) {       // NIA == 0 (A is dY, the Gram matrix): both operands
+          x0 = x0 * psc[f & 1] + psh[f & 1];
+          x1 = x1 * psc[f & 1] + psh[f & 1];
           if (prelu) { x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); }
         }
         unsigned h, m, l;
@@ -378,7 +378,7 @@ extern "C" int s2c_weight_grad_stream(long long M, int C, int N, const float *dY
 
 // The same product with the operand relu?(A pscale[n] + pshift[n]) formed on the way (a layer's input
 // activation from the previous layer's pre-activation A: the forward keeps no copy of it); shapes as
-// s2c_weight_grad_stream_parts says, except A == dY and N <= 16 single tiles (-2).
+// s2c_weight_grad_stream_parts says, except N <= 16 single tiles (-2); A == dY: the activation's Gram matrix.
 extern "C" int s2c_weight_grad_stream_act(long long M, int C, int N, const float *dY, long long ldy,
                                           const float *A, long long lda, const float *pscale,
                                           const float *pshift, int prelu, float *part, void *stream) {
@@ -391,7 +391,7 @@ static int dws_launch(long long M, int C, int N, const float *dY, long long ldy,
                       void *stream) {
   DwsArgs a;
   if (!part || !dws_plan(M, C, N, dY, ldy, A, lda, &a)) return -2;
-  if (pscale && a.ni != 8) return -2;
+  if (pscale && a.ni != 8 && a.ni != 4) return -2;      // (ni 4: A == dY, the Gram matrix of the activation)
   a.pscale = pscale; a.pshift = pshift; a.prelu = prelu;
   a.part = part;
   const int grid = dws_grid(a);
@@ -405,6 +405,8 @@ static int dws_launch(long long M, int C, int N, const float *dY, long long ldy,
         hipFuncSetAttribute((const void *)dw_private_kernel<1, 3>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
         hipFuncSetAttribute((const void *)dw_private_kernel<4, 2, true>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
+        hipFuncSetAttribute((const void *)dw_private_kernel<0, 3, true>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess) {
       (void)hipGetLastError();
       return -2;
@@ -419,6 +421,8 @@ static int dws_launch(long long M, int C, int N, const float *dY, long long ldy,
     hipLaunchKernelGGL((dw_private_kernel<4, 2, true>), dim3(grid), blk, lds, (hipStream_t)stream, a);
   else if (a.ni == 8)
     hipLaunchKernelGGL((dw_private_kernel<4, 2>), dim3(grid), blk, lds, (hipStream_t)stream, a);
+  else if (a.ni == 4 && pscale)
+    hipLaunchKernelGGL((dw_private_kernel<0, 3, true>), dim3(grid), blk, lds, (hipStream_t)stream, a);
   else if (a.ni == 4)
     hipLaunchKernelGGL((dw_private_kernel<0, 3>), dim3(grid), blk, lds, (hipStream_t)stream, a);
   else

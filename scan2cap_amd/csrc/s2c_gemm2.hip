@@ -226,6 +226,12 @@ __global__ __launch_bounds__(64 * WAVES, (NT == 4 && WAVES == 4) ? 1 : 2) void r
     // only ever hold zeros or stale FINITE activations, and meet zero weights
     for (int e = lane; e < (SLOTS * CHUNK_BYTES + AUXB) / 16; e += 64)
       reinterpret_cast<uint4 *>(mine)[e] = make_uint4(0, 0, 0, 0);
+    if (PRO == SPRO_POOLBWD && p.scale != nullptr) {
+      // the operand's BatchNorm + ReLU constants (KA <= 64, pb_ns >= 32: the second centre's half of this
+      // wave's dk buffer is never written by issue_pb) -- a copy per wave, same-wave program order
+      pb_dkbuf[128 + lane] = lane < KA ? p.scale[lane] : 1.f;
+      pb_dkbuf[192 + lane] = lane < KA ? p.shift[lane] : 0.f;
+    }
   }
   __syncthreads();
 
@@ -433,7 +439,11 @@ __global__ __launch_bounds__(64 * WAVES, (NT == 4 && WAVES == 4) ? 1 : 2) void r
         if (issue_next()) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * DEPTH) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (sp_on) sp_wait += SP_NOW() - sp_a;
-        if (PRO == SPRO_BNRELU) {
+        if (PRO == SPRO_BNRELU || (PRO == SPRO_POOLBWD && p.scale != nullptr)) {
+          // (SPRO_POOLBWD with scale: the layer's input activation is recomputed from the previous
+          // layer's pre-activation -- the forward kept no copy of it)
+          const float *c_scale = PRO == SPRO_BNRELU ? s_scale : pb_dkbuf + 128;
+          const float *c_shift = PRO == SPRO_BNRELU ? s_shift : pb_dkbuf + 192;
           // BatchNorm + ReLU applied in place on the landed chunk, every lane on the four
           // 16-byte pieces it requested (row-coalesced for the side store), before any
           // operand read of this wave (same wave: LDS operations stay in program order)
@@ -445,8 +455,8 @@ __global__ __launch_bounds__(64 * WAVES, (NT == 4 && WAVES == 4) ? 1 : 2) void r
             if (k < KA) {
               float4 *pos = reinterpret_cast<float4 *>(const_cast<unsigned char *>(sl) + i * 1024 + lane * 16);
               float4 v = *pos;
-              const float4 sc = *reinterpret_cast<const float4 *>(s_scale + k);
-              const float4 sh = *reinterpret_cast<const float4 *>(s_shift + k);
+              const float4 sc = *reinterpret_cast<const float4 *>(c_scale + k);
+              const float4 sh = *reinterpret_cast<const float4 *>(c_shift + k);
               v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y;
               v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
               if (p.relu) {
@@ -1013,6 +1023,14 @@ extern "C" int s2c_pool_bwd_supported(long long M, int N, int KA, int C3) {
          pick_cfg(M, N, KA + C3, SPRO_POOLBWD) >= 0;
 }
 
+// pscale / pshift (both or neither): the operand's first KA columns are relu?(A pscale + pshift), the
+// layer's input recomputed from the previous layer's pre-activation A.  The constants live in the half of
+// a wave's dk buffer that only ns = 16 uses, 64 floats each.
+static bool pb_act_ok(const float *pscale, const float *pshift, int KA, int ns) {
+  if (!pscale && !pshift) return true;
+  return pscale && pshift && KA <= 64 && ns >= 32;
+}
+
 // dA (M x N) = [A | dkrow] [-G^T | W3^T]^T + cvec  (see StreamArgs::pb_arg): the input gradient
 // of a max-pooled BatchNorm(+ReLU) layer from the layer's INPUT activation A (M x KA), the
 // routed pooled gradient dk / arg (J x C3) and Wcat (N x (KA + C3)), bias cvec (N).  KA % 16 == 0,
@@ -1020,17 +1038,19 @@ extern "C" int s2c_pool_bwd_supported(long long M, int N, int KA, int C3) {
 extern "C" int s2c_pool_bwd_input_grad(long long M, int N, int KA, int C3, int ns, const float *A,
                                        int lda, const short *arg, const float *dk,
                                        const float *Wcat, int ldw, const float *cvec, float *dA,
-                                       int ldd, void *stream) {
+                                       int ldd, const float *pscale, const float *pshift, int prelu,
+                                       void *stream) {
   if (M <= 0 || N <= 0 || KA <= 0 || C3 <= 0 || !A || !arg || !dk || !Wcat || !dA ||
       lda < KA || ldw < KA + C3 || !(ns == 16 || ns == 32 || ns == 64) || M % ns)
     return -1;
   if (!stream_on() || (KA & 15) || (C3 & 7) || C3 > 128 || (lda & 3) || ((uintptr_t)A & 15) ||
       (ldd & 3) || ((uintptr_t)dA & 15) || ((uintptr_t)arg & 15) || ((uintptr_t)dk & 15) ||
-      pick_cfg(M, N, KA + C3, SPRO_POOLBWD) < 0)
+      pick_cfg(M, N, KA + C3, SPRO_POOLBWD) < 0 || !pb_act_ok(pscale, pshift, KA, ns))
     return -2;
   StreamArgs a = {};
   a.M = M; a.N = N; a.K = KA + C3; a.A = A; a.lda = lda; a.W = Wcat; a.ldw = ldw; a.Y = dA; a.ldy = ldd;
   a.pb_arg = arg; a.pb_dk = dk; a.bias = cvec; a.pb_ka = KA; a.pb_c3 = C3; a.pb_ns = ns;
+  a.scale = pscale; a.shift = pshift; a.relu = prelu;
   return launch_stream<SPRO_POOLBWD>(a, (hipStream_t)stream);
 }
 
@@ -1044,20 +1064,22 @@ extern "C" int s2c_pool_bwd_input_grad_next_stats(long long M, int N, int KA, in
                                                   const float *nY, const float *nscale,
                                                   const float *nshift, const float *nmean,
                                                   const float *ninvstd, int nrelu,
-                                                  float *npartial, void *stream) {
+                                                  float *npartial, const float *pscale,
+                                                  const float *pshift, int prelu, void *stream) {
   if (M <= 0 || N <= 0 || KA <= 0 || C3 <= 0 || !A || !arg || !dk || !Wcat || !dA ||
       lda < KA || ldw < KA + C3 || !(ns == 16 || ns == 32 || ns == 64) || M % ns || ldd != N ||
       !nY || !nscale || !nshift || !nmean || !ninvstd || !npartial)
     return -1;
   if (!stream_on() || (KA & 15) || (C3 & 7) || C3 > 128 || (lda & 3) || ((uintptr_t)A & 15) ||
       (ldd & 3) || ((uintptr_t)dA & 15) || ((uintptr_t)arg & 15) || ((uintptr_t)dk & 15) ||
-      pick_cfg(M, N, KA + C3, SPRO_POOLBWD) < 0)
+      pick_cfg(M, N, KA + C3, SPRO_POOLBWD) < 0 || !pb_act_ok(pscale, pshift, KA, ns))
     return -2;
   StreamArgs a = {};
   a.M = M; a.N = N; a.K = KA + C3; a.A = A; a.lda = lda; a.W = Wcat; a.ldw = ldw; a.Y = dA; a.ldy = ldd;
   a.pb_arg = arg; a.pb_dk = dk; a.bias = cvec; a.pb_ka = KA; a.pb_c3 = C3; a.pb_ns = ns;
   a.nY = nY; a.nscale = nscale; a.nshift = nshift; a.nmean = nmean; a.ninvstd = ninvstd;
   a.nrelu = nrelu; a.partial = npartial; a.partial_rows = s2c_rows_gemm_blocks(M, N);
+  a.scale = pscale; a.shift = pshift; a.relu = prelu;
   return launch_stream<SPRO_POOLBWD>(a, (hipStream_t)stream);
 }
 

@@ -1202,11 +1202,21 @@ __device__ __forceinline__ void sp_glds16(const void *gsrc, unsigned lds_dst) {
 // one `s_waitcnt vmcnt` immediate serves all of them.
 __global__ __launch_bounds__(256) void pool_bwd_sp_kernel(
     long long J, int ns, int C3, int K, const float *__restrict__ A, const int *__restrict__ arg,
-    const float *__restrict__ dk, float *__restrict__ partial) {
+    const float *__restrict__ dk, float *__restrict__ partial, const float *__restrict__ pscale,
+    const float *__restrict__ pshift, int prelu) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int k = tid % K, grp = tid / K;                  // 256 / K channel groups
+  // pscale != nullptr: the tile holds the previous layer's pre-activation; this thread's column k of
+  // the layer's input is relu?(x pscale[k] + pshift[k])
+  const bool pro = pscale != nullptr;
+  const float psc = pro ? pscale[k] : 1.f, psh = pro ? pshift[k] : 0.f;
+  auto act = [&](float x) {
+    if (!pro) return x;
+    x = x * psc + psh;
+    return prelu ? fmaxf(x, 0.f) : x;
+  };
   const int tile_bytes = ns * K * 4;                     // multiple of 4096
   const int slot_bytes = tile_bytes + 1024;              // + dk[<=128] | arg[<=128]
   const int TI = tile_bytes / 4096;                      // DMA instructions per wave and tile
@@ -1249,12 +1259,12 @@ __global__ __launch_bounds__(256) void pool_bwd_sp_kernel(
     const float *s_dk = s_t + ns * K;
     const int *s_arg = reinterpret_cast<const int *>(s_dk + 128);
     if (grp == 0)
-      for (int rr = 0; rr < ns; ++rr) csum += s_t[rr * K + k];
+      for (int rr = 0; rr < ns; ++rr) csum += act(s_t[rr * K + k]);
     const int c0 = grp * SP_CG;
 #pragma unroll
     for (int i = 0; i < SP_CG; ++i) {
       const int c = c0 + i;
-      if (c < C3) acc[i] += s_dk[c] * s_t[s_arg[c] * K + k];
+      if (c < C3) acc[i] += s_dk[c] * act(s_t[s_arg[c] * K + k]);
     }
     __builtin_amdgcn_s_barrier();                        // slot free for the request after next
     slot = slot + 1 == SP_RING ? 0 : slot + 1;
@@ -1370,14 +1380,16 @@ extern "C" int s2c_pool_bwd_sp_blocks(long long J) { return J < 768 ? (int)J : 7
 // partial: s2c_pool_bwd_sp_blocks(J) x (C3 * K + K) floats (SP | column sums of A).
 // K in {32, 64, 128, 256}, C3 <= (256 / K) * 32, ns * K * 4 bytes of LDS (<= 64 KB).
 extern "C" int s2c_pool_bwd_sp(long long J, int ns, int C3, int K, const float *A, const int *arg,
-                               const float *dk, float *partial, void *stream) {
+                               const float *dk, float *partial, const float *pscale,
+                               const float *pshift, int prelu, void *stream) {
+  if ((pscale == nullptr) != (pshift == nullptr)) return fail2("pool_bwd_sp: pscale / pshift");
   if (J <= 0 || ns <= 0 || C3 <= 0 || !(K == 32 || K == 64 || K == 128 || K == 256) ||
       C3 > (256 / K) * SP_CG || C3 > 128 || (C3 & 3) || (ns * K * 4) % 4096 || ns * K * 4 > 16384 ||
       !A || !arg || !dk || !partial || ((uintptr_t)A & 15) || ((uintptr_t)dk & 15) || ((uintptr_t)arg & 15))
     return fail2("pool_bwd_sp: sizes / null pointer");
   const size_t lds = (size_t)SP_RING * ((size_t)ns * K * 4 + 1024);
   hipLaunchKernelGGL(pool_bwd_sp_kernel, dim3(s2c_pool_bwd_sp_blocks(J)), dim3(256), lds,
-                     (hipStream_t)stream, J, ns, C3, K, A, arg, dk, partial);
+                     (hipStream_t)stream, J, ns, C3, K, A, arg, dk, partial, pscale, pshift, prelu);
   return check2("pool_bwd_sp");
 }
 

@@ -373,7 +373,7 @@ def _bwd_dx_dw_parts(M):
         lib._fb_sized = True
     return lib.s2c_bn_bwd_dx_dw64_parts(M)
 _C.register("s2c_pool_bwd_input_grad_next_stats", [_L, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _P, _I,
-                                                   _P, _P, _P, _P, _P, _I, _P, _P])
+                                                   _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P])
 _C.register("s2c_rows_gemm_next_stats", [_L, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P])
 _C.register("s2c_bn_relu_bwd_apply", [_L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P])
 # the column sums of a layer's BatchNorm backward out of the epilogue of the GEMM that produces
@@ -385,10 +385,11 @@ BWD_STATS_IN_GEMM = True
 POOL_EXT_IN_GEMM = True
 _C.register("s2c_bn_relu_max_bwd_stats", [_L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P])
 _C.register("s2c_pool_bwd_dk", [_L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P])
-_C.register("s2c_pool_bwd_sp", [_L, _I, _I, _I, _P, _P, _P, _P, _P])
+_C.register("s2c_pool_bwd_sp", [_L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P])
 _C.register("s2c_pool_bwd_prep", [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_pool_bwd_final", [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P])
-_C.register("s2c_pool_bwd_input_grad", [_L, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _P, _I, _P])
+_C.register("s2c_pool_bwd_input_grad", [_L, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P, _P, _I, _P, _P, _I,
+                                        _P])
 
 # The pooled LAST layer of a training stack without its (M x C3) pre-activation / gradient
 # tensors (DESIGN 4.3 "pooled layer algebra"): forward = raw extrema out of the GEMM epilogue,
@@ -414,14 +415,18 @@ def pool_algebra_takes(M, Cout, K_in, pool_ns):
 
 
 def pooled_layer_backward(dOut, arg, ymax, scale, shift, mean, invstd, gamma, frozen, A, W, ns,
-                          need_dA=True, next_bn=None):
+                          need_dA=True, next_bn=None, act=None):
     """Gradients of out = max over ns rows of relu(BN(A W^T)) w.r.t. A (M x K), W (C3 x K),
     gamma, beta, given dOut (J x C3) -- without Y3 = A W^T or dY3 (M x C3 each):
         dY3 = dkrow - g (.) Y3 + e   per channel, g = k0 k2 invstd, e = g mean - k0 k1,
         dA  = dkrow W - A (W^T diag(g) W) + e W,
         dW  = SP - diag(g) W (A^T A) + e (x) colsum(A),   SP[c] = sum_j dk[j,c] A[row(j,c)].
-    (coef k0 k1 k2 = the statistics of s2c_bn_relu_max_bwd; float64 for the small matrices.)"""
+    (coef k0 k1 k2 = the statistics of s2c_bn_relu_max_bwd; float64 for the small matrices.)
+    act = (pscale, pshift, prelu): `A` is the PREVIOUS layer's pre-activation and the layer's input
+    relu?(A pscale + pshift) is formed inside the three kernels that read it (the forward kept no copy)."""
     dev = dOut.device
+    asc, ash, arelu = (act[0].data_ptr(), act[1].data_ptr(), int(act[2])) if act is not None \
+        else (None, None, 0)
     J, C3 = dOut.shape
     M, K = A.shape
     nb = _stat_blocks(J)
@@ -460,13 +465,14 @@ def pooled_layer_backward(dOut, arg, ymax, scale, shift, mean, invstd, gamma, fr
                   cvec.data_ptr(), dA.data_ptr(), K, next_bn["Y"].data_ptr(),
                   next_bn["scale"].data_ptr(), next_bn["shift"].data_ptr(),
                   next_bn["mean"].data_ptr(), next_bn["invstd"].data_ptr(),
-                  int(next_bn["relu"]), npart.data_ptr(),
+                  int(next_bn["relu"]), npart.data_ptr(), asc, ash, arelu,
                   alg_bytes=4 * (3 * M * K + 2 * J * C3), alg_flops=2 * M * K * (K + C3))
             next_bn["prestats"] = (npart, nbg)
         else:
             _call("s2c_pool_bwd_input_grad", A, M, K, K, C3, ns, A.data_ptr(), A.stride(0),
                   arg16.data_ptr(), dk.data_ptr(), Wcat.data_ptr(), Wcat.stride(0),
-                  cvec.data_ptr(), dA.data_ptr(), K, alg_bytes=4 * (2 * M * K + 2 * J * C3),
+                  cvec.data_ptr(), dA.data_ptr(), K, asc, ash, arelu,
+                  alg_bytes=4 * (2 * M * K + 2 * J * C3),
                   alg_flops=2 * M * K * (K + C3))
     # ---- weight gradient -------------------------------------------------------------------
     lib = _C.load()
@@ -475,13 +481,18 @@ def pooled_layer_backward(dOut, arg, ymax, scale, shift, mean, invstd, gamma, fr
     nblk = lib.s2c_pool_bwd_sp_blocks(J)
     sp = torch.empty((nblk, C3 * K + K), device=dev)
     _call("s2c_pool_bwd_sp", A, J, ns, C3, K, A.data_ptr(), arg.data_ptr(), dk.data_ptr(),
-          sp.data_ptr(), alg_bytes=4 * (M * K + 2 * J * C3 + nblk * (C3 + 1) * K))
+          sp.data_ptr(), asc, ash, arelu, alg_bytes=4 * (M * K + 2 * J * C3 + nblk * (C3 + 1) * K))
     # both partial tables are summed by ONE multi_colsum launch (kernel-boundary reduction).
     # NOT torch.sum: its cross-block reductions reset a semaphore buffer with hipMemsetAsync,
     # and memset nodes of a captured hipGraph are not ordered against kernels on ROCm 7.2
     # (DESIGN 5): the second replay of a two-graph step returned a wrong dW here.
     pending = []
-    gram = _weight_grad(A, A, pending)                      # A^T A  (K x K)
+    gram = _weight_grad_stream(A, A, pending, act=act) if act is not None else None
+    if gram is None:
+        if act is not None:
+            raise _C.S2CError("pooled_layer_backward: the Gram matrix of a recomputed input needs the "
+                              "streaming kernel (DW_STREAM)")
+        gram = _weight_grad(A, A, pending)                  # A^T A  (K x K)
     spsum = torch.empty(C3 * K + K, device=dev)
     pending.append((sp.view(nblk, 1, C3 * K + K), spsum))
     flush_partial_sums(pending)
@@ -632,9 +643,15 @@ class _MLPRows(Function):
                 if deferred is not None:
                     pY, pscale, pshift, prelu = deferred
                     deferred = None
-                    A = torch.empty_like(pY)
                     src, K_in = pY, pY.shape[1]
-                    pro = (pscale.data_ptr(), pshift.data_ptr(), int(prelu), A.data_ptr(), K_in)
+                    # the pooled-layer algebra reads the layer's input in three kernels; each forms it
+                    # from pY itself (POOL_ALGEBRA_ACT): no 268 MB activation side output at SA1
+                    if (POOL_ALGEBRA_ACT and DW_STREAM and pY.is_contiguous() and K_in <= 64
+                            and pool_ns >= 32 and M >= DW_STREAM_MIN_ROWS
+                            and _dw_stream_parts(M, K_in, K_in, pY, pY) > 0):
+                        act_from_prev = "algebra"
+                    A = None if act_from_prev else torch.empty_like(pY)
+                    pro = (pscale.data_ptr(), pshift.data_ptr(), int(prelu), _ptr(A), K_in)
                 else:
                     src, K_in = A, A.shape[1]
                     pro = (None, None, 0, None, 0)
@@ -867,8 +884,8 @@ class _MLPRows(Function):
             dW_fused = None
             pre, prestats = prestats, None
             point_grads = None
-            if rec.get("act_from_prev") == "stream":
-                pass    # the streaming weight gradient recomputes it (or it is materialised there)
+            if rec.get("act_from_prev") in ("stream", "algebra"):
+                pass    # the kernels that read it recompute it (or it is materialised where they do not)
             elif rec.get("act_from_prev"):
                 # this layer's input was not kept: it is the previous layer's activation, which the
                 # one-pass kernel recomputes (any other branch below gets it materialised here)
@@ -885,7 +902,7 @@ class _MLPRows(Function):
                     lazy_dw = True      # dW from point-indexed sums (GatherSpec.weight_grad)
             Cout = W.shape[0]
             M = (A_in.shape[0] if A_in is not None
-                 else rec["Y"].shape[0] if rec.get("act_from_prev") else gather.rows)
+                 else saved[li - 1]["Y"].shape[0] if rec.get("act_from_prev") else gather.rows)
             dgamma = dbeta = None
             if rec.get("algebra"):
                 # pooled last layer without Y3 / dY3 (pooled_layer_backward)
@@ -897,10 +914,16 @@ class _MLPRows(Function):
                         and specs[li - 1].bn is not None and prev.get("Y") is not None
                         and prev["Y"].shape == (M, Kin) and prev["Y"].is_contiguous()):
                     nbn = prev
+                act = None
+                if A_in is None and rec.get("act_from_prev") == "algebra":
+                    if POOL_ALGEBRA_ACT and DW_STREAM:
+                        A_in, act = prev["Y"], (prev["scale"], prev["shift"], prev["relu"])
+                    else:
+                        A_in = _activation_of(prev)
                 dA, dW, dgamma, dbeta = pooled_layer_backward(
                     dA, rec["arg"], rec["ymax"], rec["scale"], rec["shift"], rec["mean"],
                     rec["invstd"], rec["gamma"], rec["frozen"], A_in, W, pool_ns, need_dA=need_dA,
-                    next_bn=nbn)
+                    next_bn=nbn, act=act)
                 if nbn is not None:
                     prestats = nbn.pop("prestats", None)
                 g = [dW]
@@ -1551,8 +1574,6 @@ def _weight_grad_stream(dY, A, pending, act=None):
     dW = torch.empty((C, N), dtype=torch.float32, device=dev)
     same = A.data_ptr() == dY.data_ptr() and A.stride(0) == dY.stride(0) and C == N
     if act is not None:
-        if same:
-            return None
         rc = _C.call("s2c_weight_grad_stream_act", M, C, N, dY.data_ptr(), dY.stride(0), A.data_ptr(),
                      A.stride(0), act[0].data_ptr(), act[1].data_ptr(), int(act[2]), part.data_ptr(),
                      _C.stream_ptr(), allow=(-2,))
@@ -1570,6 +1591,9 @@ def _weight_grad_stream(dY, A, pending, act=None):
 # BatchNorm + ReLU prologue GEMMs) is not written where that gradient runs on the streaming kernel: the
 # kernel recomputes it from the previous layer's pre-activation (s2c_weight_grad_stream_act)
 DW_STREAM_ACT = True
+# ... and the pooled-layer algebra's three readers of its input (the pool-backward GEMM, the Gram matrix,
+# the SP sums) form it from the previous layer's pre-activation too
+POOL_ALGEBRA_ACT = True
 
 
 def _dw_will_stream(M, C, N, ref):

@@ -1602,3 +1602,23 @@ def test_pooled_layer_backward_algebra_matches_the_materialised_path(J, ns, K, C
     assert torch.equal(dgamma, dg) and torch.equal(dbeta, db)
     assert float((dA.double() - dA_ref).abs().max()) <= 2e-5 * float(dA_ref.abs().max())
     assert float((dW.double() - dW_ref).abs().max()) <= 2e-5 * float(dW_ref.abs().max())
+    if ns >= 32 and K <= 64 and M >= fused.DW_STREAM_MIN_ROWS and fused._dw_stream_parts(M, K, K, A, A) > 0:
+        # the layer's input recomputed inside the three kernels that read it (POOL_ALGEBRA_ACT): A is the
+        # float32 image of relu(P psc + psh) of a "previous layer's pre-activation" P
+        psc = torch.rand(K, device="cuda") + 0.5
+        psc[2] = -0.8
+        psh = torch.randn(K, device="cuda") * 0.2
+        P = torch.randn(M, K, device="cuda")
+        A2 = torch.relu(P * psc + psh)
+        Y2 = A2 @ W.t()
+        mean2, var2 = Y2.mean(0), Y2.var(0, unbiased=False)
+        invstd2 = 1.0 / torch.sqrt(var2 + 1e-5)
+        scale2 = gamma * invstd2
+        shift2 = beta - mean2 * scale2
+        _C.call("s2c_bn_relu_max", J, ns, C3, Y2.data_ptr(), scale2.data_ptr(), shift2.data_ptr(),
+                out.data_ptr(), arg.data_ptr(), ymax.data_ptr(), _C.stream_ptr())
+        want = fused.pooled_layer_backward(dOut, arg, ymax, scale2, shift2, mean2, invstd2, gamma, False, A2, W, ns)
+        got = fused.pooled_layer_backward(dOut, arg, ymax, scale2, shift2, mean2, invstd2, gamma, False, P, W, ns,
+                                          act=(psc, psh, True))
+        for a, b in zip(got, want):
+            assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())

@@ -15,7 +15,7 @@ for name, G, cv in (("sparse only", torch.zeros(K, K, device="cuda"), torch.zero
     Wcat = torch.cat([(-G.t()), W.t()], 1).contiguous()
     dA = torch.full((M, K), float("nan"), device="cuda")
     fused._call("s2c_pool_bwd_input_grad", A, M, K, K, C3, ns, A.data_ptr(), K, a16.data_ptr(), dkk.data_ptr(),
-                Wcat.data_ptr(), Wcat.stride(0), cv.data_ptr(), dA.data_ptr(), K)
+                Wcat.data_ptr(), Wcat.stride(0), cv.data_ptr(), dA.data_ptr(), K, None, None, 0)
     torch.cuda.synchronize()
     dense = torch.zeros(M, C3, device="cuda", dtype=torch.float64)
     rows = (torch.arange(J, device="cuda").unsqueeze(1) * ns + arg.long())
@@ -35,5 +35,5 @@ for (J, ns, K, C3) in ((16384, 64, 64, 128), (16384, 64, 64, 64), (16384, 64, 64
     Wcat = torch.cat([(-G.t()), W.t()], 1).contiguous()
     dA = torch.empty((M, K), device="cuda")
     f = lambda: fused._call("s2c_pool_bwd_input_grad", A, M, K, K, C3, ns, A.data_ptr(), K, arg16.data_ptr(), dk.data_ptr(),
-                            Wcat.data_ptr(), Wcat.stride(0), cv.data_ptr(), dA.data_ptr(), K)
+                            Wcat.data_ptr(), Wcat.stride(0), cv.data_ptr(), dA.data_ptr(), K, None, None, 0)
     print("M=%d K=%d C3=%d: %.1f us" % (M, K, C3, timeit(f, iters=10)))
