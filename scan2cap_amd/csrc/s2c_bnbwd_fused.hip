@@ -361,14 +361,17 @@ extern "C" int s2c_bn_bwd_dx_dw64(long long M, const float *dA, const float *Y, 
                                   float *dWpart, float *npartial, void *stream) {
   if (!fb_takes(M) || !dA || !Y || !nY || !W || !dX || !dWpart || !npartial || ldw < 64) return -2;
   if ((((size_t)dA | (size_t)Y | (size_t)nY | (size_t)dX) & 15) != 0) return -2;
-  static bool attr = false;
-  if (!attr) {
+  // the dynamic-LDS cap is a per-DEVICE function attribute: one flag per device of the process
+  static bool attr_dev[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -2;
+  if (!attr_dev[dev]) {
     if (hipFuncSetAttribute((const void *)bn_bwd_dx_dw64_kernel,
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
       (void)hipGetLastError();
       return -2;
     }
-    attr = true;
+    attr_dev[dev] = true;
   }
   FbArgs a{};
   a.M = M; a.nchunks = M / 16;

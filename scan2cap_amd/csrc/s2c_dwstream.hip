@@ -337,11 +337,7 @@ bool dws_plan(long long M, int C, int N, const float *dY, long long ldy, const f
 }
 
 int dws_grid(const DwsArgs &a) {
-  if (g_dws_grid == 0) {
-    const char *e = getenv("S2C_DWS_GRID");
-    g_dws_grid = e ? atoi(e) : 240;
-    if (g_dws_grid <= 0) g_dws_grid = 240;
-  }
+  if (g_dws_grid <= 0) g_dws_grid = 240;      // (changed through s2c_weight_grad_stream_set_grid only)
   long long gsz = g_dws_grid;
   const long long units = (a.nchunks + a.kg - 1) / a.kg;
   if (gsz > units) gsz = units;
@@ -392,11 +388,18 @@ static int dws_launch(long long M, int C, int N, const float *dY, long long ldy,
   DwsArgs a;
   if (!part || !dws_plan(M, C, N, dY, ldy, A, lda, &a)) return -2;
   if (pscale && a.ni != 8 && a.ni != 4) return -2;      // (ni 4: A == dY, the Gram matrix of the activation)
+  // the zero-filled pad rows of a ragged last chunk would be transformed to relu(pshift) as well: with
+  // A != dY the dY rows beside them are zero and nothing is added, on the Gram path (A == dY) both
+  // operands are transformed and each pad row would add relu(pshift)^T relu(pshift) -> not taken
+  if (pscale && a.same && M % 16 != 0) return -2;
   a.pscale = pscale; a.pshift = pshift; a.prelu = prelu;
   a.part = part;
   const int grid = dws_grid(a);
-  static bool attr = false;
-  if (!attr) {
+  // the dynamic-LDS cap is a per-DEVICE function attribute: one flag per device of the process
+  static bool attr_dev[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -2;
+  if (!attr_dev[dev]) {
     const int cap = 160 * 1024;
     if (hipFuncSetAttribute((const void *)dw_private_kernel<4, 2>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
@@ -411,7 +414,7 @@ static int dws_launch(long long M, int C, int N, const float *dY, long long ldy,
       (void)hipGetLastError();
       return -2;
     }
-    attr = true;
+    attr_dev[dev] = true;
   }
   const int PW = a.tcw * a.tnw * a.kg;
   size_t lds = (size_t)PW * a.S * a.slot_bytes + 1024;

@@ -796,11 +796,12 @@ void launch_multi_p(int b, int n, int m, int log2bs, const float *xyz, void *wor
                     size_t stride, int *idx, long long *prof, hipStream_t st) {
   const size_t lds = (size_t)n * 4;
   if (lds + 4096 <= 160 * 1024) {
-    static bool attr = false;
-    if (!attr) {
+    static bool attr_dev[64] = {};             // per device (the attribute is the device's)
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !attr_dev[dev]) {
       (void)hipFuncSetAttribute((const void *)fps_cells_multi_kernel<true, MAXP>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-      attr = true;
+      attr_dev[dev] = true;
     }
     hipLaunchKernelGGL((fps_cells_multi_kernel<true, MAXP>), dim3(b), dim3(1024), lds, st, n, m,
                        log2bs, xyz, (char *)workspace, stride, idx, prof);

@@ -1246,8 +1246,10 @@ int launch_x3(long long M, int N, int K, const float *A, int lda, const float *W
   }
   const int avec = A && ((lda & 3) == 0) && (((uintptr_t)A & 15) == 0);
   const int wvec = ((ldw & 3) == 0) && (((uintptr_t)W & 15) == 0);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_dev[64] = {};               // per device (the attribute is the device's)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+  if (!attr_dev[dev]) {
     if (hipFuncSetAttribute((const void *)rows_gemm_x3_kernel<4, 1, PRO>,
                             hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)x3_lds_bytes<4, 1>()) != hipSuccess ||
@@ -1255,7 +1257,7 @@ int launch_x3(long long M, int N, int K, const float *A, int lda, const float *W
                             hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)x3_lds_bytes<2, 2>()) != hipSuccess)
       return -1;
-    attr_done = true;
+    attr_dev[dev] = true;
   }
   const size_t lds41 = x3_lds_bytes<4, 1>(), lds22 = x3_lds_bytes<2, 2>();
   if (N <= 64) {

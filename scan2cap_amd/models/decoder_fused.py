@@ -247,7 +247,11 @@ def _drop_locks_in_child():
     for index, f in list(_DEVICE_LOCKS.items()):
         if f not in (True, False):
             try:
-                _os.close(f.fileno())
+                # close THROUGH the file object (os.close(f.fileno()) would let its finalizer close
+                # the same descriptor number a second time: EBADF noise, or an unrelated descriptor
+                # if the number was reused).  The flock belongs to the open file description the
+                # parent still holds: closing the child's duplicate does not release it.
+                f.close()
             except Exception:
                 pass
         _DEVICE_LOCKS[index] = False

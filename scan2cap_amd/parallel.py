@@ -48,6 +48,17 @@ def init_from_env(backend=None):
         local_world = min(world, max(ndev, 1))
         if ndev and local_rank >= ndev:
             local_world = local_rank + 1
+        multi_node = any(os.environ.get(k) for k in ("SLURM_NNODES", "GROUP_RANK", "NODE_RANK",
+                                                     "OMPI_COMM_WORLD_LOCAL_SIZE"))
+        if "LOCAL_RANK" not in os.environ and world > max(ndev, 1) and not multi_node:
+            # a hand-launched single-node job that sets only RANK / WORLD_SIZE with more ranks than
+            # devices: every rank would default to device 0 -> over-subscribed (the persistent decoder
+            # is switched off below, RCCL gets the clear error instead of its duplicate-GPU one)
+            local_world = world
+        if world > 1 and "LOCAL_RANK" not in os.environ:
+            import warnings
+            warnings.warn("scan2cap_amd.parallel: WORLD_SIZE=%d without LOCAL_RANK / LOCAL_WORLD_SIZE; "
+                          "assuming %d rank(s) on this node's %d device(s)" % (world, local_world, ndev))
     if world > 1 and ndev and local_world > ndev:
         # several ranks share a device (the gloo rehearsal): two persistent decoder kernels of
         # different processes could each hold part of the CUs and wait for the rest
