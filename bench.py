@@ -705,11 +705,15 @@ def main():
     model.train(wl["train"])
     cfg_loss = LossConfig(msa)
     use_graph = not args.no_graph
-    # torch's fused multi-tensor Adam: same update as scripts/train.py's optim.Adam, 3
-    # launches instead of 17 (S2C_ADAM_FUSED=0: the default foreach implementation)
-    fused_adam = True
-    optimizer = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5,
-                                 capturable=use_graph, fused=True if fused_adam else None)
+    # scripts/train.py:138's optim.Adam(lr, weight_decay) as ONE launch over every parameter tensor
+    # (scan2cap_amd/optim.py: FusedAdam, csrc/s2c_optim.hip; same update, same state_dict layout);
+    # S2C_ADAM_TORCH=1: torch's fused multi-tensor Adam (3 launches + the step counters')
+    if os.environ.get("S2C_ADAM_TORCH") == "1":
+        optimizer = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5,
+                                     capturable=use_graph, fused=True)
+    else:
+        from scan2cap_amd.optim import FusedAdam
+        optimizer = FusedAdam(model.parameters(), lr=1e-3, weight_decay=1e-5)
     # S2C_FORCE_DDP=1 exercises the multi-GPU code path (flat gradient bucket,
     # fwd/bwd graph + eager all-reduce + optimizer graph) on a single rank
     force_ddp = os.environ.get("S2C_FORCE_DDP") == "1"

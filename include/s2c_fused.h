@@ -918,6 +918,35 @@ typedef struct s2c_sgemm_args {
 } s2c_sgemm_args;
 int s2c_small_gemm_ex(const s2c_sgemm_args *g, void *stream);
 
+/* ---- the optimizer step (csrc/s2c_optim.hip) ------------------------------------------------
+ * torch.optim.Adam's update (scripts/train.py:138, lib/solver.py:293-302: `optim.Adam(params, lr,
+ * weight_decay)`, one step per batch; amsgrad / maximize off, L2 weight decay added to the gradient)
+ * of up to S2C_ADAM_MAX_TENSORS parameter tensors in ONE launch.  Tensor i: parameter and gradient
+ * (numel fp32 each; grad == NULL: skipped, as torch skips a parameter without a gradient), its first /
+ * second moments at exp_avg + offset / exp_avg_sq + offset (flat buffers of the caller; offset in
+ * elements, a multiple of 4 keeps the 16-byte path).  first_block[i] = sum over j < i of
+ * ceil(numel_j / s2c_adam_chunk()), first_block[n_tensors] = the grid.  step[i] (fp32, device) holds the
+ * number of updates tensor i has had; the kernel uses step[i] + 1 and stores it back for the tensors
+ * with a gradient (the last workgroup to finish does, through *counter, which must be 0 at the first
+ * launch and is left 0). */
+#define S2C_ADAM_MAX_TENSORS 128
+typedef struct s2c_adam_tensor {
+  float *param;
+  const float *grad;
+  int numel, offset;
+} s2c_adam_tensor;
+typedef struct s2c_adam_args {
+  int n_tensors, pad_;
+  double lr, beta1, beta2, eps, weight_decay;   /* torch passes them to its kernels as doubles too */
+  float *exp_avg, *exp_avg_sq, *step;
+  unsigned *counter;
+  int first_block[S2C_ADAM_MAX_TENSORS + 1];
+  int pad3_;
+  s2c_adam_tensor t[S2C_ADAM_MAX_TENSORS];
+} s2c_adam_args;
+int s2c_adam_chunk(void);
+int s2c_adam_multi(const s2c_adam_args *a, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
