@@ -50,12 +50,15 @@ def independent_streams(n, candidates=12, avoid=()):
     if not torch.cuda.is_available():
         return [torch.cuda.Stream() for _ in range(n)]
     main = torch.cuda.current_stream()
-    x = torch.randn(2048, 2048, device="cuda")
+    # ~1 ms of element-wise work (NOT a library GEMM: until round 6 this probe was the only
+    # rocBLAS / Tensile launch of the default bench.py command -- 120 `Cijk_*` rows in its rocprofv3
+    # table, tools/trace_lib_gemm_bench.py)
+    x = torch.randn(1 << 24, device="cuda")
 
     def probe():
         y = x
-        for _ in range(8):
-            y = torch.mm(y, x) * 1e-3
+        for _ in range(24):
+            y = torch.sin(y)
         return y
 
     for s in (main,):

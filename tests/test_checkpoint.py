@@ -118,9 +118,9 @@ def _graphed(bench, wl, model, dd, cfg, dev):
     bench.py runs it."""
     from scan2cap_amd.graphs import GraphedCallable
     from scan2cap_amd.pipeline import GeometrySlots
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5, capturable=True,
-                           fused=True)
-    step = bench.make_step(model, wl, cfg, opt, None, dev)
+    from scan2cap_amd.optim import FusedAdam          # (round 6: bench.py's optimizer; the reference
+    opt = FusedAdam(model.parameters(), lr=1e-3, weight_decay=1e-5)    # resume below loads its checkpoint
+    step = bench.make_step(model, wl, cfg, opt, None, dev)             # into a torch.optim.Adam)
     slots = GeometrySlots(model.backbone_net, dd["point_clouds"], 1)
 
     def body():

@@ -13,7 +13,8 @@ vocabulary, embeddings, table = bench.make_vocab(wl["V"])
 msa = np.random.Generator(np.random.PCG64(5)).uniform(0.3, 1.5, size=(18, 3))
 torch.manual_seed(0)
 model = bench.build_model(wl, vocabulary, embeddings, msa).to(dev).train()
-opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5, fused=True)
+from scan2cap_amd.optim import FusedAdam
+opt = FusedAdam(model.parameters(), lr=1e-3, weight_decay=1e-5)
 dd0 = bench.to_device(bench.make_batch(wl, wl["B"], 42, table, msa), dev)
 cfg = bench.LossConfig(msa)
 

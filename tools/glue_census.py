@@ -40,7 +40,8 @@ class Census(TorchDispatchMode):
 
 bench, wl, model, dd, batch, msa, dev = T._setup("cfg3")
 cfg = bench.LossConfig(msa)
-opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5, capturable=True, fused=True)
+from scan2cap_amd.optim import FusedAdam
+opt = FusedAdam(model.parameters(), lr=1e-3, weight_decay=1e-5)
 step = bench.make_step(model, wl, cfg, opt, None, dev)
 geo = model.backbone_net.compute_geometry(dd["point_clouds"])
 d0 = dict(dd); d0["_geometry"] = geo

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates the judged profile set of a round on the GPU box (run through gpurun from the
 # repo root): tools/make_profiles.sh r02   -> gpurun_out/<round>/...  (copy into profiles/)
-R=${1:-r05}
+R=${1:-r06}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$R
 mkdir -p $OUT
@@ -61,4 +61,11 @@ S2C_FORCE_DDP=1 python $ROOT/bench.py --no-cpu-baseline --no-fed > $OUT/${R}_ben
 # no library GEMM in the train step: the census of torch.mm / addmm / bmm / linear calls
 python $ROOT/tools/lib_gemm_census.py cfg3 > $OUT/${R}_lib_gemm_census_cfg3.txt 2>&1
 python $ROOT/tools/count_launches.py > $OUT/${R}_launches_cfg3.txt 2>&1
+python $ROOT/tools/glue_census.py > $OUT/${R}_glue_census_cfg3.txt 2>&1
+# every library-GEMM call site of the DEFAULT command (capture, replay, instrumented pass, stream probe):
+# round 6: none (round 5: 120 `Cijk_*` launches of pipeline.py's stream probe, outside the step)
+python $ROOT/tools/trace_lib_gemm_bench.py > /dev/null 2> $OUT/${R}_lib_gemm_sites_default_command.txt
+# cross-workgroup exchange costs inside one kernel, all workgroups / XCD-local groups (the number the
+# multi-workgroup FPS and the persistent decoder are priced with: DESIGN 4.1, 4.4)
+python $ROOT/tools/probe_sync.py > $OUT/${R}_probe_sync.txt 2>&1
 ls -la $OUT
