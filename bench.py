@@ -554,7 +554,8 @@ def self_launch(n):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
-                                      env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+                                      env=env, stdout=(_REAL_STDOUT[0] if r == 0
+                                                       else subprocess.DEVNULL)))
     code = 0
     try:
         live = list(procs)
@@ -635,7 +636,11 @@ def ddp_evidence(ddp, head, device, world, trace=lambda m: None):
     return info
 
 
-def main():
+_LAST_LINE = [None]
+_REAL_STDOUT = [None]       # the caller's stdout while fd 1 points at stderr (_main_with_one_line_stdout)
+
+
+def main(_emit=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -1121,8 +1126,36 @@ def main():
         except OSError:
             pass
         sys.stdout.flush()
-        print(line, flush=True)
+        _LAST_LINE[0] = line
+        if _emit is None:
+            print(line, flush=True)
+        else:
+            _emit(line)
+
+
+def _main_with_one_line_stdout():
+    """RCCL prints a five-line version banner and gloo a "[Gloo] Rank ..." line on STDOUT; the driver
+    reads ONE JSON line there.  File descriptor 1 points at stderr while main() runs and is restored
+    for the JSON line alone (everything else a native library writes lands on stderr)."""
+    import ctypes
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    _REAL_STDOUT[0] = saved
+    try:
+        main(_emit=lambda line: None)
+    finally:
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+        _REAL_STDOUT[0] = None
+    if _LAST_LINE[0] is not None:
+        print(_LAST_LINE[0], flush=True)
 
 
 if __name__ == "__main__":
-    main()
+    _main_with_one_line_stdout()

@@ -39,6 +39,9 @@ def test_bench_self_launches_two_ranks_on_one_gpu():
                           "--steps", "3", "--warmup", "2"], env=env, capture_output=True,
                          text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-3000:]
+    # round 6: stdout is the JSON line and NOTHING else (gloo's "[Gloo] Rank ..." line and RCCL's version
+    # banner go to stderr: bench._main_with_one_line_stdout)
+    assert len(res.stdout.strip().splitlines()) == 1, res.stdout[:500]
     line = json.loads(res.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 16
     assert line["config"]["parallelism"] == "dp2" and line["scaling"] == "weak"
