@@ -65,6 +65,12 @@ int s2c_sa_gather_add_eval(int b, int n, int m, int ns, int N, float radius, int
  * product in front of s2c_sa_gather_add (csrc/s2c_pgemm.hip). */
 int s2c_point_gemm(long long M, int N, int K, const float *A, long long lda, const float *W,
                    int ldw, float *P, int ldp, void *stream);
+/* The same product on the streaming kernel of csrc/s2c_gemm2.hip (bf16x3 split products, LDS-DMA ring;
+ * fp32-accurate like every rows GEMM) for TALL inputs (SA1 of the BASELINE workloads: 320 000 points):
+ * A rows at any 4-byte address and stride.  Returns -2 when the shape is not taken (K % 4, fewer than
+ * 131072 rows, N > 128): the caller runs s2c_point_gemm. */
+int s2c_point_gemm_stream(long long M, int N, int K, const float *A, long long lda, const float *W,
+                          int ldw, float *P, int ldp, void *stream);
 
 /* For the weight gradient of a gather-fused layer whose inputs need no gradient:
  * Z (b,n,C) = sum of the dY rows (b*m*ns x C) that gathered each point (zeroed by the

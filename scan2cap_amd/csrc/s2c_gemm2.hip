@@ -957,6 +957,22 @@ extern "C" int s2c_rows_stream_gemm(long long M, int N, int K, const float *A, i
   return launch_stream<SPRO_NONE>(a, (hipStream_t)stream);
 }
 
+// The per-POINT product of a set-abstraction stage's first layer, P (M x N) = X (M x K) W^T, on the
+// streaming kernel (round 6).  X = the feature columns of the (B,N,3+C) cloud read IN PLACE: rows of
+// 3 + C floats, so neither lda nor the row starts are multiples of 16 bytes -- the ring is filled by
+// `global_load_lds_dwordx4`, which takes dword-aligned sources (as the gather prologue's feature rows
+// always were).  K % 4 == 0, M >= the streaming threshold; -2: shape not taken (csrc/s2c_pgemm.hip).
+extern "C" int s2c_point_gemm_stream(long long M, int N, int K, const float *A, long long lda,
+                                     const float *W, int ldw, float *P, int ldp, void *stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || !A || !W || !P || lda < K || ldw < K || ldp < N) return -1;
+  if (!s2c_rows_stream_supported(M, N, K, 0) || ((uintptr_t)A & 3) || lda >= (1ll << 31) ||
+      (ldp & 3) || ((uintptr_t)P & 15))
+    return -2;
+  StreamArgs a = {};
+  a.M = M; a.N = N; a.K = K; a.A = A; a.lda = (int)lda; a.W = W; a.ldw = ldw; a.Y = P; a.ldy = ldp;
+  return launch_stream<SPRO_NONE>(a, (hipStream_t)stream);
+}
+
 // Y = relu?(A * scale + shift) W^T with the activated operand written to `side` (M x K, may be
 // NULL): one pass over the pre-activation tensor A instead of s2c_bn_relu + s2c_rows_gemm.
 // Streaming kernel only: returns -2 when the shape is not taken (call the two separately).

@@ -27,6 +27,29 @@ _C.register("s2c_sa_gather_rows", [_I, _I, _I, _I, _I, _L, _L, _F, _I, _P, _P, _
 _C.register("s2c_sa_scatter_rows", [_I, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P])
 _C.register("s2c_sa_scatter_sum", [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P])
 _C.register("s2c_point_gemm", [_L, _I, _I, _P, _L, _P, _I, _P, _I, _P])
+_C.register("s2c_point_gemm_stream", [_L, _I, _I, _P, _L, _P, _I, _P, _I, _P])
+# tall per-point products (SA1 at the BASELINE sizes: 320 000 points x 132 channels) on the streaming
+# kernel (bf16x3 split, LDS-DMA ring over the cloud's 540-byte rows read in place) instead of the exact
+# fp32 MFMA chain of csrc/s2c_pgemm.hip, which is matrix-bound at 1/16 of the bf16 rate there (91 us
+# where the 255 MB it moves allow ~55); the small stages and the fixtures (< 131072 points) stay on
+# the exact chain.  = False: s2c_point_gemm everywhere.
+POINT_GEMM_STREAM = _os.environ.get("S2C_POINT_GEMM_STREAM", "1") != "0"
+
+
+def _point_gemm(P, f2, Wf, n_points, Cout, C, alg_bytes, alg_flops):
+    """P (n_points x Cout) = f2 (n_points x C, any row stride) Wf^T."""
+    if POINT_GEMM_STREAM and _gemm_split_on():
+        if _C.TIMER.enabled:
+            _C.TIMER.alg_bytes, _C.TIMER.alg_flops = int(alg_bytes), int(alg_flops)
+            _C.TIMER.label = "s2c_sa_point_gemm"
+        with torch.cuda.device(P.device):
+            rc = _C.call("s2c_point_gemm_stream", n_points, Cout, C, f2.data_ptr(), f2.stride(0),
+                         Wf.data_ptr(), Wf.stride(0), P.data_ptr(), Cout, _C.stream_ptr(), allow=(-2,))
+        if rc == 0:
+            return
+    _call("s2c_point_gemm", P, n_points, Cout, C, f2.data_ptr(), f2.stride(0),
+          Wf.data_ptr(), Wf.stride(0), P.data_ptr(), Cout,
+          alg_bytes=alg_bytes, alg_flops=alg_flops, label="s2c_sa_point_gemm")
 _C.register("s2c_sa_gather_add", [_I, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P])
 _C.register("s2c_sa_scatter_sum_bn_bwd", [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P])
 _C.register("s2c_fp_interp_rows", [_I, _I, _I, _I, _I, _P, _P, _P, _P, _L, _L, _P, _P])
@@ -608,9 +631,7 @@ class _MLPRows(Function):
                     # the op's contract (unique source rows + idx + Y) is split over the two launches;
                     # P is an intermediate, not algorithmic traffic
                     pb, pf = 4 * min(g.B * g.N, M) * g.C, 2 * g.B * g.N * g.C * Cout
-                    _call("s2c_point_gemm", P, g.B * g.N, Cout, g.C, f2.data_ptr(), f2.stride(0),
-                          Wf.data_ptr(), Wf.stride(0), P.data_ptr(), Cout,
-                          alg_bytes=pb, alg_flops=pf, label="s2c_sa_point_gemm")
+                    _point_gemm(P, f2, Wf, g.B * g.N, Cout, g.C, pb, pf)
                 nbg = _gather_add_blocks(M)
                 gpart = torch.empty(nbg * 2 * Cout, device=dev) if gemm_stats else None
                 Y = torch.empty((M, Cout), device=dev)
@@ -1280,10 +1301,8 @@ def _eval_stack(X, gather, M, dev, specs, pool_ns, params):
             if g.C > 0:
                 f2, Wf = g.feats2d(), W[:, 3:]
                 P = torch.empty((g.B * g.N, Cout), device=dev)
-                _call("s2c_point_gemm", P, g.B * g.N, Cout, g.C, f2.data_ptr(), f2.stride(0),
-                      Wf.data_ptr(), Wf.stride(0), P.data_ptr(), Cout,
-                      alg_bytes=4 * min(g.B * g.N, M) * g.C, alg_flops=2 * g.B * g.N * g.C * Cout,
-                      label="s2c_sa_point_gemm")
+                _point_gemm(P, f2, Wf, g.B * g.N, Cout, g.C, 4 * min(g.B * g.N, M) * g.C,
+                            2 * g.B * g.N * g.C * Cout)
             _call("s2c_sa_gather_add_eval", out, g.B, g.N, g.m, g.ns, Cout, g.radius, g.normalize,
                   g.xyz.data_ptr(), g.new_xyz.data_ptr(), _ptr(P), g.idx.data_ptr(),
                   W.data_ptr(), W.stride(0), _ptr(gamma), _ptr(beta), mean.data_ptr(),

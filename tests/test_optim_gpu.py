@@ -129,3 +129,30 @@ def test_fused_adam_inside_a_captured_graph():
     assert float(oa.state[a[0]]["step"]) == 6.0
     for i, (x, y) in enumerate(zip(a, b)):
         assert _rel(x, y) <= 5e-6, i
+
+
+def test_fused_adam_many_tensors_and_two_groups():
+    """More tensors than one launch's argument block holds (128) and two parameter groups with their
+    own learning rate / weight decay: still torch.optim.Adam's numbers."""
+    from scan2cap_amd.optim import FusedAdam
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(9)
+    shapes = [(1 + (i * 37) % 300,) for i in range(150)] + [(70, 33), (5000,)]
+
+    def make():
+        gg = torch.Generator().manual_seed(9)
+        return [torch.nn.Parameter(torch.randn(s, generator=gg).to(dev)) for s in shapes]
+    a, b = make(), make()
+    groups = lambda ps: [dict(params=ps[:100], lr=1e-3, weight_decay=1e-5),
+                         dict(params=ps[100:], lr=5e-4, weight_decay=0.0)]
+    oa, ob = FusedAdam(groups(a)), torch.optim.Adam(groups(b))
+    for it in range(4):
+        for x, y in zip(a, b):
+            gr = torch.randn(tuple(x.shape), generator=g)
+            x.grad, y.grad = gr.to(dev), gr.to(dev).clone()
+        oa.step()
+        ob.step()
+    assert oa._fallback is False
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert _rel(x, y) <= 5e-6, i
+        assert float(oa.state[x]["step"]) == 4.0

@@ -129,3 +129,42 @@ def test_point_gemm_matches_float64(M, N, K, lda, off):
     finally:
         fused.set_gemm_split(prev)
     assert torch.equal(P, T)
+
+
+@pytest.mark.parametrize("Bn,C,N", [(320000, 132, 64), (160000, 128, 128), (131072 + 17, 132, 64)])
+def test_point_gemm_stream_reads_the_cloud_rows_in_place(Bn, C, N):
+    """Round 6: the per-point product of a TALL first layer (SA1 at the BASELINE sizes) on the streaming
+    kernel -- `s2c_point_gemm_stream`: feature columns of the (.., 3 + C) cloud in place (rows of 3 + C
+    floats: neither the stride nor the row starts are 16-byte multiples), bf16x3 products.  Against a
+    float64 product (2e-6, the bound of the exact fp32 chain it replaces there) and against
+    `s2c_point_gemm`; below the streaming threshold the entry declines (-2) and fused._point_gemm runs
+    the exact chain."""
+    import ctypes
+    from scan2cap_amd import _C
+    from scan2cap_amd.pointnet2 import fused
+    g = torch.Generator(device="cuda").manual_seed(Bn + C)
+    pc = torch.randn(Bn, 3 + C, device="cuda", generator=g)
+    f2 = pc[:, 3:]                                   # stride 3 + C, starts 12 bytes into the row
+    W = torch.randn(N, 3 + C, device="cuda", generator=g) / (3 + C) ** 0.5
+    Wf = W[:, 3:]
+    P = torch.full((Bn, N), float("nan"), device="cuda")
+    rc = _C.call("s2c_point_gemm_stream", Bn, N, C, f2.data_ptr(), f2.stride(0), Wf.data_ptr(),
+                 Wf.stride(0), P.data_ptr(), N, _C.stream_ptr(), allow=(-2,))
+    assert rc == 0
+    want = f2.double() @ Wf.double().t()
+    assert _rel(P, want) < 2e-6
+    Q = torch.empty_like(P)
+    fused._call("s2c_point_gemm", Q, Bn, N, C, f2.data_ptr(), f2.stride(0), Wf.data_ptr(), Wf.stride(0),
+                Q.data_ptr(), N)
+    assert _rel(P, Q) < 2e-6
+    # via the dispatcher, and a short input stays on the exact chain
+    R = torch.full((Bn, N), float("nan"), device="cuda")
+    fused._point_gemm(R, f2, Wf, Bn, N, C, 0, 0)
+    assert torch.equal(R, P)
+    small = 4096
+    rc = _C.call("s2c_point_gemm_stream", small, N, C, f2.data_ptr(), f2.stride(0), Wf.data_ptr(),
+                 Wf.stride(0), P.data_ptr(), N, _C.stream_ptr(), allow=(-2,))
+    assert rc == -2
+    S = torch.full((small, N), float("nan"), device="cuda")
+    fused._point_gemm(S, f2[:small], Wf, small, N, C, 0, 0)
+    assert torch.equal(S, Q[:small])
