@@ -5,7 +5,7 @@ C ABI in include/s2c_fused.h).
 reference computes with QueryAndGroup -> SharedMLP -> max_pool2d
 (pointnet2_modules.py:244-257), but on point-major rows: rows = (scene, centre,
 sample), channels contiguous.  The 1x1 convolutions become row-major GEMMs
-(library GEMM today, torch.mm -> hipBLASLt f32 MFMA); BatchNorm statistics,
+(the hand-written MFMA kernels of csrc/s2c_gemm*.hip, s2c_pgemm.hip, s2c_sgemm.hip); BatchNorm statistics,
 BN+ReLU, BN+ReLU+max and all their backward passes are the hand-written
 HBM-bound kernels.  `mlp_rows` is the same machinery without grouping/pooling
 for the FP / voting / proposal heads.
